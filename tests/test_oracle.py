@@ -1,0 +1,151 @@
+"""CPU tests of the oracle itself (no GPU, no HIP): the hand-written numpy backward is checked
+against torch-CPU autograd of an independent restatement of the same graph in float64, and the
+exact C k-NN against brute force / tie rules."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import dgcnn_oracle as O
+
+
+def _torch_conv_bn_act(x, W, beta, relu=True):
+    y = x @ W
+    dims = tuple(range(y.dim() - 1))
+    mu = y.mean(dim=dims)
+    var = ((y - mu) ** 2).mean(dim=dims)
+    z = (y - mu) / torch.sqrt(var + O.BN_EPS) + beta
+    return torch.relu(z) if relu else z
+
+
+def _torch_model(points, flags, P, idx_list):
+    """Independent torch restatement of model.py:9-106 (autograd supplies the backward)."""
+    L = flags.EDGE_CONV_LAYERS
+    residual = flags.MODEL_NAME != "dgcnn"
+    ecf = O._as_list(flags.EDGE_CONV_FILTERS, L, "f")
+    net = points
+    tensors = []
+    shortcut = None
+    B, N, _ = points.shape
+    for i in range(L):
+        s = "EdgeConv%d/" % i
+        idx = torch.as_tensor(idx_list[i], dtype=torch.long)
+        k = idx.shape[-1]
+        nbr = torch.stack([net[b][idx[b].reshape(-1)].reshape(N, k, -1) for b in range(B)])
+        cen = net[:, :, None, :].expand(-1, -1, k, -1)
+        E = torch.cat([cen, nbr - cen], dim=-1)
+        y = _torch_conv_bn_act(E, P[s + "conv0/weights"], P[s + "conv0/BatchNorm/beta"])
+        mx = y.amax(dim=-2, keepdim=True)
+        mn = y.mean(dim=-2, keepdim=True)
+        relu1 = not (residual and shortcut is not None)
+        out = _torch_conv_bn_act(torch.cat([mx, mn], -1), P[s + "conv1/weights"], P[s + "conv1/BatchNorm/beta"], relu1)
+        if residual and shortcut is not None:
+            sc = shortcut
+            if ecf[i] != ecf[i - 1]:
+                sc = _torch_conv_bn_act(sc, P[s + "shortcut/weights"], P[s + "shortcut/BatchNorm/beta"], False)
+            out = torch.relu(sc + out)
+        tensors += [mx, mn, out]
+        net = out[:, :, 0, :]
+        if residual:
+            shortcut = out
+    if flags.MODEL_NAME == "residual-dgcnn-nofc":
+        return _torch_conv_bn_act(tensors[-1], P["Final/weights"], P["Final/BatchNorm/beta"])[:, :, 0, :]
+    cat = torch.cat([tensors[3 * i + 2] for i in range(L)], -1)
+    merged = _torch_conv_bn_act(cat, P["MergedEdgeConv/weights"], P["MergedEdgeConv/BatchNorm/beta"])
+    tensors.append(merged)
+    g = merged.amax(dim=1, keepdim=True).expand(-1, N, -1, -1)
+    net = torch.cat([g] + tensors, dim=3)
+    for i in range(flags.FC_LAYERS):
+        net = _torch_conv_bn_act(net, P["FC%d/weights" % i], P["FC%d/BatchNorm/beta" % i])
+    return _torch_conv_bn_act(net, P["Final/weights"], P["Final/BatchNorm/beta"])[:, :, 0, :]
+
+
+@pytest.mark.parametrize("model_name,ecf", [("dgcnn", [8, 16]), ("residual-dgcnn", 64), ("residual-dgcnn-nofc", 64)])
+def test_oracle_backward_matches_autograd(model_name, ecf):
+    rng = np.random.default_rng(0)
+    B, N, C, k = 2, 24, 3, 5
+    flags = O.Flags(MODEL_NAME=model_name, EDGE_CONV_LAYERS=2, EDGE_CONV_FILTERS=ecf, FC_LAYERS=2,
+                    FC_FILTERS=[16, 8], KVALUE=k, NUM_CLASS=3, TRAIN=False)
+    pts = rng.random((B, N, C))
+    labels = rng.integers(0, 3, (B, N))
+    params = O.init_params(flags, C, seed=1, dtype=np.float64)
+    for n in params:                       # non-zero betas so that ReLU masks are non-trivial
+        if n.endswith("beta"):
+            params[n] = rng.normal(0, 0.3, params[n].shape)
+    logits, cache = O.model_forward(pts, flags, params)
+    idx_list = [l["ec"]["idx"] for l in cache["layers"]]
+    loss, sm, acc, dlogits = O.softmax_xent(logits, labels)
+    G = O.model_backward(dlogits, cache)
+
+    P = {n: torch.tensor(v, dtype=torch.float64, requires_grad=True) for n, v in params.items()}
+    tl = _torch_model(torch.tensor(pts), flags, P, idx_list)
+    np.testing.assert_allclose(tl.detach().numpy(), logits, rtol=1e-9, atol=1e-10)
+    tloss = torch.nn.functional.cross_entropy(tl.reshape(-1, 3), torch.tensor(labels).reshape(-1))
+    assert abs(float(tloss.detach()) - float(loss)) < 1e-10
+    tloss.backward()
+    assert set(G) == set(params)
+    for n in params:
+        np.testing.assert_allclose(G[n], P[n].grad.numpy(), rtol=1e-7, atol=1e-9, err_msg=n)
+
+
+def test_param_inventory_matches_survey_appendix_b():
+    flags = O.Flags(EDGE_CONV_FILTERS=[64, 64, 128])
+    specs = O.param_specs(flags, 3)
+    assert len(specs) == 20   # (SURVEY says "22 tensors"; the element total below is what it verified)
+    assert sum(int(np.prod(s)) for _, s in specs) == 1797186
+    assert dict(specs)["FC0/weights"] == (2752, 512)
+
+
+def test_knn_exact_c_tie_rule_and_self_inclusion():
+    # integer coordinates: every accumulation order gives the same bits -> pins the tie rule
+    rng = np.random.default_rng(3)
+    pts = rng.integers(0, 4, (2, 40, 3)).astype(np.float32)      # many duplicates and exact ties
+    idx = O.k_nn(pts, 7)
+    D = np.stack([O.dist_matrix_f32(p) for p in pts])
+    ref = np.argsort(D, axis=-1, kind="stable")[..., :7]
+    np.testing.assert_array_equal(idx, ref)
+    # exact integer arithmetic: equals the direct sum of squared differences as well
+    D2 = ((pts[:, :, None, :] - pts[:, None, :, :]) ** 2).sum(-1)
+    np.testing.assert_array_equal(D, D2)
+    # self (or an identical earlier duplicate) is always rank 0 with distance 0
+    assert (np.take_along_axis(D, idx[..., :1].astype(np.int64), -1) == 0).all()
+
+
+def test_knn_c_matches_float64_sets():
+    rng = np.random.default_rng(0)
+    pts = rng.random((2, 64, 3)).astype(np.float32)
+    idx32 = O.k_nn(pts, 5)
+    d = pts.astype(np.float64)
+    D = ((d[:, :, None, :] - d[:, None, :, :]) ** 2).sum(-1)
+    order = np.argsort(D, axis=-1, kind="stable")
+    gap = np.take_along_axis(D, order[..., 5:6], -1) - np.take_along_axis(D, order[..., 4:5], -1)
+    ok = gap[..., 0] > 1e-6
+    assert ok.mean() > 0.95
+    a = np.sort(idx32, -1)[ok]
+    b = np.sort(order[..., :5], -1)[ok]
+    np.testing.assert_array_equal(a, b)
+
+
+def test_knn_errors_and_list_length_errors():
+    with pytest.raises(ValueError):
+        O.k_nn(np.zeros((1, 4, 3), np.float32), 5)
+    with pytest.raises(ValueError):
+        O.param_specs(O.Flags(EDGE_CONV_LAYERS=3, EDGE_CONV_FILTERS=[64, 64]), 3)
+    with pytest.raises(NotImplementedError):
+        O.model_forward(np.zeros((1, 8, 3), np.float32), O.Flags(MODEL_NAME="nope", KVALUE=2), {})
+
+
+def test_edges_c_and_numpy_agree():
+    rng = np.random.default_rng(1)
+    pts = rng.random((2, 32, 4)).astype(np.float32)
+    idx = O.k_nn(pts, 6)
+    E = O.edges(pts, 6, idx)
+    E2 = np.empty_like(E)
+    O._lib().oracle_edges_f32(pts.ctypes.data, idx.ctypes.data, 2, 32, 4, 6, E2.ctypes.data)
+    np.testing.assert_array_equal(E, E2)
+    # backward of edges is the exact transpose: <E(dx), dE> == <dx, E^T(dE)> in float64
+    p64 = pts.astype(np.float64)
+    dE = rng.normal(size=E.shape)
+    v = rng.normal(size=p64.shape)
+    lhs = (O.edges(v, 6, idx) * dE).sum()
+    rhs = (v * O.edges_bwd(dE, idx, 2, 32, 4)).sum()
+    assert abs(lhs - rhs) < 1e-9 * max(1.0, abs(lhs))
