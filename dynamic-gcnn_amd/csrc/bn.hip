@@ -1,0 +1,314 @@
+// bn.hip -- K4/K5: slim.batch_norm (batch statistics, beta only, eps 1e-3: dgcnn/ops.py:53,68,
+// model.py:52,71,100) + activation + reduce_max / reduce_mean over k (ops.py:56-57), and their
+// backward.  All HBM-bound: one float4 column-quad per lane so that a
+// wave reads whole 256-B feature rows, k rows per point streamed with k independent loads.
+#include "common.h"
+
+namespace {
+
+constexpr int SLOTS = DGCNN_STAT_SLOTS;
+
+__global__ void bn_finalize_kernel(const double* __restrict__ stats, int F, double count, float eps,
+                                   float* __restrict__ mean, float* __restrict__ rstd) {
+  const int f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= F) return;
+  double s = 0.0, q = 0.0;
+  for (int sl = 0; sl < SLOTS; ++sl) {
+    s += stats[((int64_t)sl * 2 + 0) * F + f];
+    q += stats[((int64_t)sl * 2 + 1) * F + f];
+  }
+  const double mu = s / count;
+  double var = q / count - mu * mu;   // biased variance, in double: no fp32 cancellation
+  if (var < 0.0) var = 0.0;
+  mean[f] = (float)mu;
+  rstd[f] = (float)(1.0 / sqrt(var + (double)eps));
+}
+
+// reduce the slots of a backward reduction in place into slot 0, and emit dbeta
+__global__ void bn_bwd_finalize_kernel(double* __restrict__ red, int F, float* __restrict__ dbeta,
+                                       float dbeta_beta) {
+  const int f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= F) return;
+  double s = 0.0, q = 0.0;
+  for (int sl = 0; sl < SLOTS; ++sl) {
+    s += red[((int64_t)sl * 2 + 0) * F + f];
+    q += red[((int64_t)sl * 2 + 1) * F + f];
+  }
+  red[f] = s;
+  red[F + f] = q;
+  if (dbeta) dbeta[f] = (dbeta_beta != 0.f) ? (float)s + dbeta_beta * dbeta[f] : (float)s;
+}
+
+// One definition of xhat and z for every kernel (file is built with -ffp-contract=off), so the
+// max recomputed in the backward compares equal to the values it was taken over.
+__device__ __forceinline__ float bn_z(float y, float mu, float rs, float be, int relu, float& xh) {
+  xh = (y - mu) * rs;
+  float z = xh + be;
+  if (relu) z = fmaxf(z, 0.f);
+  return z;
+}
+
+template <int V> struct Vec;
+template <> struct Vec<4> {
+  using T = float4;
+  static __device__ __forceinline__ void ld(const float* p, float (&o)[4]) {
+    const float4 v = *reinterpret_cast<const float4*>(p); o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w; }
+  static __device__ __forceinline__ void st(float* p, const float (&o)[4]) {
+    *reinterpret_cast<float4*>(p) = make_float4(o[0], o[1], o[2], o[3]); }
+};
+template <> struct Vec<1> {
+  static __device__ __forceinline__ void ld(const float* p, float (&o)[1]) { o[0] = *p; }
+  static __device__ __forceinline__ void st(float* p, const float (&o)[1]) { *p = o[0]; }
+};
+
+// ---- forward: z = (y-mu)*rstd + beta; relu; max / mean over the k rows of each point ----
+template <int V>
+__global__ __launch_bounds__(256) void bn_act_kreduce_kernel(
+    const float* __restrict__ Y, int64_t R, int k, int F, const float* __restrict__ mean,
+    const float* __restrict__ rstd, const float* __restrict__ beta, int relu,
+    float* __restrict__ max_out, int64_t ldmax, float* __restrict__ mean_out, int64_t ldmean,
+    float* __restrict__ out2, int64_t ldout2) {
+  const int FV = F / V;
+  const int64_t items = R * FV;
+  const float invk = 1.0f / (float)k;
+  for (int64_t it = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; it < items;
+       it += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = it / FV;
+    const int f = (int)(it % FV) * V;
+    float mu[V], rs[V], be[V], mx[V], sm[V];
+    Vec<V>::ld(mean + f, mu); Vec<V>::ld(rstd + f, rs); Vec<V>::ld(beta + f, be);
+#pragma unroll
+    for (int v = 0; v < V; ++v) { mx[v] = -INFINITY; sm[v] = 0.f; }
+    const float* y = Y + (r * k) * F + f;
+    for (int m = 0; m < k; ++m) {
+      float yv[V];
+      Vec<V>::ld(y + (int64_t)m * F, yv);
+#pragma unroll
+      for (int v = 0; v < V; ++v) {
+        float xh;
+        const float z = bn_z(yv[v], mu[v], rs[v], be[v], relu, xh);
+        mx[v] = fmaxf(mx[v], z);
+        sm[v] += z;
+      }
+    }
+    Vec<V>::st(max_out + r * ldmax + f, mx);
+    if (out2) Vec<V>::st(out2 + r * ldout2 + f, mx);
+    if (mean_out) {
+#pragma unroll
+      for (int v = 0; v < V; ++v) sm[v] *= invk;
+      Vec<V>::st(mean_out + r * ldmean + f, sm);
+    }
+  }
+}
+
+// dZ for the k rows of one (point, channel-quad); shared by reduce and apply
+template <int V>
+struct KState { float mx[V]; float cnt[V]; };
+
+template <int V>
+__device__ __forceinline__ void k_pass_max(const float* y, int k, int F, const float (&mu)[V],
+                                           const float (&rs)[V], const float (&be)[V], int relu,
+                                           KState<V>& st) {
+#pragma unroll
+  for (int v = 0; v < V; ++v) { st.mx[v] = -INFINITY; st.cnt[v] = 0.f; }
+  for (int m = 0; m < k; ++m) {
+    float yv[V];
+    Vec<V>::ld(y + (int64_t)m * F, yv);
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+      float xh;
+      const float z = bn_z(yv[v], mu[v], rs[v], be[v], relu, xh);
+      if (z > st.mx[v]) { st.mx[v] = z; st.cnt[v] = 1.f; }
+      else if (z == st.mx[v]) st.cnt[v] += 1.f;
+    }
+  }
+}
+
+template <int V>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
+    const float* __restrict__ Y, int64_t R, int k, int F, const float* __restrict__ mean,
+    const float* __restrict__ rstd, const float* __restrict__ beta, int relu,
+    const float* __restrict__ dmax, int64_t lddmax, const float* __restrict__ dmean, int64_t lddmean,
+    double* __restrict__ red) {
+  extern __shared__ float lred[];  // [2][F]
+  for (int e = threadIdx.x; e < 2 * F; e += blockDim.x) lred[e] = 0.f;
+  __syncthreads();
+  const int FV = F / V;
+  const int64_t items = R * FV;
+  const float invk = 1.0f / (float)k;
+  int curf = -1;
+  float s0[V], s1[V];
+#pragma unroll
+  for (int v = 0; v < V; ++v) { s0[v] = 0.f; s1[v] = 0.f; }
+  for (int64_t it = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; it < items;
+       it += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = it / FV;
+    const int f = (int)(it % FV) * V;
+    if (f != curf) {
+      if (curf >= 0) {
+#pragma unroll
+        for (int v = 0; v < V; ++v) { atomicAdd(&lred[curf + v], s0[v]); atomicAdd(&lred[F + curf + v], s1[v]); s0[v] = 0.f; s1[v] = 0.f; }
+      }
+      curf = f;
+    }
+    float mu[V], rs[V], be[V], dmx[V], dmn[V];
+    Vec<V>::ld(mean + f, mu); Vec<V>::ld(rstd + f, rs); Vec<V>::ld(beta + f, be);
+    Vec<V>::ld(dmax + r * lddmax + f, dmx);
+    const float* y = Y + (r * k) * F + f;
+    KState<V> st;
+    if (dmean) {
+      Vec<V>::ld(dmean + r * lddmean + f, dmn);
+      k_pass_max<V>(y, k, F, mu, rs, be, relu, st);
+    }
+    for (int m = 0; m < k; ++m) {
+      float yv[V];
+      Vec<V>::ld(y + (int64_t)m * F, yv);
+#pragma unroll
+      for (int v = 0; v < V; ++v) {
+        float xh;
+        const float z = bn_z(yv[v], mu[v], rs[v], be[v], relu, xh);
+        float dz;
+        if (dmean) dz = ((z == st.mx[v]) ? dmx[v] / st.cnt[v] : 0.f) + dmn[v] * invk;
+        else dz = dmx[v];
+        if (relu && !(z > 0.f)) dz = 0.f;
+        s0[v] += dz;
+        s1[v] += dz * xh;
+      }
+    }
+  }
+  if (curf >= 0) {
+#pragma unroll
+    for (int v = 0; v < V; ++v) { atomicAdd(&lred[curf + v], s0[v]); atomicAdd(&lred[F + curf + v], s1[v]); }
+  }
+  __syncthreads();
+  const int slot = blockIdx.x % SLOTS;
+  for (int e = threadIdx.x; e < 2 * F; e += blockDim.x)
+    atomicAdd(red + (int64_t)slot * 2 * F + e, (double)lred[e]);
+}
+
+template <int V>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
+    const float* Y, int64_t R, int k, int F, const float* __restrict__ mean,
+    const float* __restrict__ rstd, const float* __restrict__ beta, int relu,
+    const float* __restrict__ dmax, int64_t lddmax, const float* __restrict__ dmean, int64_t lddmean,
+    const double* __restrict__ red, float* dY, float* __restrict__ dYsum) {
+  const int FV = F / V;
+  const int64_t items = R * FV;
+  const float invk = 1.0f / (float)k;
+  const double inv_cnt = 1.0 / ((double)R * (double)k);
+  for (int64_t it = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; it < items;
+       it += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = it / FV;
+    const int f = (int)(it % FV) * V;
+    float mu[V], rs[V], be[V], dmx[V], dmn[V], c1[V], c2[V], acc[V];
+    Vec<V>::ld(mean + f, mu); Vec<V>::ld(rstd + f, rs); Vec<V>::ld(beta + f, be);
+    Vec<V>::ld(dmax + r * lddmax + f, dmx);
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+      c1[v] = (float)(red[f + v] * inv_cnt);
+      c2[v] = (float)(red[F + f + v] * inv_cnt);
+      acc[v] = 0.f;
+    }
+    const float* y = Y + (r * k) * F + f;
+    float* dy = dY + (r * k) * F + f;
+    KState<V> st;
+    if (dmean) {
+      Vec<V>::ld(dmean + r * lddmean + f, dmn);
+      k_pass_max<V>(y, k, F, mu, rs, be, relu, st);
+    }
+    for (int m = 0; m < k; ++m) {
+      float yv[V], o[V];
+      Vec<V>::ld(y + (int64_t)m * F, yv);
+#pragma unroll
+      for (int v = 0; v < V; ++v) {
+        float xh;
+        const float z = bn_z(yv[v], mu[v], rs[v], be[v], relu, xh);
+        float dz;
+        if (dmean) dz = ((z == st.mx[v]) ? dmx[v] / st.cnt[v] : 0.f) + dmn[v] * invk;
+        else dz = dmx[v];
+        if (relu && !(z > 0.f)) dz = 0.f;
+        o[v] = rs[v] * (dz - c1[v] - xh * c2[v]);
+        acc[v] += o[v];
+      }
+      Vec<V>::st(dy + (int64_t)m * F, o);
+    }
+    if (dYsum) Vec<V>::st(dYsum + r * F + f, acc);
+  }
+}
+
+inline unsigned grid_for(int64_t items) {
+  int64_t g = dg::cdiv(items, 256);
+  if (g > 256 * 16) g = 256 * 16;
+  if (g < 1) g = 1;
+  return (unsigned)g;
+}
+
+inline bool a16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+}  // namespace
+
+extern "C" int dgcnn_bn_finalize_f32(const double* stats, int F, double count, float eps,
+                                     float* mean, float* rstd, void* stream) {
+  DG_REQUIRE(stats && mean && rstd && F > 0 && count > 0, DGCNN_EINVAL, "dgcnn_bn_finalize_f32: bad args");
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)dg::cdiv(F, 128)), dim3(128), 0, (hipStream_t)stream,
+                     stats, F, count, eps, mean, rstd);
+  return dg::check_launch("dgcnn_bn_finalize_f32");
+}
+
+extern "C" int dgcnn_bn_act_kreduce_f32(const float* Y, int64_t R, int k, int F,
+                                        const float* mean, const float* rstd, const float* beta, int relu,
+                                        float* max_out, int64_t ldmax, float* mean_out, int64_t ldmean,
+                                        float* out2, int64_t ldout2, void* stream) {
+  DG_REQUIRE(Y && mean && rstd && beta && max_out, DGCNN_EINVAL, "dgcnn_bn_act_kreduce_f32: null pointer");
+  DG_REQUIRE(R > 0 && k > 0 && F > 0, DGCNN_EINVAL, "dgcnn_bn_act_kreduce_f32: bad shape");
+  const bool vec = (F % 4 == 0) && (ldmax % 4 == 0) && a16(Y) && a16(max_out) && a16(mean) && a16(rstd) && a16(beta) &&
+                   (!mean_out || ((ldmean % 4 == 0) && a16(mean_out))) && (!out2 || ((ldout2 % 4 == 0) && a16(out2)));
+  hipStream_t st = (hipStream_t)stream;
+  if (vec)
+    hipLaunchKernelGGL((bn_act_kreduce_kernel<4>), dim3(grid_for(R * (F / 4))), dim3(256), 0, st, Y, R, k, F, mean,
+                       rstd, beta, relu, max_out, ldmax, mean_out, ldmean, out2, ldout2);
+  else
+    hipLaunchKernelGGL((bn_act_kreduce_kernel<1>), dim3(grid_for(R * F)), dim3(256), 0, st, Y, R, k, F, mean, rstd,
+                       beta, relu, max_out, ldmax, mean_out, ldmean, out2, ldout2);
+  return dg::check_launch("dgcnn_bn_act_kreduce_f32");
+}
+
+extern "C" int dgcnn_bn_bwd_reduce_f32(const float* Y, int64_t R, int k, int F,
+                                       const float* mean, const float* rstd, const float* beta, int relu,
+                                       const float* dmax, int64_t lddmax, const float* dmean, int64_t lddmean,
+                                       double* red, void* stream) {
+  DG_REQUIRE(Y && mean && rstd && beta && dmax && red, DGCNN_EINVAL, "dgcnn_bn_bwd_reduce_f32: null pointer");
+  DG_REQUIRE(R > 0 && k > 0 && F > 0 && F <= 8192, DGCNN_EINVAL, "dgcnn_bn_bwd_reduce_f32: bad shape");
+  const bool vec = (F % 4 == 0) && (lddmax % 4 == 0) && a16(Y) && a16(dmax) && a16(mean) && a16(rstd) && a16(beta) &&
+                   (!dmean || ((lddmean % 4 == 0) && a16(dmean)));
+  hipStream_t st = (hipStream_t)stream;
+  const size_t sh = (size_t)2 * F * sizeof(float);
+  if (vec)
+    hipLaunchKernelGGL((bn_bwd_reduce_kernel<4>), dim3(grid_for(R * (F / 4))), dim3(256), sh, st, Y, R, k, F, mean,
+                       rstd, beta, relu, dmax, lddmax, dmean, lddmean, red);
+  else
+    hipLaunchKernelGGL((bn_bwd_reduce_kernel<1>), dim3(grid_for(R * F)), dim3(256), sh, st, Y, R, k, F, mean, rstd,
+                       beta, relu, dmax, lddmax, dmean, lddmean, red);
+  return dg::check_launch("dgcnn_bn_bwd_reduce_f32");
+}
+
+extern "C" int dgcnn_bn_bwd_apply_f32(const float* Y, int64_t R, int k, int F,
+                                      const float* mean, const float* rstd, const float* beta, int relu,
+                                      const float* dmax, int64_t lddmax, const float* dmean, int64_t lddmean,
+                                      double* red, float* dY, float* dYsum, float* dbeta, float dbeta_beta,
+                                      void* stream) {
+  DG_REQUIRE(Y && mean && rstd && beta && dmax && red && dY, DGCNN_EINVAL, "dgcnn_bn_bwd_apply_f32: null pointer");
+  DG_REQUIRE(R > 0 && k > 0 && F > 0, DGCNN_EINVAL, "dgcnn_bn_bwd_apply_f32: bad shape");
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)dg::cdiv(F, 128)), dim3(128), 0, st, red, F, dbeta,
+                     dbeta_beta);
+  const bool vec = (F % 4 == 0) && (lddmax % 4 == 0) && a16(Y) && a16(dY) && a16(dmax) && a16(mean) && a16(rstd) &&
+                   a16(beta) && (!dmean || ((lddmean % 4 == 0) && a16(dmean))) && (!dYsum || a16(dYsum));
+  if (vec)
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<4>), dim3(grid_for(R * (F / 4))), dim3(256), 0, st, Y, R, k, F, mean, rstd,
+                       beta, relu, dmax, lddmax, dmean, lddmean, red, dY, dYsum);
+  else
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<1>), dim3(grid_for(R * F)), dim3(256), 0, st, Y, R, k, F, mean, rstd, beta,
+                       relu, dmax, lddmax, dmean, lddmean, red, dY, dYsum);
+  return dg::check_launch("dgcnn_bn_bwd_apply_f32");
+}

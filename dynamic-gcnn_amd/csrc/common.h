@@ -1,0 +1,32 @@
+// common.h -- shared helpers of libdgcnn_hip.so (gfx950 only; no CUDA compatibility paths).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include "../../include/dgcnn_hip.h"
+
+namespace dg {
+
+void set_error(const char* fmt, ...);
+
+inline int check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    set_error("%s: %s", what, hipGetErrorString(e));
+    return DGCNN_ELAUNCH;
+  }
+  return DGCNN_OK;
+}
+
+#define DG_REQUIRE(cond, code, ...)          \
+  do {                                       \
+    if (!(cond)) {                           \
+      dg::set_error(__VA_ARGS__);            \
+      return (code);                         \
+    }                                        \
+  } while (0)
+
+static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+}  // namespace dg

@@ -1,0 +1,533 @@
+// gemm.hip -- K3: fp32 MFMA (v_mfma_f32_32x32x2_f32) GEMM family for gfx950.
+//
+// One kernel template covers every 1x1 convolution of the path and its gradients
+// (dgcnn/ops.py:47-52,62-70,125-133,153-160; dgcnn/model.py:46-53,65-72,94-101):
+//   A source  A_ROW    A[m][k] row-major                      (forward, dgrad)
+//             A_COL    A stored [k][m]                         (wgrad: X^T dY, split over k)
+//             A_EDGE   rows are edges; E = [x_i, x_j - x_i] is gathered from (x, idx) straight
+//                      into the LDS A tile -- the (B,N,k,2C) edge tensor of ops.py:21-40 is
+//                      never written to HBM                    (conv0 forward)
+//             A_EDGE_T E^T, reduction over edges               (conv0 wgrad)
+//   B source  B_ROW    B[k][n] row-major;  B_COL  B stored [n][k]  (dgrad: dY W^T)
+//   epilogue  E_STORE  C = acc (+ beta C) (+ per-cloud bias) (+ BN column statistics) or
+//                      split-K partial;  E_SCATTER  dx[neighbour(row)][n] += acc (fp32 atomics)
+//
+// Tiling (wave64, 256 threads = 2x2 waves): block tile 128 x BN x 16, BN in {64,128}; each wave
+// owns (64 x BN/2) as TM x TN tiles of 32x32 MFMA accumulators (16 VGPR each).  Both LDS tiles
+// are k-major ([k][m] / [k][n]) so an MFMA operand read is one conflict-free ds_read_b32 of 32
+// consecutive floats per half-wave; row-major sources are transposed on the LDS write with a +2
+// row pad (4*(W+2) mod 32 = 8 -> the four k-quads of a half-wave hit disjoint bank octets).
+// Global->register prefetch of tile t+1 overlaps the MFMAs of tile t; LDS is double buffered
+// (one barrier per k-step).  fp32 MFMA == an fmaf chain in k order, so results are plain fp32.
+#include "common.h"
+
+namespace {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+enum { A_ROW = 0, A_COL = 1, A_EDGE = 2, A_EDGE_T = 3 };
+enum { B_ROW = 0, B_COL = 1 };
+enum { E_STORE = 0, E_SCATTER = 1 };
+
+constexpr int BM = 128;
+constexpr int BK = 16;
+constexpr int NT = 256;
+
+struct GemmP {
+  const float* A; int64_t lda;
+  const float* B; int64_t ldb;
+  float* C; int64_t ldc;
+  int M, N, K;
+  float beta;
+  const float* gbias; int64_t ldgbias; int rpg;
+  double* stats;
+  // edge sources / scatter
+  const float* x; int64_t ldx; const int32_t* idx; int npts; int cch; int knn;
+  float* dx; int64_t lddx;
+  // split-K
+  int splits; int kchunk; float* partial;
+  int avec, bvec;
+  int mtiles, ntiles;
+};
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+
+template <int ASRC, int BSRC, int EPI, int BN>
+__global__ __launch_bounds__(NT) void gemm_kernel(GemmP p) {
+  constexpr bool A_TRANS = (ASRC == A_ROW || ASRC == A_EDGE);  // needs transposing LDS store
+  constexpr bool B_TRANS = (BSRC == B_COL);
+  constexpr int SA = BM + (A_TRANS ? 2 : 4);
+  constexpr int SB = BN + (B_TRANS ? 2 : 4);
+  constexpr int NVA = BM / 64;
+  constexpr int NVB = BN / 64;
+  constexpr int TM = 2;
+  constexpr int TN = BN / 64;
+
+  __shared__ __attribute__((aligned(16))) float smem[2 * BK * SA + 2 * BK * SB];
+  float* As = smem;
+  float* Bs = smem + 2 * BK * SA;
+
+  const int t = threadIdx.x;
+  const int lane = t & 63;
+  const int wv = t >> 6;
+  const int wr = wv >> 1, wc = wv & 1;
+  const int l31 = lane & 31, lh = lane >> 5;
+
+  // XCD-aware tile order: the ntiles column blocks that share one A row-panel get the same
+  // (id % 8), i.e. the same XCD / L2 (MI355X dispatches block b to XCD b % 8).
+  const int id = blockIdx.x;
+  const int mt = ((id >> 3) / p.ntiles) * 8 + (id & 7);
+  const int nt = (id >> 3) % p.ntiles;
+  if (mt >= p.mtiles) return;
+  const int m0 = mt * BM;
+  const int n0 = nt * BN;
+  const int z = blockIdx.z;
+  const int kbeg = z * p.kchunk;
+  const int kend = (kbeg + p.kchunk < p.K) ? (kbeg + p.kchunk) : p.K;
+
+  // ---- per-thread source descriptors ----
+  // transposing items: row = (t>>2) + 64*i, kq = t&3 ; direct items: kk = t/(W/4) + i*(1024/W), c4 = (t%(W/4))*4
+  const float* a_ptr[NVA];
+  const float* a_ptr2[NVA];   // EDGE: neighbour row
+  bool a_ok[NVA];
+#pragma unroll
+  for (int i = 0; i < NVA; ++i) {
+    a_ptr[i] = nullptr; a_ptr2[i] = nullptr; a_ok[i] = false;
+    if (ASRC == A_ROW) {
+      const int row = m0 + (t >> 2) + 64 * i;
+      a_ok[i] = row < p.M;
+      a_ptr[i] = p.A + (int64_t)(a_ok[i] ? row : 0) * p.lda;
+    } else if (ASRC == A_EDGE) {
+      const int row = m0 + (t >> 2) + 64 * i;
+      a_ok[i] = row < p.M;
+      const int er = a_ok[i] ? row : 0;
+      const int g = er / p.knn;
+      const int nb = (g / p.npts) * p.npts + p.idx[er];
+      a_ptr[i] = p.x + (int64_t)g * p.ldx;
+      a_ptr2[i] = p.x + (int64_t)nb * p.ldx;
+    }
+  }
+
+  auto fetch_a = [&](int i, int k0) -> float4 {
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (ASRC == A_ROW) {
+      const int kc = k0 + 4 * (t & 3);
+      if (a_ok[i]) {
+        if (p.avec && kc + 3 < kend) v = ld4(a_ptr[i] + kc);
+        else {
+          if (kc + 0 < kend) v.x = a_ptr[i][kc + 0];
+          if (kc + 1 < kend) v.y = a_ptr[i][kc + 1];
+          if (kc + 2 < kend) v.z = a_ptr[i][kc + 2];
+          if (kc + 3 < kend) v.w = a_ptr[i][kc + 3];
+        }
+      }
+    } else if (ASRC == A_EDGE) {
+      const int kc = k0 + 4 * (t & 3);
+      const int C = p.cch;
+      if (a_ok[i]) {
+        if (p.avec && kc + 3 < kend) {   // C % 4 == 0: a quad never straddles the centre/diff split
+          if (kc < C) v = ld4(a_ptr[i] + kc);
+          else {
+            const float4 xn = ld4(a_ptr2[i] + (kc - C));
+            const float4 xc = ld4(a_ptr[i] + (kc - C));
+            v = make_float4(xn.x - xc.x, xn.y - xc.y, xn.z - xc.z, xn.w - xc.w);
+          }
+        } else {
+          float e[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int c = kc + q;
+            e[q] = 0.f;
+            if (c < kend) e[q] = (c < C) ? a_ptr[i][c] : (a_ptr2[i][c - C] - a_ptr[i][c - C]);
+          }
+          v = make_float4(e[0], e[1], e[2], e[3]);
+        }
+      }
+    } else if (ASRC == A_COL) {
+      const int kk = k0 + t / (BM / 4) + i * (1024 / BM);
+      const int m = m0 + (t % (BM / 4)) * 4;
+      if (kk < kend) {
+        const float* s = p.A + (int64_t)kk * p.lda + m;
+        if (p.avec && m + 3 < p.M) v = ld4(s);
+        else {
+          if (m + 0 < p.M) v.x = s[0];
+          if (m + 1 < p.M) v.y = s[1];
+          if (m + 2 < p.M) v.z = s[2];
+          if (m + 3 < p.M) v.w = s[3];
+        }
+      }
+    } else {  // A_EDGE_T: element (m = channel of E, kk = edge row)
+      const int er = k0 + t / (BM / 4) + i * (1024 / BM);
+      const int m = m0 + (t % (BM / 4)) * 4;
+      const int C = p.cch;
+      if (er < kend) {
+        const int g = er / p.knn;
+        const int nb = (g / p.npts) * p.npts + p.idx[er];
+        const float* pc = p.x + (int64_t)g * p.ldx;
+        const float* pn = p.x + (int64_t)nb * p.ldx;
+        if (p.avec && m + 3 < p.M) {
+          if (m < C) v = ld4(pc + m);
+          else {
+            const float4 xn = ld4(pn + (m - C));
+            const float4 xc = ld4(pc + (m - C));
+            v = make_float4(xn.x - xc.x, xn.y - xc.y, xn.z - xc.z, xn.w - xc.w);
+          }
+        } else {
+          float e[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int c = m + q;
+            e[q] = 0.f;
+            if (c < p.M) e[q] = (c < C) ? pc[c] : (pn[c - C] - pc[c - C]);
+          }
+          v = make_float4(e[0], e[1], e[2], e[3]);
+        }
+      }
+    }
+    return v;
+  };
+
+  auto fetch_b = [&](int i, int k0) -> float4 {
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (BSRC == B_ROW) {
+      const int kk = k0 + t / (BN / 4) + i * (1024 / BN);
+      const int n = n0 + (t % (BN / 4)) * 4;
+      if (kk < kend) {
+        const float* s = p.B + (int64_t)kk * p.ldb + n;
+        if (p.bvec && n + 3 < p.N) v = ld4(s);
+        else {
+          if (n + 0 < p.N) v.x = s[0];
+          if (n + 1 < p.N) v.y = s[1];
+          if (n + 2 < p.N) v.z = s[2];
+          if (n + 3 < p.N) v.w = s[3];
+        }
+      }
+    } else {
+      const int n = n0 + (t >> 2) + 64 * i;
+      const int kc = k0 + 4 * (t & 3);
+      if (n < p.N) {
+        const float* s = p.B + (int64_t)n * p.ldb + kc;
+        if (p.bvec && kc + 3 < kend) v = ld4(s);
+        else {
+          if (kc + 0 < kend) v.x = s[0];
+          if (kc + 1 < kend) v.y = s[1];
+          if (kc + 2 < kend) v.z = s[2];
+          if (kc + 3 < kend) v.w = s[3];
+        }
+      }
+    }
+    return v;
+  };
+
+  auto store_a = [&](int buf, int i, float4 v) {
+    float* d = As + buf * BK * SA;
+    if (A_TRANS) {
+      const int row = (t >> 2) + 64 * i, kq = t & 3;
+      d[(4 * kq + 0) * SA + row] = v.x;
+      d[(4 * kq + 1) * SA + row] = v.y;
+      d[(4 * kq + 2) * SA + row] = v.z;
+      d[(4 * kq + 3) * SA + row] = v.w;
+    } else {
+      const int kk = t / (BM / 4) + i * (1024 / BM), c4 = (t % (BM / 4)) * 4;
+      *reinterpret_cast<float4*>(&d[kk * SA + c4]) = v;
+    }
+  };
+  auto store_b = [&](int buf, int i, float4 v) {
+    float* d = Bs + buf * BK * SB;
+    if (B_TRANS) {
+      const int row = (t >> 2) + 64 * i, kq = t & 3;
+      d[(4 * kq + 0) * SB + row] = v.x;
+      d[(4 * kq + 1) * SB + row] = v.y;
+      d[(4 * kq + 2) * SB + row] = v.z;
+      d[(4 * kq + 3) * SB + row] = v.w;
+    } else {
+      const int kk = t / (BN / 4) + i * (1024 / BN), c4 = (t % (BN / 4)) * 4;
+      *reinterpret_cast<float4*>(&d[kk * SB + c4]) = v;
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  float4 ra[NVA], rb[NVB];
+  const int nk = (kend - kbeg + BK - 1) / BK;
+  if (nk > 0) {
+#pragma unroll
+    for (int i = 0; i < NVA; ++i) ra[i] = fetch_a(i, kbeg);
+#pragma unroll
+    for (int i = 0; i < NVB; ++i) rb[i] = fetch_b(i, kbeg);
+#pragma unroll
+    for (int i = 0; i < NVA; ++i) store_a(0, i, ra[i]);
+#pragma unroll
+    for (int i = 0; i < NVB; ++i) store_b(0, i, rb[i]);
+  }
+  __syncthreads();
+
+  const int a_off = wr * 64 + l31;
+  const int b_off = wc * (BN / 2) + l31;
+#pragma unroll 1
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    const bool more = (kt + 1 < nk);
+    if (more) {
+#pragma unroll
+      for (int i = 0; i < NVA; ++i) ra[i] = fetch_a(i, kbeg + (kt + 1) * BK);
+#pragma unroll
+      for (int i = 0; i < NVB; ++i) rb[i] = fetch_b(i, kbeg + (kt + 1) * BK);
+    }
+    const float* as = As + buf * BK * SA + lh * SA + a_off;
+    const float* bs = Bs + buf * BK * SB + lh * SB + b_off;
+#pragma unroll
+    for (int s = 0; s < BK / 2; ++s) {
+      float a[TM], b[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) a[i] = as[2 * s * SA + i * 32];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) b[j] = bs[2 * s * SB + j * 32];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    if (more) {
+#pragma unroll
+      for (int i = 0; i < NVA; ++i) store_a(buf ^ 1, i, ra[i]);
+#pragma unroll
+      for (int i = 0; i < NVB; ++i) store_b(buf ^ 1, i, rb[i]);
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue.  C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  const int colw = n0 + wc * (BN / 2) + l31;
+  const int roww = m0 + wr * 64 + 4 * lh;
+  if (EPI == E_SCATTER) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = roww + i * 32 + (r & 3) + 8 * (r >> 2);
+        if (row < p.M) {
+          const int nb = (row / (p.knn * p.npts)) * p.npts + p.idx[row];
+          float* d = p.dx + (int64_t)nb * p.lddx;
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            const int col = colw + j * 32;
+            if (col < p.N) atomicAdd(d + col, acc[i][j][r]);
+          }
+        }
+      }
+    return;
+  }
+
+  if (p.splits > 1) {
+    float* out = p.partial + (int64_t)z * p.M * p.N;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = roww + i * 32 + (r & 3) + 8 * (r >> 2);
+        if (row < p.M) {
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            const int col = colw + j * 32;
+            if (col < p.N) out[(int64_t)row * p.N + col] = acc[i][j][r];
+          }
+        }
+      }
+    return;
+  }
+
+  float cs[TN], cq[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) { cs[j] = 0.f; cq[j] = 0.f; }
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = roww + i * 32 + (r & 3) + 8 * (r >> 2);
+      if (row < p.M) {
+        const float* gb = p.gbias ? (p.gbias + (int64_t)(row / p.rpg) * p.ldgbias) : nullptr;
+        float* crow = p.C + (int64_t)row * p.ldc;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const int col = colw + j * 32;
+          if (col < p.N) {
+            float v = acc[i][j][r];
+            if (gb) v += gb[col];
+            if (p.beta != 0.f) v += p.beta * crow[col];
+            crow[col] = v;
+            cs[j] += v;
+            cq[j] += v * v;
+          }
+        }
+      }
+    }
+  if (p.stats) {
+    // column sums: lanes l and l^32 share a column; the two wr-waves share it too (LDS add)
+    __syncthreads();
+    float* red = smem;  // [2][BN]
+    for (int e = t; e < 2 * BN; e += NT) red[e] = 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      float s = cs[j] + __shfl_xor(cs[j], 32);
+      float q = cq[j] + __shfl_xor(cq[j], 32);
+      if (lh == 0) {
+        const int c = wc * (BN / 2) + j * 32 + l31;
+        atomicAdd(&red[c], s);
+        atomicAdd(&red[BN + c], q);
+      }
+    }
+    __syncthreads();
+    const int slot = mt % DGCNN_STAT_SLOTS;
+    for (int e = t; e < 2 * BN; e += NT) {
+      const int which = e / BN, c = n0 + (e % BN);
+      if (c < p.N) atomicAdd(p.stats + ((int64_t)slot * 2 + which) * p.N + c, (double)red[e]);
+    }
+  }
+}
+
+__global__ void reduce_partials_kernel(const float* __restrict__ part, int splits, int M, int N,
+                                       float* __restrict__ C, int64_t ldc, float beta) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= (int64_t)M * N) return;
+  const int row = (int)(e / N), col = (int)(e % N);
+  float s = 0.f;
+  for (int z = 0; z < splits; ++z) s += part[(int64_t)z * M * N + e];
+  float* c = C + (int64_t)row * ldc + col;
+  *c = (beta != 0.f) ? (s + beta * *c) : s;
+}
+
+template <int ASRC, int BSRC, int EPI>
+int launch(GemmP& p, hipStream_t st, const char* what) {
+  const int bn = (p.N <= 64) ? 64 : 128;
+  p.mtiles = (int)dg::cdiv(p.M, BM);
+  p.ntiles = (int)dg::cdiv(p.N, bn);
+  const unsigned gx = (unsigned)(dg::cdiv(p.mtiles, 8) * 8 * p.ntiles);
+  dim3 grid(gx, 1, (unsigned)p.splits);
+  if (bn == 64) hipLaunchKernelGGL((gemm_kernel<ASRC, BSRC, EPI, 64>), grid, dim3(NT), 0, st, p);
+  else hipLaunchKernelGGL((gemm_kernel<ASRC, BSRC, EPI, 128>), grid, dim3(NT), 0, st, p);
+  int rc = dg::check_launch(what);
+  if (rc) return rc;
+  if (p.splits > 1) {
+    const int64_t n = (int64_t)p.M * p.N;
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)dg::cdiv(n, 256)), dim3(256), 0, st,
+                       p.partial, p.splits, p.M, p.N, p.C, p.ldc, p.beta);
+    rc = dg::check_launch(what);
+  }
+  return rc;
+}
+
+inline bool aligned16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
+
+// choose a split of the reduction dimension so that ~1024 workgroups are in flight
+int plan_splits(GemmP& p, void* ws, size_t ws_bytes, const char* what) {
+  const int bn = (p.N <= 64) ? 64 : 128;
+  const int64_t tiles = dg::cdiv(p.M, BM) * dg::cdiv(p.N, bn);
+  int64_t s = dg::cdiv(1024, tiles);
+  const int64_t maxs = p.K / 256 > 0 ? p.K / 256 : 1;
+  if (s > maxs) s = maxs;
+  if (s < 1) s = 1;
+  int64_t chunk = dg::cdiv(dg::cdiv(p.K, s), BK) * BK;
+  s = dg::cdiv(p.K, chunk);
+  p.splits = (int)s;
+  p.kchunk = (int)chunk;
+  p.partial = nullptr;
+  if (s > 1) {
+    const size_t need = (size_t)s * p.M * p.N * sizeof(float);
+    if (!ws || ws_bytes < need) {
+      dg::set_error("%s: workspace too small (%zu < %zu bytes)", what, ws_bytes, need);
+      return DGCNN_ENOSPC;
+    }
+    p.partial = reinterpret_cast<float*>(ws);
+  }
+  return DGCNN_OK;
+}
+
+}  // namespace
+
+extern "C" int dgcnn_gemm_f32(int transA, int transB, int M, int N, int K,
+                              const float* A, int64_t lda, const float* B, int64_t ldb,
+                              float* C, int64_t ldc, float beta,
+                              const float* gbias, int64_t ldgbias, int rows_per_group,
+                              double* stats, void* ws, size_t ws_bytes, void* stream) {
+  DG_REQUIRE(A && B && C, DGCNN_EINVAL, "dgcnn_gemm_f32: null pointer");
+  DG_REQUIRE(M > 0 && N > 0 && K > 0, DGCNN_EINVAL, "dgcnn_gemm_f32: bad shape %d %d %d", M, N, K);
+  DG_REQUIRE(!(transA && transB), DGCNN_EUNSUP, "dgcnn_gemm_f32: transA && transB unsupported");
+  DG_REQUIRE(!gbias || rows_per_group > 0, DGCNN_EINVAL, "dgcnn_gemm_f32: rows_per_group");
+  GemmP p = {};
+  p.A = A; p.lda = lda; p.B = B; p.ldb = ldb; p.C = C; p.ldc = ldc;
+  p.M = M; p.N = N; p.K = K; p.beta = beta;
+  p.gbias = gbias; p.ldgbias = ldgbias; p.rpg = rows_per_group > 0 ? rows_per_group : 1;
+  p.stats = stats;
+  p.splits = 1; p.kchunk = K;
+  p.avec = (lda % 4 == 0) && aligned16(A);
+  p.bvec = (ldb % 4 == 0) && aligned16(B);
+  hipStream_t st = (hipStream_t)stream;
+  if (transA) {
+    DG_REQUIRE(!gbias && !stats, DGCNN_EUNSUP, "dgcnn_gemm_f32: bias/stats with transA unsupported");
+    int rc = plan_splits(p, ws, ws_bytes, "dgcnn_gemm_f32");
+    if (rc) return rc;
+    return launch<A_COL, B_ROW, E_STORE>(p, st, "dgcnn_gemm_f32(TN)");
+  }
+  if (transB) return launch<A_ROW, B_COL, E_STORE>(p, st, "dgcnn_gemm_f32(NT)");
+  return launch<A_ROW, B_ROW, E_STORE>(p, st, "dgcnn_gemm_f32(NN)");
+}
+
+extern "C" int dgcnn_edge_mlp_f32(const float* x, int64_t ldx, const int32_t* idx, const float* W0,
+                                  int B, int N, int C, int k, int F, float* Y, double* stats,
+                                  void* stream) {
+  DG_REQUIRE(x && idx && W0 && Y, DGCNN_EINVAL, "dgcnn_edge_mlp_f32: null pointer");
+  DG_REQUIRE(B > 0 && N > 0 && C > 0 && k > 0 && F > 0, DGCNN_EINVAL, "dgcnn_edge_mlp_f32: bad shape");
+  const int64_t Me = (int64_t)B * N * k;
+  DG_REQUIRE(Me < (1ll << 31), DGCNN_EUNSUP, "dgcnn_edge_mlp_f32: B*N*k >= 2^31");
+  GemmP p = {};
+  p.x = x; p.ldx = ldx; p.idx = idx; p.npts = N; p.cch = C; p.knn = k;
+  p.B = W0; p.ldb = F; p.C = Y; p.ldc = F;
+  p.M = (int)Me; p.N = F; p.K = 2 * C; p.beta = 0.f; p.rpg = 1;
+  p.stats = stats; p.splits = 1; p.kchunk = p.K;
+  p.avec = (C % 4 == 0) && (ldx % 4 == 0) && aligned16(x);
+  p.bvec = (F % 4 == 0) && aligned16(W0);
+  return launch<A_EDGE, B_ROW, E_STORE>(p, (hipStream_t)stream, "dgcnn_edge_mlp_f32");
+}
+
+extern "C" int dgcnn_edge_mlp_wgrad_f32(const float* x, int64_t ldx, const int32_t* idx, const float* dY,
+                                        int B, int N, int C, int k, int F, float* dW0, float beta,
+                                        void* ws, size_t ws_bytes, void* stream) {
+  DG_REQUIRE(x && idx && dY && dW0, DGCNN_EINVAL, "dgcnn_edge_mlp_wgrad_f32: null pointer");
+  const int64_t Me = (int64_t)B * N * k;
+  DG_REQUIRE(Me < (1ll << 31), DGCNN_EUNSUP, "dgcnn_edge_mlp_wgrad_f32: B*N*k >= 2^31");
+  GemmP p = {};
+  p.x = x; p.ldx = ldx; p.idx = idx; p.npts = N; p.cch = C; p.knn = k;
+  p.B = dY; p.ldb = F; p.C = dW0; p.ldc = F;
+  p.M = 2 * C; p.N = F; p.K = (int)Me; p.beta = beta; p.rpg = 1;
+  p.avec = (C % 4 == 0) && (ldx % 4 == 0) && aligned16(x);
+  p.bvec = (F % 4 == 0) && aligned16(dY);
+  int rc = plan_splits(p, ws, ws_bytes, "dgcnn_edge_mlp_wgrad_f32");
+  if (rc) return rc;
+  return launch<A_EDGE_T, B_ROW, E_STORE>(p, (hipStream_t)stream, "dgcnn_edge_mlp_wgrad_f32");
+}
+
+extern "C" int dgcnn_edge_mlp_dgrad_scatter_f32(const float* dY, const float* W0, const int32_t* idx,
+                                                int B, int N, int C, int k, int F, float* dx,
+                                                int64_t lddx, void* stream) {
+  DG_REQUIRE(dY && W0 && idx && dx, DGCNN_EINVAL, "dgcnn_edge_mlp_dgrad_scatter_f32: null pointer");
+  const int64_t Me = (int64_t)B * N * k;
+  DG_REQUIRE(Me < (1ll << 31), DGCNN_EUNSUP, "dgcnn_edge_mlp_dgrad_scatter_f32: B*N*k >= 2^31");
+  GemmP p = {};
+  // G[e][c] = sum_f dY[e][f] * W0[C + c][f]  (B stored [n][k] = rows C..2C of W0), scattered to dx[nbr(e)]
+  p.A = dY; p.lda = F; p.B = W0 + (int64_t)C * F; p.ldb = F;
+  p.M = (int)Me; p.N = C; p.K = F; p.rpg = 1;
+  p.idx = idx; p.npts = N; p.cch = C; p.knn = k; p.dx = dx; p.lddx = lddx;
+  p.splits = 1; p.kchunk = F;
+  p.avec = (F % 4 == 0) && aligned16(dY);
+  p.bvec = (F % 4 == 0) && aligned16(p.B);
+  return launch<A_ROW, B_COL, E_SCATTER>(p, (hipStream_t)stream, "dgcnn_edge_mlp_dgrad_scatter_f32");
+}

@@ -1,0 +1,227 @@
+// knn.hip -- K1: fused pairwise squared distance + per-row top-k select (dgcnn/ops.py:8-19).
+//
+// MUST be compiled with -ffp-contract=off: the arithmetic order is normative
+// (oracle/knn_oracle.c) and the indices are bit-exact against it:
+//     s_i  = sequential sum of fl(x*x)          (no FMA)
+//     p_ij = fmaf chain over c ascending from +0
+//     D_ij = fl( fl(s_i + s_j) - 2 p_ij )
+// Selection: k smallest by (D_ij, j) lexicographic, ascending, self included.
+//
+// Mapping (wave64): a workgroup owns 64 query rows (one per lane, x_i in VGPRs) and 4 waves that
+// split every 128-candidate LDS tile four ways, so B*N/64*4 waves are in flight (3072 at the
+// headline shape).  All lanes of a wave read the same candidate row from LDS (broadcast, no bank
+// conflicts); each lane keeps a private sorted (d, j) list of KC entries in registers and inserts
+// with a branch-free v_med3/v_cndmask network, skipped wave-uniformly when no lane improves.
+// The four per-wave lists are merged through LDS at the end.  The (B,N,N) matrix never exists.
+#include "common.h"
+#include <math.h>
+
+namespace {
+
+constexpr int ROWS = 64;
+constexpr int WAVES = 4;
+constexpr int TJ = 128;
+constexpr int PERW = TJ / WAVES;
+
+__global__ void sqnorm_kernel(const float* __restrict__ x, int64_t ldx, int64_t rows, int C,
+                              float* __restrict__ sq) {
+  int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= rows) return;
+  const float* p = x + r * ldx;
+  float s = 0.0f;
+  for (int c = 0; c < C; ++c) {
+    float q = p[c] * p[c];
+    s = s + q;
+  }
+  sq[r] = s;
+}
+
+template <bool LEX>
+__device__ __forceinline__ bool key_less(float d, int j, float dt, int jt) {
+  return LEX ? ((d < dt) || (d == dt && j < jt)) : (d < dt);
+}
+
+// Branch-free sorted insert of (d, j) into an ascending list held in registers.
+// new dl[t] = clamp(d, dl[t-1], dl[t]) (v_med3_f32); indices follow the two compare masks.
+template <int KC, bool LEX>
+__device__ __forceinline__ void list_insert(float (&dl)[KC], int (&jl)[KC], float d, int j) {
+  bool ct = key_less<LEX>(d, j, dl[KC - 1], jl[KC - 1]);
+#pragma unroll
+  for (int t = KC - 1; t >= 1; --t) {
+    const bool cp = key_less<LEX>(d, j, dl[t - 1], jl[t - 1]);
+    dl[t] = __builtin_amdgcn_fmed3f(dl[t - 1], d, dl[t]);
+    jl[t] = ct ? (cp ? jl[t - 1] : j) : jl[t];
+    ct = cp;
+  }
+  dl[0] = ct ? d : dl[0];
+  jl[0] = ct ? j : jl[0];
+}
+
+// Register budget: x_i (CP) + list (2*KC) + ~40 for the candidate stream -> waves/SIMD target.
+template <int CP, int KC>
+constexpr int knn_min_waves() {
+  return (CP + 2 * KC + 70 <= 128) ? 4 : ((CP + 2 * KC + 70 <= 168) ? 3 : ((CP + 2 * KC + 70 <= 256) ? 2 : 1));
+}
+
+template <int CP, int KC>
+__global__ __launch_bounds__(256, (knn_min_waves<CP, KC>())) void knn_kernel(const float* __restrict__ x,
+                                                  const float* __restrict__ sq, int N, int C,
+                                                  int64_t ldx, int k, int vec_ok,
+                                                  int32_t* __restrict__ idx) {
+  constexpr int TILE_F = TJ * CP;
+  constexpr int MERGE_F = ROWS * KC * 2;
+  constexpr int SH = (TILE_F > MERGE_F ? TILE_F : MERGE_F);
+  __shared__ __attribute__((aligned(16))) float smem[SH + TJ];
+  float* xs = smem;
+  float* sjs = smem + SH;
+
+  const int lane = threadIdx.x & 63;
+  const int w = threadIdx.x >> 6;
+  const int b = blockIdx.y;
+  const int row = blockIdx.x * ROWS + lane;
+  const float* xb = x + (int64_t)b * N * ldx;
+  const float* sqb = sq + (int64_t)b * N;
+
+  const int rowc = row < N ? row : N - 1;
+  float xi[CP];
+#pragma unroll
+  for (int c = 0; c < CP; ++c) xi[c] = (c < C) ? xb[(int64_t)rowc * ldx + c] : 0.0f;
+  const float si = sqb[rowc];
+
+  float dl[KC];
+  int jl[KC];
+#pragma unroll
+  for (int t = 0; t < KC; ++t) {
+    dl[t] = INFINITY;
+    jl[t] = 0x7fffffff;
+  }
+
+#pragma unroll 1
+  for (int j0 = 0; j0 < N; j0 += TJ) {
+    __syncthreads();
+    // ---- stage TJ candidate rows (zero padded to CP channels) into LDS ----
+    for (int e = threadIdx.x; e < TJ * (CP / 4); e += 256) {
+      const int r = e / (CP / 4);
+      const int c4 = (e % (CP / 4)) * 4;
+      const int j = j0 + r;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (j < N) {
+        const float* src = xb + (int64_t)j * ldx + c4;
+        if (vec_ok && c4 + 3 < C) {
+          v = *reinterpret_cast<const float4*>(src);
+        } else {
+          if (c4 + 0 < C) v.x = src[0];
+          if (c4 + 1 < C) v.y = src[1];
+          if (c4 + 2 < C) v.z = src[2];
+          if (c4 + 3 < C) v.w = src[3];
+        }
+      }
+      *reinterpret_cast<float4*>(&xs[r * CP + c4]) = v;
+    }
+    if (threadIdx.x < TJ) {
+      const int j = j0 + threadIdx.x;
+      sjs[threadIdx.x] = (j < N) ? sqb[j] : INFINITY;
+    }
+    __syncthreads();
+
+    // ---- this wave's 32 candidates, 2 at a time (2 independent fmaf chains); the channel
+    // loop is fully unrolled (x_i stays in registers) but fenced every 16 channels so the
+    // scheduler cannot hoist all LDS reads and blow the register budget ----
+#pragma unroll 1
+    for (int g = 0; g < PERW; g += 2) {
+      const int jl0 = w * PERW + g;
+      if (j0 + jl0 >= N) break;  // wave-uniform
+      const float* c0 = &xs[jl0 * CP];
+      float p0 = 0.f, p1 = 0.f;
+#pragma unroll
+      for (int c = 0; c < CP; c += 4) {
+        const float4 v0 = *reinterpret_cast<const float4*>(c0 + c);
+        const float4 v1 = *reinterpret_cast<const float4*>(c0 + CP + c);
+        p0 = fmaf(xi[c], v0.x, p0); p1 = fmaf(xi[c], v1.x, p1);
+        p0 = fmaf(xi[c + 1], v0.y, p0); p1 = fmaf(xi[c + 1], v1.y, p1);
+        p0 = fmaf(xi[c + 2], v0.z, p0); p1 = fmaf(xi[c + 2], v1.z, p1);
+        p0 = fmaf(xi[c + 3], v0.w, p0); p1 = fmaf(xi[c + 3], v1.w, p1);
+        if ((c & 15) == 12) __builtin_amdgcn_sched_barrier(0);
+      }
+      const float pp[2] = {p0, p1};
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const float t = si + sjs[jl0 + q];
+        const float tp = 2.0f * pp[q];
+        const float d = t - tp;
+        if (__any(d < dl[KC - 1])) list_insert<KC, false>(dl, jl, d, j0 + jl0 + q);
+      }
+    }
+  }
+
+  // ---- merge the 4 per-wave lists into wave 0 through LDS (lexicographic (d, j)) ----
+  float* md = smem;
+  int* mj = reinterpret_cast<int*>(smem + ROWS * KC);
+#pragma unroll 1
+  for (int src = 1; src < WAVES; ++src) {
+    __syncthreads();
+    if (w == src) {
+#pragma unroll
+      for (int t = 0; t < KC; ++t) {
+        md[t * ROWS + lane] = dl[t];
+        mj[t * ROWS + lane] = jl[t];
+      }
+    }
+    __syncthreads();
+    if (w == 0) {
+#pragma unroll 1
+      for (int t = 0; t < KC; ++t) {
+        const float d = md[t * ROWS + lane];
+        const int j = mj[t * ROWS + lane];
+        const bool need = (d < dl[KC - 1]) || (d == dl[KC - 1] && j < jl[KC - 1]);
+        if (!__any(need)) break;  // source list is ascending: nothing later can enter either
+        list_insert<KC, true>(dl, jl, d, j);
+      }
+    }
+  }
+  if (w == 0 && row < N) {
+    int32_t* out = idx + ((int64_t)b * N + row) * k;
+#pragma unroll
+    for (int t = 0; t < KC; ++t)
+      if (t < k) out[t] = jl[t];
+  }
+}
+
+template <int CP, int KC>
+void launch_knn(const float* x, const float* sq, int B, int N, int C, int64_t ldx, int k, int vec_ok,
+                int32_t* idx, hipStream_t st) {
+  dim3 grid((unsigned)dg::cdiv(N, ROWS), (unsigned)B);
+  hipLaunchKernelGGL((knn_kernel<CP, KC>), grid, dim3(256), 0, st, x, sq, N, C, ldx, k, vec_ok, idx);
+}
+
+template <int CP>
+int dispatch_k(const float* x, const float* sq, int B, int N, int C, int64_t ldx, int k, int vec_ok,
+               int32_t* idx, hipStream_t st) {
+  if (k <= 8) launch_knn<CP, 8>(x, sq, B, N, C, ldx, k, vec_ok, idx, st);
+  else if (k <= 20) launch_knn<CP, 20>(x, sq, B, N, C, ldx, k, vec_ok, idx, st);
+  else if (k <= 40) launch_knn<CP, 40>(x, sq, B, N, C, ldx, k, vec_ok, idx, st);
+  else launch_knn<CP, 64>(x, sq, B, N, C, ldx, k, vec_ok, idx, st);
+  return dg::check_launch("dgcnn_knn_f32");
+}
+
+}  // namespace
+
+extern "C" int dgcnn_knn_workspace_bytes(int B, int N) { return (int)sizeof(float) * B * N; }
+
+extern "C" int dgcnn_knn_f32(const float* x, int B, int N, int C, int64_t ldx, int k, int32_t* idx,
+                             float* sq_ws, void* stream) {
+  DG_REQUIRE(x && idx && sq_ws, DGCNN_EINVAL, "dgcnn_knn_f32: null pointer");
+  DG_REQUIRE(B > 0 && N > 0 && C > 0 && ldx >= C, DGCNN_EINVAL, "dgcnn_knn_f32: bad shape B=%d N=%d C=%d", B, N, C);
+  DG_REQUIRE(k > 0 && k <= N, DGCNN_EINVAL,
+             "dgcnn_knn_f32: k=%d must be in [1, N=%d] (tf.nn.top_k raises otherwise)", k, N);
+  DG_REQUIRE(k <= 64, DGCNN_EUNSUP, "dgcnn_knn_f32: k=%d > 64 unsupported", k);
+  DG_REQUIRE(C <= 128, DGCNN_EUNSUP, "dgcnn_knn_f32: C=%d > 128 unsupported", C);
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t rows = (int64_t)B * N;
+  hipLaunchKernelGGL(sqnorm_kernel, dim3((unsigned)dg::cdiv(rows, 256)), dim3(256), 0, st, x, ldx, rows, C, sq_ws);
+  const int vec_ok = (ldx % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
+  if (C <= 4) return dispatch_k<4>(x, sq_ws, B, N, C, ldx, k, vec_ok, idx, st);
+  if (C <= 16) return dispatch_k<16>(x, sq_ws, B, N, C, ldx, k, vec_ok, idx, st);
+  if (C <= 64) return dispatch_k<64>(x, sq_ws, B, N, C, ldx, k, vec_ok, idx, st);
+  return dispatch_k<128>(x, sq_ws, B, N, C, ldx, k, vec_ok, idx, st);
+}

@@ -1,0 +1,304 @@
+// misc.hip -- the small HBM-bound kernels either side of the GEMMs: edge gather (the explicit
+// dgcnn/ops.py:21-40 tensor, API/tests only -- the model path gathers inside the GEMM), global
+// max-pool + its gradient (model.py:76-81), tf.tile^T column sums, dropout (model.py:91),
+// residual add+relu (ops.py:134), strided copies (tf.concat), softmax / CE / accuracy
+// (trainval.py:39-52), gradient accumulation and Adam (trainval.py:17,75-80).
+#include "common.h"
+
+namespace {
+
+inline unsigned grid1d(int64_t n, int bs = 256) {
+  int64_t g = dg::cdiv(n, bs);
+  if (g > 65536) g = 65536;
+  if (g < 1) g = 1;
+  return (unsigned)g;
+}
+
+#define GRID_STRIDE(i, n) \
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (n); i += (int64_t)gridDim.x * blockDim.x)
+
+__global__ void edge_gather_kernel(const float* __restrict__ x, int64_t ldx, const int32_t* __restrict__ idx,
+                                   int N, int C, int k, int64_t total, float* __restrict__ E) {
+  GRID_STRIDE(i, total) {
+    const int c = (int)(i % (2 * C));
+    const int64_t e = i / (2 * C);
+    const int64_t g = e / k;
+    const float xc = x[g * ldx + (c < C ? c : c - C)];
+    float v = xc;
+    if (c >= C) {
+      const int64_t nb = (g / N) * N + idx[e];
+      v = x[nb * ldx + (c - C)] - xc;
+    }
+    E[i] = v;
+  }
+}
+
+__global__ void edge_gather_bwd_kernel(const float* __restrict__ dE, const int32_t* __restrict__ idx, int N, int C,
+                                       int k, int64_t total, float* __restrict__ dx, int64_t lddx) {
+  GRID_STRIDE(i, total) {   // i over (edge, c<C)
+    const int c = (int)(i % C);
+    const int64_t e = i / C;
+    const int64_t g = e / k;
+    const float dc = dE[e * 2 * C + c];
+    const float dn = dE[e * 2 * C + C + c];
+    const int64_t nb = (g / N) * N + idx[e];
+    atomicAdd(dx + g * lddx + c, dc - dn);
+    atomicAdd(dx + nb * lddx + c, dn);
+  }
+}
+
+// block = 64 channels x 4 row groups; first arg-max on ties (tf max_pool gradient routing)
+__global__ __launch_bounds__(256) void global_max_kernel(const float* __restrict__ x, int64_t ldx, int N, int F,
+                                                         float* __restrict__ out, int32_t* __restrict__ arg) {
+  __shared__ float sv[4][64];
+  __shared__ int si[4][64];
+  const int b = blockIdx.y;
+  const int f = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int rg = threadIdx.x >> 6;
+  float best = -INFINITY;
+  int bi = 0x7fffffff;
+  if (f < F) {
+    const float* p = x + (int64_t)b * N * ldx + f;
+    for (int i = rg; i < N; i += 4) {
+      const float v = p[(int64_t)i * ldx];
+      if (v > best) { best = v; bi = i; }
+    }
+  }
+  sv[rg][threadIdx.x & 63] = best;
+  si[rg][threadIdx.x & 63] = bi;
+  __syncthreads();
+  if (rg == 0 && f < F) {
+    for (int q = 1; q < 4; ++q) {
+      const float v = sv[q][threadIdx.x];
+      const int i = si[q][threadIdx.x];
+      if (v > best || (v == best && i < bi)) { best = v; bi = i; }
+    }
+    out[(int64_t)b * F + f] = best;
+    if (arg) arg[(int64_t)b * F + f] = bi;
+  }
+}
+
+__global__ void global_max_bwd_kernel(const float* __restrict__ dout, const int32_t* __restrict__ arg, int N, int F,
+                                      int64_t total, float* __restrict__ dx, int64_t lddx) {
+  GRID_STRIDE(i, total) {
+    const int64_t b = i / F;
+    const int f = (int)(i % F);
+    dx[(b * N + arg[i]) * lddx + f] += dout[i];
+  }
+}
+
+__global__ __launch_bounds__(256) void group_colsum_kernel(const float* __restrict__ x, int64_t ldx, int rows, int F,
+                                                           float* __restrict__ out) {
+  __shared__ float sv[4][64];
+  const int g = blockIdx.y;
+  const int f = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int rg = threadIdx.x >> 6;
+  float s = 0.f;
+  if (f < F) {
+    const float* p = x + (int64_t)g * rows * ldx + f;
+    for (int i = rg; i < rows; i += 4) s += p[(int64_t)i * ldx];
+  }
+  sv[rg][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (rg == 0 && f < F) out[(int64_t)g * F + f] = (sv[0][threadIdx.x] + sv[1][threadIdx.x]) + (sv[2][threadIdx.x] + sv[3][threadIdx.x]);
+}
+
+__device__ __forceinline__ uint32_t mix32(uint64_t z) {   // splitmix64 finaliser
+  z += 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z = z ^ (z >> 31);
+  return (uint32_t)(z >> 32);
+}
+
+__global__ void dropout_kernel(const float* x, float* y, int64_t n, float keep, uint64_t seed) {
+  const float scale = 1.0f / keep;
+  const uint32_t thr = (keep >= 1.f) ? 0xffffffffu : (uint32_t)((double)keep * 4294967296.0);
+  GRID_STRIDE(i, n) {
+    const uint32_t r = mix32(seed * 0xD1342543DE82EF95ull + (uint64_t)i);
+    y[i] = (r < thr) ? x[i] * scale : 0.f;
+  }
+}
+
+__global__ void add_relu_kernel(const float* __restrict__ a, int64_t lda, const float* __restrict__ b, int64_t ldb,
+                                int64_t R, int F, float* __restrict__ out, int64_t ldo) {
+  GRID_STRIDE(i, R * F) {
+    const int64_t r = i / F;
+    const int f = (int)(i % F);
+    out[r * ldo + f] = fmaxf(a[r * lda + f] + b[r * ldb + f], 0.f);
+  }
+}
+
+__global__ void relu_bwd_kernel(const float* __restrict__ dout, int64_t lddo, const float* __restrict__ out,
+                                int64_t ldo, int64_t R, int F, float* __restrict__ d, int64_t ldd) {
+  GRID_STRIDE(i, R * F) {
+    const int64_t r = i / F;
+    const int f = (int)(i % F);
+    d[r * ldd + f] = (out[r * ldo + f] > 0.f) ? dout[r * lddo + f] : 0.f;
+  }
+}
+
+__global__ void copy2d_kernel(const float* __restrict__ src, int64_t lds, float* __restrict__ dst, int64_t ldd,
+                              int64_t R, int F, int accumulate) {
+  GRID_STRIDE(i, R * F) {
+    const int64_t r = i / F;
+    const int f = (int)(i % F);
+    const float v = src[r * lds + f];
+    if (accumulate) dst[r * ldd + f] += v;
+    else dst[r * ldd + f] = v;
+  }
+}
+
+__global__ __launch_bounds__(256) void softmax_xent_kernel(const float* __restrict__ logits,
+                                                           const int32_t* __restrict__ labels,
+                                                           const float* __restrict__ weight, int64_t rows, int ncls,
+                                                           float* __restrict__ softmax, float* __restrict__ dlogits,
+                                                           float* __restrict__ scal) {
+  __shared__ float sl[256], sc[256];
+  float loss = 0.f, corr = 0.f;
+  const float inv_rows = 1.0f / (float)rows;
+  GRID_STRIDE(r, rows) {
+    const float* z = logits + r * ncls;
+    float mx = z[0];
+    int am = 0;
+    for (int c = 1; c < ncls; ++c)
+      if (z[c] > mx) { mx = z[c]; am = c; }
+    float se = 0.f;
+    for (int c = 0; c < ncls; ++c) se += expf(z[c] - mx);
+    const float inv = 1.0f / se;
+    const int lab = labels ? labels[r] : -1;
+    const float w = weight ? weight[r] : 1.f;
+    for (int c = 0; c < ncls; ++c) {
+      const float p = expf(z[c] - mx) * inv;
+      if (softmax) softmax[r * ncls + c] = p;
+      if (dlogits) dlogits[r * ncls + c] = (p - (c == lab ? 1.f : 0.f)) * w * inv_rows;
+    }
+    if (lab >= 0) {
+      loss += (logf(se) - (z[lab] - mx)) * w;
+      corr += (am == lab) ? 1.f : 0.f;
+    }
+  }
+  sl[threadIdx.x] = loss;
+  sc[threadIdx.x] = corr;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) { sl[threadIdx.x] += sl[threadIdx.x + s]; sc[threadIdx.x] += sc[threadIdx.x + s]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0 && scal) {
+    atomicAdd(scal + 0, sl[0] * inv_rows);
+    atomicAdd(scal + 1, sc[0] * inv_rows);
+  }
+}
+
+__global__ void axpby_kernel(const float* __restrict__ x, float a, float* __restrict__ y, float b, int64_t n) {
+  GRID_STRIDE(i, n) y[i] = (b == 0.f) ? a * x[i] : a * x[i] + b * y[i];
+}
+
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                            float* __restrict__ v, int64_t n, float lr_t, float b1, float b2, float eps) {
+  GRID_STRIDE(i, n) {
+    const float gi = g[i];
+    const float mi = m[i] + (gi - m[i]) * (1.f - b1);
+    const float vi = v[i] + (gi * gi - v[i]) * (1.f - b2);
+    m[i] = mi;
+    v[i] = vi;
+    p[i] -= lr_t * mi / (sqrtf(vi) + eps);
+  }
+}
+
+}  // namespace
+
+#define ST ((hipStream_t)stream)
+
+extern "C" int dgcnn_edge_gather_f32(const float* x, int64_t ldx, const int32_t* idx, int B, int N, int C, int k,
+                                     float* E, void* stream) {
+  DG_REQUIRE(x && idx && E && B > 0 && N > 0 && C > 0 && k > 0, DGCNN_EINVAL, "dgcnn_edge_gather_f32: bad args");
+  const int64_t total = (int64_t)B * N * k * 2 * C;
+  hipLaunchKernelGGL(edge_gather_kernel, dim3(grid1d(total)), dim3(256), 0, ST, x, ldx, idx, N, C, k, total, E);
+  return dg::check_launch("dgcnn_edge_gather_f32");
+}
+
+extern "C" int dgcnn_edge_gather_bwd_f32(const float* dE, const int32_t* idx, int B, int N, int C, int k,
+                                         float* dx, int64_t lddx, void* stream) {
+  DG_REQUIRE(dE && idx && dx && B > 0 && N > 0 && C > 0 && k > 0, DGCNN_EINVAL, "dgcnn_edge_gather_bwd_f32: bad args");
+  const int64_t total = (int64_t)B * N * k * C;
+  hipLaunchKernelGGL(edge_gather_bwd_kernel, dim3(grid1d(total)), dim3(256), 0, ST, dE, idx, N, C, k, total, dx, lddx);
+  return dg::check_launch("dgcnn_edge_gather_bwd_f32");
+}
+
+extern "C" int dgcnn_global_max_f32(const float* x, int64_t ldx, int B, int N, int F, float* out, int32_t* arg,
+                                    void* stream) {
+  DG_REQUIRE(x && out && B > 0 && N > 0 && F > 0, DGCNN_EINVAL, "dgcnn_global_max_f32: bad args");
+  hipLaunchKernelGGL(global_max_kernel, dim3((unsigned)dg::cdiv(F, 64), (unsigned)B), dim3(256), 0, ST, x, ldx, N, F,
+                     out, arg);
+  return dg::check_launch("dgcnn_global_max_f32");
+}
+
+extern "C" int dgcnn_global_max_bwd_f32(const float* dout, const int32_t* arg, int B, int N, int F, float* dx,
+                                        int64_t lddx, void* stream) {
+  DG_REQUIRE(dout && arg && dx && B > 0 && N > 0 && F > 0, DGCNN_EINVAL, "dgcnn_global_max_bwd_f32: bad args");
+  const int64_t total = (int64_t)B * F;
+  hipLaunchKernelGGL(global_max_bwd_kernel, dim3(grid1d(total)), dim3(256), 0, ST, dout, arg, N, F, total, dx, lddx);
+  return dg::check_launch("dgcnn_global_max_bwd_f32");
+}
+
+extern "C" int dgcnn_group_colsum_f32(const float* x, int64_t ldx, int G, int rows_per_group, int F, float* out,
+                                      void* stream) {
+  DG_REQUIRE(x && out && G > 0 && rows_per_group > 0 && F > 0, DGCNN_EINVAL, "dgcnn_group_colsum_f32: bad args");
+  hipLaunchKernelGGL(group_colsum_kernel, dim3((unsigned)dg::cdiv(F, 64), (unsigned)G), dim3(256), 0, ST, x, ldx,
+                     rows_per_group, F, out);
+  return dg::check_launch("dgcnn_group_colsum_f32");
+}
+
+extern "C" int dgcnn_dropout_f32(const float* x, float* y, int64_t n, float keep, uint64_t seed, void* stream) {
+  DG_REQUIRE(x && y && n > 0 && keep > 0.f && keep <= 1.f, DGCNN_EINVAL, "dgcnn_dropout_f32: bad args");
+  hipLaunchKernelGGL(dropout_kernel, dim3(grid1d(n)), dim3(256), 0, ST, x, y, n, keep, seed);
+  return dg::check_launch("dgcnn_dropout_f32");
+}
+
+extern "C" int dgcnn_add_relu_f32(const float* a, int64_t lda, const float* b, int64_t ldb, int64_t R, int F,
+                                  float* out, int64_t ldo, void* stream) {
+  DG_REQUIRE(a && b && out && R > 0 && F > 0, DGCNN_EINVAL, "dgcnn_add_relu_f32: bad args");
+  hipLaunchKernelGGL(add_relu_kernel, dim3(grid1d(R * F)), dim3(256), 0, ST, a, lda, b, ldb, R, F, out, ldo);
+  return dg::check_launch("dgcnn_add_relu_f32");
+}
+
+extern "C" int dgcnn_relu_bwd_f32(const float* dout, int64_t lddo, const float* out, int64_t ldo, int64_t R, int F,
+                                  float* d, int64_t ldd, void* stream) {
+  DG_REQUIRE(dout && out && d && R > 0 && F > 0, DGCNN_EINVAL, "dgcnn_relu_bwd_f32: bad args");
+  hipLaunchKernelGGL(relu_bwd_kernel, dim3(grid1d(R * F)), dim3(256), 0, ST, dout, lddo, out, ldo, R, F, d, ldd);
+  return dg::check_launch("dgcnn_relu_bwd_f32");
+}
+
+extern "C" int dgcnn_copy2d_f32(const float* src, int64_t lds, float* dst, int64_t ldd, int64_t R, int F,
+                                int accumulate, void* stream) {
+  DG_REQUIRE(src && dst && R > 0 && F > 0, DGCNN_EINVAL, "dgcnn_copy2d_f32: bad args");
+  hipLaunchKernelGGL(copy2d_kernel, dim3(grid1d(R * F)), dim3(256), 0, ST, src, lds, dst, ldd, R, F, accumulate);
+  return dg::check_launch("dgcnn_copy2d_f32");
+}
+
+extern "C" int dgcnn_softmax_xent_f32(const float* logits, const int32_t* labels, const float* weight,
+                                      int64_t rows, int ncls, float* softmax, float* dlogits, float* scal,
+                                      void* stream) {
+  DG_REQUIRE(logits && rows > 0 && ncls > 0, DGCNN_EINVAL, "dgcnn_softmax_xent_f32: bad args");
+  DG_REQUIRE(!dlogits || labels, DGCNN_EINVAL, "dgcnn_softmax_xent_f32: dlogits needs labels");
+  unsigned g = grid1d(rows);
+  if (g > 1024) g = 1024;
+  hipLaunchKernelGGL(softmax_xent_kernel, dim3(g), dim3(256), 0, ST, logits, labels, weight, rows, ncls, softmax,
+                     dlogits, scal);
+  return dg::check_launch("dgcnn_softmax_xent_f32");
+}
+
+extern "C" int dgcnn_axpby_f32(const float* x, float a, float* y, float b, int64_t n, void* stream) {
+  DG_REQUIRE(x && y && n > 0, DGCNN_EINVAL, "dgcnn_axpby_f32: bad args");
+  hipLaunchKernelGGL(axpby_kernel, dim3(grid1d(n)), dim3(256), 0, ST, x, a, y, b, n);
+  return dg::check_launch("dgcnn_axpby_f32");
+}
+
+extern "C" int dgcnn_adam_f32(float* param, const float* grad, float* m, float* v, int64_t n, float lr_t, float b1,
+                              float b2, float eps, void* stream) {
+  DG_REQUIRE(param && grad && m && v && n > 0, DGCNN_EINVAL, "dgcnn_adam_f32: bad args");
+  hipLaunchKernelGGL(adam_kernel, dim3(grid1d(n)), dim3(256), 0, ST, param, grad, m, v, n, lr_t, b1, b2, eps);
+  return dg::check_launch("dgcnn_adam_f32");
+}

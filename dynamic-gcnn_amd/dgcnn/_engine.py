@@ -1,0 +1,469 @@
+"""Host-side engine: variable store, backward tape and the composite EdgeConv / conv+BN blocks.
+
+The reference builds a TF1 graph once and replays it with sess.run (dgcnn/trainval.py:12-85).
+Here every call runs the HIP kernels immediately on the current stream and records one closure
+per block on a tape; `backward()` replays the tape in reverse.  There is no autograd and no
+torch math on the path: torch tensors only hold memory.
+
+Layout conventions (DESIGN.md "Data layout"):
+  * every activation is a 2-D row-major view (rows = points or edges, cols = channels) with an
+    explicit leading dimension, so the outputs of one block can be written straight into column
+    slices of a wider buffer (the tf.concat of dgcnn/ops.py:58 and model.py:63,85 never copies);
+  * gradients mirror the forward buffers: the gradient of a column slice is the same slice of the
+    gradient of its parent buffer (found by address), zero-initialised, always accumulated into;
+  * parameters, their gradient accumulators and the Adam moments live in four flat fp32 buckets
+    (one RCCL all-reduce, one fused Adam launch per step).
+"""
+from __future__ import annotations
+
+import contextlib
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from . import _hip as H
+
+BN_EPS = 1e-3          # slim.batch_norm default epsilon [TF1-lib]
+DROPOUT_KEEP = 0.7     # tf.nn.dropout(net, 0.7): dgcnn/model.py:91
+WS_BYTES = 256 << 20
+
+
+class Context(object):
+    def __init__(self):
+        self.vars = OrderedDict()        # name -> 2-D / 1-D tensor (views of flat_param when allocated)
+        self.var_grads = {}              # name -> tensor (views of flat_grad)
+        self.flat_param = self.flat_grad = self.flat_m = self.flat_v = None
+        self.scope = []
+        self.tape = []
+        self.roots = []                  # [(buffer, [grad or None])]
+        self.recording = False
+        self.ws = None
+        self.seed = 1
+        self._rng = None
+        self.stat_arena = None
+        self.stat_off = 0
+        self.step_seed = 0
+        self.debug = False
+
+    # ---- device / scratch -------------------------------------------------------------
+    @property
+    def device(self):
+        if not torch.cuda.is_available():
+            raise H.HipError("no GPU visible: the dgcnn HIP path has no CPU fallback")
+        return torch.device("cuda", torch.cuda.current_device())
+
+    def workspace(self):
+        if self.ws is None or self.ws.device != self.device:
+            self.ws = torch.empty(WS_BYTES, dtype=torch.uint8, device=self.device)
+        return self.ws
+
+    def stats(self, F):
+        """Zeroed double[SLOTS][2][F] carved from one arena that is memset once per step."""
+        n = H.STAT_SLOTS * 2 * F
+        if self.stat_arena is None or self.stat_arena.device != self.device:
+            self.stat_arena = torch.zeros(1 << 20, dtype=torch.float64, device=self.device)
+            self.stat_off = 0
+        if self.stat_off + n > self.stat_arena.numel():
+            return torch.zeros(n, dtype=torch.float64, device=self.device)
+        s = self.stat_arena[self.stat_off:self.stat_off + n]
+        self.stat_off += n
+        return s
+
+    def begin_step(self):
+        """Drop the previous tape / gradient roots and re-zero the statistics arena."""
+        self.tape = []
+        self.roots = []
+        if self.stat_arena is not None and self.stat_off > 0:
+            self.stat_arena[:self.stat_off].zero_()
+        self.stat_off = 0
+        self.step_seed += 1
+
+    # ---- variables (tf.variable_scope / slim variables) ---------------------------------
+    def full_name(self, leaf):
+        return "/".join(self.scope + [leaf])
+
+    def allocate_variables(self, specs, seed=1):
+        """Create every variable of `specs` ([(name, shape)] in creation order) inside flat buckets."""
+        dev = self.device
+        total = sum(int(np.prod(s)) for _, s in specs)
+        self.flat_param = torch.empty(total, dtype=torch.float32, device=dev)
+        self.flat_grad = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.flat_m = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.flat_v = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.vars = OrderedDict()
+        self.var_grads = {}
+        rng = np.random.default_rng(seed)
+        host = np.empty(total, np.float32)
+        off = 0
+        for name, shape in specs:
+            n = int(np.prod(shape))
+            if name.endswith("weights"):     # slim default: xavier_initializer (uniform)
+                lim = np.sqrt(6.0 / (shape[0] + shape[1]))
+                host[off:off + n] = rng.uniform(-lim, lim, size=shape).astype(np.float32).reshape(-1)
+            else:                            # BatchNorm beta: zeros
+                host[off:off + n] = 0
+            self.vars[name] = self.flat_param[off:off + n].view(*shape)
+            self.var_grads[name] = self.flat_grad[off:off + n].view(*shape)
+            off += n
+        self.flat_param.copy_(torch.from_numpy(host))
+        self.adam_t = 0
+
+    def get_variable(self, leaf, shape):
+        name = self.full_name(leaf)
+        v = self.vars.get(name)
+        if v is None:        # stand-alone use of an op outside trainval: create on first use
+            dev = self.device
+            if self._rng is None:
+                self._rng = np.random.default_rng(self.seed)
+            if leaf.endswith("weights"):
+                lim = np.sqrt(6.0 / (shape[0] + shape[1]))
+                host = self._rng.uniform(-lim, lim, size=shape).astype(np.float32)
+            else:
+                host = np.zeros(shape, np.float32)
+            v = torch.from_numpy(host).to(dev)
+            self.vars[name] = v
+            self.var_grads[name] = torch.zeros_like(v)
+        if tuple(v.shape) != tuple(shape):
+            raise ValueError("variable %s has shape %s, requested %s" % (name, tuple(v.shape), tuple(shape)))
+        return name, v
+
+    def set_variable(self, name, array):
+        self.vars[name].copy_(torch.as_tensor(np.ascontiguousarray(array, np.float32)).to(self.vars[name].device))
+
+    # ---- gradient buffers ---------------------------------------------------------------
+    def new_buffer(self, rows, cols):
+        t = torch.empty((rows, cols), dtype=torch.float32, device=self.device)
+        if self.recording:
+            self.roots.append((t, [None]))
+        return t
+
+    def grad(self, v):
+        """Gradient view matching the 2-D view `v` (same slice of its root's gradient) or None."""
+        if not self.recording:
+            return None
+        ptr = v.data_ptr()
+        for root, slot in self.roots:
+            base = root.data_ptr()
+            if base <= ptr < base + root.numel() * 4:
+                if slot[0] is None:
+                    slot[0] = torch.zeros_like(root)
+                off = (ptr - base) // 4
+                ld = root.shape[1]
+                r0, c0 = off // ld, off % ld
+                assert H.ld2(v) == ld or v.shape[0] == 1, (v.shape, v.stride(), ld)
+                return slot[0][r0:r0 + v.shape[0], c0:c0 + v.shape[1]]
+        return None
+
+    def backward(self):
+        for fn in reversed(self.tape):
+            fn()
+        self.tape = []
+
+
+_CTX = Context()
+
+
+def ctx():
+    return _CTX
+
+
+def reset():
+    """Forget all variables / state (tf.reset_default_graph analogue)."""
+    global _CTX
+    _CTX = Context()
+    return _CTX
+
+
+@contextlib.contextmanager
+def variable_scope(name):
+    c = ctx()
+    c.scope.append(name)
+    try:
+        yield
+    finally:
+        c.scope.pop()
+
+
+# ----------------------------------------------------------------------------------------------
+# shape helpers
+# ----------------------------------------------------------------------------------------------
+def as2d(t):
+    """(B,N,C) / (B,N,1,C) / (R,C) -> ((R,C) row-major view with stride (ld,1), B, N)."""
+    H.require_gpu(t)
+    H.f32(t)
+    if t.dim() == 4:
+        if t.shape[2] != 1:
+            raise ValueError("rank-4 inputs must have a singleton axis -2, got %s" % (tuple(t.shape),))
+        t = t[:, :, 0, :]
+    if t.dim() == 2:
+        if t.stride(1) != 1 and t.shape[1] != 1:
+            t = t.contiguous()
+        return t, 1, t.shape[0]
+    if t.dim() != 3:
+        raise ValueError("expected a rank 2/3/4 tensor, got rank %d" % t.dim())
+    B, N, C = t.shape
+    ok = (t.stride(2) == 1 or C == 1) and (B == 1 or t.stride(0) == N * t.stride(1)) and t.stride(1) >= C
+    if not ok:
+        t = t.contiguous()
+    v = t.as_strided((B * N, C), (t.stride(1), 1), t.storage_offset())
+    return v, B, N
+
+
+def rank4(v, B, N):
+    """(R,C) view -> (B,N,1,C) view (the rank the reference's ops return, ops.py:73)."""
+    return v.as_strided((B, N, 1, v.shape[1]), (N * v.stride(0), v.stride(0), v.stride(0), 1), v.storage_offset())
+
+
+# ----------------------------------------------------------------------------------------------
+# thin kernel wrappers (2-D views in, explicit leading dimensions out)
+# ----------------------------------------------------------------------------------------------
+def knn(x2d, B, N, k):
+    C = x2d.shape[1]
+    idx = torch.empty((B, N, k), dtype=torch.int32, device=x2d.device)
+    sq = torch.empty((B * N,), dtype=torch.float32, device=x2d.device)
+    H.call("dgcnn_knn_f32", x2d.data_ptr(), B, N, C, H.ld2(x2d), k, idx.data_ptr(), sq.data_ptr())
+    return idx
+
+
+def gemm(A, Bm, C, transA=False, transB=False, beta=0.0, gbias=None, rpg=0, stats=None):
+    """C (+)= op(A) op(B); shapes are those of the stored matrices."""
+    M = A.shape[1] if transA else A.shape[0]
+    K = A.shape[0] if transA else A.shape[1]
+    N = Bm.shape[0] if transB else Bm.shape[1]
+    Kb = Bm.shape[1] if transB else Bm.shape[0]
+    assert K == Kb and tuple(C.shape) == (M, N), (A.shape, Bm.shape, C.shape, transA, transB)
+    ws = ctx().workspace()
+    H.call("dgcnn_gemm_f32", int(transA), int(transB), M, N, K, A.data_ptr(), H.ld2(A), Bm.data_ptr(), H.ld2(Bm),
+           C.data_ptr(), H.ld2(C), float(beta), H._p(gbias), 0 if gbias is None else H.ld2(gbias), int(rpg),
+           H._p(stats), ws.data_ptr(), ws.numel())
+
+
+def bn_finalize(stats, F, count):
+    dev = stats.device
+    mr = torch.empty((2, F), dtype=torch.float32, device=dev)
+    H.call("dgcnn_bn_finalize_f32", stats.data_ptr(), F, float(count), BN_EPS, mr[0].data_ptr(), mr[1].data_ptr())
+    return mr[0], mr[1]
+
+
+# ----------------------------------------------------------------------------------------------
+# slim.conv2d(1x1, no bias) + slim.batch_norm + activation on per-point tensors (k = 1)
+# dgcnn/ops.py:62-70,125-133,153-160 ; dgcnn/model.py:46-53,65-72,94-101
+# ----------------------------------------------------------------------------------------------
+def conv_bn_act(x, leaf_scope, num_outputs, relu=True, out=None, out2=None, gbias=None, rpg=0, w_rows=None):
+    """x: (R,Cin) view.  Variables `<scope>/weights` [Cin(+extra), Cout], `<scope>/BatchNorm/beta`.
+    w_rows: (lo, hi) row range of the weight that multiplies x (FC0 with the folded global feature).
+    Returns the (R,Cout) output (a fresh tracked buffer unless `out` is given)."""
+    c = ctx()
+    R, Cin = x.shape
+    with variable_scope(leaf_scope):
+        if w_rows is None:
+            wname, W = c.get_variable("weights", (Cin, num_outputs))
+            Wx = W
+        else:
+            wname, W = c.get_variable("weights", (w_rows[2], num_outputs))
+            Wx = W[w_rows[0]:w_rows[1]]
+        bname, beta = c.get_variable("BatchNorm/beta", (num_outputs,))
+    F = num_outputs
+    T = torch.empty((R, F), dtype=torch.float32, device=x.device)
+    st = c.stats(F)
+    gemm(x, Wx, T, gbias=gbias, rpg=rpg, stats=st)
+    mean, rstd = bn_finalize(st, F, R)
+    if out is None:
+        out = c.new_buffer(R, F)
+    H.call("dgcnn_bn_act_kreduce_f32", T.data_ptr(), R, 1, F, mean.data_ptr(), rstd.data_ptr(), beta.data_ptr(),
+           int(relu), out.data_ptr(), H.ld2(out), 0, 0, H._p(out2), 0 if out2 is None else H.ld2(out2))
+
+    if c.recording:
+        def bwd():
+            dout = c.grad(out)
+            if dout is None:
+                return
+            if out2 is not None:
+                d2 = c.grad(out2)
+                if d2 is not None:      # the second copy's gradient joins the first
+                    H.call("dgcnn_copy2d_f32", d2.data_ptr(), H.ld2(d2), dout.data_ptr(), H.ld2(dout), R, F, 1)
+            red = c.stats(F)
+            H.call("dgcnn_bn_bwd_reduce_f32", T.data_ptr(), R, 1, F, mean.data_ptr(), rstd.data_ptr(), beta.data_ptr(),
+                   int(relu), dout.data_ptr(), H.ld2(dout), 0, 0, red.data_ptr())
+            H.call("dgcnn_bn_bwd_apply_f32", T.data_ptr(), R, 1, F, mean.data_ptr(), rstd.data_ptr(), beta.data_ptr(),
+                   int(relu), dout.data_ptr(), H.ld2(dout), 0, 0, red.data_ptr(), T.data_ptr(), 0,
+                   c.var_grads[bname].data_ptr(), 1.0)
+            dT = T
+            dWx = c.var_grads[wname] if w_rows is None else c.var_grads[wname][w_rows[0]:w_rows[1]]
+            gemm(x, dT, dWx, transA=True, beta=1.0)                    # dW += x^T dT
+            dx = c.grad(x)
+            if dx is not None:
+                gemm(dT, Wx, dx, transB=True, beta=1.0)                # dx += dT W^T
+            if gbias is not None:
+                dgb = c.grad(gbias)
+                if dgb is not None:                                     # tf.tile^T: sum over the cloud
+                    tmp = torch.empty_like(gbias)
+                    H.call("dgcnn_group_colsum_f32", dT.data_ptr(), H.ld2(dT), gbias.shape[0], rpg, F, tmp.data_ptr())
+                    H.call("dgcnn_axpby_f32", tmp.data_ptr(), 1.0, dgb.data_ptr(), 1.0, tmp.numel())
+        c.tape.append(bwd)
+    return out
+
+
+# ----------------------------------------------------------------------------------------------
+# dgcnn/ops.py:42-73 edge_conv as one block
+# ----------------------------------------------------------------------------------------------
+def edge_conv_block(x, B, N, k, num_filters, relu1=True, outs=None, net2=None):
+    """x: (B*N, C) view.  Returns (mm, net, idx): mm = (R,2F) [max | mean], net = (R,64).
+    outs = (mm_view, net_view) destination slices (model path) or None (fresh buffers)."""
+    c = ctx()
+    R, C = x.shape
+    F = int(num_filters)
+    if k > N:
+        raise ValueError("k_nn: k=%d > N=%d (tf.nn.top_k raises InvalidArgument)" % (k, N))
+    with variable_scope("conv0"):
+        w0name, W0 = c.get_variable("weights", (2 * C, F))
+        b0name, beta0 = c.get_variable("BatchNorm/beta", (F,))
+    idx = knn(x, B, N, k)                                               # ops.py:8-19
+    Y = torch.empty((R * k, F), dtype=torch.float32, device=x.device)
+    st = c.stats(F)
+    H.call("dgcnn_edge_mlp_f32", x.data_ptr(), H.ld2(x), idx.data_ptr(), W0.data_ptr(), B, N, C, k, F,
+           Y.data_ptr(), st.data_ptr())                                 # ops.py:21-52 (gather fused)
+    mean, rstd = bn_finalize(st, F, R * k)                              # ops.py:53
+    if outs is None:
+        mm = c.new_buffer(R, 2 * F)
+        net_out = None
+    else:
+        mm, net_out = outs
+    mx, mn = mm[:, :F], mm[:, F:]
+    H.call("dgcnn_bn_act_kreduce_f32", Y.data_ptr(), R, k, F, mean.data_ptr(), rstd.data_ptr(), beta0.data_ptr(), 1,
+           mx.data_ptr(), H.ld2(mx), mn.data_ptr(), H.ld2(mn), 0, 0)    # ops.py:54-58
+
+    if c.recording:
+        def bwd():
+            dmm = c.grad(mm)
+            if dmm is None:
+                return
+            dmx, dmn = dmm[:, :F], dmm[:, F:]
+            red = c.stats(F)
+            H.call("dgcnn_bn_bwd_reduce_f32", Y.data_ptr(), R, k, F, mean.data_ptr(), rstd.data_ptr(),
+                   beta0.data_ptr(), 1, dmx.data_ptr(), H.ld2(dmx), dmn.data_ptr(), H.ld2(dmn), red.data_ptr())
+            dx = c.grad(x)
+            dysum = torch.empty((R, F), dtype=torch.float32, device=x.device) if dx is not None else None
+            H.call("dgcnn_bn_bwd_apply_f32", Y.data_ptr(), R, k, F, mean.data_ptr(), rstd.data_ptr(), beta0.data_ptr(),
+                   1, dmx.data_ptr(), H.ld2(dmx), dmn.data_ptr(), H.ld2(dmn), red.data_ptr(), Y.data_ptr(),
+                   H._p(dysum), c.var_grads[b0name].data_ptr(), 1.0)
+            dY = Y
+            ws = c.workspace()
+            H.call("dgcnn_edge_mlp_wgrad_f32", x.data_ptr(), H.ld2(x), idx.data_ptr(), dY.data_ptr(), B, N, C, k, F,
+                   c.var_grads[w0name].data_ptr(), 1.0, ws.data_ptr(), ws.numel())
+            if dx is not None:
+                # E = [x_i, x_j - x_i]  =>  dx_i += (sum_m dY) (W0[:C]-W0[C:])^T ; dx_j += dY W0[C:]^T
+                wd = torch.empty((C, F), dtype=torch.float32, device=x.device)
+                H.call("dgcnn_copy2d_f32", W0[:C].data_ptr(), F, wd.data_ptr(), F, C, F, 0)
+                H.call("dgcnn_axpby_f32", W0[C:].data_ptr(), -1.0, wd.data_ptr(), 1.0, C * F)
+                gemm(dysum, wd, dx, transB=True, beta=1.0)
+                H.call("dgcnn_edge_mlp_dgrad_scatter_f32", dY.data_ptr(), W0.data_ptr(), idx.data_ptr(), B, N, C, k, F,
+                       dx.data_ptr(), H.ld2(dx))
+        c.tape.append(bwd)
+
+    net = conv_bn_act(mm, "conv1", 64, relu=relu1, out=net_out, out2=net2)   # ops.py:62-70 (64 hard-coded)
+    return mm, net, idx
+
+
+# ----------------------------------------------------------------------------------------------
+# residual add (ops.py:134), dropout (model.py:91), global max-pool (model.py:76-81)
+# ----------------------------------------------------------------------------------------------
+def add_relu(a, b, out=None):
+    c = ctx()
+    R, F = a.shape
+    if tuple(b.shape) != (R, F):
+        raise ValueError("residual shortcut shape mismatch %s vs %s (ops.py:134)" % (tuple(a.shape), tuple(b.shape)))
+    if out is None:
+        out = c.new_buffer(R, F)
+    H.call("dgcnn_add_relu_f32", a.data_ptr(), H.ld2(a), b.data_ptr(), H.ld2(b), R, F, out.data_ptr(), H.ld2(out))
+    if c.recording:
+        def bwd():
+            dout = c.grad(out)
+            if dout is None:
+                return
+            d = torch.empty((R, F), dtype=torch.float32, device=a.device)
+            H.call("dgcnn_relu_bwd_f32", dout.data_ptr(), H.ld2(dout), out.data_ptr(), H.ld2(out), R, F, d.data_ptr(), F)
+            for t in (a, b):
+                g = c.grad(t)
+                if g is not None:
+                    H.call("dgcnn_copy2d_f32", d.data_ptr(), F, g.data_ptr(), H.ld2(g), R, F, 1)
+        c.tape.append(bwd)
+    return out
+
+
+def dropout(x, keep=DROPOUT_KEEP):
+    c = ctx()
+    R, F = x.shape
+    assert x.is_contiguous()
+    out = c.new_buffer(R, F)
+    seed = (c.seed * 1000003 + c.step_seed) & 0xFFFFFFFFFFFF
+    H.call("dgcnn_dropout_f32", x.data_ptr(), out.data_ptr(), R * F, float(keep), seed)
+    if c.recording:
+        def bwd():
+            dout = c.grad(out)
+            dx = c.grad(x)
+            if dout is None or dx is None:
+                return
+            tmp = torch.empty_like(dout)
+            H.call("dgcnn_dropout_f32", dout.data_ptr(), tmp.data_ptr(), R * F, float(keep), seed)
+            H.call("dgcnn_copy2d_f32", tmp.data_ptr(), F, dx.data_ptr(), H.ld2(dx), R, F, 1)
+        c.tape.append(bwd)
+    return out
+
+
+def global_max(x, B, N):
+    """(B*N,F) -> (B,F) max over the points of each cloud, first arg-max remembered for the backward."""
+    c = ctx()
+    F = x.shape[1]
+    out = c.new_buffer(B, F)
+    arg = torch.empty((B, F), dtype=torch.int32, device=x.device)
+    H.call("dgcnn_global_max_f32", x.data_ptr(), H.ld2(x), B, N, F, out.data_ptr(), arg.data_ptr())
+    if c.recording:
+        def bwd():
+            dout = c.grad(out)
+            dx = c.grad(x)
+            if dout is None or dx is None:
+                return
+            H.call("dgcnn_global_max_bwd_f32", dout.data_ptr(), arg.data_ptr(), B, N, F, dx.data_ptr(), H.ld2(dx))
+        c.tape.append(bwd)
+    return out
+
+
+def plain_gemm(a, leaf_scope_weight, w_rows, Cout):
+    """out = a @ W[lo:hi]  (the per-cloud part of FC0: global feature x its 1024 weight rows)."""
+    c = ctx()
+    wname, W = leaf_scope_weight
+    Wx = W[w_rows[0]:w_rows[1]]
+    out = c.new_buffer(a.shape[0], Cout)
+    gemm(a, Wx, out)
+    if c.recording:
+        def bwd():
+            dout = c.grad(out)
+            if dout is None:
+                return
+            gemm(a, dout, c.var_grads[wname][w_rows[0]:w_rows[1]], transA=True, beta=1.0)
+            da = c.grad(a)
+            if da is not None:
+                gemm(dout, Wx, da, transB=True, beta=1.0)
+        c.tape.append(bwd)
+    return out
+
+
+# ----------------------------------------------------------------------------------------------
+# dgcnn/trainval.py:39-52 softmax / accuracy / loss (+ the seed of the backward pass)
+# ----------------------------------------------------------------------------------------------
+def softmax_loss(logits2d, labels, weight, want_grad):
+    """-> (softmax (R,ncls), scal tensor [loss, accuracy] on device).  Seeds d(logits) if want_grad."""
+    c = ctx()
+    R, ncls = logits2d.shape
+    assert logits2d.is_contiguous()
+    sm = torch.empty((R, ncls), dtype=torch.float32, device=logits2d.device)
+    scal = torch.zeros(2, dtype=torch.float32, device=logits2d.device)
+    dl = None
+    if want_grad:
+        dl = c.grad(logits2d)
+        assert dl is not None and dl.is_contiguous()
+    H.call("dgcnn_softmax_xent_f32", logits2d.data_ptr(), H._p(labels), H._p(weight), R, ncls, sm.data_ptr(),
+           H._p(dl), scal.data_ptr())
+    return sm, scal

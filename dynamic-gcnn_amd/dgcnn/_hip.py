@@ -1,0 +1,112 @@
+"""ctypes binding of libdgcnn_hip.so (the C ABI declared in include/dgcnn_hip.h).
+
+PyTorch-ROCm tensors are only memory holders here: every wrapper passes `tensor.data_ptr()` and
+the current HIP stream to the C entry point.  There is NO fallback: if the shared library is
+missing, or a call is made without a visible GPU, this module raises -- the product path never
+routes through the oracle or through torch math.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdgcnn_hip.so")
+STAT_SLOTS = 32
+
+c_int, c_i64, c_f32, c_f64, c_vp, c_sz, c_u64 = (ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_double,
+                                                  ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint64)
+
+# name -> argtypes, exactly as include/dgcnn_hip.h declares them (restype is int unless noted)
+PROTOTYPES = {
+    "dgcnn_version": [],
+    "dgcnn_last_error": [],
+    "dgcnn_knn_workspace_bytes": [c_int, c_int],
+    "dgcnn_knn_f32": [c_vp, c_int, c_int, c_int, c_i64, c_int, c_vp, c_vp, c_vp],
+    "dgcnn_edge_gather_f32": [c_vp, c_i64, c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp],
+    "dgcnn_edge_gather_bwd_f32": [c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp, c_i64, c_vp],
+    "dgcnn_edge_mlp_f32": [c_vp, c_i64, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp],
+    "dgcnn_edge_mlp_wgrad_f32": [c_vp, c_i64, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_f32,
+                                 c_vp, c_sz, c_vp],
+    "dgcnn_edge_mlp_dgrad_scatter_f32": [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_i64, c_vp],
+    "dgcnn_gemm_f32": [c_int, c_int, c_int, c_int, c_int, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_f32,
+                       c_vp, c_i64, c_int, c_vp, c_vp, c_sz, c_vp],
+    "dgcnn_bn_finalize_f32": [c_vp, c_int, c_f64, c_f32, c_vp, c_vp, c_vp],
+    "dgcnn_bn_act_kreduce_f32": [c_vp, c_i64, c_int, c_int, c_vp, c_vp, c_vp, c_int, c_vp, c_i64, c_vp, c_i64,
+                                 c_vp, c_i64, c_vp],
+    "dgcnn_bn_bwd_reduce_f32": [c_vp, c_i64, c_int, c_int, c_vp, c_vp, c_vp, c_int, c_vp, c_i64, c_vp, c_i64,
+                                c_vp, c_vp],
+    "dgcnn_bn_bwd_apply_f32": [c_vp, c_i64, c_int, c_int, c_vp, c_vp, c_vp, c_int, c_vp, c_i64, c_vp, c_i64,
+                               c_vp, c_vp, c_vp, c_vp, c_f32, c_vp],
+    "dgcnn_global_max_f32": [c_vp, c_i64, c_int, c_int, c_int, c_vp, c_vp, c_vp],
+    "dgcnn_global_max_bwd_f32": [c_vp, c_vp, c_int, c_int, c_int, c_vp, c_i64, c_vp],
+    "dgcnn_group_colsum_f32": [c_vp, c_i64, c_int, c_int, c_int, c_vp, c_vp],
+    "dgcnn_dropout_f32": [c_vp, c_vp, c_i64, c_f32, c_u64, c_vp],
+    "dgcnn_add_relu_f32": [c_vp, c_i64, c_vp, c_i64, c_i64, c_int, c_vp, c_i64, c_vp],
+    "dgcnn_relu_bwd_f32": [c_vp, c_i64, c_vp, c_i64, c_i64, c_int, c_vp, c_i64, c_vp],
+    "dgcnn_copy2d_f32": [c_vp, c_i64, c_vp, c_i64, c_i64, c_int, c_int, c_vp],
+    "dgcnn_softmax_xent_f32": [c_vp, c_vp, c_vp, c_i64, c_int, c_vp, c_vp, c_vp, c_vp],
+    "dgcnn_axpby_f32": [c_vp, c_f32, c_vp, c_f32, c_i64, c_vp],
+    "dgcnn_adam_f32": [c_vp, c_vp, c_vp, c_vp, c_i64, c_f32, c_f32, c_f32, c_f32, c_vp],
+}
+
+_lib = None
+
+
+class HipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the library (no GPU needed for loading / symbol checks)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise HipError("libdgcnn_hip.so not built (%s); run `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "or `make -C dynamic-gcnn_amd/csrc` -- there is no CPU fallback" % LIB_PATH)
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, args in PROTOTYPES.items():
+            fn = getattr(lib, name)
+            fn.argtypes = args
+            fn.restype = ctypes.c_char_p if name == "dgcnn_last_error" else ctypes.c_int
+        _lib = lib
+    return _lib
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def call(name, *args):
+    """Invoke an entry point on the current stream; raise ValueError/HipError on a negative code."""
+    lib = load()
+    rc = getattr(lib, name)(*args, _stream())
+    if rc != 0:
+        msg = lib.dgcnn_last_error().decode()
+        if rc == -1:
+            raise ValueError(msg)
+        raise HipError("%s failed (%d): %s" % (name, rc, msg))
+
+
+def require_gpu(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise HipError("dgcnn ops need device (ROCm) tensors; got a %s tensor -- no CPU fallback" % t.device)
+
+
+def f32(t):
+    if t.dtype != torch.float32:
+        raise TypeError("expected float32, got %s" % t.dtype)
+    return t
+
+
+def ld2(t):
+    """Leading dimension (row stride, in elements) of a 2-D row-major view."""
+    assert t.dim() == 2 and (t.stride(1) == 1 or t.shape[1] == 1), (t.shape, t.stride())
+    return t.stride(0) if t.shape[0] > 1 else max(t.stride(0), t.shape[1])

@@ -1,0 +1,88 @@
+"""MI355X-native counterpart of dgcnn/model.py:9-106 -- `build(point_cloud, flags) -> logits`.
+
+Same control flow as the reference (EdgeConv stack -> concat -> MergedEdgeConv -> global max ->
+tile -> concat-all -> fc -> dropout -> Final).  Two things are laid out differently in HBM, with
+identical results up to fp32 rounding:
+  * tf.concat never copies: every block writes its outputs straight into column slices of one
+    (B*N, sum(2F_i+64)+1024) buffer (channel order of model.py:83-85 minus the leading global block);
+  * the tiled global feature (model.py:80-85: 1024 identical channels for all N points of a cloud)
+    is not materialised: FC0 = x_local W[1024:] + (g_cloud W[:1024]) with the second term computed
+    once per cloud and added in the GEMM epilogue (distributivity of the 1x1 convolution).
+"""
+from __future__ import annotations
+
+from . import _engine as E
+from . import ops
+
+
+def build(point_cloud, flags):
+    num_edge_conv = int(flags.EDGE_CONV_LAYERS)
+    num_edge_filters = flags.EDGE_CONV_FILTERS
+    num_fc = int(flags.FC_LAYERS)
+    num_fc_filters = flags.FC_FILTERS
+    is_training = bool(flags.TRAIN)
+    k = int(flags.KVALUE)
+    debug = bool(flags.DEBUG)
+    num_class = int(flags.NUM_CLASS)
+    c = E.ctx()
+
+    if flags.MODEL_NAME not in ("dgcnn", "residual-dgcnn", "residual-dgcnn-nofc"):
+        print("Unsupported MODEL_NAME: %s" % flags.MODEL_NAME)
+        raise NotImplementedError("Unsupported MODEL_NAME: %s" % flags.MODEL_NAME)     # model.py:41-43
+
+    x, B, N = E.as2d(point_cloud)
+    R = B * N
+    ecf = ops._listify(num_edge_filters, num_edge_conv, "num_filters")
+    nofc = flags.MODEL_NAME == "residual-dgcnn-nofc"
+
+    plan = None
+    if not nofc:
+        # one buffer for [L0 max|mean|net, L1 ..., merged(1024)]  (model.py:83-85 without the tiled global)
+        widths = []
+        for f in ecf:
+            widths += [2 * f, 64]
+        ctot = sum(widths) + 1024
+        big = c.new_buffer(R, ctot)
+        merged_in = c.new_buffer(R, 64 * num_edge_conv)          # model.py:60-63 concat of the conv1 outputs
+        offs = []
+        o = 0
+        for f in ecf:
+            offs.append(o)
+            o += 2 * f + 64
+
+        def plan(i):
+            o = offs[i]
+            f = ecf[i]
+            return (big[:, o:o + 2 * f], big[:, o + 2 * f:o + 2 * f + 64]), merged_in[:, 64 * i:64 * (i + 1)]
+
+    if flags.MODEL_NAME == "dgcnn":
+        tensors = ops.repeat_edge_conv(point_cloud, repeat=num_edge_conv, k=k, num_filters=num_edge_filters,
+                                       trainable=is_training, debug=debug, _plan=plan)
+    else:
+        tensors = ops.repeat_residual_edge_conv(point_cloud, repeat=num_edge_conv, k=k,
+                                                num_filters=num_edge_filters, trainable=is_training,
+                                                debug=debug, _plan=plan)
+
+    if nofc:                                                       # model.py:45-58
+        last, _, _ = E.as2d(tensors[-1])
+        fin = E.conv_bn_act(last, "Final", num_class, relu=True)
+        return fin.view(B, N, num_class)
+
+    merged = E.conv_bn_act(merged_in, "MergedEdgeConv", 1024, relu=True, out=big[:, ctot - 1024:])  # model.py:65-72
+    tensors.append(E.rank4(merged, B, N))                          # model.py:74
+    g = E.global_max(merged, B, N)                                 # model.py:76-77 (B,1024)
+
+    # model.py:80-88: concat([tile(g)] + tensors) -> fc.  FC0 is split as described in the docstring.
+    fcf = ops._listify(num_fc_filters, num_fc, "num_filters")
+    if num_fc < 1:
+        raise NotImplementedError("FC_LAYERS=0 is not supported by the HIP path (reference default is 2)")
+    with E.variable_scope("FC0"):
+        wleaf = c.get_variable("weights", (1024 + ctot, fcf[0]))
+    gb = E.plain_gemm(g, wleaf, (0, 1024), fcf[0])                 # per-cloud term (B, fcf0)
+    net = E.conv_bn_act(big, "FC0", fcf[0], relu=True, gbias=gb, rpg=N, w_rows=(1024, 1024 + ctot, 1024 + ctot))
+    for i in range(1, num_fc):                                     # ops.py:151-160
+        net = E.conv_bn_act(net, "FC%d" % i, fcf[i], relu=True)
+    if is_training:
+        net = E.dropout(net, E.DROPOUT_KEEP)                       # model.py:90-91
+    fin = E.conv_bn_act(net, "Final", num_class, relu=True)        # model.py:94-101 (BN + ReLU on the logits)
+    return fin.view(B, N, num_class)                                # model.py:104 squeeze

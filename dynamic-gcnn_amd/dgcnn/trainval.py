@@ -1,0 +1,188 @@
+"""MI355X-native counterpart of dgcnn/trainval.py:7-129 (same class name and method surface).
+
+Reference: one process, one TF tower per entry of flags.GPUS, gradients copied to the host and
+averaged there (trainval.py:16,64-73).  Here: ONE PROCESS PER GPU (rank r <-> HIP device
+LOCAL_RANK); each process runs the towers it was given (normally one) on its own device, adds the
+tower-mean gradient into a flat fp32 accumulator (sum over micro-steps, trainval.py:75-79), and
+`apply_gradient` issues ONE RCCL all-reduce of that 7.2 MB bucket over xGMI (torch.distributed
+backend "nccl" == RCCL; "gloo" in the CPU tests of the host logic), scales by 1/world and runs a
+fused Adam (tf.train.AdamOptimizer defaults).  BatchNorm statistics stay local to a replica, as
+in the reference.  `sess` arguments are accepted and ignored.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+
+from . import _engine as E
+from . import _hip as H
+from . import model
+
+
+def param_specs(flags, num_channel):
+    """[(name, shape)] in the creation order of tf.trainable_variables()."""
+    from .ops import _listify
+    L = int(flags.EDGE_CONV_LAYERS)
+    ecf = _listify(flags.EDGE_CONV_FILTERS, L, "num_filters")
+    residual = flags.MODEL_NAME in ("residual-dgcnn", "residual-dgcnn-nofc")
+    specs = []
+    cin = int(num_channel)
+    for i in range(L):
+        s = "EdgeConv%d" % i
+        specs += [(s + "/conv0/weights", (2 * cin, ecf[i])), (s + "/conv0/BatchNorm/beta", (ecf[i],)),
+                  (s + "/conv1/weights", (2 * ecf[i], 64)), (s + "/conv1/BatchNorm/beta", (64,))]
+        if residual and i > 0 and ecf[i] != ecf[i - 1]:
+            specs += [(s + "/shortcut/weights", (64, ecf[i])), (s + "/shortcut/BatchNorm/beta", (ecf[i],))]
+        cin = 64
+    nc = int(flags.NUM_CLASS)
+    if flags.MODEL_NAME == "residual-dgcnn-nofc":
+        return specs + [("Final/weights", (64, nc)), ("Final/BatchNorm/beta", (nc,))]
+    specs += [("MergedEdgeConv/weights", (64 * L, 1024)), ("MergedEdgeConv/BatchNorm/beta", (1024,))]
+    cin = 1024 + sum(2 * f + 64 for f in ecf) + 1024
+    fcl = int(flags.FC_LAYERS)
+    fcf = _listify(flags.FC_FILTERS, fcl, "num_filters")
+    for i in range(fcl):
+        specs += [("FC%d/weights" % i, (cin, fcf[i])), ("FC%d/BatchNorm/beta" % i, (fcf[i],))]
+        cin = fcf[i]
+    return specs + [("Final/weights", (cin, nc)), ("Final/BatchNorm/beta", (nc,))]
+
+
+class trainval(object):
+
+    def __init__(self, flags):
+        self._flags = flags
+
+    # ------------------------------------------------------------------ trainval.py:12-85
+    def initialize(self):
+        f = self._flags
+        if f.MODEL_NAME not in ("dgcnn", "residual-dgcnn", "residual-dgcnn-nofc"):
+            raise NotImplementedError("Unsupported MODEL_NAME: %s" % f.MODEL_NAME)
+        self._ctx = E.reset()
+        self._ctx.seed = int(getattr(f, "SEED", 1)) if int(getattr(f, "SEED", 1)) >= 0 else 1
+        self._ctx.allocate_variables(param_specs(f, int(f.NUM_CHANNEL)), seed=self._ctx.seed)
+        self._lr = float(f.LEARNING_RATE)
+        self._world = 1
+        self._dist = None
+        try:
+            import torch.distributed as dist
+            if dist.is_available() and dist.is_initialized():
+                self._dist = dist
+                self._world = dist.get_world_size()
+                dist.broadcast(self._ctx.flat_param, src=0)     # variables are shared by all towers (AUTO_REUSE)
+        except ImportError:
+            pass
+        return self
+
+    @property
+    def variables(self):
+        return self._ctx.vars
+
+    @property
+    def gradients(self):
+        return self._ctx.var_grads
+
+    def feed_dict(self, data, label=None, weight=None):
+        """trainval.py:87-95: one entry per tower (GPU) in each list."""
+        res = {"data": list(data)}
+        if label is not None:
+            res["label"] = list(label)
+        if weight is not None:
+            res["weight"] = list(weight)
+        n = len(res["data"])
+        for key in ("label", "weight"):
+            if key in res and len(res[key]) != n:
+                raise ValueError("feed_dict: %d data towers but %d %s towers" % (n, len(res[key]), key))
+        return res
+
+    def _to_dev(self, a, dtype):
+        if a is None:
+            return None
+        t = a if isinstance(a, torch.Tensor) else torch.as_tensor(a)
+        return t.to(device=self._ctx.device, dtype=dtype, non_blocking=True).contiguous()
+
+    def _tower(self, data, label, weight, train):
+        """forward (+ backward when train) of one tower; returns (softmax (MBS,N,ncls), scal[loss, acc])."""
+        c = self._ctx
+        pts = self._to_dev(data, torch.float32)
+        lab = self._to_dev(label, torch.int32)
+        wgt = self._to_dev(weight, torch.float32)
+        if pts.dim() != 3:
+            raise ValueError("points must be (MINIBATCH_SIZE, N, NUM_CHANNEL), got %s" % (tuple(pts.shape),))
+        c.begin_step()
+        c.recording = bool(train)
+        logits = model.build(pts, self._flags)                       # trainval.py:38
+        B, N, ncls = logits.shape
+        sm, scal = E.softmax_loss(logits.view(B * N, ncls), None if lab is None else lab.view(-1),
+                                  None if wgt is None else wgt.view(-1), want_grad=bool(train))
+        if train:
+            c.backward()                                             # compute_gradients, trainval.py:54
+        c.recording = False
+        return sm.view(B, N, ncls), scal
+
+    def make_summary(self, sess, data, label, weight):
+        if not self._flags.TRAIN:
+            raise NotImplementedError
+        res = self.inference(sess, data, label, weight)
+        return {"accuracy": float(res[-2]), "loss": float(res[-1])}
+
+    def inference(self, sess, data, label=None, weight=None):
+        """trainval.py:103-108: [softmax_tower0, ..., (accuracy, loss)]."""
+        fd = self.feed_dict(data, label, weight)
+        outs, scals = [], []
+        for i in range(len(fd["data"])):
+            sm, scal = self._tower(fd["data"][i], fd["label"][i] if label is not None else None,
+                                   fd["weight"][i] if weight is not None else None, train=False)
+            outs.append(sm)
+            scals.append(scal)
+        if label is not None:
+            s = torch.stack(scals).mean(0)                           # trainval.py:59-60
+            outs += [s[1], s[0]]
+        return outs
+
+    def accum_gradient(self, sess, data, label, weight=None, summary=False):
+        """trainval.py:110-119: [accum_results, accuracy, loss(, summary)]; tower-mean gradient is
+        ADDED to the accumulators (sum over micro-steps, trainval.py:79)."""
+        if not self._flags.TRAIN:
+            raise NotImplementedError
+        c = self._ctx
+        fd = self.feed_dict(data, label, weight)
+        T = len(fd["data"])
+        saved = None
+        if T > 1:
+            saved = c.flat_grad.clone()
+            c.flat_grad.zero_()
+        scals = []
+        for i in range(T):
+            _, scal = self._tower(fd["data"][i], fd["label"][i], fd["weight"][i] if weight is not None else None,
+                                  train=True)
+            scals.append(scal)
+        if T > 1:                                                     # mean over towers, trainval.py:64-73
+            H.call("dgcnn_axpby_f32", saved.data_ptr(), 1.0, c.flat_grad.data_ptr(), 1.0 / T, c.flat_grad.numel())
+        s = scals[0] if T == 1 else torch.stack(scals).mean(0)
+        res = [c.flat_grad, s[1], s[0]]
+        if summary:
+            res.append({"accuracy": s[1], "loss": s[0]})
+        return res
+
+    def zero_gradients(self, sess):
+        if not self._flags.TRAIN:
+            raise NotImplementedError
+        self._ctx.flat_grad.zero_()                                   # trainval.py:76
+        return [self._ctx.flat_grad]
+
+    def apply_gradient(self, sess):
+        """trainval.py:80,126-129 + the cross-replica mean of :64-73 (one flat RCCL all-reduce)."""
+        if not self._flags.TRAIN:
+            raise NotImplementedError
+        c = self._ctx
+        g = c.flat_grad
+        if self._world > 1:
+            self._dist.all_reduce(g)                                  # sum over replicas
+            H.call("dgcnn_axpby_f32", g.data_ptr(), 1.0 / self._world, g.data_ptr(), 0.0, g.numel())
+        c.adam_t += 1
+        b1, b2, eps = 0.9, 0.999, 1e-8                                # tf.train.AdamOptimizer defaults
+        lr_t = self._lr * math.sqrt(1.0 - b2 ** c.adam_t) / (1.0 - b1 ** c.adam_t)
+        H.call("dgcnn_adam_f32", c.flat_param.data_ptr(), g.data_ptr(), c.flat_m.data_ptr(), c.flat_v.data_ptr(),
+               g.numel(), lr_t, b1, b2, eps)
+        return None

@@ -1,0 +1,150 @@
+/*
+ * dgcnn_hip.h -- C ABI of libdgcnn_hip.so: the MI355X (gfx950) EdgeConv hot path of DGCNN.
+ *
+ * The reference (DeepLearnPhysics/dynamic-gcnn) has no FFI of its own: its hot path is Python
+ * that composes stock TensorFlow-1 ops.  Each entry point below therefore names
+ * the reference *call site* (file:line under /root/reference) whose TF op group it replaces; the
+ * Python mirror of the reference's operator surface (dynamic-gcnn_amd/dgcnn/{ops,model,trainval}.py)
+ * binds exactly these symbols through ctypes.
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative DGCNN_E* code; dgcnn_last_error() gives
+ *     the message of the last failure on the calling thread;
+ *   - all pointers are DEVICE pointers owned by the caller (the library allocates nothing and
+ *     keeps no state), tensors are dense row-major fp32 unless a leading dimension `ld*`
+ *     (in elements) is given; indices are batch-local int32;
+ *   - every call is asynchronous on the caller-supplied hipStream_t (passed as void*);
+ *   - `stats` buffers are double[DGCNN_STAT_SLOTS][2][F] (sum, sum of squares), zeroed by the
+ *     caller, accumulated by the producing kernel's epilogue, reduced by dgcnn_bn_finalize_f32.
+ */
+#ifndef DGCNN_HIP_H_
+#define DGCNN_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DGCNN_OK 0
+#define DGCNN_EINVAL (-1)   /* bad argument (e.g. k > N: tf.nn.top_k would raise, dgcnn/ops.py:18) */
+#define DGCNN_ELAUNCH (-2)  /* HIP launch/runtime error */
+#define DGCNN_ENOSPC (-3)   /* workspace too small */
+#define DGCNN_EUNSUP (-4)   /* shape not supported by this build */
+
+#define DGCNN_STAT_SLOTS 32
+
+int dgcnn_version(void);
+const char* dgcnn_last_error(void);
+
+/* ---- K1: dgcnn/ops.py:8-19 k_nn --------------------------------------------------------
+ * idx[b][i][0..k) = the k smallest D_ij = (s_i + s_j) - 2 <x_i,x_j> of row i (self included),
+ * ascending, ties -> lower j.  Arithmetic order is normative (oracle/knn_oracle.c): bit-exact.
+ * x: (B,N,C) with row stride ldx.  No (B,N,N) matrix is ever written to HBM.
+ * sq_ws: caller scratch of dgcnn_knn_workspace_bytes(B,N) bytes (the s_i of ops.py:14). */
+int dgcnn_knn_workspace_bytes(int B, int N);
+int dgcnn_knn_f32(const float* x, int B, int N, int C, int64_t ldx, int k, int32_t* idx,
+                  float* sq_ws, void* stream);
+
+/* ---- K2: dgcnn/ops.py:21-40 edges (gather + tile + sub + concat) ------------------------
+ * E[b][i][m][0..C) = x_i ; E[b][i][m][C..2C) = x_{idx[b][i][m]} - x_i.                    */
+int dgcnn_edge_gather_f32(const float* x, int64_t ldx, const int32_t* idx, int B, int N, int C, int k,
+                          float* E, void* stream);
+/* transpose of the above (tf.gather^T = scatter-add, tf.tile^T = sum over k): dx += ...   */
+int dgcnn_edge_gather_bwd_f32(const float* dE, const int32_t* idx, int B, int N, int C, int k,
+                              float* dx, int64_t lddx, void* stream);
+
+/* ---- K3: dgcnn/ops.py:47-52 slim.conv2d 1x1 on the edge tensor (conv0) --------------------
+ * Y[(b,i,m)][f] = sum_c E[(b,i,m)][c] W0[c][f], E gathered on the fly from (x, idx) into the LDS
+ * A-tile (never written to HBM); fp32 MFMA; epilogue accumulates per-channel sum / sum-of-squares
+ * of Y for the batch-norm statistics (ops.py:53).                                           */
+int dgcnn_edge_mlp_f32(const float* x, int64_t ldx, const int32_t* idx, const float* W0,
+                       int B, int N, int C, int k, int F, float* Y, double* stats, void* stream);
+/* dW0[2C][F] (+)= E^T dY  (split over the edge dimension; ws = workspace)                   */
+int dgcnn_edge_mlp_wgrad_f32(const float* x, int64_t ldx, const int32_t* idx, const float* dY,
+                             int B, int N, int C, int k, int F, float* dW0, float beta,
+                             void* ws, size_t ws_bytes, void* stream);
+/* dx[nbr] += dY W0[C:2C]^T (scatter, fp32 atomics); the centre part
+ * dx[i] += (sum_m dY[i,m]) (W0[:C]-W0[C:])^T is a plain GEMM issued by the host.            */
+int dgcnn_edge_mlp_dgrad_scatter_f32(const float* dY, const float* W0, const int32_t* idx,
+                                     int B, int N, int C, int k, int F, float* dx, int64_t lddx,
+                                     void* stream);
+
+/* ---- plain fp32 MFMA GEMM: every other slim.conv2d 1x1 (ops.py:62-70,125-133,153-160;
+ * model.py:46-53,65-72,94-101) and their dgrad / wgrad --------------------------------------
+ * C[M][N] = op(A)[M][K] op(B)[K][N] (+ beta*C) (+ gbias[row / rows_per_group][n]);
+ * transA: A stored [K][M]; transB: B stored [N][K].  stats (optional): BN sums of C's columns.
+ * ws is needed when the library decides to split K (transA, tall reductions).                */
+int dgcnn_gemm_f32(int transA, int transB, int M, int N, int K,
+                   const float* A, int64_t lda, const float* B, int64_t ldb,
+                   float* C, int64_t ldc, float beta,
+                   const float* gbias, int64_t ldgbias, int rows_per_group,
+                   double* stats, void* ws, size_t ws_bytes, void* stream);
+
+/* ---- K4/K5: slim.batch_norm (ops.py:53,68 ...) + activation + reduce_max/mean (ops.py:56-57)
+ * mean/rstd from the stats slots: mean = S/count, var = Q/count - mean^2 (double), rstd=1/sqrt(var+eps) */
+int dgcnn_bn_finalize_f32(const double* stats, int F, double count, float eps,
+                          float* mean, float* rstd, void* stream);
+/* z = (Y - mean)*rstd + beta ; relu? ; over the k rows of each of the R points:
+ * max_out[r][f] = max_m z, mean_out[r][f] = (sum_m z)/k.  k = 1: out = act(bn(Y)) -> max_out
+ * (mean_out may be NULL; out2 optionally receives a second copy of max_out).                 */
+int dgcnn_bn_act_kreduce_f32(const float* Y, int64_t R, int k, int F,
+                             const float* mean, const float* rstd, const float* beta, int relu,
+                             float* max_out, int64_t ldmax, float* mean_out, int64_t ldmean,
+                             float* out2, int64_t ldout2, void* stream);
+/* backward, pass 1: red[0][f] = sum dZ, red[1][f] = sum dZ*xhat over all R*k rows, where
+ * dZ = relu'(z) * ( dmax*[z==max]/ties + dmean/k ).  red: double[DGCNN_STAT_SLOTS][2][F], zeroed. */
+int dgcnn_bn_bwd_reduce_f32(const float* Y, int64_t R, int k, int F,
+                            const float* mean, const float* rstd, const float* beta, int relu,
+                            const float* dmax, int64_t lddmax, const float* dmean, int64_t lddmean,
+                            double* red, void* stream);
+/* backward, pass 2: dY = rstd*(dZ - red0/cnt - xhat*red1/cnt) written to dY (may alias Y);
+ * dbeta[f] (+)= red0 ; dYsum[r][f] = sum_m dY (optional, feeds the centre dgrad).
+ * `red` is reduced over its slots in place (slot 0 then holds the totals).                  */
+int dgcnn_bn_bwd_apply_f32(const float* Y, int64_t R, int k, int F,
+                           const float* mean, const float* rstd, const float* beta, int relu,
+                           const float* dmax, int64_t lddmax, const float* dmean, int64_t lddmean,
+                           double* red, float* dY, float* dYsum, float* dbeta, float dbeta_beta,
+                           void* stream);
+
+/* ---- head helpers (model.py:76-91) and residual add (ops.py:134) -------------------------- */
+/* max_pool_v2 over the N points of each cloud: out[b][f] = max_i x[b][i][f], arg[b][f] = first i */
+int dgcnn_global_max_f32(const float* x, int64_t ldx, int B, int N, int F, float* out, int32_t* arg,
+                         void* stream);
+/* its gradient: dx[b][arg[b][f]][f] += dout[b][f] */
+int dgcnn_global_max_bwd_f32(const float* dout, const int32_t* arg, int B, int N, int F,
+                             float* dx, int64_t lddx, void* stream);
+/* out[g][f] = sum over the rows_per_group rows of group g (tf.tile^T, model.py:81) */
+int dgcnn_group_colsum_f32(const float* x, int64_t ldx, int G, int rows_per_group, int F,
+                           float* out, void* stream);
+/* tf.nn.dropout(net, keep) (model.py:91): counter-based RNG keyed by (seed, element index) so the
+ * backward regenerates the same mask.  y may alias x. */
+int dgcnn_dropout_f32(const float* x, float* y, int64_t n, float keep, uint64_t seed, void* stream);
+/* out = relu(a + b) (ops.py:134); bwd: d = dout * [out > 0] */
+int dgcnn_add_relu_f32(const float* a, int64_t lda, const float* b, int64_t ldb, int64_t R, int F,
+                       float* out, int64_t ldo, void* stream);
+int dgcnn_relu_bwd_f32(const float* dout, int64_t lddo, const float* out, int64_t ldo, int64_t R, int F,
+                       float* d, int64_t ldd, void* stream);
+/* strided 2-D copy / accumulate: dst (+)= src   (views of concatenated buffers, tf.concat) */
+int dgcnn_copy2d_f32(const float* src, int64_t lds, float* dst, int64_t ldd, int64_t R, int F,
+                     int accumulate, void* stream);
+
+/* ---- dgcnn/trainval.py:39-52: softmax, accuracy, sparse softmax CE (x weight), mean --------
+ * scal[0] += sum loss*w / rows ; scal[1] += #correct / rows (caller zeroes scal).
+ * dlogits = (softmax - onehot) * w / rows (NULL to skip); softmax optional.                   */
+int dgcnn_softmax_xent_f32(const float* logits, const int32_t* labels, const float* weight,
+                           int64_t rows, int ncls, float* softmax, float* dlogits, float* scal,
+                           void* stream);
+
+/* ---- dgcnn/trainval.py:17,75-80: accumulators + tf.train.AdamOptimizer ---------------------- */
+/* y = a*x + b*y over n elements */
+int dgcnn_axpby_f32(const float* x, float a, float* y, float b, int64_t n, void* stream);
+/* one Adam step on a flat parameter bucket; lr_t = lr*sqrt(1-b2^t)/(1-b1^t) computed by caller */
+int dgcnn_adam_f32(float* param, const float* grad, float* m, float* v, int64_t n,
+                   float lr_t, float b1, float b2, float eps, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DGCNN_HIP_H_ */

@@ -1,0 +1,377 @@
+"""GPU parity tests (run with -m gpu on an MI355X): every HIP entry point, called through the
+C ABI via the dgcnn package, against the CPU oracle on identical seeded inputs.
+
+Bars (BASELINE.json north_star): k-NN indices bit-exact; floating point within the tolerance
+written at each assert (logits 1e-3 absolute, fp32)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import dgcnn_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def host(t):
+    return t.detach().cpu().numpy()
+
+
+@pytest.fixture()
+def dg():
+    import dgcnn
+    dgcnn.reset()
+    return dgcnn
+
+
+def _assert_idx_equal(idx_gpu, idx_ref, what):
+    a, b = host(idx_gpu), idx_ref
+    if not np.array_equal(a, b):
+        bad = np.argwhere((a != b).any(-1))
+        raise AssertionError("%s: %d / %d rows differ, first %s: gpu %s ref %s" % (
+            what, len(bad), a.shape[0] * a.shape[1], bad[0], a[tuple(bad[0])], b[tuple(bad[0])]))
+
+
+# ------------------------------------------------------------------------------------------
+# K1 k_nn: bit-exact indices
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("B,N,C,k,kind", [
+    (2, 64, 3, 5, "uniform"),          # golden G1 shape
+    (2, 100, 3, 7, "integer"),         # ties + duplicates, N not a multiple of 64 (G2)
+    (2, 256, 64, 20, "relu"),          # feature-space graph, many zeros (G3)
+    (1, 130, 4, 8, "uniform"),         # C = 4 inputs (iotool.py:82), ragged N
+    (2, 512, 3, 10, "uniform"),        # BASELINE config 1
+    (1, 300, 64, 40, "relu"),          # production k = 40 (scripts/lsf/train_dgcnn.sh:8)
+    (1, 64, 3, 64, "integer"),         # k == N: everything selected
+    (1, 200, 20, 33, "uniform"),       # odd C / k, exercises padding and the 64-slot list
+    (3, 2048, 3, 20, "uniform"),       # headline N, k
+    (2, 2048, 64, 20, "relu"),
+])
+def test_knn_bit_exact(dg, B, N, C, k, kind):
+    rng = np.random.default_rng(B * 1000 + N + C + k)
+    if kind == "uniform":
+        pts = rng.random((B, N, C), dtype=np.float32)
+    elif kind == "integer":
+        pts = rng.integers(0, 6, (B, N, C)).astype(np.float32)
+    else:
+        pts = np.maximum(rng.normal(0, 1, (B, N, C)), 0).astype(np.float32)
+    ref = O.k_nn(pts, k)
+    idx = dg.ops.k_nn(dev(pts), k)
+    assert idx.dtype == torch.int32 and tuple(idx.shape) == (B, N, k)
+    _assert_idx_equal(idx, ref, "k_nn %s" % ((B, N, C, k, kind),))
+
+
+def test_knn_strided_view_and_errors(dg):
+    rng = np.random.default_rng(5)
+    wide = rng.random((2, 128, 200), dtype=np.float32)
+    t = dev(wide)[:, :, 72:136]                       # 64 channels inside a wider buffer (ld = 200)
+    ref = O.k_nn(np.ascontiguousarray(wide[:, :, 72:136]), 9)
+    _assert_idx_equal(dg.ops.k_nn(t, 9), ref, "strided")
+    with pytest.raises(ValueError):
+        dg.ops.k_nn(dev(wide[:, :4, :3]), 5)           # N < k  (tf.nn.top_k raises)
+    with pytest.raises(Exception):
+        dg.ops.k_nn(torch.zeros(1, 8, 3), 2)           # CPU tensor: no fallback
+
+
+def test_knn_headline_shape_properties(dg):
+    """(24,2048,3) k=20: full bit-exact compare + size-independent properties."""
+    rng = np.random.default_rng(0)
+    pts = rng.random((24, 2048, 3), dtype=np.float32)
+    idx = host(dg.ops.k_nn(dev(pts), 20))
+    assert idx.min() >= 0 and idx.max() < 2048
+    assert ((idx == np.arange(2048)[None, :, None]).sum(-1) == 1).all()     # self is always among the k (ops.py:18: no exclusion)
+    for b in (0, 11, 23):
+        D = O.dist_matrix_f32(pts[b])
+        dsel = np.take_along_axis(D, idx[b].astype(np.int64), 1)
+        assert (np.diff(dsel, axis=1) >= 0).all()                    # ascending
+        kth = dsel[:, -1:]
+        assert ((D < kth).sum(1) <= 19).all()                        # nothing closer was left out
+    np.testing.assert_array_equal(idx, O.k_nn(pts, 20))
+
+
+# ------------------------------------------------------------------------------------------
+# K2 edges
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("B,N,C,k", [(2, 64, 3, 5), (1, 96, 64, 20)])
+def test_edges_exact(dg, B, N, C, k):
+    rng = np.random.default_rng(1)
+    pts = rng.random((B, N, C), dtype=np.float32)
+    E = host(dg.ops.edges(dev(pts), k))
+    np.testing.assert_array_equal(E, O.edges(pts, k))                # gather + one subtract: exact
+
+
+# ------------------------------------------------------------------------------------------
+# GEMM family
+# ------------------------------------------------------------------------------------------
+def _gemm(dg, A, B, C, **kw):
+    from dgcnn import _engine as E
+    E.gemm(A, B, C, **kw)
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 64, 16), (300, 70, 50), (1024, 512, 192), (257, 2, 256), (640, 128, 6),
+                                   (129, 130, 131)])
+def test_gemm_nn_nt(dg, M, N, K):
+    rng = np.random.default_rng(M + N + K)
+    A = rng.normal(size=(M, K)).astype(np.float32)
+    B = rng.normal(size=(K, N)).astype(np.float32)
+    ref = A.astype(np.float64) @ B.astype(np.float64)
+    tol = 2e-6 * K ** 0.5 * 4 + 1e-5
+    C = torch.empty((M, N), device="cuda")
+    _gemm(dg, dev(A), dev(B), C)
+    np.testing.assert_allclose(host(C), ref, rtol=1e-5, atol=tol)
+    # NT: B given as [N][K]
+    C2 = torch.empty((M, N), device="cuda")
+    _gemm(dg, dev(A), dev(B.T.copy()), C2, transB=True)
+    np.testing.assert_allclose(host(C2), ref, rtol=1e-5, atol=tol)
+    # beta = 1 accumulate
+    C3 = dev(np.ones((M, N), np.float32))
+    _gemm(dg, dev(A), dev(B), C3, beta=1.0)
+    np.testing.assert_allclose(host(C3), ref + 1, rtol=1e-5, atol=tol)
+
+
+@pytest.mark.parametrize("M,N,K", [(192, 1024, 3000), (128, 64, 8192), (6, 64, 5000), (1728, 512, 4096), (70, 3, 1000)])
+def test_gemm_tn_splitk(dg, M, N, K):
+    rng = np.random.default_rng(M + N + K)
+    X = rng.normal(size=(K, M)).astype(np.float32)      # stored [K][M]
+    dY = rng.normal(size=(K, N)).astype(np.float32)
+    ref = X.astype(np.float64).T @ dY.astype(np.float64)
+    C = dev(np.full((M, N), 2.0, np.float32))
+    _gemm(dg, dev(X), dev(dY), C, transA=True, beta=1.0)
+    np.testing.assert_allclose(host(C), ref + 2, rtol=1e-4, atol=1e-5 * K ** 0.5 * 4)
+
+
+def test_gemm_strided_stats_and_group_bias(dg):
+    from dgcnn import _engine as E
+    rng = np.random.default_rng(7)
+    R, Cin, F, G = 384, 96, 64, 3
+    wide = rng.normal(size=(R, 300)).astype(np.float32)
+    A = dev(wide)[:, 100:100 + Cin]
+    W = rng.normal(size=(Cin, F)).astype(np.float32)
+    gb = rng.normal(size=(G, F)).astype(np.float32)
+    outw = torch.zeros((R, 200), device="cuda")
+    C = outw[:, 40:40 + F]
+    st = torch.zeros(E.H.STAT_SLOTS * 2 * F, dtype=torch.float64, device="cuda")
+    E.gemm(A, dev(W), C, gbias=dev(gb), rpg=R // G, stats=st)
+    ref = wide[:, 100:100 + Cin].astype(np.float64) @ W + np.repeat(gb, R // G, 0)
+    np.testing.assert_allclose(host(C), ref, rtol=1e-5, atol=1e-4)
+    assert host(outw)[:, :40].max() == 0 and host(outw)[:, 40 + F:].max() == 0     # nothing outside the slice
+    s = host(st).reshape(E.H.STAT_SLOTS, 2, F).sum(0)
+    np.testing.assert_allclose(s[0], ref.sum(0), rtol=1e-5, atol=1e-3)
+    np.testing.assert_allclose(s[1], (ref ** 2).sum(0), rtol=1e-5, atol=1e-3)
+    mean, rstd = E.bn_finalize(st, F, R)
+    np.testing.assert_allclose(host(mean), ref.mean(0), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(host(rstd), 1 / np.sqrt(ref.var(0) + 1e-3), rtol=1e-5)
+
+
+# ------------------------------------------------------------------------------------------
+# edge_conv block: forward + backward against the oracle
+# ------------------------------------------------------------------------------------------
+def _set_vars(dg, params):
+    c = dg.ctx()
+    for n, v in params.items():
+        c.set_variable(n, v)
+
+
+@pytest.mark.parametrize("B,N,C,k,F", [(2, 64, 3, 5, 8), (2, 128, 64, 20, 64), (1, 96, 4, 7, 128), (2, 64, 64, 10, 32)])
+def test_edge_conv_forward_backward(dg, B, N, C, k, F):
+    """max / mean / net and gradients w.r.t. X, W0, beta0, W1, beta1."""
+    from dgcnn import _engine as E
+    rng = np.random.default_rng(C * 10 + F)
+    pts = rng.random((B, N, C), dtype=np.float32)
+    P = {"conv0/weights": rng.normal(0, 0.5, (2 * C, F)).astype(np.float32),
+         "conv0/BatchNorm/beta": rng.normal(0, 0.3, F).astype(np.float32),
+         "conv1/weights": rng.normal(0, 0.3, (2 * F, 64)).astype(np.float32),
+         "conv1/BatchNorm/beta": rng.normal(0, 0.3, 64).astype(np.float32)}
+    c = dg.ctx()
+    c.begin_step()
+    c.recording = True
+    x = c.new_buffer(B * N, C)                 # tracked, so that d(point_cloud) is produced
+    x.copy_(dev(pts.reshape(B * N, C)))
+    for n, v in P.items():                     # create the variables, then load the oracle's values
+        c.get_variable(n, v.shape)
+    _set_vars(dg, P)
+    outs = dg.ops.edge_conv(x.view(B, N, C), k, F, True)
+    idx = host(dg.ops.edge_conv.last_idx)
+    np.testing.assert_array_equal(idx, O.k_nn(pts, k))
+
+    ref, cache = O.edge_conv(pts.astype(np.float64), k, *[P[n].astype(np.float64) for n in P], idx=idx)
+    for name, a, b in zip(("max", "mean", "net"), outs, ref):
+        assert tuple(a.shape) == b.shape                      # (B,N,1,ch): ops.py:73
+        np.testing.assert_allclose(host(a), b, rtol=1e-4, atol=1e-4, err_msg=name)   # tol 1e-4 (fp32 vs fp64 twin)
+
+    d = [rng.normal(size=r.shape) for r in ref]
+    for t, g in zip(outs, d):
+        v, _, _ = E.as2d(t)
+        c.grad(v).copy_(dev(g.reshape(B * N, -1).astype(np.float32)))
+    c.backward()
+    dx_ref, g_ref = O.edge_conv_bwd(d[0], d[1], d[2], cache)
+    scale = lambda r: 1e-3 * max(1.0, float(np.abs(r).max()))
+    np.testing.assert_allclose(host(c.grad(x)).reshape(B, N, C), dx_ref, rtol=1e-3, atol=scale(dx_ref), err_msg="dx")
+    for n, key in (("conv0/weights", "W0"), ("conv0/BatchNorm/beta", "beta0"), ("conv1/weights", "W1"),
+                   ("conv1/BatchNorm/beta", "beta1")):
+        np.testing.assert_allclose(host(c.var_grads[n]), g_ref[key], rtol=1e-3, atol=scale(g_ref[key]), err_msg=n)
+
+
+# ------------------------------------------------------------------------------------------
+# model.build: logits within 1e-3 of the oracle (north_star), all three MODEL_NAMEs
+# ------------------------------------------------------------------------------------------
+def _run_model(dg, flags, pts, params, train, labels=None):
+    from dgcnn import _engine as E
+    tv = dg.trainval(flags)
+    tv.initialize()
+    _set_vars(dg, params)
+    cap = {}
+    orig = E.edge_conv_block
+
+    def capture(x, B, N, k, F, **kw):
+        mm, net, idx = orig(x, B, N, k, F, **kw)
+        cap["/".join(E.ctx().scope)] = (host(x).reshape(B, N, -1).copy(), host(idx))
+        return mm, net, idx
+    E.edge_conv_block = capture
+    try:
+        if train:
+            tv.zero_gradients(None)
+            res = tv.accum_gradient(None, [pts], [labels])
+        else:
+            res = tv.inference(None, [pts], None if labels is None else [labels])
+    finally:
+        E.edge_conv_block = orig
+    return tv, res, cap
+
+
+CONFIGS = [
+    # BASELINE config 1: B=2 N=512 k=10 C=3, 1 EdgeConv layer, FC 512,256, 2 classes
+    dict(MODEL_NAME="dgcnn", EDGE_CONV_LAYERS=1, EDGE_CONV_FILTERS=64, KVALUE=10, B=2, N=512, C=3),
+    # config-2 architecture at reduced B, N
+    dict(MODEL_NAME="dgcnn", EDGE_CONV_LAYERS=3, EDGE_CONV_FILTERS=[64, 64, 128], KVALUE=20, B=3, N=256, C=3),
+    dict(MODEL_NAME="residual-dgcnn", EDGE_CONV_LAYERS=3, EDGE_CONV_FILTERS=64, KVALUE=12, B=2, N=192, C=4),   # G8
+    dict(MODEL_NAME="residual-dgcnn-nofc", EDGE_CONV_LAYERS=2, EDGE_CONV_FILTERS=64, KVALUE=8, B=2, N=128, C=3),
+]
+
+
+@pytest.mark.parametrize("cfg", CONFIGS)
+def test_model_logits_and_gradients(dg, cfg):
+    cfg = dict(cfg)
+    B, N, C = cfg.pop("B"), cfg.pop("N"), cfg.pop("C")
+    flags = dg.DGCNN_FLAGS(NUM_CLASS=2, FC_LAYERS=2, FC_FILTERS=[512, 256], TRAIN=False, NUM_CHANNEL=C, **cfg)
+    rng = np.random.default_rng(0)
+    pts = rng.random((B, N, C), dtype=np.float32)
+    labels = rng.integers(0, 2, (B, N)).astype(np.int32)
+    params = O.init_params(flags, C, seed=1)
+    for n in params:
+        if n.endswith("beta"):
+            params[n] = rng.normal(0, 0.2, params[n].shape).astype(np.float32)
+
+    # ---- inference graph (TRAIN False: no dropout), logits via softmax inversion is lossy -> use build()
+    tv, res, cap = _run_model(dg, flags, pts, params, train=False, labels=labels)
+    L = int(flags.EDGE_CONV_LAYERS)
+    idx_list = []
+    for i in range(L):
+        xin, idx = cap["EdgeConv%d" % i]
+        np.testing.assert_array_equal(idx, O.k_nn(xin, int(flags.KVALUE)))       # bit-exact on identical inputs
+        idx_list.append(idx)
+    logits_ref, _ = O.model_forward(pts, flags, params, idx_list=idx_list)
+    loss_ref, sm_ref, acc_ref, _ = O.softmax_xent(logits_ref, labels)
+    import dgcnn
+    dg.ctx().recording = False
+    logits = host(dgcnn.build(dev(pts), flags))
+    assert logits.shape == (B, N, 2)
+    np.testing.assert_allclose(logits, logits_ref, rtol=0, atol=1e-3)             # north_star: 1e-3 fp32
+    np.testing.assert_allclose(host(res[0]), sm_ref, rtol=0, atol=1e-3)
+    assert abs(float(res[-1]) - float(loss_ref)) < 1e-3 and abs(float(res[-2]) - float(acc_ref)) < 2.0 / (B * N)
+
+    # ---- training graph without dropout randomness: compare every gradient with the fp64 twin
+    flags.TRAIN = True
+    import dgcnn._engine as E
+    keep = E.DROPOUT_KEEP
+    E.DROPOUT_KEEP = 1.0
+    try:
+        tv, res, cap = _run_model(dg, flags, pts, params, train=True, labels=labels)
+    finally:
+        E.DROPOUT_KEEP = keep
+    idx_list = [cap["EdgeConv%d" % i][1] for i in range(L)]
+    p64 = {n: v.astype(np.float64) for n, v in params.items()}
+    G, loss64, _, _ = O.train_step_grads(pts.astype(np.float64), labels, flags, p64, idx_list=idx_list)
+    assert abs(float(res[2]) - float(loss64)) < 1e-3
+    for n in params:
+        g = host(tv.gradients[n])
+        ref = G[n]
+        tol = 2e-3 * max(float(np.abs(ref).max()), 1e-3)
+        np.testing.assert_allclose(g, ref, rtol=2e-3, atol=tol, err_msg=n)
+
+
+def test_two_microsteps_and_adam(dg):
+    """gradients are SUMMED over micro-steps (trainval.py:79), then one Adam step."""
+    flags = dg.DGCNN_FLAGS(EDGE_CONV_LAYERS=1, KVALUE=6, FC_FILTERS=[32, 16], NUM_CHANNEL=3, TRAIN=True)
+    rng = np.random.default_rng(3)
+    import dgcnn._engine as E
+    keep = E.DROPOUT_KEEP
+    E.DROPOUT_KEEP = 1.0
+    try:
+        tv = dg.trainval(flags).initialize()
+        params = {n: host(v).copy() for n, v in tv.variables.items()}
+        tv.zero_gradients(None)
+        gsum = {n: np.zeros_like(v, dtype=np.float64) for n, v in params.items()}
+        for step in range(2):
+            pts = rng.random((2, 64, 3), dtype=np.float32)
+            lab = rng.integers(0, 2, (2, 64)).astype(np.int32)
+            w = rng.random((2, 64), dtype=np.float32)
+            tv.accum_gradient(None, [pts], [lab], [w])
+            G, _, _, _ = O.train_step_grads(pts.astype(np.float64), lab, flags,
+                                            {n: v.astype(np.float64) for n, v in params.items()}, weight=w)
+            for n in G:
+                gsum[n] += G[n]
+        for n in params:
+            np.testing.assert_allclose(host(tv.gradients[n]), gsum[n], rtol=2e-3,
+                                       atol=2e-3 * max(np.abs(gsum[n]).max(), 1e-3), err_msg=n)
+        tv.apply_gradient(None)
+        for n in params:
+            p = params[n].astype(np.float64).copy()
+            m = np.zeros_like(p)
+            v = np.zeros_like(p)
+            O.adam_step(p, host(tv.gradients[n]).astype(np.float64), m, v, 1, flags.LEARNING_RATE)
+            np.testing.assert_allclose(host(tv.variables[n]), p, rtol=1e-5, atol=1e-6, err_msg=n)
+    finally:
+        E.DROPOUT_KEEP = keep
+
+
+def test_errors_match_reference(dg):
+    flags = dg.DGCNN_FLAGS(MODEL_NAME="nope")
+    with pytest.raises(NotImplementedError):
+        dg.trainval(flags).initialize()
+    with pytest.raises(ValueError):
+        dg.ops.repeat_edge_conv(torch.zeros(1, 32, 3, device="cuda"), 3, [5, 5], 64, True)   # ops.py:80-82
+    f2 = dg.DGCNN_FLAGS(TRAIN=False)
+    tv = dg.trainval(f2).initialize()
+    for call in (lambda: tv.zero_gradients(None), lambda: tv.apply_gradient(None),
+                 lambda: tv.accum_gradient(None, [None], [None])):
+        with pytest.raises(NotImplementedError):                                              # trainval.py:111-128
+            call()
+
+
+def test_dropout_and_misc_kernels(dg):
+    from dgcnn import _engine as E, _hip as H
+    x = torch.ones(1 << 20, device="cuda")
+    y = torch.empty_like(x)
+    H.call("dgcnn_dropout_f32", x.data_ptr(), y.data_ptr(), x.numel(), 0.7, 1234)
+    yh = host(y)
+    kept = (yh != 0)
+    assert abs(kept.mean() - 0.7) < 5e-3 and np.allclose(yh[kept], 1 / 0.7)
+    y2 = torch.empty_like(x)
+    H.call("dgcnn_dropout_f32", x.data_ptr(), y2.data_ptr(), x.numel(), 0.7, 1234)
+    assert torch.equal(y, y2)                                            # same seed -> same mask (backward)
+    rng = np.random.default_rng(0)
+    a = rng.normal(size=(3, 500, 70)).astype(np.float32)
+    a[1, 17] = a[1, 400] = 9.0                                          # tie -> first arg-max
+    c = E.ctx()
+    out = torch.empty((3, 70), device="cuda")
+    arg = torch.empty((3, 70), dtype=torch.int32, device="cuda")
+    H.call("dgcnn_global_max_f32", dev(a).data_ptr(), 70, 3, 500, 70, out.data_ptr(), arg.data_ptr())
+    np.testing.assert_array_equal(host(out), a.max(1))
+    np.testing.assert_array_equal(host(arg), a.argmax(1))
+    cs = torch.empty((3, 70), device="cuda")
+    H.call("dgcnn_group_colsum_f32", dev(a).data_ptr(), 70, 3, 500, 70, cs.data_ptr())
+    np.testing.assert_allclose(host(cs), a.astype(np.float64).sum(1), rtol=1e-5, atol=1e-4)
