@@ -1,0 +1,188 @@
+#!/usr/bin/env python
+"""bench.py -- headline metric of BASELINE.json on MI355X.
+
+  metric : point-clouds/sec, forward+backward (one training micro-step: zero accumulators, forward,
+           loss, backward, gradient all-reduce for N>1, Adam) at (B,N,k,C)=(24,2048,20,3),
+           3 EdgeConv layers (64,64,128) + FC (512,256), 2 classes, fp32 (BASELINE.json configs[1]).
+  step   : one pass of the hot path over one synthetic batch of 24 clouds per GPU (weak scaling:
+           per-GPU work fixed); inputs are resident in HBM before the timed region.
+  value  : clouds processed by ALL ranks / max-over-ranks wall time of K steps.
+
+Launch:  python bench.py [--gpus N --steps K --warmup W]
+   N>1 : python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+            --master-port P bench.py --gpus N --steps K --warmup W      (one rank per GPU, RCCL)
+Prints ONE JSON line on rank 0 (roofline + cpu_baseline objects: see DESIGN.md "Measurement").
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "dynamic-gcnn_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np
+import torch
+
+B, N, K_NN, C = 24, 2048, 20, 3
+PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_HBM_GBS = 8000.0             # HBM3E spec
+
+
+def make_flags(dgcnn, train=True):
+    return dgcnn.DGCNN_FLAGS(MODEL_NAME="dgcnn", EDGE_CONV_LAYERS=3, EDGE_CONV_FILTERS=[64, 64, 128], FC_LAYERS=2,
+                             FC_FILTERS=[512, 256], NUM_CLASS=2, KVALUE=K_NN, NUM_CHANNEL=C, MINIBATCH_SIZE=B,
+                             LEARNING_RATE=1e-3, TRAIN=train, DEBUG=False, SEED=1)
+
+
+def cpu_baseline(clouds=8, iters=2):
+    """The reference graph restated op-for-op on torch-CPU (oracle/torch_twin.py), fwd+bwd, timed on
+    this host's cores on a bounded sample of the same workload."""
+    from oracle import dgcnn_oracle as O
+    from oracle import torch_twin as T
+    ncores = os.cpu_count() or 1
+    torch.set_num_threads(ncores)
+    flags = O.Flags(EDGE_CONV_FILTERS=[64, 64, 128], FC_FILTERS=[512, 256], KVALUE=K_NN, TRAIN=True)
+    rng = np.random.default_rng(0)
+    P = {n: torch.tensor(v, requires_grad=True) for n, v in O.init_params(flags, C, seed=1).items()}
+    pts = torch.from_numpy(rng.random((clouds, N, C), dtype=np.float32))
+    lab = torch.from_numpy(rng.integers(0, 2, (clouds, N)).astype(np.int64))
+    T.train_step(pts[:2], lab[:2], flags, P)           # thread-pool / allocator warm-up
+    ts = []
+    for _ in range(iters):
+        t0 = time.perf_counter()
+        T.train_step(pts, lab, flags, P)
+        ts.append(time.perf_counter() - t0)
+    best = min(ts)
+    return {"value": round(clouds / best, 3), "unit": "clouds/s", "cores": ncores, "kind": "port",
+            "sample": "%d of the 24 clouds (N=2048,k=20,C=3, same model) fwd+bwd, best of %d, %.1f s/iter; "
+                      "torch-CPU op-for-op restatement of the TF1 graph (TF1 itself cannot run, BASELINE.md 2)"
+                      % (clouds, iters, best)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--kernel-table", action="store_true", help="print per-kernel event timings to stderr")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world and world == 1 and args.gpus > 1:
+        raise SystemExit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d bench.py ...`"
+                         % (args.gpus, args.gpus))
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+
+    import dgcnn
+    from dgcnn import _hip as H
+    flags = make_flags(dgcnn)
+    tv = dgcnn.trainval(flags).initialize()
+
+    rng = np.random.default_rng(rank)                     # per-rank synthetic shard
+    pts = torch.from_numpy(rng.random((B, N, C), dtype=np.float32)).cuda()
+    lab = torch.from_numpy(rng.integers(0, 2, (B, N)).astype(np.int32)).cuda()
+
+    def step():
+        tv.zero_gradients(None)
+        res = tv.accum_gradient(None, [pts], [lab])
+        tv.apply_gradient(None)
+        return res
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    # ---- warm-up; the first warm-up step is event-timed per kernel to find the dominant one ----
+    H.TIMER = H.Timer()
+    step()
+    table = H.TIMER.summary()
+    H.TIMER = None
+    dominant = max(table, key=lambda t: table[t][1])
+    for _ in range(max(args.warmup - 1, 0)):
+        step()
+
+    # ---- timed region: exactly K steps, events only around the dominant kernel's launches ----
+    H.TIMER = H.Timer(watch={dominant})
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    dom = H.TIMER.summary()[dominant]
+    H.TIMER = None
+    loss = float(res[2])
+
+    if dist is not None:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    if rank == 0:
+        is_gemm = dominant.startswith("gemm") or dominant.startswith("knn")
+        launches, secs, work = dom
+        if is_gemm:
+            achieved = work / secs / 1e12
+            roof = {"kernel": dominant, "bound": "mfma" if dominant.startswith("gemm") else "valu",
+                    "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                    "launches": launches, "avg_us": round(secs / launches * 1e6, 1)}
+        else:
+            achieved = work / secs / 1e9
+            roof = {"kernel": dominant, "bound": "hbm", "achieved": round(achieved, 1), "peak": PEAK_HBM_GBS,
+                    "unit": "GB/s", "frac": round(achieved / PEAK_HBM_GBS, 4), "traffic": None,
+                    "launches": launches, "avg_us": round(secs / launches * 1e6, 1)}
+        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(pmc):
+            try:
+                roof["traffic"] = json.load(open(pmc)).get(dominant)
+            except Exception:
+                pass
+        if args.kernel_table:
+            tot = sum(v[1] for v in table.values())
+            for t, (n, s, w) in sorted(table.items(), key=lambda kv: -kv[1][1]):
+                sys.stderr.write("%-46s launches %3d  %8.3f ms  %5.1f%%  work/s %.3e\n" % (t, n, s * 1e3, 100 * s / tot, w / s))
+        out = {
+            "metric": "point-clouds/sec fwd+bwd at (B,N,k,C)=(24,2048,20,3), 1/2/4/8 MI355X",
+            "value": round(world * B * args.steps / elapsed, 2),
+            "unit": "clouds/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: B=24/GPU N=2048 k=20 C=3, 3 EdgeConv (64,64,128) + merged 1024 + "
+                                   "FC (512,256) + Final, fp32, dropout on; step = zero-grad + fwd + loss + bwd + "
+                                   "(RCCL all-reduce) + Adam",
+                       "global_batch": world * B, "points_per_cloud": N, "parallelism": "dp%d" % world,
+                       "final_loss": round(loss, 5)},
+            "roofline": roof,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

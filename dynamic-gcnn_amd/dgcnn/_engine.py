@@ -222,7 +222,10 @@ def knn(x2d, B, N, k):
     C = x2d.shape[1]
     idx = torch.empty((B, N, k), dtype=torch.int32, device=x2d.device)
     sq = torch.empty((B * N,), dtype=torch.float32, device=x2d.device)
-    H.call("dgcnn_knn_f32", x2d.data_ptr(), B, N, C, H.ld2(x2d), k, idx.data_ptr(), sq.data_ptr())
+    H.call("dgcnn_knn_f32", x2d.data_ptr(), B, N, C, H.ld2(x2d), k, idx.data_ptr(), sq.data_ptr(),
+           tag="knn_kernel<C%d,k%d>" % (4 if C <= 4 else 16 if C <= 16 else 64 if C <= 64 else 128,
+                                         8 if k <= 8 else 20 if k <= 20 else 40 if k <= 40 else 64),
+           work=2.0 * B * N * N * C)
     return idx
 
 
@@ -236,7 +239,9 @@ def gemm(A, Bm, C, transA=False, transB=False, beta=0.0, gbias=None, rpg=0, stat
     ws = ctx().workspace()
     H.call("dgcnn_gemm_f32", int(transA), int(transB), M, N, K, A.data_ptr(), H.ld2(A), Bm.data_ptr(), H.ld2(Bm),
            C.data_ptr(), H.ld2(C), float(beta), H._p(gbias), 0 if gbias is None else H.ld2(gbias), int(rpg),
-           H._p(stats), ws.data_ptr(), ws.numel())
+           H._p(stats), ws.data_ptr(), ws.numel(),
+           tag="gemm_kernel<%s,%s,STORE,%d>" % ("A_COL" if transA else "A_ROW", "B_COL" if transB else "B_ROW",
+                                                 64 if N <= 64 else 128), work=2.0 * M * N * K)
 
 
 def bn_finalize(stats, F, count):
@@ -323,7 +328,8 @@ def edge_conv_block(x, B, N, k, num_filters, relu1=True, outs=None, net2=None):
     Y = torch.empty((R * k, F), dtype=torch.float32, device=x.device)
     st = c.stats(F)
     H.call("dgcnn_edge_mlp_f32", x.data_ptr(), H.ld2(x), idx.data_ptr(), W0.data_ptr(), B, N, C, k, F,
-           Y.data_ptr(), st.data_ptr())                                 # ops.py:21-52 (gather fused)
+           Y.data_ptr(), st.data_ptr(), tag="gemm_kernel<A_EDGE,B_ROW,STORE,%d>" % (64 if F <= 64 else 128),
+           work=2.0 * R * k * 2 * C * F)                                # ops.py:21-52 (gather fused)
     mean, rstd = bn_finalize(st, F, R * k)                              # ops.py:53
     if outs is None:
         mm = c.new_buffer(R, 2 * F)
@@ -332,7 +338,8 @@ def edge_conv_block(x, B, N, k, num_filters, relu1=True, outs=None, net2=None):
         mm, net_out = outs
     mx, mn = mm[:, :F], mm[:, F:]
     H.call("dgcnn_bn_act_kreduce_f32", Y.data_ptr(), R, k, F, mean.data_ptr(), rstd.data_ptr(), beta0.data_ptr(), 1,
-           mx.data_ptr(), H.ld2(mx), mn.data_ptr(), H.ld2(mn), 0, 0)    # ops.py:54-58
+           mx.data_ptr(), H.ld2(mx), mn.data_ptr(), H.ld2(mn), 0, 0,
+           tag="bn_act_kreduce_kernel", work=4.0 * (R * k * F + 2 * R * F))   # ops.py:54-58
 
     if c.recording:
         def bwd():
@@ -342,16 +349,19 @@ def edge_conv_block(x, B, N, k, num_filters, relu1=True, outs=None, net2=None):
             dmx, dmn = dmm[:, :F], dmm[:, F:]
             red = c.stats(F)
             H.call("dgcnn_bn_bwd_reduce_f32", Y.data_ptr(), R, k, F, mean.data_ptr(), rstd.data_ptr(),
-                   beta0.data_ptr(), 1, dmx.data_ptr(), H.ld2(dmx), dmn.data_ptr(), H.ld2(dmn), red.data_ptr())
+                   beta0.data_ptr(), 1, dmx.data_ptr(), H.ld2(dmx), dmn.data_ptr(), H.ld2(dmn), red.data_ptr(),
+                   tag="bn_bwd_reduce_kernel", work=4.0 * (R * k * F + 2 * R * F))
             dx = c.grad(x)
             dysum = torch.empty((R, F), dtype=torch.float32, device=x.device) if dx is not None else None
             H.call("dgcnn_bn_bwd_apply_f32", Y.data_ptr(), R, k, F, mean.data_ptr(), rstd.data_ptr(), beta0.data_ptr(),
                    1, dmx.data_ptr(), H.ld2(dmx), dmn.data_ptr(), H.ld2(dmn), red.data_ptr(), Y.data_ptr(),
-                   H._p(dysum), c.var_grads[b0name].data_ptr(), 1.0)
+                   H._p(dysum), c.var_grads[b0name].data_ptr(), 1.0,
+                   tag="bn_bwd_apply_kernel", work=4.0 * (2 * R * k * F + 3 * R * F))
             dY = Y
             ws = c.workspace()
             H.call("dgcnn_edge_mlp_wgrad_f32", x.data_ptr(), H.ld2(x), idx.data_ptr(), dY.data_ptr(), B, N, C, k, F,
-                   c.var_grads[w0name].data_ptr(), 1.0, ws.data_ptr(), ws.numel())
+                   c.var_grads[w0name].data_ptr(), 1.0, ws.data_ptr(), ws.numel(),
+                   tag="gemm_kernel<A_EDGE_T,B_ROW,STORE,%d>" % (64 if F <= 64 else 128), work=2.0 * R * k * 2 * C * F)
             if dx is not None:
                 # E = [x_i, x_j - x_i]  =>  dx_i += (sum_m dY) (W0[:C]-W0[C:])^T ; dx_j += dY W0[C:]^T
                 wd = torch.empty((C, F), dtype=torch.float32, device=x.device)
@@ -359,7 +369,8 @@ def edge_conv_block(x, B, N, k, num_filters, relu1=True, outs=None, net2=None):
                 H.call("dgcnn_axpby_f32", W0[C:].data_ptr(), -1.0, wd.data_ptr(), 1.0, C * F)
                 gemm(dysum, wd, dx, transB=True, beta=1.0)
                 H.call("dgcnn_edge_mlp_dgrad_scatter_f32", dY.data_ptr(), W0.data_ptr(), idx.data_ptr(), B, N, C, k, F,
-                       dx.data_ptr(), H.ld2(dx))
+                       dx.data_ptr(), H.ld2(dx), tag="gemm_kernel<A_ROW,B_COL,SCATTER,%d>" % (64 if C <= 64 else 128),
+                       work=2.0 * R * k * C * F)
         c.tape.append(bwd)
 
     net = conv_bn_act(mm, "conv1", 64, relu=relu1, out=net_out, out2=net2)   # ops.py:62-70 (64 hard-coded)

@@ -83,10 +83,42 @@ def _p(t):
     return 0 if t is None else t.data_ptr()
 
 
-def call(name, *args):
-    """Invoke an entry point on the current stream; raise ValueError/HipError on a negative code."""
+class Timer(object):
+    """Optional per-launch HIP-event timing (bench.py): events are recorded on the stream the
+    kernel is launched on (torch's current stream)."""
+
+    def __init__(self, watch=None):
+        self.watch = watch          # None = every tagged call, else a set of tags
+        self.records = []           # (tag, start_event, stop_event, work)
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for tag, a, b, work in self.records:
+            d = out.setdefault(tag, [0, 0.0, 0.0])
+            d[0] += 1
+            d[1] += a.elapsed_time(b) * 1e-3
+            d[2] += work
+        return out                  # tag -> [launches, seconds, work]
+
+
+TIMER = None
+
+
+def call(name, *args, tag=None, work=0.0):
+    """Invoke an entry point on the current stream; raise ValueError/HipError on a negative code.
+    tag/work: kernel identity and algorithmic flops-or-bytes of this launch, for bench.py's roofline."""
     lib = load()
-    rc = getattr(lib, name)(*args, _stream())
+    tm = TIMER
+    if tm is not None and tag is not None and (tm.watch is None or tag in tm.watch):
+        a = torch.cuda.Event(enable_timing=True)
+        b = torch.cuda.Event(enable_timing=True)
+        a.record()
+        rc = getattr(lib, name)(*args, _stream())
+        b.record()
+        tm.records.append((tag, a, b, work))
+    else:
+        rc = getattr(lib, name)(*args, _stream())
     if rc != 0:
         msg = lib.dgcnn_last_error().decode()
         if rc == -1:

@@ -6,57 +6,11 @@ import pytest
 import torch
 
 from oracle import dgcnn_oracle as O
-
-
-def _torch_conv_bn_act(x, W, beta, relu=True):
-    y = x @ W
-    dims = tuple(range(y.dim() - 1))
-    mu = y.mean(dim=dims)
-    var = ((y - mu) ** 2).mean(dim=dims)
-    z = (y - mu) / torch.sqrt(var + O.BN_EPS) + beta
-    return torch.relu(z) if relu else z
+from oracle import torch_twin as T
 
 
 def _torch_model(points, flags, P, idx_list):
-    """Independent torch restatement of model.py:9-106 (autograd supplies the backward)."""
-    L = flags.EDGE_CONV_LAYERS
-    residual = flags.MODEL_NAME != "dgcnn"
-    ecf = O._as_list(flags.EDGE_CONV_FILTERS, L, "f")
-    net = points
-    tensors = []
-    shortcut = None
-    B, N, _ = points.shape
-    for i in range(L):
-        s = "EdgeConv%d/" % i
-        idx = torch.as_tensor(idx_list[i], dtype=torch.long)
-        k = idx.shape[-1]
-        nbr = torch.stack([net[b][idx[b].reshape(-1)].reshape(N, k, -1) for b in range(B)])
-        cen = net[:, :, None, :].expand(-1, -1, k, -1)
-        E = torch.cat([cen, nbr - cen], dim=-1)
-        y = _torch_conv_bn_act(E, P[s + "conv0/weights"], P[s + "conv0/BatchNorm/beta"])
-        mx = y.amax(dim=-2, keepdim=True)
-        mn = y.mean(dim=-2, keepdim=True)
-        relu1 = not (residual and shortcut is not None)
-        out = _torch_conv_bn_act(torch.cat([mx, mn], -1), P[s + "conv1/weights"], P[s + "conv1/BatchNorm/beta"], relu1)
-        if residual and shortcut is not None:
-            sc = shortcut
-            if ecf[i] != ecf[i - 1]:
-                sc = _torch_conv_bn_act(sc, P[s + "shortcut/weights"], P[s + "shortcut/BatchNorm/beta"], False)
-            out = torch.relu(sc + out)
-        tensors += [mx, mn, out]
-        net = out[:, :, 0, :]
-        if residual:
-            shortcut = out
-    if flags.MODEL_NAME == "residual-dgcnn-nofc":
-        return _torch_conv_bn_act(tensors[-1], P["Final/weights"], P["Final/BatchNorm/beta"])[:, :, 0, :]
-    cat = torch.cat([tensors[3 * i + 2] for i in range(L)], -1)
-    merged = _torch_conv_bn_act(cat, P["MergedEdgeConv/weights"], P["MergedEdgeConv/BatchNorm/beta"])
-    tensors.append(merged)
-    g = merged.amax(dim=1, keepdim=True).expand(-1, N, -1, -1)
-    net = torch.cat([g] + tensors, dim=3)
-    for i in range(flags.FC_LAYERS):
-        net = _torch_conv_bn_act(net, P["FC%d/weights" % i], P["FC%d/BatchNorm/beta" % i])
-    return _torch_conv_bn_act(net, P["Final/weights"], P["Final/BatchNorm/beta"])[:, :, 0, :]
+    return T.model(points, flags, P, idx_list=idx_list)
 
 
 @pytest.mark.parametrize("model_name,ecf", [("dgcnn", [8, 16]), ("residual-dgcnn", 64), ("residual-dgcnn-nofc", 64)])
