@@ -47,7 +47,7 @@ struct GemmP {
   // split-K
   int splits; int kchunk; float* partial;
   int avec, bvec;
-  int mtiles, ntiles;
+  int mtiles, ntiles, xcd_group;
 };
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
@@ -73,11 +73,19 @@ __global__ __launch_bounds__(NT) void gemm_kernel(GemmP p) {
   const int wr = wv >> 1, wc = wv & 1;
   const int l31 = lane & 31, lh = lane >> 5;
 
-  // XCD-aware tile order: the ntiles column blocks that share one A row-panel get the same
-  // (id % 8), i.e. the same XCD / L2 (MI355X dispatches block b to XCD b % 8).
+  // Tile order.  MI355X dispatches block b to XCD b % 8 (private L2 each).  When several column
+  // blocks share one A row-panel (ntiles > 1, many row panels) they are given the same (id % 8) so
+  // the panel is fetched into ONE L2; otherwise (few row panels, split-K) ids map 1:1 so that
+  // consecutive blocks spread over all 8 XCDs.
   const int id = blockIdx.x;
-  const int mt = ((id >> 3) / p.ntiles) * 8 + (id & 7);
-  const int nt = (id >> 3) % p.ntiles;
+  int mt, nt;
+  if (p.xcd_group) {
+    mt = ((id >> 3) / p.ntiles) * 8 + (id & 7);
+    nt = (id >> 3) % p.ntiles;
+  } else {
+    mt = id / p.ntiles;
+    nt = id % p.ntiles;
+  }
   if (mt >= p.mtiles) return;
   const int m0 = mt * BM;
   const int n0 = nt * BN;
@@ -394,15 +402,33 @@ __global__ __launch_bounds__(NT) void gemm_kernel(GemmP p) {
   }
 }
 
-__global__ void reduce_partials_kernel(const float* __restrict__ part, int splits, int M, int N,
-                                       float* __restrict__ C, int64_t ldc, float beta) {
-  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= (int64_t)M * N) return;
-  const int row = (int)(e / N), col = (int)(e % N);
-  float s = 0.f;
-  for (int z = 0; z < splits; ++z) s += part[(int64_t)z * M * N + e];
-  float* c = C + (int64_t)row * ldc + col;
-  *c = (beta != 0.f) ? (s + beta * *c) : s;
+// C (+)= sum over splits of the partial tiles.  64 consecutive elements x 4 split-lanes per block:
+// coalesced 256-B rows, 4-way split parallelism, 4 independent loads in flight per lane.
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ part, int splits, int M,
+                                                              int N, float* __restrict__ C, int64_t ldc, float beta) {
+  __shared__ float sh[4][64];
+  const int64_t MN = (int64_t)M * N;
+  const int64_t e = (int64_t)blockIdx.x * 64 + (threadIdx.x & 63);
+  const int zl = threadIdx.x >> 6;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (e < MN) {
+    int z = zl;
+    for (; z + 12 < splits; z += 16) {
+      s0 += part[(int64_t)z * MN + e];
+      s1 += part[(int64_t)(z + 4) * MN + e];
+      s2 += part[(int64_t)(z + 8) * MN + e];
+      s3 += part[(int64_t)(z + 12) * MN + e];
+    }
+    for (; z < splits; z += 4) s0 += part[(int64_t)z * MN + e];
+  }
+  sh[zl][threadIdx.x & 63] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (zl == 0 && e < MN) {
+    const float s = (sh[0][threadIdx.x] + sh[1][threadIdx.x]) + (sh[2][threadIdx.x] + sh[3][threadIdx.x]);
+    const int row = (int)(e / N), col = (int)(e % N);
+    float* c = C + (int64_t)row * ldc + col;
+    *c = (beta != 0.f) ? (s + beta * *c) : s;
+  }
 }
 
 template <int ASRC, int BSRC, int EPI>
@@ -410,7 +436,8 @@ int launch(GemmP& p, hipStream_t st, const char* what) {
   const int bn = (p.N <= 64) ? 64 : 128;
   p.mtiles = (int)dg::cdiv(p.M, BM);
   p.ntiles = (int)dg::cdiv(p.N, bn);
-  const unsigned gx = (unsigned)(dg::cdiv(p.mtiles, 8) * 8 * p.ntiles);
+  p.xcd_group = (p.ntiles > 1 && p.mtiles >= 16 && p.splits == 1) ? 1 : 0;
+  const unsigned gx = p.xcd_group ? (unsigned)(dg::cdiv(p.mtiles, 8) * 8 * p.ntiles) : (unsigned)(p.mtiles * p.ntiles);
   dim3 grid(gx, 1, (unsigned)p.splits);
   if (bn == 64) hipLaunchKernelGGL((gemm_kernel<ASRC, BSRC, EPI, 64>), grid, dim3(NT), 0, st, p);
   else hipLaunchKernelGGL((gemm_kernel<ASRC, BSRC, EPI, 128>), grid, dim3(NT), 0, st, p);
@@ -418,7 +445,7 @@ int launch(GemmP& p, hipStream_t st, const char* what) {
   if (rc) return rc;
   if (p.splits > 1) {
     const int64_t n = (int64_t)p.M * p.N;
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)dg::cdiv(n, 256)), dim3(256), 0, st,
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)dg::cdiv(n, 64)), dim3(256), 0, st,
                        p.partial, p.splits, p.M, p.N, p.C, p.ldc, p.beta);
     rc = dg::check_launch(what);
   }

@@ -36,28 +36,48 @@ __global__ void sqnorm_kernel(const float* __restrict__ x, int64_t ldx, int64_t 
   sq[r] = s;
 }
 
-template <bool LEX>
-__device__ __forceinline__ bool key_less(float d, int j, float dt, int jt) {
-  return LEX ? ((d < dt) || (d == dt && j < jt)) : (d < dt);
+// ---- lane-mask helpers.  hipcc turns nested ?: on register arrays into exec-masked branches (20
+// s_and_saveexec/s_cbranch per insert, measured 10x slower); v_cmp -> SGPR-pair mask -> v_cndmask
+// is forced with the fcmp/icmp builtins and a one-instruction asm select.
+typedef unsigned long long lmask_t;
+__device__ __forceinline__ lmask_t m_flt(float a, float b) { return __builtin_amdgcn_fcmpf(a, b, 4); }   // a <  b (ordered)
+__device__ __forceinline__ lmask_t m_feq(float a, float b) { return __builtin_amdgcn_fcmpf(a, b, 1); }   // a == b
+__device__ __forceinline__ lmask_t m_ilt(int a, int b) { return __builtin_amdgcn_sicmp(a, b, 40); }      // a <  b (signed)
+__device__ __forceinline__ lmask_t m_ine(int a, int b) { return __builtin_amdgcn_sicmp(a, b, 33); }      // a != b
+__device__ __forceinline__ float sel_f(lmask_t m, float t, float f) {
+  float r;
+  asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(f), "v"(t), "s"(m));
+  return r;
+}
+__device__ __forceinline__ int sel_i(lmask_t m, int t, int f) {
+  int r;
+  asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(f), "v"(t), "s"(m));
+  return r;
 }
 
-// Branch-free sorted insert of (d, j) into an ascending list held in registers.
-// new dl[t] = clamp(d, dl[t-1], dl[t]) (v_med3_f32); indices follow the two compare masks.
+template <bool LEX>
+__device__ __forceinline__ lmask_t key_less(float d, int j, float dt, int jt) {
+  return LEX ? (m_flt(d, dt) | (m_feq(d, dt) & m_ilt(j, jt))) : m_flt(d, dt);
+}
+
+// Branch-free sorted insert of (d, j) into an ascending list held in registers: per slot one
+// v_cmp, one v_med3_f32 (new dl[t] = clamp(d, dl[t-1], dl[t])) and two v_cndmask for the index.
+// A lane whose (d, j) is not smaller than its last entry is left unchanged (d = +inf is a no-op).
 template <int KC, bool LEX>
 __device__ __forceinline__ void list_insert(float (&dl)[KC], int (&jl)[KC], float d, int j) {
-  bool ct = key_less<LEX>(d, j, dl[KC - 1], jl[KC - 1]);
+  lmask_t ct = key_less<LEX>(d, j, dl[KC - 1], jl[KC - 1]);
 #pragma unroll
   for (int t = KC - 1; t >= 1; --t) {
-    const bool cp = key_less<LEX>(d, j, dl[t - 1], jl[t - 1]);
+    const lmask_t cp = key_less<LEX>(d, j, dl[t - 1], jl[t - 1]);
     dl[t] = __builtin_amdgcn_fmed3f(dl[t - 1], d, dl[t]);
-    jl[t] = ct ? (cp ? jl[t - 1] : j) : jl[t];
+    jl[t] = sel_i(ct, sel_i(cp, jl[t - 1], j), jl[t]);
     ct = cp;
   }
-  dl[0] = ct ? d : dl[0];
-  jl[0] = ct ? j : jl[0];
+  dl[0] = sel_f(ct, d, dl[0]);
+  jl[0] = sel_i(ct, j, jl[0]);
 }
 
-// Register budget: x_i (CP) + list (2*KC) + ~40 for the candidate stream -> waves/SIMD target.
+// Register budget: x_i (CP) + list (2*KC) + ~70 for the candidate stream -> waves/SIMD target.
 template <int CP, int KC>
 constexpr int knn_min_waves() {
   return (CP + 2 * KC + 70 <= 128) ? 4 : ((CP + 2 * KC + 70 <= 168) ? 3 : ((CP + 2 * KC + 70 <= 256) ? 2 : 1));
@@ -65,18 +85,21 @@ constexpr int knn_min_waves() {
 
 template <int CP, int KC>
 __global__ __launch_bounds__(256, (knn_min_waves<CP, KC>())) void knn_kernel(const float* __restrict__ x,
-                                                  const float* __restrict__ sq, int N, int C,
-                                                  int64_t ldx, int k, int vec_ok,
-                                                  int32_t* __restrict__ idx) {
+                                                                            const float* __restrict__ sq, int N, int C,
+                                                                            int64_t ldx, int k, int vec_ok,
+                                                                            int32_t* __restrict__ idx) {
   constexpr int TILE_F = TJ * CP;
+  constexpr int DQ_F = PERW * 256;           // per-lane distance slots of the current 32 candidates
   constexpr int MERGE_F = ROWS * KC * 2;
-  constexpr int SH = (TILE_F > MERGE_F ? TILE_F : MERGE_F);
+  constexpr int SH = (TILE_F + DQ_F > MERGE_F ? TILE_F + DQ_F : MERGE_F);
   __shared__ __attribute__((aligned(16))) float smem[SH + TJ];
   float* xs = smem;
+  float* dq = smem + TILE_F;
   float* sjs = smem + SH;
 
-  const int lane = threadIdx.x & 63;
-  const int w = threadIdx.x >> 6;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int w = tid >> 6;
   const int b = blockIdx.y;
   const int row = blockIdx.x * ROWS + lane;
   const float* xb = x + (int64_t)b * N * ldx;
@@ -100,7 +123,7 @@ __global__ __launch_bounds__(256, (knn_min_waves<CP, KC>())) void knn_kernel(con
   for (int j0 = 0; j0 < N; j0 += TJ) {
     __syncthreads();
     // ---- stage TJ candidate rows (zero padded to CP channels) into LDS ----
-    for (int e = threadIdx.x; e < TJ * (CP / 4); e += 256) {
+    for (int e = tid; e < TJ * (CP / 4); e += 256) {
       const int r = e / (CP / 4);
       const int c4 = (e % (CP / 4)) * 4;
       const int j = j0 + r;
@@ -118,19 +141,22 @@ __global__ __launch_bounds__(256, (knn_min_waves<CP, KC>())) void knn_kernel(con
       }
       *reinterpret_cast<float4*>(&xs[r * CP + c4]) = v;
     }
-    if (threadIdx.x < TJ) {
-      const int j = j0 + threadIdx.x;
-      sjs[threadIdx.x] = (j < N) ? sqb[j] : INFINITY;
+    if (tid < TJ) {
+      const int j = j0 + tid;
+      sjs[tid] = (j < N) ? sqb[j] : INFINITY;
     }
     __syncthreads();
+    if (j0 + w * PERW >= N) continue;        // wave-uniform: nothing for this wave in the tile
 
-    // ---- this wave's 32 candidates, 2 at a time (2 independent fmaf chains); the channel
-    // loop is fully unrolled (x_i stays in registers) but fenced every 16 channels so the
-    // scheduler cannot hoist all LDS reads and blow the register budget ----
+    // ---- phase A: distances of this wave's 32 candidates (2 independent fmaf chains at a time;
+    // the channel loop is fully unrolled so x_i stays in registers, fenced every 16 channels so
+    // the scheduler cannot hoist every LDS read).  Each lane parks d in its LDS slot and keeps a
+    // 32-bit mask of the candidates that beat its current k-th distance. ----
+    const float thr = dl[KC - 1];
+    unsigned mask = 0u;
 #pragma unroll 1
     for (int g = 0; g < PERW; g += 2) {
       const int jl0 = w * PERW + g;
-      if (j0 + jl0 >= N) break;  // wave-uniform
       const float* c0 = &xs[jl0 * CP];
       float p0 = 0.f, p1 = 0.f;
 #pragma unroll
@@ -143,23 +169,33 @@ __global__ __launch_bounds__(256, (knn_min_waves<CP, KC>())) void knn_kernel(con
         p0 = fmaf(xi[c + 3], v0.w, p0); p1 = fmaf(xi[c + 3], v1.w, p1);
         if ((c & 15) == 12) __builtin_amdgcn_sched_barrier(0);
       }
-      const float pp[2] = {p0, p1};
-#pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        const float t = si + sjs[jl0 + q];
-        const float tp = 2.0f * pp[q];
-        const float d = t - tp;
-        if (__any(d < dl[KC - 1])) list_insert<KC, false>(dl, jl, d, j0 + jl0 + q);
-      }
+      const float t0 = si + sjs[jl0], t1 = si + sjs[jl0 + 1];
+      const float tp0 = 2.0f * p0, tp1 = 2.0f * p1;
+      const float d0 = t0 - tp0, d1 = t1 - tp1;
+      dq[g * 256 + tid] = d0;
+      dq[(g + 1) * 256 + tid] = d1;
+      mask |= (unsigned)sel_i(m_flt(d0, thr), (int)(1u << g), 0);
+      mask |= (unsigned)sel_i(m_flt(d1, thr), (int)(2u << g), 0);
+    }
+    // ---- phase B: drain.  Every iteration each lane pops ITS lowest surviving candidate (ascending
+    // j, which the tie rule needs) and all lanes run one insert: max-over-lanes(popcount) inserts
+    // per 32 candidates instead of one per candidate with any taker. ----
+    while (__any(mask != 0u)) {
+      const lmask_t live = m_ine((int)mask, 0);
+      const int g = sel_i(live, __builtin_ctz(mask | 0x80000000u), 0);
+      const float d = sel_f(live, dq[g * 256 + tid], INFINITY);
+      mask &= mask - 1u;
+      list_insert<KC, false>(dl, jl, d, j0 + w * PERW + g);
     }
   }
 
   // ---- merge the 4 per-wave lists into wave 0 through LDS (lexicographic (d, j)) ----
+  __syncthreads();
   float* md = smem;
   int* mj = reinterpret_cast<int*>(smem + ROWS * KC);
 #pragma unroll 1
   for (int src = 1; src < WAVES; ++src) {
-    __syncthreads();
+    if (src > 1) __syncthreads();
     if (w == src) {
 #pragma unroll
       for (int t = 0; t < KC; ++t) {
@@ -173,8 +209,8 @@ __global__ __launch_bounds__(256, (knn_min_waves<CP, KC>())) void knn_kernel(con
       for (int t = 0; t < KC; ++t) {
         const float d = md[t * ROWS + lane];
         const int j = mj[t * ROWS + lane];
-        const bool need = (d < dl[KC - 1]) || (d == dl[KC - 1] && j < jl[KC - 1]);
-        if (!__any(need)) break;  // source list is ascending: nothing later can enter either
+        const lmask_t need = key_less<true>(d, j, dl[KC - 1], jl[KC - 1]);
+        if (need == 0) break;  // wave-uniform; the source list is ascending: nothing later can enter either
         list_insert<KC, true>(dl, jl, d, j);
       }
     }

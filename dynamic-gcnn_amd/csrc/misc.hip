@@ -47,11 +47,13 @@ __global__ void edge_gather_bwd_kernel(const float* __restrict__ dE, const int32
   }
 }
 
-// block = 64 channels x 4 row groups; first arg-max on ties (tf max_pool gradient routing)
-__global__ __launch_bounds__(256) void global_max_kernel(const float* __restrict__ x, int64_t ldx, int N, int F,
-                                                         float* __restrict__ out, int32_t* __restrict__ arg) {
-  __shared__ float sv[4][64];
-  __shared__ int si[4][64];
+// block = 64 channels x RG row groups (1024 threads: 16 waves/block, B*F/64 blocks fill the chip);
+// first arg-max on ties (tf max_pool gradient routing)
+constexpr int RG = 16;
+__global__ __launch_bounds__(64 * RG) void global_max_kernel(const float* __restrict__ x, int64_t ldx, int N, int F,
+                                                             float* __restrict__ out, int32_t* __restrict__ arg) {
+  __shared__ float sv[RG][64];
+  __shared__ int si[RG][64];
   const int b = blockIdx.y;
   const int f = blockIdx.x * 64 + (threadIdx.x & 63);
   const int rg = threadIdx.x >> 6;
@@ -59,7 +61,7 @@ __global__ __launch_bounds__(256) void global_max_kernel(const float* __restrict
   int bi = 0x7fffffff;
   if (f < F) {
     const float* p = x + (int64_t)b * N * ldx + f;
-    for (int i = rg; i < N; i += 4) {
+    for (int i = rg; i < N; i += RG) {
       const float v = p[(int64_t)i * ldx];
       if (v > best) { best = v; bi = i; }
     }
@@ -68,7 +70,7 @@ __global__ __launch_bounds__(256) void global_max_kernel(const float* __restrict
   si[rg][threadIdx.x & 63] = bi;
   __syncthreads();
   if (rg == 0 && f < F) {
-    for (int q = 1; q < 4; ++q) {
+    for (int q = 1; q < RG; ++q) {
       const float v = sv[q][threadIdx.x];
       const int i = si[q][threadIdx.x];
       if (v > best || (v == best && i < bi)) { best = v; bi = i; }
@@ -87,20 +89,24 @@ __global__ void global_max_bwd_kernel(const float* __restrict__ dout, const int3
   }
 }
 
-__global__ __launch_bounds__(256) void group_colsum_kernel(const float* __restrict__ x, int64_t ldx, int rows, int F,
-                                                           float* __restrict__ out) {
-  __shared__ float sv[4][64];
+__global__ __launch_bounds__(64 * RG) void group_colsum_kernel(const float* __restrict__ x, int64_t ldx, int rows,
+                                                               int F, float* __restrict__ out) {
+  __shared__ float sv[RG][64];
   const int g = blockIdx.y;
   const int f = blockIdx.x * 64 + (threadIdx.x & 63);
   const int rg = threadIdx.x >> 6;
   float s = 0.f;
   if (f < F) {
     const float* p = x + (int64_t)g * rows * ldx + f;
-    for (int i = rg; i < rows; i += 4) s += p[(int64_t)i * ldx];
+    for (int i = rg; i < rows; i += RG) s += p[(int64_t)i * ldx];
   }
   sv[rg][threadIdx.x & 63] = s;
   __syncthreads();
-  if (rg == 0 && f < F) out[(int64_t)g * F + f] = (sv[0][threadIdx.x] + sv[1][threadIdx.x]) + (sv[2][threadIdx.x] + sv[3][threadIdx.x]);
+  if (rg == 0 && f < F) {
+    float t = 0.f;
+    for (int q = 0; q < RG; ++q) t += sv[q][threadIdx.x];   // fixed order: deterministic
+    out[(int64_t)g * F + f] = t;
+  }
 }
 
 __device__ __forceinline__ uint32_t mix32(uint64_t z) {   // splitmix64 finaliser
@@ -230,7 +236,7 @@ extern "C" int dgcnn_edge_gather_bwd_f32(const float* dE, const int32_t* idx, in
 extern "C" int dgcnn_global_max_f32(const float* x, int64_t ldx, int B, int N, int F, float* out, int32_t* arg,
                                     void* stream) {
   DG_REQUIRE(x && out && B > 0 && N > 0 && F > 0, DGCNN_EINVAL, "dgcnn_global_max_f32: bad args");
-  hipLaunchKernelGGL(global_max_kernel, dim3((unsigned)dg::cdiv(F, 64), (unsigned)B), dim3(256), 0, ST, x, ldx, N, F,
+  hipLaunchKernelGGL(global_max_kernel, dim3((unsigned)dg::cdiv(F, 64), (unsigned)B), dim3(64 * RG), 0, ST, x, ldx, N, F,
                      out, arg);
   return dg::check_launch("dgcnn_global_max_f32");
 }
@@ -246,7 +252,7 @@ extern "C" int dgcnn_global_max_bwd_f32(const float* dout, const int32_t* arg, i
 extern "C" int dgcnn_group_colsum_f32(const float* x, int64_t ldx, int G, int rows_per_group, int F, float* out,
                                       void* stream) {
   DG_REQUIRE(x && out && G > 0 && rows_per_group > 0 && F > 0, DGCNN_EINVAL, "dgcnn_group_colsum_f32: bad args");
-  hipLaunchKernelGGL(group_colsum_kernel, dim3((unsigned)dg::cdiv(F, 64), (unsigned)G), dim3(256), 0, ST, x, ldx,
+  hipLaunchKernelGGL(group_colsum_kernel, dim3((unsigned)dg::cdiv(F, 64), (unsigned)G), dim3(64 * RG), 0, ST, x, ldx,
                      rows_per_group, F, out);
   return dg::check_launch("dgcnn_group_colsum_f32");
 }
