@@ -52,7 +52,17 @@ struct GemmP {
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 
-template <int ASRC, int BSRC, int EPI, int BN>
+__device__ __forceinline__ float4 sub4(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
+__device__ __forceinline__ int imin(int a, int b) { return a < b ? a : b; }
+
+// VEC = every operand is float4-loadable (16-B aligned, leading dimensions and the contiguous
+// extent multiples of 4).  Then each prefetch is ONE unconditional global_load_dwordx4 from a
+// clamped (always valid) address, and the out-of-range predicate is applied when the value is
+// written to LDS *after* the MFMAs of the current tile -- no control flow and no s_waitcnt between
+// the loads and the MFMA block (the first version branched per element and drained vmcnt(0)
+// between loads: rocprof showed the GEMMs at 40-50 % of the fp32 MFMA peak).  VEC = false is the
+// generic (slow, fully predicated, scalar) path for odd shapes such as C = 3 or N = 2.
+template <int ASRC, int BSRC, int EPI, int BN, bool VEC>
 __global__ __launch_bounds__(NT) void gemm_kernel(GemmP p) {
   constexpr bool A_TRANS = (ASRC == A_ROW || ASRC == A_EDGE);  // needs transposing LDS store
   constexpr bool B_TRANS = (BSRC == B_COL);
@@ -104,11 +114,11 @@ __global__ __launch_bounds__(NT) void gemm_kernel(GemmP p) {
     if (ASRC == A_ROW) {
       const int row = m0 + (t >> 2) + 64 * i;
       a_ok[i] = row < p.M;
-      a_ptr[i] = p.A + (int64_t)(a_ok[i] ? row : 0) * p.lda;
+      a_ptr[i] = p.A + (int64_t)imin(row, p.M - 1) * p.lda;
     } else if (ASRC == A_EDGE) {
       const int row = m0 + (t >> 2) + 64 * i;
       a_ok[i] = row < p.M;
-      const int er = a_ok[i] ? row : 0;
+      const int er = imin(row, p.M - 1);
       const int g = er / p.knn;
       const int nb = (g / p.npts) * p.npts + p.idx[er];
       a_ptr[i] = p.x + (int64_t)g * p.ldx;
@@ -116,55 +126,88 @@ __global__ __launch_bounds__(NT) void gemm_kernel(GemmP p) {
     }
   }
 
+  bool oka[NVA], okb[NVB];    // predicates of the tile currently held in ra / rb
+
   auto fetch_a = [&](int i, int k0) -> float4 {
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (VEC) {
+      if (ASRC == A_ROW) {
+        const int kc = k0 + 4 * (t & 3);
+        oka[i] = a_ok[i] && (kc < kend);
+        v = ld4(a_ptr[i] + imin(kc, kend - 4));
+      } else if (ASRC == A_EDGE) {
+        const int kc = k0 + 4 * (t & 3);
+        const int C = p.cch;
+        oka[i] = a_ok[i] && (kc < kend);
+        const int kcc = imin(kc, kend - 4);
+        if (k0 + BK <= C) {                       // wave-uniform: the whole k-chunk is centre features
+          v = ld4(a_ptr[i] + kcc);
+        } else {
+          const bool cen = kcc < C;
+          const int col = cen ? kcc : kcc - C;
+          const float4 xc = ld4(a_ptr[i] + col);
+          const float4 xn = ld4((cen ? a_ptr[i] : a_ptr2[i]) + col);
+          const float4 df = sub4(xn, xc);
+          v = cen ? xc : df;
+        }
+      } else if (ASRC == A_COL) {
+        const int kk = k0 + t / (BM / 4) + i * (1024 / BM);
+        const int m = m0 + (t % (BM / 4)) * 4;
+        oka[i] = (kk < kend) && (m < p.M);
+        v = ld4(p.A + (int64_t)imin(kk, kend - 1) * p.lda + imin(m, p.M - 4));
+      } else {  // A_EDGE_T: element (m = channel of E, kk = edge row)
+        const int er = k0 + t / (BM / 4) + i * (1024 / BM);
+        const int m = m0 + (t % (BM / 4)) * 4;
+        const int C = p.cch;
+        oka[i] = (er < kend) && (m < p.M);
+        const int erc = imin(er, kend - 1);
+        const int g = erc / p.knn;
+        const int nb = (g / p.npts) * p.npts + p.idx[erc];
+        const float* pc = p.x + (int64_t)g * p.ldx;
+        const float* pn = p.x + (int64_t)nb * p.ldx;
+        const int mc = imin(m, p.M - 4);
+        const bool cen = mc < C;
+        const int col = cen ? mc : mc - C;
+        const float4 xc = ld4(pc + col);
+        const float4 xn = ld4((cen ? pc : pn) + col);
+        const float4 df = sub4(xn, xc);
+        v = cen ? xc : df;
+      }
+      return v;
+    }
+    oka[i] = true;
     if (ASRC == A_ROW) {
       const int kc = k0 + 4 * (t & 3);
       if (a_ok[i]) {
-        if (p.avec && kc + 3 < kend) v = ld4(a_ptr[i] + kc);
-        else {
-          if (kc + 0 < kend) v.x = a_ptr[i][kc + 0];
-          if (kc + 1 < kend) v.y = a_ptr[i][kc + 1];
-          if (kc + 2 < kend) v.z = a_ptr[i][kc + 2];
-          if (kc + 3 < kend) v.w = a_ptr[i][kc + 3];
-        }
+        if (kc + 0 < kend) v.x = a_ptr[i][kc + 0];
+        if (kc + 1 < kend) v.y = a_ptr[i][kc + 1];
+        if (kc + 2 < kend) v.z = a_ptr[i][kc + 2];
+        if (kc + 3 < kend) v.w = a_ptr[i][kc + 3];
       }
     } else if (ASRC == A_EDGE) {
       const int kc = k0 + 4 * (t & 3);
       const int C = p.cch;
       if (a_ok[i]) {
-        if (p.avec && kc + 3 < kend) {   // C % 4 == 0: a quad never straddles the centre/diff split
-          if (kc < C) v = ld4(a_ptr[i] + kc);
-          else {
-            const float4 xn = ld4(a_ptr2[i] + (kc - C));
-            const float4 xc = ld4(a_ptr[i] + (kc - C));
-            v = make_float4(xn.x - xc.x, xn.y - xc.y, xn.z - xc.z, xn.w - xc.w);
-          }
-        } else {
-          float e[4];
+        float e[4];
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const int c = kc + q;
-            e[q] = 0.f;
-            if (c < kend) e[q] = (c < C) ? a_ptr[i][c] : (a_ptr2[i][c - C] - a_ptr[i][c - C]);
-          }
-          v = make_float4(e[0], e[1], e[2], e[3]);
+        for (int q = 0; q < 4; ++q) {
+          const int c = kc + q;
+          e[q] = 0.f;
+          if (c < kend) e[q] = (c < C) ? a_ptr[i][c] : (a_ptr2[i][c - C] - a_ptr[i][c - C]);
         }
+        v = make_float4(e[0], e[1], e[2], e[3]);
       }
     } else if (ASRC == A_COL) {
       const int kk = k0 + t / (BM / 4) + i * (1024 / BM);
       const int m = m0 + (t % (BM / 4)) * 4;
       if (kk < kend) {
         const float* s = p.A + (int64_t)kk * p.lda + m;
-        if (p.avec && m + 3 < p.M) v = ld4(s);
-        else {
-          if (m + 0 < p.M) v.x = s[0];
-          if (m + 1 < p.M) v.y = s[1];
-          if (m + 2 < p.M) v.z = s[2];
-          if (m + 3 < p.M) v.w = s[3];
-        }
+        if (m + 0 < p.M) v.x = s[0];
+        if (m + 1 < p.M) v.y = s[1];
+        if (m + 2 < p.M) v.z = s[2];
+        if (m + 3 < p.M) v.w = s[3];
       }
-    } else {  // A_EDGE_T: element (m = channel of E, kk = edge row)
+    } else {
       const int er = k0 + t / (BM / 4) + i * (1024 / BM);
       const int m = m0 + (t % (BM / 4)) * 4;
       const int C = p.cch;
@@ -173,23 +216,14 @@ __global__ __launch_bounds__(NT) void gemm_kernel(GemmP p) {
         const int nb = (g / p.npts) * p.npts + p.idx[er];
         const float* pc = p.x + (int64_t)g * p.ldx;
         const float* pn = p.x + (int64_t)nb * p.ldx;
-        if (p.avec && m + 3 < p.M) {
-          if (m < C) v = ld4(pc + m);
-          else {
-            const float4 xn = ld4(pn + (m - C));
-            const float4 xc = ld4(pc + (m - C));
-            v = make_float4(xn.x - xc.x, xn.y - xc.y, xn.z - xc.z, xn.w - xc.w);
-          }
-        } else {
-          float e[4];
+        float e[4];
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const int c = m + q;
-            e[q] = 0.f;
-            if (c < p.M) e[q] = (c < C) ? pc[c] : (pn[c - C] - pc[c - C]);
-          }
-          v = make_float4(e[0], e[1], e[2], e[3]);
+        for (int q = 0; q < 4; ++q) {
+          const int c = m + q;
+          e[q] = 0.f;
+          if (c < p.M) e[q] = (c < C) ? pc[c] : (pn[c - C] - pc[c - C]);
         }
+        v = make_float4(e[0], e[1], e[2], e[3]);
       }
     }
     return v;
@@ -197,31 +231,40 @@ __global__ __launch_bounds__(NT) void gemm_kernel(GemmP p) {
 
   auto fetch_b = [&](int i, int k0) -> float4 {
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (VEC) {
+      if (BSRC == B_ROW) {
+        const int kk = k0 + t / (BN / 4) + i * (1024 / BN);
+        const int n = n0 + (t % (BN / 4)) * 4;
+        okb[i] = (kk < kend) && (n < p.N);
+        v = ld4(p.B + (int64_t)imin(kk, kend - 1) * p.ldb + imin(n, p.N - 4));
+      } else {
+        const int n = n0 + (t >> 2) + 64 * i;
+        const int kc = k0 + 4 * (t & 3);
+        okb[i] = (n < p.N) && (kc < kend);
+        v = ld4(p.B + (int64_t)imin(n, p.N - 1) * p.ldb + imin(kc, kend - 4));
+      }
+      return v;
+    }
+    okb[i] = true;
     if (BSRC == B_ROW) {
       const int kk = k0 + t / (BN / 4) + i * (1024 / BN);
       const int n = n0 + (t % (BN / 4)) * 4;
       if (kk < kend) {
         const float* s = p.B + (int64_t)kk * p.ldb + n;
-        if (p.bvec && n + 3 < p.N) v = ld4(s);
-        else {
-          if (n + 0 < p.N) v.x = s[0];
-          if (n + 1 < p.N) v.y = s[1];
-          if (n + 2 < p.N) v.z = s[2];
-          if (n + 3 < p.N) v.w = s[3];
-        }
+        if (n + 0 < p.N) v.x = s[0];
+        if (n + 1 < p.N) v.y = s[1];
+        if (n + 2 < p.N) v.z = s[2];
+        if (n + 3 < p.N) v.w = s[3];
       }
     } else {
       const int n = n0 + (t >> 2) + 64 * i;
       const int kc = k0 + 4 * (t & 3);
       if (n < p.N) {
         const float* s = p.B + (int64_t)n * p.ldb + kc;
-        if (p.bvec && kc + 3 < kend) v = ld4(s);
-        else {
-          if (kc + 0 < kend) v.x = s[0];
-          if (kc + 1 < kend) v.y = s[1];
-          if (kc + 2 < kend) v.z = s[2];
-          if (kc + 3 < kend) v.w = s[3];
-        }
+        if (kc + 0 < kend) v.x = s[0];
+        if (kc + 1 < kend) v.y = s[1];
+        if (kc + 2 < kend) v.z = s[2];
+        if (kc + 3 < kend) v.w = s[3];
       }
     }
     return v;
@@ -229,6 +272,7 @@ __global__ __launch_bounds__(NT) void gemm_kernel(GemmP p) {
 
   auto store_a = [&](int buf, int i, float4 v) {
     float* d = As + buf * BK * SA;
+    if (!oka[i]) v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (A_TRANS) {
       const int row = (t >> 2) + 64 * i, kq = t & 3;
       d[(4 * kq + 0) * SA + row] = v.x;
@@ -242,6 +286,7 @@ __global__ __launch_bounds__(NT) void gemm_kernel(GemmP p) {
   };
   auto store_b = [&](int buf, int i, float4 v) {
     float* d = Bs + buf * BK * SB;
+    if (!okb[i]) v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (B_TRANS) {
       const int row = (t >> 2) + 64 * i, kq = t & 3;
       d[(4 * kq + 0) * SB + row] = v.x;
@@ -290,18 +335,34 @@ __global__ __launch_bounds__(NT) void gemm_kernel(GemmP p) {
     }
     const float* as = As + buf * BK * SA + lh * SA + a_off;
     const float* bs = Bs + buf * BK * SB + lh * SB + b_off;
+    // operand reads run one k-pair ahead of the MFMAs (two register sets, static indices)
+    float a0[TM], b0[TN], a1[TM], b1[TN];
 #pragma unroll
-    for (int s = 0; s < BK / 2; ++s) {
-      float a[TM], b[TN];
+    for (int i = 0; i < TM; ++i) a0[i] = as[i * 32];
 #pragma unroll
-      for (int i = 0; i < TM; ++i) a[i] = as[2 * s * SA + i * 32];
+    for (int j = 0; j < TN; ++j) b0[j] = bs[j * 32];
 #pragma unroll
-      for (int j = 0; j < TN; ++j) b[j] = bs[2 * s * SB + j * 32];
+    for (int s = 0; s < BK / 2; s += 2) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i) a1[i] = as[2 * (s + 1) * SA + i * 32];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) b1[j] = bs[2 * (s + 1) * SB + j * 32];
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[i], b0[j], acc[i][j], 0, 0, 0);
+      if (s + 2 < BK / 2) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) a0[i] = as[2 * (s + 2) * SA + i * 32];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) b0[j] = bs[2 * (s + 2) * SB + j * 32];
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[i], b1[j], acc[i][j], 0, 0, 0);
     }
     if (more) {
 #pragma unroll
@@ -355,25 +416,38 @@ __global__ __launch_bounds__(NT) void gemm_kernel(GemmP p) {
   float cs[TN], cq[TN];
 #pragma unroll
   for (int j = 0; j < TN; ++j) { cs[j] = 0.f; cq[j] = 0.f; }
+  const bool has_beta = (p.beta != 0.f);
+  // per-cloud bias: a 128-row tile almost always lies inside one cloud -> one value per column
+  const bool has_gb = (p.gbias != nullptr);
+  const int rlast = imin(m0 + BM, p.M) - 1;
+  const bool gb_uniform = has_gb && ((m0 / p.rpg) == (rlast / p.rpg));
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = roww + i * 32 + (r & 3) + 8 * (r >> 2);
-      if (row < p.M) {
-        const float* gb = p.gbias ? (p.gbias + (int64_t)(row / p.rpg) * p.ldgbias) : nullptr;
-        float* crow = p.C + (int64_t)row * p.ldc;
+    for (int j = 0; j < TN; ++j) {
+      const int col = colw + j * 32;
+      const bool cok = col < p.N;
+      const int colc = cok ? col : 0;
+      float gbu = 0.f;
+      if (gb_uniform) gbu = p.gbias[(int64_t)(m0 / p.rpg) * p.ldgbias + colc];
+      float old[16];
+      if (has_beta) {          // all 16 read-modify-write loads in flight before the first use
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-          const int col = colw + j * 32;
-          if (col < p.N) {
-            float v = acc[i][j][r];
-            if (gb) v += gb[col];
-            if (p.beta != 0.f) v += p.beta * crow[col];
-            crow[col] = v;
-            cs[j] += v;
-            cq[j] += v * v;
-          }
+        for (int r = 0; r < 16; ++r) {
+          const int row = roww + i * 32 + (r & 3) + 8 * (r >> 2);
+          old[r] = p.C[(int64_t)imin(row, p.M - 1) * p.ldc + colc];
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = roww + i * 32 + (r & 3) + 8 * (r >> 2);
+        float v = acc[i][j][r];
+        if (has_gb) v += gb_uniform ? gbu : p.gbias[(int64_t)(imin(row, p.M - 1) / p.rpg) * p.ldgbias + colc];
+        if (has_beta) v += p.beta * old[r];
+        if (cok && row < p.M) {
+          p.C[(int64_t)row * p.ldc + col] = v;
+          cs[j] += v;
+          cq[j] += v * v;
         }
       }
     }
@@ -439,8 +513,17 @@ int launch(GemmP& p, hipStream_t st, const char* what) {
   p.xcd_group = (p.ntiles > 1 && p.mtiles >= 16 && p.splits == 1) ? 1 : 0;
   const unsigned gx = p.xcd_group ? (unsigned)(dg::cdiv(p.mtiles, 8) * 8 * p.ntiles) : (unsigned)(p.mtiles * p.ntiles);
   dim3 grid(gx, 1, (unsigned)p.splits);
-  if (bn == 64) hipLaunchKernelGGL((gemm_kernel<ASRC, BSRC, EPI, 64>), grid, dim3(NT), 0, st, p);
-  else hipLaunchKernelGGL((gemm_kernel<ASRC, BSRC, EPI, 128>), grid, dim3(NT), 0, st, p);
+  // float4 path: pointers / leading dimensions checked by the caller (avec, bvec); here the extents
+  const bool a_ext = (ASRC == A_ROW || ASRC == A_EDGE) ? (p.K % 4 == 0 && p.K >= 4) : (p.M % 4 == 0 && p.M >= 4);
+  const bool b_ext = (BSRC == B_ROW) ? (p.N % 4 == 0 && p.N >= 4) : (p.K % 4 == 0 && p.K >= 4);
+  const bool vec = p.avec && p.bvec && a_ext && b_ext;
+  if (bn == 64) {
+    if (vec) hipLaunchKernelGGL((gemm_kernel<ASRC, BSRC, EPI, 64, true>), grid, dim3(NT), 0, st, p);
+    else hipLaunchKernelGGL((gemm_kernel<ASRC, BSRC, EPI, 64, false>), grid, dim3(NT), 0, st, p);
+  } else {
+    if (vec) hipLaunchKernelGGL((gemm_kernel<ASRC, BSRC, EPI, 128, true>), grid, dim3(NT), 0, st, p);
+    else hipLaunchKernelGGL((gemm_kernel<ASRC, BSRC, EPI, 128, false>), grid, dim3(NT), 0, st, p);
+  }
   int rc = dg::check_launch(what);
   if (rc) return rc;
   if (p.splits > 1) {
