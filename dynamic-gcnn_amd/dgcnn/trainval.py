@@ -18,6 +18,7 @@ import torch
 from . import _engine as E
 from . import _hip as H
 from . import model
+from . import parallel
 
 
 def param_specs(flags, num_channel):
@@ -62,16 +63,8 @@ class trainval(object):
         self._ctx.seed = int(getattr(f, "SEED", 1)) if int(getattr(f, "SEED", 1)) >= 0 else 1
         self._ctx.allocate_variables(param_specs(f, int(f.NUM_CHANNEL)), seed=self._ctx.seed)
         self._lr = float(f.LEARNING_RATE)
-        self._world = 1
-        self._dist = None
-        try:
-            import torch.distributed as dist
-            if dist.is_available() and dist.is_initialized():
-                self._dist = dist
-                self._world = dist.get_world_size()
-                dist.broadcast(self._ctx.flat_param, src=0)     # variables are shared by all towers (AUTO_REUSE)
-        except ImportError:
-            pass
+        self._dist, self._rank, self._world = parallel.dist_state()
+        parallel.broadcast_(self._ctx.flat_param, self._dist, src=0)
         return self
 
     @property
@@ -177,9 +170,7 @@ class trainval(object):
             raise NotImplementedError
         c = self._ctx
         g = c.flat_grad
-        if self._world > 1:
-            self._dist.all_reduce(g)                                  # sum over replicas
-            H.call("dgcnn_axpby_f32", g.data_ptr(), 1.0 / self._world, g.data_ptr(), 0.0, g.numel())
+        parallel.allreduce_mean_(g, self._dist, self._world)          # sum over replicas / world
         c.adam_t += 1
         b1, b2, eps = 0.9, 0.999, 1e-8                                # tf.train.AdamOptimizer defaults
         lr_t = self._lr * math.sqrt(1.0 - b2 ** c.adam_t) / (1.0 - b1 ** c.adam_t)

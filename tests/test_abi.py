@@ -1,0 +1,63 @@
+"""CPU checks of the drop-in boundary: libdgcnn_hip.so loads without a GPU and exports exactly the
+symbols include/dgcnn_hip.h declares, and the ctypes prototypes mirror the header's arity."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_functions():
+    text = open(os.path.join(ROOT, "include", "dgcnn_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    out = {}
+    for m in re.finditer(r"\b(?:int|const char\*)\s+(dgcnn_\w+)\s*\(([^;]*?)\)\s*;", text, flags=re.S):
+        args = m.group(2).strip()
+        out[m.group(1)] = 0 if args in ("", "void") else len([a for a in args.split(",") if a.strip()])
+    return out
+
+
+def test_library_exports_every_declared_symbol():
+    from dgcnn import _hip
+    lib = ctypes.CDLL(_hip.LIB_PATH)
+    decl = header_functions()
+    assert len(decl) >= 24
+    for name in decl:
+        assert hasattr(lib, name), "missing export %s" % name
+    assert lib.dgcnn_version() >= 100
+
+
+def test_ctypes_prototypes_match_header():
+    from dgcnn import _hip
+    decl = header_functions()
+    assert set(decl) == set(_hip.PROTOTYPES), set(decl) ^ set(_hip.PROTOTYPES)
+    for name, n in decl.items():
+        protos = _hip.PROTOTYPES[name]
+        extra = 0 if name in ("dgcnn_version", "dgcnn_last_error", "dgcnn_knn_workspace_bytes") else 0
+        assert len(protos) == n + extra, (name, len(protos), n)
+
+
+def test_ops_fail_loudly_without_gpu_or_library():
+    import torch
+    import dgcnn
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(Exception):
+        dgcnn.ops.k_nn(torch.zeros(1, 8, 3), 2)           # CPU tensor: no fallback path exists
+    with pytest.raises(Exception):
+        dgcnn.trainval(dgcnn.DGCNN_FLAGS()).initialize()    # no device
+
+
+def test_host_logic_errors_without_gpu():
+    import dgcnn
+    with pytest.raises(ValueError):
+        dgcnn.ops._listify([1, 2], 3, "k")                  # ops.py:80-82
+    with pytest.raises(NotImplementedError):
+        dgcnn.trainval(dgcnn.DGCNN_FLAGS(MODEL_NAME="nope")).initialize()   # model.py:41-43
+    f = dgcnn.DGCNN_FLAGS(edge_conv_filters="64,64,128", fc_filters="512,256", gpus="0,1")
+    assert f.EDGE_CONV_FILTERS == [64, 64, 128] and f.FC_FILTERS == [512, 256] and f.GPUS == [0, 1]   # flags.py:154-164
+    from dgcnn.trainval import param_specs
+    specs = param_specs(f, 3)
+    assert sum(int(__import__("numpy").prod(s)) for _, s in specs) == 1797186

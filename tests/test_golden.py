@@ -1,0 +1,120 @@
+"""Known-answer tests against the committed fixtures of tests/golden/ (made by tests/make_golden.py).
+
+CPU half (-m "not gpu"): the oracle reproduces every stored vector -- pins the checker.
+GPU half (-m gpu): the HIP path reproduces them through the C ABI; nothing here reads /root/reference."""
+import ast
+import os
+
+import numpy as np
+import pytest
+
+from oracle import dgcnn_oracle as O
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load(name):
+    return dict(np.load(os.path.join(GOLD, name + ".npz"), allow_pickle=False))
+
+
+def params_of(g, prefix="param:"):
+    return {k[len(prefix):]: v for k, v in g.items() if k.startswith(prefix)}
+
+
+KNN_CASES = ["g1_knn_uniform", "g2_knn_integer_ties", "g3_knn_features"]
+
+
+# ------------------------------------------------------------------ CPU: oracle vs fixtures
+@pytest.mark.parametrize("name", KNN_CASES)
+def test_oracle_knn_matches_golden(name):
+    g = load(name)
+    np.testing.assert_array_equal(O.k_nn(g["points"], int(g["k"])), g["idx"])
+    if "edges" in g:
+        np.testing.assert_array_equal(O.edges(g["points"], int(g["k"])), g["edges"])
+
+
+def test_oracle_edge_conv_matches_golden():
+    g = load("g6_edge_conv")
+    f8 = lambda a: a.astype(np.float64)
+    outs, cache = O.edge_conv(f8(g["points"]), int(g["k"]), f8(g["W0"]), f8(g["beta0"]), f8(g["W1"]), f8(g["beta1"]))
+    np.testing.assert_array_equal(cache["idx"], g["idx"])
+    for a, n in zip(outs, ("net_max", "net_mean", "net")):
+        np.testing.assert_allclose(a, g[n], rtol=1e-12, atol=1e-12)
+    dx, gr = O.edge_conv_bwd(g["d_max"], g["d_mean"], g["d_net"], cache)
+    np.testing.assert_allclose(dx, g["dx"], rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(gr["W0"], g["dW0"], rtol=1e-10, atol=1e-12)
+
+
+@pytest.mark.parametrize("name", ["g7_model_config1", "g8_model_residual"])
+def test_oracle_model_matches_golden(name):
+    g = load(name)
+    cfg = ast.literal_eval(str(g["cfg"]))
+    flags = O.Flags(TRAIN=False, NUM_CLASS=2, FC_LAYERS=2, **cfg)
+    logits, cache = O.model_forward(g["points"], flags, params_of(g))           # fp32 oracle, own k-NN
+    for i, l in enumerate(cache["layers"]):
+        np.testing.assert_array_equal(l["ec"]["idx"], g["idx%d" % i])
+    np.testing.assert_allclose(logits, g["logits"], rtol=0, atol=1e-3)            # fp32 vs stored fp64 twin
+
+
+# ------------------------------------------------------------------ GPU: HIP path vs fixtures
+def _dev(a):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", KNN_CASES)
+def test_hip_knn_matches_golden(name):
+    import dgcnn
+    g = load(name)
+    idx = dgcnn.ops.k_nn(_dev(g["points"]), int(g["k"])).cpu().numpy()
+    np.testing.assert_array_equal(idx, g["idx"])                                    # bit-exact
+    if "edges" in g:
+        np.testing.assert_array_equal(dgcnn.ops.edges(_dev(g["points"]), int(g["k"])).cpu().numpy(), g["edges"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["g7_model_config1", "g8_model_residual"])
+def test_hip_model_matches_golden(name):
+    import dgcnn
+    g = load(name)
+    cfg = ast.literal_eval(str(g["cfg"]))
+    C = g["points"].shape[-1]
+    flags = dgcnn.DGCNN_FLAGS(TRAIN=False, NUM_CLASS=2, FC_LAYERS=2, NUM_CHANNEL=C, **cfg)
+    tv = dgcnn.trainval(flags).initialize()
+    for n, v in params_of(g).items():
+        dgcnn.ctx().set_variable(n, v)
+    res = tv.inference(None, [g["points"]], [g["labels"]])
+    logits = dgcnn.build(_dev(g["points"]), flags).cpu().numpy()
+    np.testing.assert_allclose(logits, g["logits"], rtol=0, atol=1e-3)              # north_star bar
+    np.testing.assert_allclose(res[0].cpu().numpy(), g["softmax"], rtol=0, atol=1e-3)
+    assert abs(float(res[-1]) - float(g["loss"])) < 1e-3
+    assert abs(float(res[-2]) - float(g["accuracy"])) <= 2.0 / g["labels"].size
+
+
+@pytest.mark.gpu
+def test_hip_two_replicas_adam_matches_golden():
+    """G9: each replica is one tower of this process (trainval.py:26-55 semantics): mean over
+    towers, sum over micro-steps, one Adam step."""
+    import dgcnn
+    import dgcnn._engine as E
+    g = load("g9_two_replicas_adam")
+    flags = dgcnn.DGCNN_FLAGS(EDGE_CONV_LAYERS=1, KVALUE=6, FC_FILTERS=[32, 16], TRAIN=True, EDGE_CONV_FILTERS=64,
+                              NUM_CHANNEL=3, LEARNING_RATE=1e-3)
+    keep, E.DROPOUT_KEEP = E.DROPOUT_KEEP, 1.0
+    try:
+        tv = dgcnn.trainval(flags).initialize()
+        for n, v in params_of(g).items():
+            dgcnn.ctx().set_variable(n, v)
+        tv.zero_gradients(None)
+        for s in range(2):
+            tv.accum_gradient(None, [g["points_s%d_r0" % s], g["points_s%d_r1" % s]],
+                              [g["labels_s%d_r0" % s], g["labels_s%d_r1" % s]])
+        for n, ref in params_of(g, "accum:").items():
+            got = tv.gradients[n].cpu().numpy()
+            assert np.linalg.norm(got - ref) <= 1e-2 * max(np.linalg.norm(ref), 1e-6), n
+        tv.apply_gradient(None)
+        for n, ref in params_of(g, "new:").items():
+            np.testing.assert_allclose(tv.variables[n].cpu().numpy(), ref, rtol=0, atol=2.5e-3, err_msg=n)
+    finally:
+        E.DROPOUT_KEEP = keep
