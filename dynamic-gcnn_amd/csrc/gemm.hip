@@ -12,8 +12,8 @@
 //   epilogue  E_STORE  C = acc (+ beta C) (+ per-cloud bias) (+ BN column statistics) or
 //                      split-K partial;  E_SCATTER  dx[neighbour(row)][n] += acc (fp32 atomics)
 //
-// Tiling (wave64, 256 threads = 2x2 waves): block tile 128 x BN x 16, BN in {64,128}; each wave
-// owns (64 x BN/2) as TM x TN tiles of 32x32 MFMA accumulators (16 VGPR each).  Both LDS tiles
+// Tiling (wave64, 256 threads = 2x2 waves): block tile BM x BN x 16, BM in {128,256}, BN in {64,128};
+// each wave owns (BM/2 x BN/2) as TM x TN tiles of 32x32 MFMA accumulators (16 VGPR each).  Both LDS tiles
 // are k-major ([k][m] / [k][n]) so an MFMA operand read is one conflict-free ds_read_b32 of 32
 // consecutive floats per half-wave; row-major sources are transposed on the LDS write with a +2
 // row pad (4*(W+2) mod 32 = 8 -> the four k-quads of a half-wave hit disjoint bank octets).
@@ -29,7 +29,6 @@ enum { A_ROW = 0, A_COL = 1, A_EDGE = 2, A_EDGE_T = 3 };
 enum { B_ROW = 0, B_COL = 1 };
 enum { E_STORE = 0, E_SCATTER = 1 };
 
-constexpr int BM = 128;
 constexpr int BK = 16;
 constexpr int NT = 256;
 
@@ -47,7 +46,7 @@ struct GemmP {
   // split-K
   int splits; int kchunk; float* partial;
   int avec, bvec;
-  int mtiles, ntiles, xcd_group;
+  int mtiles, ntiles, xcd_group, bm, cvec;
 };
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
@@ -62,7 +61,7 @@ __device__ __forceinline__ int imin(int a, int b) { return a < b ? a : b; }
 // the loads and the MFMA block (the first version branched per element and drained vmcnt(0)
 // between loads: rocprof showed the GEMMs at 40-50 % of the fp32 MFMA peak).  VEC = false is the
 // generic (slow, fully predicated, scalar) path for odd shapes such as C = 3 or N = 2.
-template <int ASRC, int BSRC, int EPI, int BN, bool VEC>
+template <int ASRC, int BSRC, int EPI, int BM, int BN, bool VEC>
 __global__ __launch_bounds__(NT) void gemm_kernel(GemmP p) {
   constexpr bool A_TRANS = (ASRC == A_ROW || ASRC == A_EDGE);  // needs transposing LDS store
   constexpr bool B_TRANS = (BSRC == B_COL);
@@ -70,7 +69,7 @@ __global__ __launch_bounds__(NT) void gemm_kernel(GemmP p) {
   constexpr int SB = BN + (B_TRANS ? 2 : 4);
   constexpr int NVA = BM / 64;
   constexpr int NVB = BN / 64;
-  constexpr int TM = 2;
+  constexpr int TM = BM / 64;
   constexpr int TN = BN / 64;
 
   __shared__ __attribute__((aligned(16))) float smem[2 * BK * SA + 2 * BK * SB];
@@ -321,7 +320,7 @@ __global__ __launch_bounds__(NT) void gemm_kernel(GemmP p) {
   }
   __syncthreads();
 
-  const int a_off = wr * 64 + l31;
+  const int a_off = wr * (BM / 2) + l31;
   const int b_off = wc * (BN / 2) + l31;
 #pragma unroll 1
   for (int kt = 0; kt < nk; ++kt) {
@@ -375,7 +374,7 @@ __global__ __launch_bounds__(NT) void gemm_kernel(GemmP p) {
 
   // ---- epilogue.  C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
   const int colw = n0 + wc * (BN / 2) + l31;
-  const int roww = m0 + wr * 64 + 4 * lh;
+  const int roww = m0 + wr * (BM / 2) + 4 * lh;
   if (EPI == E_SCATTER) {
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -395,77 +394,92 @@ __global__ __launch_bounds__(NT) void gemm_kernel(GemmP p) {
     return;
   }
 
-  if (p.splits > 1) {
-    float* out = p.partial + (int64_t)z * p.M * p.N;
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = roww + i * 32 + (r & 3) + 8 * (r >> 2);
-        if (row < p.M) {
-#pragma unroll
-          for (int j = 0; j < TN; ++j) {
-            const int col = colw + j * 32;
-            if (col < p.N) out[(int64_t)row * p.N + col] = acc[i][j][r];
-          }
-        }
-      }
-    return;
-  }
-
-  float cs[TN], cq[TN];
-#pragma unroll
-  for (int j = 0; j < TN; ++j) { cs[j] = 0.f; cq[j] = 0.f; }
+  // ---- E_STORE: accumulators -> LDS (64 block rows at a time) -> coalesced float4 row stores.
+  // Keeps the epilogue at one global_store_dwordx4 per 4 outputs, lets the read-modify-write
+  // (beta) and the per-cloud bias be float4 loads, and needs no per-row pointer registers.
+  float* tile = smem;                       // [64][BN]
+  constexpr int QV = BN / 4;                // float4 per row
+  constexpr int RSTEP = NT / QV;            // rows covered per pass of the 256 threads
+  const int c4 = (t % QV) * 4;
+  const int rr0 = t / QV;
+  const int gcol = n0 + c4;
+  const bool col_ok = gcol < p.N;
   const bool has_beta = (p.beta != 0.f);
-  // per-cloud bias: a 128-row tile almost always lies inside one cloud -> one value per column
   const bool has_gb = (p.gbias != nullptr);
+  const bool split = (p.splits > 1);
+  float* outp = split ? (p.partial + (int64_t)z * p.M * p.N) : p.C;
+  const int64_t ldo = split ? (int64_t)p.N : p.ldc;
+  const bool vec_st = VEC && p.cvec && (gcol + 3 < p.N);
   const int rlast = imin(m0 + BM, p.M) - 1;
   const bool gb_uniform = has_gb && ((m0 / p.rpg) == (rlast / p.rpg));
+  float gbu[4] = {0.f, 0.f, 0.f, 0.f};
+  if (gb_uniform && col_ok) {
 #pragma unroll
-  for (int i = 0; i < TM; ++i)
+    for (int q = 0; q < 4; ++q)
+      if (gcol + q < p.N) gbu[q] = p.gbias[(int64_t)(m0 / p.rpg) * p.ldgbias + gcol + q];
+  }
+  float cs[4] = {0.f, 0.f, 0.f, 0.f}, cq[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int col = colw + j * 32;
-      const bool cok = col < p.N;
-      const int colc = cok ? col : 0;
-      float gbu = 0.f;
-      if (gb_uniform) gbu = p.gbias[(int64_t)(m0 / p.rpg) * p.ldgbias + colc];
-      float old[16];
-      if (has_beta) {          // all 16 read-modify-write loads in flight before the first use
+  for (int i = 0; i < TM; ++i) {
+    __syncthreads();
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = roww + i * 32 + (r & 3) + 8 * (r >> 2);
-          old[r] = p.C[(int64_t)imin(row, p.M - 1) * p.ldc + colc];
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        tile[(wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * BN + wc * (BN / 2) + j * 32 + l31] = acc[i][j][r];
+    __syncthreads();
+#pragma unroll
+    for (int q0 = 0; q0 < 64 / RSTEP; ++q0) {
+      const int rl = rr0 + q0 * RSTEP;
+      const int grow = m0 + (rl >> 5) * (BM / 2) + i * 32 + (rl & 31);
+      if (grow < p.M && col_ok) {
+        const float4 tv = *reinterpret_cast<const float4*>(&tile[rl * BN + c4]);
+        float v[4] = {tv.x, tv.y, tv.z, tv.w};
+        float* dst = outp + (int64_t)grow * ldo + gcol;
+        if (!split) {
+          if (has_gb) {
+            if (gb_uniform) {
+#pragma unroll
+              for (int q = 0; q < 4; ++q) v[q] += gbu[q];
+            } else {
+              const float* gb = p.gbias + (int64_t)(grow / p.rpg) * p.ldgbias + gcol;
+#pragma unroll
+              for (int q = 0; q < 4; ++q)
+                if (gcol + q < p.N) v[q] += gb[q];
+            }
+          }
+          if (has_beta) {
+            if (vec_st) {
+              const float4 o = *reinterpret_cast<const float4*>(dst);
+              v[0] += p.beta * o.x; v[1] += p.beta * o.y; v[2] += p.beta * o.z; v[3] += p.beta * o.w;
+            } else {
+#pragma unroll
+              for (int q = 0; q < 4; ++q)
+                if (gcol + q < p.N) v[q] += p.beta * dst[q];
+            }
+          }
         }
-      }
+        if (vec_st) {
+          *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = roww + i * 32 + (r & 3) + 8 * (r >> 2);
-        float v = acc[i][j][r];
-        if (has_gb) v += gb_uniform ? gbu : p.gbias[(int64_t)(imin(row, p.M - 1) / p.rpg) * p.ldgbias + colc];
-        if (has_beta) v += p.beta * old[r];
-        if (cok && row < p.M) {
-          p.C[(int64_t)row * p.ldc + col] = v;
-          cs[j] += v;
-          cq[j] += v * v;
+          for (int q = 0; q < 4; ++q) { cs[q] += v[q]; cq[q] += v[q] * v[q]; }
+        } else {
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            if (gcol + q < p.N) { dst[q] = v[q]; cs[q] += v[q]; cq[q] += v[q] * v[q]; }
         }
       }
     }
-  if (p.stats) {
-    // column sums: lanes l and l^32 share a column; the two wr-waves share it too (LDS add)
+  }
+  if (p.stats && !split) {
     __syncthreads();
     float* red = smem;  // [2][BN]
     for (int e = t; e < 2 * BN; e += NT) red[e] = 0.f;
     __syncthreads();
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      float s = cs[j] + __shfl_xor(cs[j], 32);
-      float q = cq[j] + __shfl_xor(cq[j], 32);
-      if (lh == 0) {
-        const int c = wc * (BN / 2) + j * 32 + l31;
-        atomicAdd(&red[c], s);
-        atomicAdd(&red[BN + c], q);
-      }
+    for (int q = 0; q < 4; ++q) {
+      atomicAdd(&red[c4 + q], cs[q]);
+      atomicAdd(&red[BN + c4 + q], cq[q]);
     }
     __syncthreads();
     const int slot = mt % DGCNN_STAT_SLOTS;
@@ -505,25 +519,43 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
   }
 }
 
-template <int ASRC, int BSRC, int EPI>
-int launch(GemmP& p, hipStream_t st, const char* what) {
-  const int bn = (p.N <= 64) ? 64 : 128;
+template <int ASRC, int BSRC, int EPI, int BM>
+void launch_bm(GemmP& p, hipStream_t st, bool vec, int bn) {
   p.mtiles = (int)dg::cdiv(p.M, BM);
   p.ntiles = (int)dg::cdiv(p.N, bn);
   p.xcd_group = (p.ntiles > 1 && p.mtiles >= 16 && p.splits == 1) ? 1 : 0;
   const unsigned gx = p.xcd_group ? (unsigned)(dg::cdiv(p.mtiles, 8) * 8 * p.ntiles) : (unsigned)(p.mtiles * p.ntiles);
   dim3 grid(gx, 1, (unsigned)p.splits);
+  if (bn == 64) {
+    if (vec) hipLaunchKernelGGL((gemm_kernel<ASRC, BSRC, EPI, BM, 64, true>), grid, dim3(NT), 0, st, p);
+    else hipLaunchKernelGGL((gemm_kernel<ASRC, BSRC, EPI, BM, 64, false>), grid, dim3(NT), 0, st, p);
+  } else {
+    if (vec) hipLaunchKernelGGL((gemm_kernel<ASRC, BSRC, EPI, BM, 128, true>), grid, dim3(NT), 0, st, p);
+    else hipLaunchKernelGGL((gemm_kernel<ASRC, BSRC, EPI, BM, 128, false>), grid, dim3(NT), 0, st, p);
+  }
+}
+
+inline int tile_m(int M, int N, int splits) {
+  // 256-row tiles halve the A/B bytes fetched per flop; use them when there are enough tiles to
+  // fill 256 CUs twice over, else 128 rows for parallelism.
+  const int bn = (N <= 64) ? 64 : 128;
+  const int64_t tiles256 = dg::cdiv(M, 256) * dg::cdiv(N, bn) * splits;
+  return (M >= 256 && tiles256 >= 512) ? 256 : 128;
+}
+
+template <int ASRC, int BSRC, int EPI>
+int launch(GemmP& p, hipStream_t st, const char* what) {
+  const int bn = (p.N <= 64) ? 64 : 128;
   // float4 path: pointers / leading dimensions checked by the caller (avec, bvec); here the extents
   const bool a_ext = (ASRC == A_ROW || ASRC == A_EDGE) ? (p.K % 4 == 0 && p.K >= 4) : (p.M % 4 == 0 && p.M >= 4);
   const bool b_ext = (BSRC == B_ROW) ? (p.N % 4 == 0 && p.N >= 4) : (p.K % 4 == 0 && p.K >= 4);
   const bool vec = p.avec && p.bvec && a_ext && b_ext;
-  if (bn == 64) {
-    if (vec) hipLaunchKernelGGL((gemm_kernel<ASRC, BSRC, EPI, 64, true>), grid, dim3(NT), 0, st, p);
-    else hipLaunchKernelGGL((gemm_kernel<ASRC, BSRC, EPI, 64, false>), grid, dim3(NT), 0, st, p);
-  } else {
-    if (vec) hipLaunchKernelGGL((gemm_kernel<ASRC, BSRC, EPI, 128, true>), grid, dim3(NT), 0, st, p);
-    else hipLaunchKernelGGL((gemm_kernel<ASRC, BSRC, EPI, 128, false>), grid, dim3(NT), 0, st, p);
+  if (EPI == E_STORE) {
+    if (p.splits > 1) p.cvec = (p.N % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.partial) & 15) == 0);
+    else p.cvec = (p.ldc % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.C) & 15) == 0);
   }
+  if (p.bm == 256) launch_bm<ASRC, BSRC, EPI, 256>(p, st, vec, bn);
+  else launch_bm<ASRC, BSRC, EPI, 128>(p, st, vec, bn);
   int rc = dg::check_launch(what);
   if (rc) return rc;
   if (p.splits > 1) {
@@ -540,7 +572,8 @@ inline bool aligned16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 
 // choose a split of the reduction dimension so that ~1024 workgroups are in flight
 int plan_splits(GemmP& p, void* ws, size_t ws_bytes, const char* what) {
   const int bn = (p.N <= 64) ? 64 : 128;
-  const int64_t tiles = dg::cdiv(p.M, BM) * dg::cdiv(p.N, bn);
+  p.bm = 128;
+  const int64_t tiles = dg::cdiv(p.M, 128) * dg::cdiv(p.N, bn);
   int64_t s = dg::cdiv(1024, tiles);
   const int64_t maxs = p.K / 256 > 0 ? p.K / 256 : 1;
   if (s > maxs) s = maxs;
@@ -587,6 +620,7 @@ extern "C" int dgcnn_gemm_f32(int transA, int transB, int M, int N, int K,
     if (rc) return rc;
     return launch<A_COL, B_ROW, E_STORE>(p, st, "dgcnn_gemm_f32(TN)");
   }
+  p.bm = tile_m(M, N, 1);
   if (transB) return launch<A_ROW, B_COL, E_STORE>(p, st, "dgcnn_gemm_f32(NT)");
   return launch<A_ROW, B_ROW, E_STORE>(p, st, "dgcnn_gemm_f32(NN)");
 }
@@ -605,6 +639,7 @@ extern "C" int dgcnn_edge_mlp_f32(const float* x, int64_t ldx, const int32_t* id
   p.stats = stats; p.splits = 1; p.kchunk = p.K;
   p.avec = (C % 4 == 0) && (ldx % 4 == 0) && aligned16(x);
   p.bvec = (F % 4 == 0) && aligned16(W0);
+  p.bm = tile_m(p.M, p.N, 1);
   return launch<A_EDGE, B_ROW, E_STORE>(p, (hipStream_t)stream, "dgcnn_edge_mlp_f32");
 }
 
@@ -639,5 +674,6 @@ extern "C" int dgcnn_edge_mlp_dgrad_scatter_f32(const float* dY, const float* W0
   p.splits = 1; p.kchunk = F;
   p.avec = (F % 4 == 0) && aligned16(dY);
   p.bvec = (F % 4 == 0) && aligned16(p.B);
+  p.bm = tile_m(p.M, p.N, 1);
   return launch<A_ROW, B_COL, E_SCATTER>(p, (hipStream_t)stream, "dgcnn_edge_mlp_dgrad_scatter_f32");
 }
