@@ -67,7 +67,7 @@ __global__ __launch_bounds__(256) void bn_act_kreduce_kernel(
     const float* __restrict__ Y, int64_t R, int k, int F, const float* __restrict__ mean,
     const float* __restrict__ rstd, const float* __restrict__ beta, int relu,
     float* __restrict__ max_out, int64_t ldmax, float* __restrict__ mean_out, int64_t ldmean,
-    float* __restrict__ out2, int64_t ldout2) {
+    float* __restrict__ out2, int64_t ldout2, float* __restrict__ cnt_out) {
   const int FV = F / V;
   const int64_t items = R * FV;
   const float invk = 1.0f / (float)k;
@@ -75,10 +75,10 @@ __global__ __launch_bounds__(256) void bn_act_kreduce_kernel(
        it += (int64_t)gridDim.x * blockDim.x) {
     const int64_t r = it / FV;
     const int f = (int)(it % FV) * V;
-    float mu[V], rs[V], be[V], mx[V], sm[V];
+    float mu[V], rs[V], be[V], mx[V], sm[V], cn[V];
     Vec<V>::ld(mean + f, mu); Vec<V>::ld(rstd + f, rs); Vec<V>::ld(beta + f, be);
 #pragma unroll
-    for (int v = 0; v < V; ++v) { mx[v] = -INFINITY; sm[v] = 0.f; }
+    for (int v = 0; v < V; ++v) { mx[v] = -INFINITY; sm[v] = 0.f; cn[v] = 0.f; }
     const float* y = Y + (r * k) * F + f;
     for (int m = 0; m < k; ++m) {
       float yv[V];
@@ -87,12 +87,15 @@ __global__ __launch_bounds__(256) void bn_act_kreduce_kernel(
       for (int v = 0; v < V; ++v) {
         float xh;
         const float z = bn_z(yv[v], mu[v], rs[v], be[v], relu, xh);
-        mx[v] = fmaxf(mx[v], z);
+        const bool gt = z > mx[v];
+        cn[v] = gt ? 1.f : ((z == mx[v]) ? cn[v] + 1.f : cn[v]);   // ties share the max gradient (A.5)
+        mx[v] = gt ? z : mx[v];
         sm[v] += z;
       }
     }
     Vec<V>::st(max_out + r * ldmax + f, mx);
     if (out2) Vec<V>::st(out2 + r * ldout2 + f, mx);
+    if (cnt_out) Vec<V>::st(cnt_out + r * F + f, cn);
     if (mean_out) {
 #pragma unroll
       for (int v = 0; v < V; ++v) sm[v] *= invk;
@@ -129,7 +132,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
     const float* __restrict__ Y, int64_t R, int k, int F, const float* __restrict__ mean,
     const float* __restrict__ rstd, const float* __restrict__ beta, int relu,
     const float* __restrict__ dmax, int64_t lddmax, const float* __restrict__ dmean, int64_t lddmean,
-    double* __restrict__ red) {
+    const float* __restrict__ mx_in, int64_t ldmx, const float* __restrict__ cnt_in, double* __restrict__ red) {
   extern __shared__ float lred[];  // [2][F]
   for (int e = threadIdx.x; e < 2 * F; e += blockDim.x) lred[e] = 0.f;
   __syncthreads();
@@ -158,7 +161,12 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
     KState<V> st;
     if (dmean) {
       Vec<V>::ld(dmean + r * lddmean + f, dmn);
-      k_pass_max<V>(y, k, F, mu, rs, be, relu, st);
+      if (mx_in) {                 // forward kept (max, #ties): Y is read once
+        Vec<V>::ld(mx_in + r * ldmx + f, st.mx);
+        Vec<V>::ld(cnt_in + r * F + f, st.cnt);
+      } else {
+        k_pass_max<V>(y, k, F, mu, rs, be, relu, st);
+      }
     }
     for (int m = 0; m < k; ++m) {
       float yv[V];
@@ -191,6 +199,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
     const float* Y, int64_t R, int k, int F, const float* __restrict__ mean,
     const float* __restrict__ rstd, const float* __restrict__ beta, int relu,
     const float* __restrict__ dmax, int64_t lddmax, const float* __restrict__ dmean, int64_t lddmean,
+    const float* __restrict__ mx_in, int64_t ldmx, const float* __restrict__ cnt_in,
     const double* __restrict__ red, float* dY, float* __restrict__ dYsum) {
   const int FV = F / V;
   const int64_t items = R * FV;
@@ -214,7 +223,12 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
     KState<V> st;
     if (dmean) {
       Vec<V>::ld(dmean + r * lddmean + f, dmn);
-      k_pass_max<V>(y, k, F, mu, rs, be, relu, st);
+      if (mx_in) {                 // forward kept (max, #ties): Y is read once
+        Vec<V>::ld(mx_in + r * ldmx + f, st.mx);
+        Vec<V>::ld(cnt_in + r * F + f, st.cnt);
+      } else {
+        k_pass_max<V>(y, k, F, mu, rs, be, relu, st);
+      }
     }
     for (int m = 0; m < k; ++m) {
       float yv[V], o[V];
@@ -258,43 +272,48 @@ extern "C" int dgcnn_bn_finalize_f32(const double* stats, int F, double count, f
 extern "C" int dgcnn_bn_act_kreduce_f32(const float* Y, int64_t R, int k, int F,
                                         const float* mean, const float* rstd, const float* beta, int relu,
                                         float* max_out, int64_t ldmax, float* mean_out, int64_t ldmean,
-                                        float* out2, int64_t ldout2, void* stream) {
+                                        float* out2, int64_t ldout2, float* cnt_out, void* stream) {
   DG_REQUIRE(Y && mean && rstd && beta && max_out, DGCNN_EINVAL, "dgcnn_bn_act_kreduce_f32: null pointer");
   DG_REQUIRE(R > 0 && k > 0 && F > 0, DGCNN_EINVAL, "dgcnn_bn_act_kreduce_f32: bad shape");
   const bool vec = (F % 4 == 0) && (ldmax % 4 == 0) && a16(Y) && a16(max_out) && a16(mean) && a16(rstd) && a16(beta) &&
-                   (!mean_out || ((ldmean % 4 == 0) && a16(mean_out))) && (!out2 || ((ldout2 % 4 == 0) && a16(out2)));
+                   (!mean_out || ((ldmean % 4 == 0) && a16(mean_out))) && (!out2 || ((ldout2 % 4 == 0) && a16(out2))) &&
+                   (!cnt_out || a16(cnt_out));
   hipStream_t st = (hipStream_t)stream;
   if (vec)
     hipLaunchKernelGGL((bn_act_kreduce_kernel<4>), dim3(grid_for(R * (F / 4))), dim3(256), 0, st, Y, R, k, F, mean,
-                       rstd, beta, relu, max_out, ldmax, mean_out, ldmean, out2, ldout2);
+                       rstd, beta, relu, max_out, ldmax, mean_out, ldmean, out2, ldout2, cnt_out);
   else
     hipLaunchKernelGGL((bn_act_kreduce_kernel<1>), dim3(grid_for(R * F)), dim3(256), 0, st, Y, R, k, F, mean, rstd,
-                       beta, relu, max_out, ldmax, mean_out, ldmean, out2, ldout2);
+                       beta, relu, max_out, ldmax, mean_out, ldmean, out2, ldout2, cnt_out);
   return dg::check_launch("dgcnn_bn_act_kreduce_f32");
 }
 
 extern "C" int dgcnn_bn_bwd_reduce_f32(const float* Y, int64_t R, int k, int F,
                                        const float* mean, const float* rstd, const float* beta, int relu,
                                        const float* dmax, int64_t lddmax, const float* dmean, int64_t lddmean,
+                                       const float* mx_in, int64_t ldmx, const float* cnt_in,
                                        double* red, void* stream) {
   DG_REQUIRE(Y && mean && rstd && beta && dmax && red, DGCNN_EINVAL, "dgcnn_bn_bwd_reduce_f32: null pointer");
   DG_REQUIRE(R > 0 && k > 0 && F > 0 && F <= 8192, DGCNN_EINVAL, "dgcnn_bn_bwd_reduce_f32: bad shape");
   const bool vec = (F % 4 == 0) && (lddmax % 4 == 0) && a16(Y) && a16(dmax) && a16(mean) && a16(rstd) && a16(beta) &&
-                   (!dmean || ((lddmean % 4 == 0) && a16(dmean)));
+                   (!dmean || ((lddmean % 4 == 0) && a16(dmean))) &&
+                   (!mx_in || ((ldmx % 4 == 0) && a16(mx_in) && a16(cnt_in)));
+  DG_REQUIRE(!mx_in || cnt_in, DGCNN_EINVAL, "dgcnn_bn_bwd_reduce_f32: mx_in needs cnt_in");
   hipStream_t st = (hipStream_t)stream;
   const size_t sh = (size_t)2 * F * sizeof(float);
   if (vec)
     hipLaunchKernelGGL((bn_bwd_reduce_kernel<4>), dim3(grid_for(R * (F / 4))), dim3(256), sh, st, Y, R, k, F, mean,
-                       rstd, beta, relu, dmax, lddmax, dmean, lddmean, red);
+                       rstd, beta, relu, dmax, lddmax, dmean, lddmean, mx_in, ldmx, cnt_in, red);
   else
     hipLaunchKernelGGL((bn_bwd_reduce_kernel<1>), dim3(grid_for(R * F)), dim3(256), sh, st, Y, R, k, F, mean, rstd,
-                       beta, relu, dmax, lddmax, dmean, lddmean, red);
+                       beta, relu, dmax, lddmax, dmean, lddmean, mx_in, ldmx, cnt_in, red);
   return dg::check_launch("dgcnn_bn_bwd_reduce_f32");
 }
 
 extern "C" int dgcnn_bn_bwd_apply_f32(const float* Y, int64_t R, int k, int F,
                                       const float* mean, const float* rstd, const float* beta, int relu,
                                       const float* dmax, int64_t lddmax, const float* dmean, int64_t lddmean,
+                                      const float* mx_in, int64_t ldmx, const float* cnt_in,
                                       double* red, float* dY, float* dYsum, float* dbeta, float dbeta_beta,
                                       void* stream) {
   DG_REQUIRE(Y && mean && rstd && beta && dmax && red && dY, DGCNN_EINVAL, "dgcnn_bn_bwd_apply_f32: null pointer");
@@ -303,12 +322,13 @@ extern "C" int dgcnn_bn_bwd_apply_f32(const float* Y, int64_t R, int k, int F,
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)dg::cdiv(F, 128)), dim3(128), 0, st, red, F, dbeta,
                      dbeta_beta);
   const bool vec = (F % 4 == 0) && (lddmax % 4 == 0) && a16(Y) && a16(dY) && a16(dmax) && a16(mean) && a16(rstd) &&
-                   a16(beta) && (!dmean || ((lddmean % 4 == 0) && a16(dmean))) && (!dYsum || a16(dYsum));
+                   a16(beta) && (!dmean || ((lddmean % 4 == 0) && a16(dmean))) && (!dYsum || a16(dYsum)) &&
+                   (!mx_in || ((ldmx % 4 == 0) && a16(mx_in) && a16(cnt_in)));
   if (vec)
     hipLaunchKernelGGL((bn_bwd_apply_kernel<4>), dim3(grid_for(R * (F / 4))), dim3(256), 0, st, Y, R, k, F, mean, rstd,
-                       beta, relu, dmax, lddmax, dmean, lddmean, red, dY, dYsum);
+                       beta, relu, dmax, lddmax, dmean, lddmean, mx_in, ldmx, cnt_in, red, dY, dYsum);
   else
     hipLaunchKernelGGL((bn_bwd_apply_kernel<1>), dim3(grid_for(R * F)), dim3(256), 0, st, Y, R, k, F, mean, rstd, beta,
-                       relu, dmax, lddmax, dmean, lddmean, red, dY, dYsum);
+                       relu, dmax, lddmax, dmean, lddmean, mx_in, ldmx, cnt_in, red, dY, dYsum);
   return dg::check_launch("dgcnn_bn_bwd_apply_f32");
 }

@@ -229,6 +229,13 @@ def knn(x2d, B, N, k):
     return idx
 
 
+def _tile_m(M, N):
+    """Mirror of gemm.hip:tile_m (only used to name the kernel instance in bench.py's roofline tags)."""
+    bn = 64 if N <= 64 else 128
+    tiles256 = -(-M // 256) * -(-N // bn)
+    return 256 if (M >= 256 and tiles256 >= 512) else 128
+
+
 def gemm(A, Bm, C, transA=False, transB=False, beta=0.0, gbias=None, rpg=0, stats=None):
     """C (+)= op(A) op(B); shapes are those of the stored matrices."""
     M = A.shape[1] if transA else A.shape[0]
@@ -240,8 +247,9 @@ def gemm(A, Bm, C, transA=False, transB=False, beta=0.0, gbias=None, rpg=0, stat
     H.call("dgcnn_gemm_f32", int(transA), int(transB), M, N, K, A.data_ptr(), H.ld2(A), Bm.data_ptr(), H.ld2(Bm),
            C.data_ptr(), H.ld2(C), float(beta), H._p(gbias), 0 if gbias is None else H.ld2(gbias), int(rpg),
            H._p(stats), ws.data_ptr(), ws.numel(),
-           tag="gemm_kernel<%s,%s,STORE,%d>" % ("A_COL" if transA else "A_ROW", "B_COL" if transB else "B_ROW",
-                                                 64 if N <= 64 else 128), work=2.0 * M * N * K)
+           tag="gemm_kernel<%s,%s,STORE,%d,%d>" % ("A_COL" if transA else "A_ROW", "B_COL" if transB else "B_ROW",
+                                                    128 if transA else _tile_m(M, N), 64 if N <= 64 else 128),
+           work=2.0 * M * N * K)
 
 
 def bn_finalize(stats, F, count):
@@ -277,7 +285,7 @@ def conv_bn_act(x, leaf_scope, num_outputs, relu=True, out=None, out2=None, gbia
     if out is None:
         out = c.new_buffer(R, F)
     H.call("dgcnn_bn_act_kreduce_f32", T.data_ptr(), R, 1, F, mean.data_ptr(), rstd.data_ptr(), beta.data_ptr(),
-           int(relu), out.data_ptr(), H.ld2(out), 0, 0, H._p(out2), 0 if out2 is None else H.ld2(out2))
+           int(relu), out.data_ptr(), H.ld2(out), 0, 0, H._p(out2), 0 if out2 is None else H.ld2(out2), 0)
 
     if c.recording:
         def bwd():
@@ -290,9 +298,9 @@ def conv_bn_act(x, leaf_scope, num_outputs, relu=True, out=None, out2=None, gbia
                     H.call("dgcnn_copy2d_f32", d2.data_ptr(), H.ld2(d2), dout.data_ptr(), H.ld2(dout), R, F, 1)
             red = c.stats(F)
             H.call("dgcnn_bn_bwd_reduce_f32", T.data_ptr(), R, 1, F, mean.data_ptr(), rstd.data_ptr(), beta.data_ptr(),
-                   int(relu), dout.data_ptr(), H.ld2(dout), 0, 0, red.data_ptr())
+                   int(relu), dout.data_ptr(), H.ld2(dout), 0, 0, 0, 0, 0, red.data_ptr())
             H.call("dgcnn_bn_bwd_apply_f32", T.data_ptr(), R, 1, F, mean.data_ptr(), rstd.data_ptr(), beta.data_ptr(),
-                   int(relu), dout.data_ptr(), H.ld2(dout), 0, 0, red.data_ptr(), T.data_ptr(), 0,
+                   int(relu), dout.data_ptr(), H.ld2(dout), 0, 0, 0, 0, 0, red.data_ptr(), T.data_ptr(), 0,
                    c.var_grads[bname].data_ptr(), 1.0)
             dT = T
             dWx = c.var_grads[wname] if w_rows is None else c.var_grads[wname][w_rows[0]:w_rows[1]]
@@ -328,7 +336,7 @@ def edge_conv_block(x, B, N, k, num_filters, relu1=True, outs=None, net2=None):
     Y = torch.empty((R * k, F), dtype=torch.float32, device=x.device)
     st = c.stats(F)
     H.call("dgcnn_edge_mlp_f32", x.data_ptr(), H.ld2(x), idx.data_ptr(), W0.data_ptr(), B, N, C, k, F,
-           Y.data_ptr(), st.data_ptr(), tag="gemm_kernel<A_EDGE,B_ROW,STORE,%d>" % (64 if F <= 64 else 128),
+           Y.data_ptr(), st.data_ptr(), tag="gemm_kernel<A_EDGE,B_ROW,STORE,%d,%d>" % (_tile_m(R * k, F), 64 if F <= 64 else 128),
            work=2.0 * R * k * 2 * C * F)                                # ops.py:21-52 (gather fused)
     mean, rstd = bn_finalize(st, F, R * k)                              # ops.py:53
     if outs is None:
@@ -337,8 +345,9 @@ def edge_conv_block(x, B, N, k, num_filters, relu1=True, outs=None, net2=None):
     else:
         mm, net_out = outs
     mx, mn = mm[:, :F], mm[:, F:]
+    cnt = torch.empty((R, F), dtype=torch.float32, device=x.device) if c.recording else None   # ties of the max
     H.call("dgcnn_bn_act_kreduce_f32", Y.data_ptr(), R, k, F, mean.data_ptr(), rstd.data_ptr(), beta0.data_ptr(), 1,
-           mx.data_ptr(), H.ld2(mx), mn.data_ptr(), H.ld2(mn), 0, 0,
+           mx.data_ptr(), H.ld2(mx), mn.data_ptr(), H.ld2(mn), 0, 0, H._p(cnt),
            tag="bn_act_kreduce_kernel", work=4.0 * (R * k * F + 2 * R * F))   # ops.py:54-58
 
     if c.recording:
@@ -349,19 +358,21 @@ def edge_conv_block(x, B, N, k, num_filters, relu1=True, outs=None, net2=None):
             dmx, dmn = dmm[:, :F], dmm[:, F:]
             red = c.stats(F)
             H.call("dgcnn_bn_bwd_reduce_f32", Y.data_ptr(), R, k, F, mean.data_ptr(), rstd.data_ptr(),
-                   beta0.data_ptr(), 1, dmx.data_ptr(), H.ld2(dmx), dmn.data_ptr(), H.ld2(dmn), red.data_ptr(),
+                   beta0.data_ptr(), 1, dmx.data_ptr(), H.ld2(dmx), dmn.data_ptr(), H.ld2(dmn),
+                   mx.data_ptr(), H.ld2(mx), cnt.data_ptr(), red.data_ptr(),
                    tag="bn_bwd_reduce_kernel", work=4.0 * (R * k * F + 2 * R * F))
             dx = c.grad(x)
             dysum = torch.empty((R, F), dtype=torch.float32, device=x.device) if dx is not None else None
             H.call("dgcnn_bn_bwd_apply_f32", Y.data_ptr(), R, k, F, mean.data_ptr(), rstd.data_ptr(), beta0.data_ptr(),
-                   1, dmx.data_ptr(), H.ld2(dmx), dmn.data_ptr(), H.ld2(dmn), red.data_ptr(), Y.data_ptr(),
+                   1, dmx.data_ptr(), H.ld2(dmx), dmn.data_ptr(), H.ld2(dmn), mx.data_ptr(), H.ld2(mx), cnt.data_ptr(),
+                   red.data_ptr(), Y.data_ptr(),
                    H._p(dysum), c.var_grads[b0name].data_ptr(), 1.0,
                    tag="bn_bwd_apply_kernel", work=4.0 * (2 * R * k * F + 3 * R * F))
             dY = Y
             ws = c.workspace()
             H.call("dgcnn_edge_mlp_wgrad_f32", x.data_ptr(), H.ld2(x), idx.data_ptr(), dY.data_ptr(), B, N, C, k, F,
                    c.var_grads[w0name].data_ptr(), 1.0, ws.data_ptr(), ws.numel(),
-                   tag="gemm_kernel<A_EDGE_T,B_ROW,STORE,%d>" % (64 if F <= 64 else 128), work=2.0 * R * k * 2 * C * F)
+                   tag="gemm_kernel<A_EDGE_T,B_ROW,STORE,128,%d>" % (64 if F <= 64 else 128), work=2.0 * R * k * 2 * C * F)
             if dx is not None:
                 # E = [x_i, x_j - x_i]  =>  dx_i += (sum_m dY) (W0[:C]-W0[C:])^T ; dx_j += dY W0[C:]^T
                 wd = torch.empty((C, F), dtype=torch.float32, device=x.device)
@@ -369,7 +380,7 @@ def edge_conv_block(x, B, N, k, num_filters, relu1=True, outs=None, net2=None):
                 H.call("dgcnn_axpby_f32", W0[C:].data_ptr(), -1.0, wd.data_ptr(), 1.0, C * F)
                 gemm(dysum, wd, dx, transB=True, beta=1.0)
                 H.call("dgcnn_edge_mlp_dgrad_scatter_f32", dY.data_ptr(), W0.data_ptr(), idx.data_ptr(), B, N, C, k, F,
-                       dx.data_ptr(), H.ld2(dx), tag="gemm_kernel<A_ROW,B_COL,SCATTER,%d>" % (64 if C <= 64 else 128),
+                       dx.data_ptr(), H.ld2(dx), tag="gemm_kernel<A_ROW,B_COL,SCATTER,%d,%d>" % (_tile_m(R * k, C), 64 if C <= 64 else 128),
                        work=2.0 * R * k * C * F)
         c.tape.append(bwd)
 

@@ -88,16 +88,18 @@ int dgcnn_bn_finalize_f32(const double* stats, int F, double count, float eps,
                           float* mean, float* rstd, void* stream);
 /* z = (Y - mean)*rstd + beta ; relu? ; over the k rows of each of the R points:
  * max_out[r][f] = max_m z, mean_out[r][f] = (sum_m z)/k.  k = 1: out = act(bn(Y)) -> max_out
- * (mean_out may be NULL; out2 optionally receives a second copy of max_out).                 */
+ * (mean_out may be NULL; out2 optionally receives a second copy of max_out; cnt_out (R,F), optional,
+ * receives the number of rows attaining the max -- reduce_max's gradient is shared among ties).  */
 int dgcnn_bn_act_kreduce_f32(const float* Y, int64_t R, int k, int F,
                              const float* mean, const float* rstd, const float* beta, int relu,
                              float* max_out, int64_t ldmax, float* mean_out, int64_t ldmean,
-                             float* out2, int64_t ldout2, void* stream);
+                             float* out2, int64_t ldout2, float* cnt_out, void* stream);
 /* backward, pass 1: red[0][f] = sum dZ, red[1][f] = sum dZ*xhat over all R*k rows, where
  * dZ = relu'(z) * ( dmax*[z==max]/ties + dmean/k ).  red: double[DGCNN_STAT_SLOTS][2][F], zeroed. */
 int dgcnn_bn_bwd_reduce_f32(const float* Y, int64_t R, int k, int F,
                             const float* mean, const float* rstd, const float* beta, int relu,
                             const float* dmax, int64_t lddmax, const float* dmean, int64_t lddmean,
+                            const float* mx_in, int64_t ldmx, const float* cnt_in,   /* forward's max / #ties, or NULL: recompute */
                             double* red, void* stream);
 /* backward, pass 2: dY = rstd*(dZ - red0/cnt - xhat*red1/cnt) written to dY (may alias Y);
  * dbeta[f] (+)= red0 ; dYsum[r][f] = sum_m dY (optional, feeds the centre dgrad).
@@ -105,6 +107,7 @@ int dgcnn_bn_bwd_reduce_f32(const float* Y, int64_t R, int k, int F,
 int dgcnn_bn_bwd_apply_f32(const float* Y, int64_t R, int k, int F,
                            const float* mean, const float* rstd, const float* beta, int relu,
                            const float* dmax, int64_t lddmax, const float* dmean, int64_t lddmean,
+                           const float* mx_in, int64_t ldmx, const float* cnt_in,
                            double* red, float* dY, float* dYsum, float* dbeta, float dbeta_beta,
                            void* stream);
 
