@@ -15,6 +15,7 @@
 // The four per-wave lists are merged through LDS at the end.  The (B,N,N) matrix never exists.
 #include "common.h"
 #include <math.h>
+#include <stdlib.h>
 
 namespace {
 
@@ -223,10 +224,181 @@ __global__ __launch_bounds__(256, (knn_min_waves<CP, KC>())) void knn_kernel(con
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// MFMA variant for feature-space graphs (C > 4): the inner products p_ij come from
+// v_mfma_f32_32x32x2_f32, which on gfx950 is bit-for-bit an fmaf chain in k order (one rounding per
+// product, no wider accumulation; MI355X_MICROARCH.md "Matrix cores"): feeding c = 2s, 2s+1 at step
+// s reproduces the normative chain exactly -- the bit-exact tests against oracle/knn_oracle.c run on
+// this kernel.  The matrix pipe does the 2*N^2*C flops; the VALU is left for the selection.
+//   A operand = candidates (k-major LDS tile [c][cand], one conflict-free ds_read_b32 per step),
+//   B operand = this wave's 32 query rows, resident in CP/2 VGPRs for the whole kernel.
+//   D layout: lane l holds query row (l & 31) and candidates (r&3) + 8(r>>2) + 4(l>>5), r = 0..15:
+//   two lanes per row, each with its own register-resident sorted list over its candidate subset.
+// Block = 64 query rows x 2 candidate halves (4 waves); 4 lists per row merged through LDS.
+template <int CP, int KC>
+__global__ __launch_bounds__(256, 2) void knn_mfma_kernel(const float* __restrict__ x, const float* __restrict__ sq,
+                                                          int N, int C, int64_t ldx, int k, int vec_ok,
+                                                          int32_t* __restrict__ idx) {
+  using f32x16 = __attribute__((ext_vector_type(16))) float;
+  constexpr int ST = TJ + 2;                 // k-major candidate tile [CP][ST]
+  constexpr int TILE_F = CP * ST;
+  constexpr int DQ_F = 16 * 256;
+  constexpr int MERGE_F = ROWS * KC * 2;
+  constexpr int SH = (TILE_F + DQ_F > MERGE_F ? TILE_F + DQ_F : MERGE_F);
+  __shared__ __attribute__((aligned(16))) float smem[SH + TJ];
+  float* xsT = smem;
+  float* dq = smem + TILE_F;
+  float* sjs = smem + SH;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int w = tid >> 6;
+  const int l31 = lane & 31, h = lane >> 5;
+  const int qg = w & 1;                      // which 32 query rows of the block
+  const int cs = w >> 1;                     // which 64 candidates of every 128-candidate tile
+  const int b = blockIdx.y;
+  const int row = blockIdx.x * ROWS + qg * 32 + l31;
+  const float* xb = x + (int64_t)b * N * ldx;
+  const float* sqb = sq + (int64_t)b * N;
+  const int rowc = row < N ? row : N - 1;
+
+  float bq[CP / 2];                          // B operand: x_q[row][2s + h]
+#pragma unroll
+  for (int s2 = 0; s2 < CP / 2; ++s2) {
+    const int c = 2 * s2 + h;
+    bq[s2] = (c < C) ? xb[(int64_t)rowc * ldx + c] : 0.0f;
+  }
+  const float si = sqb[rowc];
+
+  float dl[KC];
+  int jl[KC];
+#pragma unroll
+  for (int t = 0; t < KC; ++t) {
+    dl[t] = INFINITY;
+    jl[t] = 0x7fffffff;
+  }
+
+#pragma unroll 1
+  for (int j0 = 0; j0 < N; j0 += TJ) {
+    __syncthreads();
+    // ---- stage 128 candidate rows transposed ([c][cand]), zero padded to CP channels ----
+    for (int e = tid; e < TJ * (CP / 4); e += 256) {
+      const int r = e / (CP / 4);
+      const int c4 = (e % (CP / 4)) * 4;
+      const int j = j0 + r;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (j < N) {
+        const float* src = xb + (int64_t)j * ldx + c4;
+        if (vec_ok && c4 + 3 < C) {
+          v = *reinterpret_cast<const float4*>(src);
+        } else {
+          if (c4 + 0 < C) v.x = src[0];
+          if (c4 + 1 < C) v.y = src[1];
+          if (c4 + 2 < C) v.z = src[2];
+          if (c4 + 3 < C) v.w = src[3];
+        }
+      }
+      xsT[(c4 + 0) * ST + r] = v.x;
+      xsT[(c4 + 1) * ST + r] = v.y;
+      xsT[(c4 + 2) * ST + r] = v.z;
+      xsT[(c4 + 3) * ST + r] = v.w;
+    }
+    if (tid < TJ) {
+      const int j = j0 + tid;
+      sjs[tid] = (j < N) ? sqb[j] : INFINITY;
+    }
+    __syncthreads();
+
+#pragma unroll 1
+    for (int sub = 0; sub < 2; ++sub) {
+      const int cbase = cs * 64 + sub * 32;
+      if (j0 + cbase >= N) break;            // wave-uniform
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+      const float* ap = xsT + h * ST + cbase + l31;
+#pragma unroll
+      for (int s2 = 0; s2 < CP / 2; ++s2)
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * s2 * ST], bq[s2], acc, 0, 0, 0);
+
+      // ---- distances of this lane's 16 candidates; park them, flag the ones that beat the k-th ----
+      const float thr = dl[KC - 1];
+      unsigned mask = 0u;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int i = (r & 3) + 8 * (r >> 2) + 4 * h;
+        const float t = si + sjs[cbase + i];
+        const float tp = 2.0f * acc[r];
+        const float d = t - tp;
+        dq[r * 256 + tid] = d;
+        mask |= (unsigned)sel_i(m_flt(d, thr), 1 << r, 0);
+      }
+      while (__any(mask != 0u)) {
+        const lmask_t live = m_ine((int)mask, 0);
+        const int g = sel_i(live, __builtin_ctz(mask | 0x80000000u), 0);
+        const float d = sel_f(live, dq[g * 256 + tid], INFINITY);
+        mask &= mask - 1u;
+        const int i = (g & 3) + 8 * (g >> 2) + 4 * h;
+        list_insert<KC, false>(dl, jl, d, j0 + cbase + i);
+      }
+    }
+  }
+
+  // ---- merge: 4 lists per query row (2 lane halves x 2 candidate halves) -> lanes 0..31 of waves 0,1 ----
+  __syncthreads();
+  float* md = smem;
+  int* mj = reinterpret_cast<int*>(smem + ROWS * KC);
+  const int me = cs * 2 + h;                 // list id of this lane; id 0 is the destination
+  const int slot = qg * 32 + l31;            // row within the block
+#pragma unroll 1
+  for (int src = 1; src < 4; ++src) {
+    if (src > 1) __syncthreads();
+    if (me == src) {
+#pragma unroll
+      for (int t = 0; t < KC; ++t) {
+        md[t * ROWS + slot] = dl[t];
+        mj[t * ROWS + slot] = jl[t];
+      }
+    }
+    __syncthreads();
+    if (cs == 0) {                           // wave-uniform; lanes with h == 1 idle along (d = +inf)
+#pragma unroll 1
+      for (int t = 0; t < KC; ++t) {
+        const float d = (h == 0) ? md[t * ROWS + slot] : INFINITY;
+        const int j = (h == 0) ? mj[t * ROWS + slot] : 0x7fffffff;
+        const lmask_t need = key_less<true>(d, j, dl[KC - 1], jl[KC - 1]);
+        if (need == 0) break;
+        list_insert<KC, true>(dl, jl, d, j);
+      }
+    }
+  }
+  if (me == 0 && row < N) {
+    int32_t* out = idx + ((int64_t)b * N + row) * k;
+#pragma unroll
+    for (int t = 0; t < KC; ++t)
+      if (t < k) out[t] = jl[t];
+  }
+}
+
+bool knn_force_valu() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("DGCNN_KNN_VALU");   // A/B switch: VALU fmaf distance for every C
+    v = (e && e[0] == '1') ? 1 : 0;
+  }
+  return v == 1;
+}
+
 template <int CP, int KC>
 void launch_knn(const float* x, const float* sq, int B, int N, int C, int64_t ldx, int k, int vec_ok,
                 int32_t* idx, hipStream_t st) {
   dim3 grid((unsigned)dg::cdiv(N, ROWS), (unsigned)B);
+  if constexpr (CP >= 16 && CP <= 64) {
+    if (!knn_force_valu()) {
+      hipLaunchKernelGGL((knn_mfma_kernel<CP, KC>), grid, dim3(256), 0, st, x, sq, N, C, ldx, k, vec_ok, idx);
+      return;
+    }
+  }
   hipLaunchKernelGGL((knn_kernel<CP, KC>), grid, dim3(256), 0, st, x, sq, N, C, ldx, k, vec_ok, idx);
 }
 
