@@ -334,7 +334,9 @@ __global__ __launch_bounds__(NT) void gemm_kernel(GemmP p) {
     }
     const float* as = As + buf * BK * SA + lh * SA + a_off;
     const float* bs = Bs + buf * BK * SB + lh * SB + b_off;
-    // operand reads run one k-pair ahead of the MFMAs (two register sets, static indices)
+    // operand reads run one k-pair ahead of the MFMAs (two register sets, static indices); the
+    // sched_barriers pin "issue next reads -> MFMAs of the current pair" so the LDS latency of pair
+    // s+1 hides under the 8 MFMAs of pair s (hipcc otherwise sinks each read next to its use).
     float a0[TM], b0[TN], a1[TM], b1[TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i) a0[i] = as[i * 32];
@@ -346,22 +348,26 @@ __global__ __launch_bounds__(NT) void gemm_kernel(GemmP p) {
       for (int i = 0; i < TM; ++i) a1[i] = as[2 * (s + 1) * SA + i * 32];
 #pragma unroll
       for (int j = 0; j < TN; ++j) b1[j] = bs[2 * (s + 1) * SB + j * 32];
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[i], b0[j], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
       if (s + 2 < BK / 2) {
 #pragma unroll
         for (int i = 0; i < TM; ++i) a0[i] = as[2 * (s + 2) * SA + i * 32];
 #pragma unroll
         for (int j = 0; j < TN; ++j) b0[j] = bs[2 * (s + 2) * SB + j * 32];
       }
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[i], b1[j], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
     }
     if (more) {
 #pragma unroll
@@ -519,6 +525,72 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
   }
 }
 
+// conv0 wgrad for raw point clouds (C <= 4, i.e. 2C <= 8 rows of dW0): the MFMA tile would be 95 %
+// padding and its generic loader is scalar.  HBM-bound instead: stream dY once (coalesced 256-B
+// rows), rebuild the 2C edge features of each edge from (x, idx) -- wave-uniform, so they sit in
+// SGPRs -- and keep 2C x (F/64) partial sums per lane.  One partial tile per block, combined by
+// reduce_partials_kernel (deterministic).
+template <int CC>
+__global__ __launch_bounds__(256) void edge_wgrad_smallc_kernel(const float* __restrict__ x, int64_t ldx,
+                                                                const int32_t* __restrict__ idx,
+                                                                const float* __restrict__ dY, int64_t Me, int npts,
+                                                                int knn, int C, int F, int chunk,
+                                                                float* __restrict__ partial) {
+  constexpr int FB = 4;                       // F <= 256
+  __shared__ float sh[4][2 * CC * 64];
+  const int t = threadIdx.x;
+  const int fl = t & 63, sub = t >> 6;
+  float acc[FB][2 * CC];
+#pragma unroll
+  for (int fb = 0; fb < FB; ++fb)
+#pragma unroll
+    for (int c = 0; c < 2 * CC; ++c) acc[fb][c] = 0.f;
+  const int64_t e0 = (int64_t)blockIdx.x * chunk;
+  const int64_t e1 = (e0 + chunk < Me) ? (e0 + chunk) : Me;
+  for (int64_t e = e0 + sub; e < e1; e += 4) {
+    const int64_t g = e / knn;
+    const int64_t nb = (g / npts) * npts + idx[e];
+    float ev[2 * CC];
+#pragma unroll
+    for (int c = 0; c < CC; ++c) {
+      const float xc = (c < C) ? x[g * ldx + c] : 0.f;
+      const float xn = (c < C) ? x[nb * ldx + c] : 0.f;
+      ev[c] = xc;
+      ev[CC + c] = xn - xc;
+    }
+    const float* dy = dY + e * F;
+#pragma unroll
+    for (int fb = 0; fb < FB; ++fb) {
+      const int f = fl + 64 * fb;
+      if (f < F) {
+        const float d = dy[f];
+#pragma unroll
+        for (int c = 0; c < 2 * CC; ++c) acc[fb][c] = fmaf(ev[c], d, acc[fb][c]);
+      }
+    }
+  }
+  float* out = partial + (int64_t)blockIdx.x * 2 * C * F;
+#pragma unroll
+  for (int fb = 0; fb < FB; ++fb) {
+    if (64 * fb >= F) break;
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < 2 * CC; ++c) sh[sub][c * 64 + fl] = acc[fb][c];
+    __syncthreads();
+    if (sub == 0) {
+      const int f = fl + 64 * fb;
+      if (f < F) {
+#pragma unroll
+        for (int c = 0; c < 2 * CC; ++c) {
+          const float v = (sh[0][c * 64 + fl] + sh[1][c * 64 + fl]) + (sh[2][c * 64 + fl] + sh[3][c * 64 + fl]);
+          const int cr = (c < CC) ? c : (C + (c - CC));     // row of dW0: centre rows 0..C-1, diff rows C..2C-1
+          if ((c < CC ? c : c - CC) < C) out[(int64_t)cr * F + f] = v;
+        }
+      }
+    }
+  }
+}
+
 template <int ASRC, int BSRC, int EPI, int BM>
 void launch_bm(GemmP& p, hipStream_t st, bool vec, int bn) {
   p.mtiles = (int)dg::cdiv(p.M, BM);
@@ -572,8 +644,8 @@ inline bool aligned16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 
 // choose a split of the reduction dimension so that ~1024 workgroups are in flight
 int plan_splits(GemmP& p, void* ws, size_t ws_bytes, const char* what) {
   const int bn = (p.N <= 64) ? 64 : 128;
-  p.bm = 128;
-  const int64_t tiles = dg::cdiv(p.M, 128) * dg::cdiv(p.N, bn);
+  p.bm = (p.M >= 1024) ? 256 : 128;          // big weight matrices (FC0: 1728 x 512): 256-row tiles
+  const int64_t tiles = dg::cdiv(p.M, p.bm) * dg::cdiv(p.N, bn);
   int64_t s = dg::cdiv(1024, tiles);
   const int64_t maxs = p.K / 256 > 0 ? p.K / 256 : 1;
   if (s > maxs) s = maxs;
@@ -655,6 +727,21 @@ extern "C" int dgcnn_edge_mlp_wgrad_f32(const float* x, int64_t ldx, const int32
   p.M = 2 * C; p.N = F; p.K = (int)Me; p.beta = beta; p.rpg = 1;
   p.avec = (C % 4 == 0) && (ldx % 4 == 0) && aligned16(x);
   p.bvec = (F % 4 == 0) && aligned16(dY);
+  if (C <= 4 && F <= 256) {
+    const int nblk = (int)(Me < 1024 * 64 ? dg::cdiv(Me, 64) : 1024);
+    const int chunk = (int)dg::cdiv(Me, nblk);
+    const size_t need = (size_t)nblk * 2 * C * F * sizeof(float);
+    DG_REQUIRE(ws && ws_bytes >= need, DGCNN_ENOSPC, "dgcnn_edge_mlp_wgrad_f32: workspace too small (%zu < %zu)", ws_bytes, need);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL((edge_wgrad_smallc_kernel<4>), dim3((unsigned)nblk), dim3(256), 0, st, x, ldx, idx, dY, Me, N, k,
+                       C, F, chunk, reinterpret_cast<float*>(ws));
+    int rc0 = dg::check_launch("dgcnn_edge_mlp_wgrad_f32(small C)");
+    if (rc0) return rc0;
+    const int64_t n = (int64_t)2 * C * F;
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)dg::cdiv(n, 64)), dim3(256), 0, st,
+                       reinterpret_cast<const float*>(ws), nblk, 2 * C, F, dW0, (int64_t)F, beta);
+    return dg::check_launch("dgcnn_edge_mlp_wgrad_f32(small C reduce)");
+  }
   int rc = plan_splits(p, ws, ws_bytes, "dgcnn_edge_mlp_wgrad_f32");
   if (rc) return rc;
   return launch<A_EDGE_T, B_ROW, E_STORE>(p, (hipStream_t)stream, "dgcnn_edge_mlp_wgrad_f32");

@@ -155,6 +155,19 @@ class Context(object):
                 return slot[0][r0:r0 + v.shape[0], c0:c0 + v.shape[1]]
         return None
 
+    def grad_w(self, v):
+        """(gradient view, beta) for a GEMM that adds into d(v): beta = 0.0 -- and the buffer is left
+        uninitialised instead of zero-filled -- when this is the first touch and v IS its whole root
+        (saves a memset and a read-modify-write pass over e.g. the 340 MB d(big) of FC0's dgrad)."""
+        if not self.recording:
+            return None, 1.0
+        ptr = v.data_ptr()
+        for root, slot in self.roots:
+            if root.data_ptr() == ptr and tuple(root.shape) == tuple(v.shape) and slot[0] is None:
+                slot[0] = torch.empty_like(root)
+                return slot[0], 0.0
+        return self.grad(v), 1.0
+
     def backward(self):
         for fn in reversed(self.tape):
             fn()
@@ -248,7 +261,7 @@ def gemm(A, Bm, C, transA=False, transB=False, beta=0.0, gbias=None, rpg=0, stat
            C.data_ptr(), H.ld2(C), float(beta), H._p(gbias), 0 if gbias is None else H.ld2(gbias), int(rpg),
            H._p(stats), ws.data_ptr(), ws.numel(),
            tag="gemm_kernel<%s,%s,STORE,%d,%d>" % ("A_COL" if transA else "A_ROW", "B_COL" if transB else "B_ROW",
-                                                    128 if transA else _tile_m(M, N), 64 if N <= 64 else 128),
+                                                    (256 if M >= 1024 else 128) if transA else _tile_m(M, N), 64 if N <= 64 else 128),
            work=2.0 * M * N * K)
 
 
@@ -305,9 +318,9 @@ def conv_bn_act(x, leaf_scope, num_outputs, relu=True, out=None, out2=None, gbia
             dT = T
             dWx = c.var_grads[wname] if w_rows is None else c.var_grads[wname][w_rows[0]:w_rows[1]]
             gemm(x, dT, dWx, transA=True, beta=1.0)                    # dW += x^T dT
-            dx = c.grad(x)
+            dx, bx = c.grad_w(x)
             if dx is not None:
-                gemm(dT, Wx, dx, transB=True, beta=1.0)                # dx += dT W^T
+                gemm(dT, Wx, dx, transB=True, beta=bx)                 # dx (+)= dT W^T
             if gbias is not None:
                 dgb = c.grad(gbias)
                 if dgb is not None:                                     # tf.tile^T: sum over the cloud
@@ -372,7 +385,8 @@ def edge_conv_block(x, B, N, k, num_filters, relu1=True, outs=None, net2=None):
             ws = c.workspace()
             H.call("dgcnn_edge_mlp_wgrad_f32", x.data_ptr(), H.ld2(x), idx.data_ptr(), dY.data_ptr(), B, N, C, k, F,
                    c.var_grads[w0name].data_ptr(), 1.0, ws.data_ptr(), ws.numel(),
-                   tag="gemm_kernel<A_EDGE_T,B_ROW,STORE,128,%d>" % (64 if F <= 64 else 128), work=2.0 * R * k * 2 * C * F)
+                   tag=("edge_wgrad_smallc_kernel" if C <= 4 else "gemm_kernel<A_EDGE_T,B_ROW,STORE,128,%d>" % (64 if F <= 64 else 128)),
+                   work=2.0 * R * k * 2 * C * F)
             if dx is not None:
                 # E = [x_i, x_j - x_i]  =>  dx_i += (sum_m dY) (W0[:C]-W0[C:])^T ; dx_j += dY W0[C:]^T
                 wd = torch.empty((C, F), dtype=torch.float32, device=x.device)
@@ -424,8 +438,13 @@ def dropout(x, keep=DROPOUT_KEEP):
     if c.recording:
         def bwd():
             dout = c.grad(out)
-            dx = c.grad(x)
-            if dout is None or dx is None:
+            if dout is None:
+                return
+            dx, bx = c.grad_w(x)
+            if dx is None:
+                return
+            if bx == 0.0:                                   # first touch of d(x): write the masked gradient in place
+                H.call("dgcnn_dropout_f32", dout.data_ptr(), dx.data_ptr(), R * F, float(keep), seed)
                 return
             tmp = torch.empty_like(dout)
             H.call("dgcnn_dropout_f32", dout.data_ptr(), tmp.data_ptr(), R * F, float(keep), seed)
