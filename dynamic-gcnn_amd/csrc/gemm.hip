@@ -547,27 +547,42 @@ __global__ __launch_bounds__(256) void edge_wgrad_smallc_kernel(const float* __r
     for (int c = 0; c < 2 * CC; ++c) acc[fb][c] = 0.f;
   const int64_t e0 = (int64_t)blockIdx.x * chunk;
   const int64_t e1 = (e0 + chunk < Me) ? (e0 + chunk) : Me;
-  for (int64_t e = e0 + sub; e < e1; e += 4) {
-    const int64_t g = e / knn;
-    const int64_t nb = (g / npts) * npts + idx[e];
-    float ev[2 * CC];
+  // 4 edges in flight per lane-group: index, feature and dY loads of all four are issued before
+  // the first use (the chain idx -> x -> fma is otherwise three exposed memory latencies per edge)
+  for (int64_t eb = e0 + sub; eb < e1; eb += 16) {
+    int64_t ee[4], gg[4], nn[4];
+    bool ok[4];
 #pragma unroll
-    for (int c = 0; c < CC; ++c) {
-      const float xc = (c < C) ? x[g * ldx + c] : 0.f;
-      const float xn = (c < C) ? x[nb * ldx + c] : 0.f;
-      ev[c] = xc;
-      ev[CC + c] = xn - xc;
+    for (int u = 0; u < 4; ++u) {
+      ok[u] = (eb + 4 * u) < e1;
+      ee[u] = ok[u] ? (eb + 4 * u) : (e1 - 1);
+      gg[u] = ee[u] / knn;
+      nn[u] = (gg[u] / npts) * npts + idx[ee[u]];
     }
-    const float* dy = dY + e * F;
+    float ev[4][2 * CC];
 #pragma unroll
-    for (int fb = 0; fb < FB; ++fb) {
-      const int f = fl + 64 * fb;
-      if (f < F) {
-        const float d = dy[f];
+    for (int u = 0; u < 4; ++u)
 #pragma unroll
-        for (int c = 0; c < 2 * CC; ++c) acc[fb][c] = fmaf(ev[c], d, acc[fb][c]);
+      for (int c = 0; c < CC; ++c) {
+        const float xc = (c < C) ? x[gg[u] * ldx + c] : 0.f;
+        const float xn = (c < C) ? x[nn[u] * ldx + c] : 0.f;
+        ev[u][c] = xc;
+        ev[u][CC + c] = xn - xc;
       }
-    }
+    float dv[4][FB];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int fb = 0; fb < FB; ++fb) {
+        const int f = fl + 64 * fb;
+        dv[u][fb] = (f < F && ok[u]) ? dY[ee[u] * F + f] : 0.f;
+      }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int fb = 0; fb < FB; ++fb)
+#pragma unroll
+        for (int c = 0; c < 2 * CC; ++c) acc[fb][c] = fmaf(ev[u][c], dv[u][fb], acc[fb][c]);
   }
   float* out = partial + (int64_t)blockIdx.x * 2 * C * F;
 #pragma unroll
@@ -728,7 +743,7 @@ extern "C" int dgcnn_edge_mlp_wgrad_f32(const float* x, int64_t ldx, const int32
   p.avec = (C % 4 == 0) && (ldx % 4 == 0) && aligned16(x);
   p.bvec = (F % 4 == 0) && aligned16(dY);
   if (C <= 4 && F <= 256) {
-    const int nblk = (int)(Me < 1024 * 64 ? dg::cdiv(Me, 64) : 1024);
+    const int nblk = (int)(Me < 4096 * 64 ? dg::cdiv(Me, 64) : 4096);
     const int chunk = (int)dg::cdiv(Me, nblk);
     const size_t need = (size_t)nblk * 2 * C * F * sizeof(float);
     DG_REQUIRE(ws && ws_bytes >= need, DGCNN_ENOSPC, "dgcnn_edge_mlp_wgrad_f32: workspace too small (%zu < %zu)", ws_bytes, need);

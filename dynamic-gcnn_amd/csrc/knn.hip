@@ -317,9 +317,33 @@ __global__ __launch_bounds__(256, 2) void knn_mfma_kernel(const float* __restric
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[r] = 0.f;
       const float* ap = xsT + h * ST + cbase + l31;
+      {
+        // A operands are read in batches of BQ one batch ahead of the MFMAs that consume them
+        // (sched_barriers pin the order), so the LDS latency hides under the dependent MFMA chain.
+        constexpr int NS = CP / 2;
+        constexpr int BQ = (NS >= 16) ? 8 : NS / 2;
+        float av0[BQ], av1[BQ];
 #pragma unroll
-      for (int s2 = 0; s2 < CP / 2; ++s2)
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * s2 * ST], bq[s2], acc, 0, 0, 0);
+        for (int q = 0; q < BQ; ++q) av0[q] = ap[2 * q * ST];
+#pragma unroll
+        for (int s2 = 0; s2 < NS; s2 += 2 * BQ) {
+#pragma unroll
+          for (int q = 0; q < BQ; ++q) av1[q] = ap[2 * (s2 + BQ + q) * ST];
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int q = 0; q < BQ; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[q], bq[s2 + q], acc, 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+          if (s2 + 2 * BQ < NS) {
+#pragma unroll
+            for (int q = 0; q < BQ; ++q) av0[q] = ap[2 * (s2 + 2 * BQ + q) * ST];
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int q = 0; q < BQ; ++q)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[q], bq[s2 + BQ + q], acc, 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
 
       // ---- distances of this lane's 16 candidates; park them, flag the ones that beat the k-th ----
       const float thr = dl[KC - 1];
@@ -333,13 +357,20 @@ __global__ __launch_bounds__(256, 2) void knn_mfma_kernel(const float* __restric
         dq[r * 256 + tid] = d;
         mask |= (unsigned)sel_i(m_flt(d, thr), 1 << r, 0);
       }
+      // drain: the parked distance of the NEXT surviving candidate is fetched before the insert of
+      // the current one (LDS round trip hidden behind ~90 VALU ops)
+      int g = __builtin_ctz(mask | 0x80000000u) & 15;
+      float dcur = dq[g * 256 + tid];
       while (__any(mask != 0u)) {
         const lmask_t live = m_ine((int)mask, 0);
-        const int g = sel_i(live, __builtin_ctz(mask | 0x80000000u), 0);
-        const float d = sel_f(live, dq[g * 256 + tid], INFINITY);
+        const int gc = g;
         mask &= mask - 1u;
-        const int i = (g & 3) + 8 * (g >> 2) + 4 * h;
+        g = __builtin_ctz(mask | 0x80000000u) & 15;
+        const float dnext = dq[g * 256 + tid];
+        const float d = sel_f(live, dcur, INFINITY);
+        const int i = (gc & 3) + 8 * (gc >> 2) + 4 * h;
         list_insert<KC, false>(dl, jl, d, j0 + cbase + i);
+        dcur = dnext;
       }
     }
   }

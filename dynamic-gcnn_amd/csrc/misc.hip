@@ -47,6 +47,82 @@ __global__ void edge_gather_bwd_kernel(const float* __restrict__ dE, const int32
   }
 }
 
+// ---- transposed adjacency (who points at me?) of the k-NN graph: the backward of tf.gather
+// (ops.py:34) is a scatter-add over neighbours; instead of 63 M fp32 atomics per layer the edges
+// are bucketed by target once (counting sort: histogram, per-cloud exclusive scan -- a cloud owns
+// exactly N*k edges -- and fill), and every point then SUMS its incoming dY rows (a gather).
+__global__ void csr_count_kernel(const int32_t* __restrict__ idx, int N, int k, int64_t Me, int32_t* __restrict__ cnt) {
+  GRID_STRIDE(e, Me) {
+    const int64_t g = e / k;
+    atomicAdd(cnt + (g / N) * N + idx[e], 1);
+  }
+}
+
+__global__ __launch_bounds__(1024) void csr_scan_kernel(const int32_t* __restrict__ cnt, int N, int k,
+                                                        int32_t* __restrict__ off) {
+  __shared__ int part[1024];
+  const int b = blockIdx.x;
+  const int t = threadIdx.x;
+  const int per = (N + 1023) / 1024;
+  const int lo = t * per, hi = (lo + per < N) ? (lo + per) : N;
+  int s = 0;
+  for (int i = lo; i < hi; ++i) s += cnt[(int64_t)b * N + i];
+  part[t] = s;
+  __syncthreads();
+  for (int d = 1; d < 1024; d <<= 1) {          // Hillis-Steele inclusive scan of the 1024 partial sums
+    const int v = (t >= d) ? part[t - d] : 0;
+    __syncthreads();
+    part[t] += v;
+    __syncthreads();
+  }
+  int run = b * N * k + part[t] - s;              // exclusive prefix of this thread's slice
+  for (int i = lo; i < hi; ++i) {
+    off[(int64_t)b * N + i] = run;
+    run += cnt[(int64_t)b * N + i];
+  }
+  if (b == gridDim.x - 1 && t == 1023) off[(int64_t)gridDim.x * N] = gridDim.x * N * k;
+}
+
+__global__ void csr_fill_kernel(const int32_t* __restrict__ idx, int N, int k, int64_t Me,
+                                const int32_t* __restrict__ off, int32_t* __restrict__ cur, int32_t* __restrict__ rev) {
+  GRID_STRIDE(e, Me) {
+    const int64_t g = e / k;
+    const int64_t tgt = (g / N) * N + idx[e];
+    const int pos = off[tgt] + atomicAdd(cur + tgt, 1);
+    rev[pos] = (int32_t)e;
+  }
+}
+
+// S[j][:] = sum of dY[e][:] over the edges e that point at j.  One float4 channel-quad per lane
+// (a wave covers whole 256-B rows), 4 rows in flight.
+__global__ __launch_bounds__(256) void csr_gather_sum_kernel(const float* __restrict__ dY, const int32_t* __restrict__ off,
+                                                             const int32_t* __restrict__ rev, int64_t R, int F,
+                                                             float* __restrict__ S) {
+  const int FV = F / 4;
+  GRID_STRIDE(it, R * FV) {
+    const int64_t j = it / FV;
+    const int f = (int)(it % FV) * 4;
+    const int p0 = off[j], p1 = off[j + 1];
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    int p = p0;
+    for (; p + 3 < p1; p += 4) {
+      const float4 v0 = *reinterpret_cast<const float4*>(dY + (int64_t)rev[p] * F + f);
+      const float4 v1 = *reinterpret_cast<const float4*>(dY + (int64_t)rev[p + 1] * F + f);
+      const float4 v2 = *reinterpret_cast<const float4*>(dY + (int64_t)rev[p + 2] * F + f);
+      const float4 v3 = *reinterpret_cast<const float4*>(dY + (int64_t)rev[p + 3] * F + f);
+      a.x += (v0.x + v1.x) + (v2.x + v3.x);
+      a.y += (v0.y + v1.y) + (v2.y + v3.y);
+      a.z += (v0.z + v1.z) + (v2.z + v3.z);
+      a.w += (v0.w + v1.w) + (v2.w + v3.w);
+    }
+    for (; p < p1; ++p) {
+      const float4 v = *reinterpret_cast<const float4*>(dY + (int64_t)rev[p] * F + f);
+      a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    }
+    *reinterpret_cast<float4*>(S + j * F + f) = a;
+  }
+}
+
 // block = 64 channels x RG row groups (1024 threads: 16 waves/block, B*F/64 blocks fill the chip);
 // first arg-max on ties (tf max_pool gradient routing)
 constexpr int RG = 16;
@@ -217,6 +293,7 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
 
 #define ST ((hipStream_t)stream)
 
+
 extern "C" int dgcnn_edge_gather_f32(const float* x, int64_t ldx, const int32_t* idx, int B, int N, int C, int k,
                                      float* E, void* stream) {
   DG_REQUIRE(x && idx && E && B > 0 && N > 0 && C > 0 && k > 0, DGCNN_EINVAL, "dgcnn_edge_gather_f32: bad args");
@@ -231,6 +308,26 @@ extern "C" int dgcnn_edge_gather_bwd_f32(const float* dE, const int32_t* idx, in
   const int64_t total = (int64_t)B * N * k * C;
   hipLaunchKernelGGL(edge_gather_bwd_kernel, dim3(grid1d(total)), dim3(256), 0, ST, dE, idx, N, C, k, total, dx, lddx);
   return dg::check_launch("dgcnn_edge_gather_bwd_f32");
+}
+
+extern "C" int dgcnn_edge_csr_build(const int32_t* idx, int B, int N, int k, int32_t* cnt_ws, int32_t* off,
+                                    int32_t* rev, void* stream) {
+  DG_REQUIRE(idx && cnt_ws && off && rev && B > 0 && N > 0 && k > 0, DGCNN_EINVAL, "dgcnn_edge_csr_build: bad args");
+  const int64_t Me = (int64_t)B * N * k;
+  DG_REQUIRE(Me < (1ll << 31), DGCNN_EUNSUP, "dgcnn_edge_csr_build: B*N*k >= 2^31");
+  hipMemsetAsync(cnt_ws, 0, sizeof(int32_t) * 2 * (size_t)B * N, ST);      // [counts | cursors]
+  hipLaunchKernelGGL(csr_count_kernel, dim3(grid1d(Me)), dim3(256), 0, ST, idx, N, k, Me, cnt_ws);
+  hipLaunchKernelGGL(csr_scan_kernel, dim3((unsigned)B), dim3(1024), 0, ST, cnt_ws, N, k, off);
+  hipLaunchKernelGGL(csr_fill_kernel, dim3(grid1d(Me)), dim3(256), 0, ST, idx, N, k, Me, off, cnt_ws + (size_t)B * N, rev);
+  return dg::check_launch("dgcnn_edge_csr_build");
+}
+
+extern "C" int dgcnn_edge_gather_sum_f32(const float* dY, const int32_t* off, const int32_t* rev, int64_t R, int F,
+                                         float* S, void* stream) {
+  DG_REQUIRE(dY && off && rev && S && R > 0 && F > 0 && F % 4 == 0, DGCNN_EINVAL, "dgcnn_edge_gather_sum_f32: bad args");
+  unsigned g = grid1d(R * (F / 4));
+  hipLaunchKernelGGL(csr_gather_sum_kernel, dim3(g), dim3(256), 0, ST, dY, off, rev, R, F, S);
+  return dg::check_launch("dgcnn_edge_gather_sum_f32");
 }
 
 extern "C" int dgcnn_global_max_f32(const float* x, int64_t ldx, int B, int N, int F, float* out, int32_t* arg,

@@ -27,6 +27,7 @@ from . import _hip as H
 BN_EPS = 1e-3          # slim.batch_norm default epsilon [TF1-lib]
 DROPOUT_KEEP = 0.7     # tf.nn.dropout(net, 0.7): dgcnn/model.py:91
 WS_BYTES = 256 << 20
+SCATTER_ATOMICS = False  # True: dx_j += dY W^T by fp32 atomics in the GEMM epilogue (A/B switch)
 
 
 class Context(object):
@@ -393,9 +394,21 @@ def edge_conv_block(x, B, N, k, num_filters, relu1=True, outs=None, net2=None):
                 H.call("dgcnn_copy2d_f32", W0[:C].data_ptr(), F, wd.data_ptr(), F, C, F, 0)
                 H.call("dgcnn_axpby_f32", W0[C:].data_ptr(), -1.0, wd.data_ptr(), 1.0, C * F)
                 gemm(dysum, wd, dx, transB=True, beta=1.0)
-                H.call("dgcnn_edge_mlp_dgrad_scatter_f32", dY.data_ptr(), W0.data_ptr(), idx.data_ptr(), B, N, C, k, F,
-                       dx.data_ptr(), H.ld2(dx), tag="gemm_kernel<A_ROW,B_COL,SCATTER,%d,%d>" % (_tile_m(R * k, C), 64 if C <= 64 else 128),
-                       work=2.0 * R * k * C * F)
+                if SCATTER_ATOMICS or F % 4 != 0:
+                    H.call("dgcnn_edge_mlp_dgrad_scatter_f32", dY.data_ptr(), W0.data_ptr(), idx.data_ptr(), B, N, C, k,
+                           F, dx.data_ptr(), H.ld2(dx),
+                           tag="gemm_kernel<A_ROW,B_COL,SCATTER,%d,%d>" % (_tile_m(R * k, C), 64 if C <= 64 else 128),
+                           work=2.0 * R * k * C * F)
+                else:
+                    # tf.gather^T as a gather: bucket edges by target, sum incoming dY rows, one small GEMM
+                    cws = torch.empty(2 * R, dtype=torch.int32, device=x.device)
+                    off = torch.empty(R + 1, dtype=torch.int32, device=x.device)
+                    rev = torch.empty(R * k, dtype=torch.int32, device=x.device)
+                    H.call("dgcnn_edge_csr_build", idx.data_ptr(), B, N, k, cws.data_ptr(), off.data_ptr(), rev.data_ptr())
+                    S = torch.empty((R, F), dtype=torch.float32, device=x.device)
+                    H.call("dgcnn_edge_gather_sum_f32", dY.data_ptr(), off.data_ptr(), rev.data_ptr(), R, F, S.data_ptr(),
+                           tag="csr_gather_sum_kernel", work=4.0 * (R * k * F + R * F))
+                    gemm(S, W0[C:], dx, transB=True, beta=1.0)
         c.tape.append(bwd)
 
     net = conv_bn_act(mm, "conv1", 64, relu=relu1, out=net_out, out2=net2)   # ops.py:62-70 (64 hard-coded)

@@ -71,6 +71,15 @@ int dgcnn_edge_mlp_dgrad_scatter_f32(const float* dY, const float* W0, const int
                                      int B, int N, int C, int k, int F, float* dx, int64_t lddx,
                                      void* stream);
 
+/* Deterministic-shape alternative to the scatter: bucket the edges by target once (transposed
+ * adjacency: off[B*N+1], rev[B*N*k]; cnt_ws = 2*B*N int32 scratch) ...                         */
+int dgcnn_edge_csr_build(const int32_t* idx, int B, int N, int k, int32_t* cnt_ws, int32_t* off,
+                         int32_t* rev, void* stream);
+/* ... then S[j][:] = sum over incoming edges e of dY[e][:] (tf.gather^T as a gather); the host
+ * finishes with a plain GEMM dx += S W0[C:2C]^T.                                              */
+int dgcnn_edge_gather_sum_f32(const float* dY, const int32_t* off, const int32_t* rev, int64_t R, int F,
+                              float* S, void* stream);
+
 /* ---- plain fp32 MFMA GEMM: every other slim.conv2d 1x1 (ops.py:62-70,125-133,153-160;
  * model.py:46-53,65-72,94-101) and their dgrad / wgrad --------------------------------------
  * C[M][N] = op(A)[M][K] op(B)[K][N] (+ beta*C) (+ gbias[row / rows_per_group][n]);
