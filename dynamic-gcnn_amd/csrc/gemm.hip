@@ -496,29 +496,33 @@ __global__ __launch_bounds__(NT) void gemm_kernel(GemmP p) {
   }
 }
 
-// C (+)= sum over splits of the partial tiles.  64 consecutive elements x 4 split-lanes per block:
-// coalesced 256-B rows, 4-way split parallelism, 4 independent loads in flight per lane.
-__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ part, int splits, int M,
-                                                              int N, float* __restrict__ C, int64_t ldc, float beta) {
-  __shared__ float sh[4][64];
+// C (+)= sum over splits of the partial tiles.  64 consecutive elements x 16 split-lanes per block
+// (1024 threads): coalesced 256-B rows, 16-way split parallelism, 4 independent loads in flight per
+// lane, fixed summation order (deterministic).
+constexpr int RL = 16;
+__global__ __launch_bounds__(64 * RL) void reduce_partials_kernel(const float* __restrict__ part, int splits, int M,
+                                                                 int N, float* __restrict__ C, int64_t ldc, float beta) {
+  __shared__ float sh[RL][64];
   const int64_t MN = (int64_t)M * N;
   const int64_t e = (int64_t)blockIdx.x * 64 + (threadIdx.x & 63);
   const int zl = threadIdx.x >> 6;
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
   if (e < MN) {
     int z = zl;
-    for (; z + 12 < splits; z += 16) {
+    for (; z + 3 * RL < splits; z += 4 * RL) {
       s0 += part[(int64_t)z * MN + e];
-      s1 += part[(int64_t)(z + 4) * MN + e];
-      s2 += part[(int64_t)(z + 8) * MN + e];
-      s3 += part[(int64_t)(z + 12) * MN + e];
+      s1 += part[(int64_t)(z + RL) * MN + e];
+      s2 += part[(int64_t)(z + 2 * RL) * MN + e];
+      s3 += part[(int64_t)(z + 3 * RL) * MN + e];
     }
-    for (; z < splits; z += 4) s0 += part[(int64_t)z * MN + e];
+    for (; z < splits; z += RL) s0 += part[(int64_t)z * MN + e];
   }
   sh[zl][threadIdx.x & 63] = (s0 + s1) + (s2 + s3);
   __syncthreads();
   if (zl == 0 && e < MN) {
-    const float s = (sh[0][threadIdx.x] + sh[1][threadIdx.x]) + (sh[2][threadIdx.x] + sh[3][threadIdx.x]);
+    float s = 0.f;
+#pragma unroll
+    for (int q = 0; q < RL; ++q) s += sh[q][threadIdx.x];
     const int row = (int)(e / N), col = (int)(e % N);
     float* c = C + (int64_t)row * ldc + col;
     *c = (beta != 0.f) ? (s + beta * *c) : s;
@@ -647,7 +651,7 @@ int launch(GemmP& p, hipStream_t st, const char* what) {
   if (rc) return rc;
   if (p.splits > 1) {
     const int64_t n = (int64_t)p.M * p.N;
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)dg::cdiv(n, 64)), dim3(256), 0, st,
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)dg::cdiv(n, 64)), dim3(64 * RL), 0, st,
                        p.partial, p.splits, p.M, p.N, p.C, p.ldc, p.beta);
     rc = dg::check_launch(what);
   }
@@ -743,7 +747,7 @@ extern "C" int dgcnn_edge_mlp_wgrad_f32(const float* x, int64_t ldx, const int32
   p.avec = (C % 4 == 0) && (ldx % 4 == 0) && aligned16(x);
   p.bvec = (F % 4 == 0) && aligned16(dY);
   if (C <= 4 && F <= 256) {
-    const int nblk = (int)(Me < 4096 * 64 ? dg::cdiv(Me, 64) : 4096);
+    const int nblk = (int)(Me < 1024 * 64 ? dg::cdiv(Me, 64) : 1024);
     const int chunk = (int)dg::cdiv(Me, nblk);
     const size_t need = (size_t)nblk * 2 * C * F * sizeof(float);
     DG_REQUIRE(ws && ws_bytes >= need, DGCNN_ENOSPC, "dgcnn_edge_mlp_wgrad_f32: workspace too small (%zu < %zu)", ws_bytes, need);
@@ -753,7 +757,7 @@ extern "C" int dgcnn_edge_mlp_wgrad_f32(const float* x, int64_t ldx, const int32
     int rc0 = dg::check_launch("dgcnn_edge_mlp_wgrad_f32(small C)");
     if (rc0) return rc0;
     const int64_t n = (int64_t)2 * C * F;
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)dg::cdiv(n, 64)), dim3(256), 0, st,
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)dg::cdiv(n, 64)), dim3(64 * RL), 0, st,
                        reinterpret_cast<const float*>(ws), nblk, 2 * C, F, dW0, (int64_t)F, beta);
     return dg::check_launch("dgcnn_edge_mlp_wgrad_f32(small C reduce)");
   }

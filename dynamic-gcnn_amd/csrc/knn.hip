@@ -234,28 +234,32 @@ __global__ __launch_bounds__(256, (knn_min_waves<CP, KC>())) void knn_kernel(con
 //   B operand = this wave's 32 query rows, resident in CP/2 VGPRs for the whole kernel.
 //   D layout: lane l holds query row (l & 31) and candidates (r&3) + 8(r>>2) + 4(l>>5), r = 0..15:
 //   two lanes per row, each with its own register-resident sorted list over its candidate subset.
-// Block = 64 query rows x 2 candidate halves (4 waves); 4 lists per row merged through LDS.
+// Block = 64 query rows x 2 candidate halves (4 waves); 64-candidate LDS tiles, double buffered, next
+// tile prefetched into registers under the MFMAs; 4 lists per row merged through LDS.
 template <int CP, int KC>
 __global__ __launch_bounds__(256, 2) void knn_mfma_kernel(const float* __restrict__ x, const float* __restrict__ sq,
                                                           int N, int C, int64_t ldx, int k, int vec_ok,
                                                           int32_t* __restrict__ idx) {
   using f32x16 = __attribute__((ext_vector_type(16))) float;
-  constexpr int ST = TJ + 2;                 // k-major candidate tile [CP][ST]
+  constexpr int TJM = 64;                    // candidates per LDS tile: 32 per candidate-half wave
+  constexpr int ST = TJM + 2;                // k-major candidate tile [CP][ST]
   constexpr int TILE_F = CP * ST;
   constexpr int DQ_F = 16 * 256;
   constexpr int MERGE_F = ROWS * KC * 2;
-  constexpr int SH = (TILE_F + DQ_F > MERGE_F ? TILE_F + DQ_F : MERGE_F);
-  __shared__ __attribute__((aligned(16))) float smem[SH + TJ];
-  float* xsT = smem;
-  float* dq = smem + TILE_F;
-  float* sjs = smem + SH;
+  constexpr int WORK_F = 2 * TILE_F + DQ_F + 2 * TJM;
+  constexpr int SH = (WORK_F > MERGE_F ? WORK_F : MERGE_F);
+  constexpr int NV = (TJM * (CP / 4)) / 256;  // float4 staged per thread per tile
+  static_assert(NV >= 1, "tile too small");
+  __shared__ __attribute__((aligned(16))) float smem[SH];
+  float* dq = smem + 2 * TILE_F;
+  float* sjs = smem + 2 * TILE_F + DQ_F;     // [2][TJM]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int w = tid >> 6;
   const int l31 = lane & 31, h = lane >> 5;
   const int qg = w & 1;                      // which 32 query rows of the block
-  const int cs = w >> 1;                     // which 64 candidates of every 128-candidate tile
+  const int cs = w >> 1;                     // which 32 candidates of every 64-candidate tile
   const int b = blockIdx.y;
   const int row = blockIdx.x * ROWS + qg * 32 + l31;
   const float* xb = x + (int64_t)b * N * ldx;
@@ -278,11 +282,14 @@ __global__ __launch_bounds__(256, 2) void knn_mfma_kernel(const float* __restric
     jl[t] = 0x7fffffff;
   }
 
-#pragma unroll 1
-  for (int j0 = 0; j0 < N; j0 += TJ) {
-    __syncthreads();
-    // ---- stage 128 candidate rows transposed ([c][cand]), zero padded to CP channels ----
-    for (int e = tid; e < TJ * (CP / 4); e += 256) {
+  // ---- candidate tiles: global -> registers one tile ahead, transposed ([c][cand]) into the other
+  // LDS buffer after the current tile's MFMAs; one barrier per tile ----
+  float4 pre[NV];
+  float pre_s = INFINITY;
+  auto fetch = [&](int j0) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int e = tid + 256 * i;
       const int r = e / (CP / 4);
       const int c4 = (e % (CP / 4)) * 4;
       const int j = j0 + r;
@@ -298,21 +305,38 @@ __global__ __launch_bounds__(256, 2) void knn_mfma_kernel(const float* __restric
           if (c4 + 3 < C) v.w = src[3];
         }
       }
-      xsT[(c4 + 0) * ST + r] = v.x;
-      xsT[(c4 + 1) * ST + r] = v.y;
-      xsT[(c4 + 2) * ST + r] = v.z;
-      xsT[(c4 + 3) * ST + r] = v.w;
+      pre[i] = v;
     }
-    if (tid < TJ) {
-      const int j = j0 + tid;
-      sjs[tid] = (j < N) ? sqb[j] : INFINITY;
+    if (tid < TJM) pre_s = (j0 + tid < N) ? sqb[j0 + tid] : INFINITY;
+  };
+  auto stash = [&](int buf) {
+    float* d = smem + buf * TILE_F;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int e = tid + 256 * i;
+      const int r = e / (CP / 4);
+      const int c4 = (e % (CP / 4)) * 4;
+      d[(c4 + 0) * ST + r] = pre[i].x;
+      d[(c4 + 1) * ST + r] = pre[i].y;
+      d[(c4 + 2) * ST + r] = pre[i].z;
+      d[(c4 + 3) * ST + r] = pre[i].w;
     }
-    __syncthreads();
+    if (tid < TJM) sjs[buf * TJM + tid] = pre_s;
+  };
+
+  const int nt = (N + TJM - 1) / TJM;
+  fetch(0);
+  stash(0);
+  __syncthreads();
 
 #pragma unroll 1
-    for (int sub = 0; sub < 2; ++sub) {
-      const int cbase = cs * 64 + sub * 32;
-      if (j0 + cbase >= N) break;            // wave-uniform
+  for (int t = 0; t < nt; ++t) {
+    const int buf = t & 1;
+    const int j0 = t * TJM;
+    if (t + 1 < nt) fetch(j0 + TJM);
+    const int cbase = cs * 32;
+    if (j0 + cbase < N) {                    // wave-uniform
+      const float* xsT = smem + buf * TILE_F;
       f32x16 acc;
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -347,13 +371,14 @@ __global__ __launch_bounds__(256, 2) void knn_mfma_kernel(const float* __restric
 
       // ---- distances of this lane's 16 candidates; park them, flag the ones that beat the k-th ----
       const float thr = dl[KC - 1];
+      const float* sj = sjs + buf * TJM + cbase;
       unsigned mask = 0u;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int i = (r & 3) + 8 * (r >> 2) + 4 * h;
-        const float t = si + sjs[cbase + i];
+        const float tt = si + sj[i];
         const float tp = 2.0f * acc[r];
-        const float d = t - tp;
+        const float d = tt - tp;
         dq[r * 256 + tid] = d;
         mask |= (unsigned)sel_i(m_flt(d, thr), 1 << r, 0);
       }
@@ -373,6 +398,8 @@ __global__ __launch_bounds__(256, 2) void knn_mfma_kernel(const float* __restric
         dcur = dnext;
       }
     }
+    if (t + 1 < nt) stash(buf ^ 1);
+    __syncthreads();
   }
 
   // ---- merge: 4 lists per query row (2 lane halves x 2 candidate halves) -> lanes 0..31 of waves 0,1 ----
