@@ -20,6 +20,7 @@
 // Global->register prefetch of tile t+1 overlaps the MFMAs of tile t; LDS is double buffered
 // (one barrier per k-step).  fp32 MFMA == an fmaf chain in k order, so results are plain fp32.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -626,7 +627,14 @@ void launch_bm(GemmP& p, hipStream_t st, bool vec, int bn) {
   }
 }
 
+inline int tile_m_env() {
+  static int v = -2;
+  if (v == -2) { const char* e = getenv("DGCNN_GEMM_BM"); v = e ? atoi(e) : -1; }   // experiments only
+  return v;
+}
+
 inline int tile_m(int M, int N, int splits) {
+  if (tile_m_env() > 0) return tile_m_env();
   // 256-row tiles halve the A/B bytes fetched per flop; use them when there are enough tiles to
   // fill 256 CUs twice over, else 128 rows for parallelism.
   const int bn = (N <= 64) ? 64 : 128;
@@ -646,7 +654,8 @@ int launch(GemmP& p, hipStream_t st, const char* what) {
     else p.cvec = (p.ldc % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.C) & 15) == 0);
   }
   if (p.bm == 256) launch_bm<ASRC, BSRC, EPI, 256>(p, st, vec, bn);
-  else launch_bm<ASRC, BSRC, EPI, 128>(p, st, vec, bn);
+  else if (p.bm == 192 && (ASRC == A_ROW || ASRC == A_EDGE)) launch_bm<ASRC, BSRC, EPI, (ASRC == A_ROW || ASRC == A_EDGE) ? 192 : 128>(p, st, vec, bn);
+  else { p.bm = 128; launch_bm<ASRC, BSRC, EPI, 128>(p, st, vec, bn); }
   int rc = dg::check_launch(what);
   if (rc) return rc;
   if (p.splits > 1) {

@@ -438,13 +438,13 @@ __global__ __launch_bounds__(256, 2) void knn_mfma_kernel(const float* __restric
   }
 }
 
+int g_knn_valu = -1;
 bool knn_force_valu() {
-  static int v = -1;
-  if (v < 0) {
+  if (g_knn_valu < 0) {
     const char* e = getenv("DGCNN_KNN_VALU");   // A/B switch: VALU fmaf distance for every C
-    v = (e && e[0] == '1') ? 1 : 0;
+    g_knn_valu = (e && e[0] == '1') ? 1 : 0;
   }
-  return v == 1;
+  return g_knn_valu == 1;
 }
 
 template <int CP, int KC>
@@ -471,6 +471,12 @@ int dispatch_k(const float* x, const float* sq, int B, int N, int C, int64_t ldx
 }
 
 }  // namespace
+
+extern "C" int dgcnn_knn_force_valu(int on) {   // A/B switch (tests): 1 = VALU fmaf distances for every C, 0 = MFMA for C > 4
+  const int prev = knn_force_valu() ? 1 : 0;
+  g_knn_valu = on ? 1 : 0;
+  return prev;
+}
 
 extern "C" int dgcnn_knn_workspace_bytes(int B, int N) { return (int)sizeof(float) * B * N; }
 

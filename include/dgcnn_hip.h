@@ -44,6 +44,10 @@ const char* dgcnn_last_error(void);
  * x: (B,N,C) with row stride ldx.  No (B,N,N) matrix is ever written to HBM.
  * sq_ws: caller scratch of dgcnn_knn_workspace_bytes(B,N) bytes (the s_i of ops.py:14). */
 int dgcnn_knn_workspace_bytes(int B, int N);
+/* A/B switch: 1 = distances by VALU fmaf chains for every C (exact by construction), 0 (default) =
+ * v_mfma_f32_32x32x2_f32 for C > 4 (bit-identical on gfx950; the tests compare both).  Returns the
+ * previous setting. */
+int dgcnn_knn_force_valu(int on);
 int dgcnn_knn_f32(const float* x, int B, int N, int C, int64_t ldx, int k, int32_t* idx,
                   float* sq_ws, void* stream);
 

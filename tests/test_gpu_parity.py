@@ -76,6 +76,27 @@ def test_knn_strided_view_and_errors(dg):
         dg.ops.k_nn(torch.zeros(1, 8, 3), 2)           # CPU tensor: no fallback
 
 
+def test_knn_mfma_equals_valu_at_large_n(dg):
+    """Feature-space graph at N=8192, k=40 (production k, scripts/lsf/train_dgcnn.sh:8): the MFMA distance
+    kernel must reproduce the VALU fmaf-chain kernel (exact by construction) bit for bit; the raw-point
+    graph (C=3) at the same N is compared with the C oracle."""
+    from dgcnn import _hip as H
+    rng = np.random.default_rng(8)
+    feats = np.maximum(rng.normal(0, 1, (2, 8192, 64)), 0).astype(np.float32)
+    t = dev(feats)
+    a = dg.ops.k_nn(t, 40)
+    prev = H.load().dgcnn_knn_force_valu(1)
+    try:
+        b = dg.ops.k_nn(t, 40)
+    finally:
+        H.load().dgcnn_knn_force_valu(prev)
+    assert torch.equal(a, b)
+    ia = host(a)
+    assert ((ia == np.arange(8192)[None, :, None]).sum(-1) == 1).all()          # self among the k
+    pts = rng.random((1, 8192, 3), dtype=np.float32)
+    np.testing.assert_array_equal(host(dg.ops.k_nn(dev(pts), 40)), O.k_nn(pts, 40))
+
+
 def test_knn_headline_shape_properties(dg):
     """(24,2048,3) k=20: full bit-exact compare + size-independent properties."""
     rng = np.random.default_rng(0)
