@@ -634,12 +634,12 @@ inline int tile_m_env() {
 }
 
 inline int tile_m(int M, int N, int splits) {
+  // Measured on MI355X (profiles/r01_gemm_tile_height.txt): 128-row tiles (4 workgroups = 16 waves
+  // per CU) match or beat 192 / 256 rows on every shape of the model -- the kernel is MFMA-issue
+  // bound (~105 TFLOP/s), not L2-bound -- so the taller variants are kept for experiments only.
   if (tile_m_env() > 0) return tile_m_env();
-  // 256-row tiles halve the A/B bytes fetched per flop; use them when there are enough tiles to
-  // fill 256 CUs twice over, else 128 rows for parallelism.
-  const int bn = (N <= 64) ? 64 : 128;
-  const int64_t tiles256 = dg::cdiv(M, 256) * dg::cdiv(N, bn) * splits;
-  return (M >= 256 && tiles256 >= 512) ? 256 : 128;
+  (void)M; (void)N; (void)splits;
+  return 128;
 }
 
 template <int ASRC, int BSRC, int EPI>
@@ -672,7 +672,7 @@ inline bool aligned16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 
 // choose a split of the reduction dimension so that ~1024 workgroups are in flight
 int plan_splits(GemmP& p, void* ws, size_t ws_bytes, const char* what) {
   const int bn = (p.N <= 64) ? 64 : 128;
-  p.bm = (p.M >= 1024) ? 256 : 128;          // big weight matrices (FC0: 1728 x 512): 256-row tiles
+  p.bm = 128;
   const int64_t tiles = dg::cdiv(p.M, p.bm) * dg::cdiv(p.N, bn);
   int64_t s = dg::cdiv(1024, tiles);
   const int64_t maxs = p.K / 256 > 0 ? p.K / 256 : 1;

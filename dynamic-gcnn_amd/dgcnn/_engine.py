@@ -245,9 +245,7 @@ def knn(x2d, B, N, k):
 
 def _tile_m(M, N):
     """Mirror of gemm.hip:tile_m (only used to name the kernel instance in bench.py's roofline tags)."""
-    bn = 64 if N <= 64 else 128
-    tiles256 = -(-M // 256) * -(-N // bn)
-    return 256 if (M >= 256 and tiles256 >= 512) else 128
+    return 128
 
 
 def gemm(A, Bm, C, transA=False, transB=False, beta=0.0, gbias=None, rpg=0, stats=None):
@@ -262,7 +260,7 @@ def gemm(A, Bm, C, transA=False, transB=False, beta=0.0, gbias=None, rpg=0, stat
            C.data_ptr(), H.ld2(C), float(beta), H._p(gbias), 0 if gbias is None else H.ld2(gbias), int(rpg),
            H._p(stats), ws.data_ptr(), ws.numel(),
            tag="gemm_kernel<%s,%s,STORE,%d,%d>" % ("A_COL" if transA else "A_ROW", "B_COL" if transB else "B_ROW",
-                                                    (256 if M >= 1024 else 128) if transA else _tile_m(M, N), 64 if N <= 64 else 128),
+                                                    _tile_m(M, N), 64 if N <= 64 else 128),
            work=2.0 * M * N * K)
 
 
