@@ -48,6 +48,22 @@ __device__ __forceinline__ float bn_z(float y, float mu, float rs, float be, int
   return z;
 }
 
+// item -> (row, first channel).  FV (channel quads per row) is a power of two for every width of the
+// model, so the 64-bit division that used to dominate the k = 1 kernels becomes a shift.
+__device__ __forceinline__ void split_item(int64_t it, int FV, int fv_shift, int64_t& r, int& fq) {
+  if (fv_shift >= 0) {
+    r = it >> fv_shift;
+    fq = (int)(it & (FV - 1));
+  } else if (it < 0x7fffffffll) {
+    const unsigned u = (unsigned)it, d = (unsigned)FV;
+    r = u / d;
+    fq = (int)(u % d);
+  } else {
+    r = it / FV;
+    fq = (int)(it % FV);
+  }
+}
+
 template <int V> struct Vec;
 template <> struct Vec<4> {
   using T = float4;
@@ -67,14 +83,16 @@ __global__ __launch_bounds__(256) void bn_act_kreduce_kernel(
     const float* __restrict__ Y, int64_t R, int k, int F, const float* __restrict__ mean,
     const float* __restrict__ rstd, const float* __restrict__ beta, int relu,
     float* __restrict__ max_out, int64_t ldmax, float* __restrict__ mean_out, int64_t ldmean,
-    float* __restrict__ out2, int64_t ldout2, float* __restrict__ cnt_out) {
+    float* __restrict__ out2, int64_t ldout2, float* __restrict__ cnt_out, int fv_shift) {
   const int FV = F / V;
   const int64_t items = R * FV;
   const float invk = 1.0f / (float)k;
   for (int64_t it = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; it < items;
        it += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t r = it / FV;
-    const int f = (int)(it % FV) * V;
+    int64_t r;
+    int fq;
+    split_item(it, FV, fv_shift, r, fq);
+    const int f = fq * V;
     float mu[V], rs[V], be[V], mx[V], sm[V], cn[V];
     Vec<V>::ld(mean + f, mu); Vec<V>::ld(rstd + f, rs); Vec<V>::ld(beta + f, be);
 #pragma unroll
@@ -132,7 +150,8 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
     const float* __restrict__ Y, int64_t R, int k, int F, const float* __restrict__ mean,
     const float* __restrict__ rstd, const float* __restrict__ beta, int relu,
     const float* __restrict__ dmax, int64_t lddmax, const float* __restrict__ dmean, int64_t lddmean,
-    const float* __restrict__ mx_in, int64_t ldmx, const float* __restrict__ cnt_in, double* __restrict__ red) {
+    const float* __restrict__ mx_in, int64_t ldmx, const float* __restrict__ cnt_in, double* __restrict__ red,
+    int fv_shift) {
   extern __shared__ float lred[];  // [2][F]
   for (int e = threadIdx.x; e < 2 * F; e += blockDim.x) lred[e] = 0.f;
   __syncthreads();
@@ -145,8 +164,10 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
   for (int v = 0; v < V; ++v) { s0[v] = 0.f; s1[v] = 0.f; }
   for (int64_t it = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; it < items;
        it += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t r = it / FV;
-    const int f = (int)(it % FV) * V;
+    int64_t r;
+    int fq;
+    split_item(it, FV, fv_shift, r, fq);
+    const int f = fq * V;
     if (f != curf) {
       if (curf >= 0) {
 #pragma unroll
@@ -200,15 +221,17 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
     const float* __restrict__ rstd, const float* __restrict__ beta, int relu,
     const float* __restrict__ dmax, int64_t lddmax, const float* __restrict__ dmean, int64_t lddmean,
     const float* __restrict__ mx_in, int64_t ldmx, const float* __restrict__ cnt_in,
-    const double* __restrict__ red, float* dY, float* __restrict__ dYsum) {
+    const double* __restrict__ red, float* dY, float* __restrict__ dYsum, int fv_shift) {
   const int FV = F / V;
   const int64_t items = R * FV;
   const float invk = 1.0f / (float)k;
   const double inv_cnt = 1.0 / ((double)R * (double)k);
   for (int64_t it = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; it < items;
        it += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t r = it / FV;
-    const int f = (int)(it % FV) * V;
+    int64_t r;
+    int fq;
+    split_item(it, FV, fv_shift, r, fq);
+    const int f = fq * V;
     float mu[V], rs[V], be[V], dmx[V], dmn[V], c1[V], c2[V], acc[V];
     Vec<V>::ld(mean + f, mu); Vec<V>::ld(rstd + f, rs); Vec<V>::ld(beta + f, be);
     Vec<V>::ld(dmax + r * lddmax + f, dmx);
@@ -259,6 +282,21 @@ inline unsigned grid_for(int64_t items) {
 
 inline bool a16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
+inline int shift_of(int fv) {
+  if (fv <= 0 || (fv & (fv - 1))) return -1;
+  int s = 0;
+  while ((1 << s) < fv) ++s;
+  return s;
+}
+
+// the reduce kernel ends with 2F atomics per block: keep the grid small (4 blocks per CU)
+inline unsigned grid_reduce(int64_t items) {
+  int64_t g = dg::cdiv(items, 256);
+  if (g > 1024) g = 1024;
+  if (g < 1) g = 1;
+  return (unsigned)g;
+}
+
 }  // namespace
 
 extern "C" int dgcnn_bn_finalize_f32(const double* stats, int F, double count, float eps,
@@ -281,10 +319,10 @@ extern "C" int dgcnn_bn_act_kreduce_f32(const float* Y, int64_t R, int k, int F,
   hipStream_t st = (hipStream_t)stream;
   if (vec)
     hipLaunchKernelGGL((bn_act_kreduce_kernel<4>), dim3(grid_for(R * (F / 4))), dim3(256), 0, st, Y, R, k, F, mean,
-                       rstd, beta, relu, max_out, ldmax, mean_out, ldmean, out2, ldout2, cnt_out);
+                       rstd, beta, relu, max_out, ldmax, mean_out, ldmean, out2, ldout2, cnt_out, shift_of(F / 4));
   else
     hipLaunchKernelGGL((bn_act_kreduce_kernel<1>), dim3(grid_for(R * F)), dim3(256), 0, st, Y, R, k, F, mean, rstd,
-                       beta, relu, max_out, ldmax, mean_out, ldmean, out2, ldout2, cnt_out);
+                       beta, relu, max_out, ldmax, mean_out, ldmean, out2, ldout2, cnt_out, shift_of(F));
   return dg::check_launch("dgcnn_bn_act_kreduce_f32");
 }
 
@@ -302,11 +340,11 @@ extern "C" int dgcnn_bn_bwd_reduce_f32(const float* Y, int64_t R, int k, int F,
   hipStream_t st = (hipStream_t)stream;
   const size_t sh = (size_t)2 * F * sizeof(float);
   if (vec)
-    hipLaunchKernelGGL((bn_bwd_reduce_kernel<4>), dim3(grid_for(R * (F / 4))), dim3(256), sh, st, Y, R, k, F, mean,
-                       rstd, beta, relu, dmax, lddmax, dmean, lddmean, mx_in, ldmx, cnt_in, red);
+    hipLaunchKernelGGL((bn_bwd_reduce_kernel<4>), dim3(grid_reduce(R * (F / 4))), dim3(256), sh, st, Y, R, k, F, mean,
+                       rstd, beta, relu, dmax, lddmax, dmean, lddmean, mx_in, ldmx, cnt_in, red, shift_of(F / 4));
   else
-    hipLaunchKernelGGL((bn_bwd_reduce_kernel<1>), dim3(grid_for(R * F)), dim3(256), sh, st, Y, R, k, F, mean, rstd,
-                       beta, relu, dmax, lddmax, dmean, lddmean, mx_in, ldmx, cnt_in, red);
+    hipLaunchKernelGGL((bn_bwd_reduce_kernel<1>), dim3(grid_reduce(R * F)), dim3(256), sh, st, Y, R, k, F, mean, rstd,
+                       beta, relu, dmax, lddmax, dmean, lddmean, mx_in, ldmx, cnt_in, red, shift_of(F));
   return dg::check_launch("dgcnn_bn_bwd_reduce_f32");
 }
 
@@ -326,9 +364,9 @@ extern "C" int dgcnn_bn_bwd_apply_f32(const float* Y, int64_t R, int k, int F,
                    (!mx_in || ((ldmx % 4 == 0) && a16(mx_in) && a16(cnt_in)));
   if (vec)
     hipLaunchKernelGGL((bn_bwd_apply_kernel<4>), dim3(grid_for(R * (F / 4))), dim3(256), 0, st, Y, R, k, F, mean, rstd,
-                       beta, relu, dmax, lddmax, dmean, lddmean, mx_in, ldmx, cnt_in, red, dY, dYsum);
+                       beta, relu, dmax, lddmax, dmean, lddmean, mx_in, ldmx, cnt_in, red, dY, dYsum, shift_of(F / 4));
   else
     hipLaunchKernelGGL((bn_bwd_apply_kernel<1>), dim3(grid_for(R * F)), dim3(256), 0, st, Y, R, k, F, mean, rstd, beta,
-                       relu, dmax, lddmax, dmean, lddmean, mx_in, ldmx, cnt_in, red, dY, dYsum);
+                       relu, dmax, lddmax, dmean, lddmean, mx_in, ldmx, cnt_in, red, dY, dYsum, shift_of(F));
   return dg::check_launch("dgcnn_bn_bwd_apply_f32");
 }

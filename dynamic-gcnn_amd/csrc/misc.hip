@@ -52,9 +52,9 @@ __global__ void edge_gather_bwd_kernel(const float* __restrict__ dE, const int32
 // are bucketed by target once (counting sort: histogram, per-cloud exclusive scan -- a cloud owns
 // exactly N*k edges -- and fill), and every point then SUMS its incoming dY rows (a gather).
 __global__ void csr_count_kernel(const int32_t* __restrict__ idx, int N, int k, int64_t Me, int32_t* __restrict__ cnt) {
-  GRID_STRIDE(e, Me) {
-    const int64_t g = e / k;
-    atomicAdd(cnt + (g / N) * N + idx[e], 1);
+  GRID_STRIDE(e, Me) {                          // Me < 2^31: 32-bit divisions
+    const unsigned g = (unsigned)e / (unsigned)k;
+    atomicAdd(cnt + (g / (unsigned)N) * (unsigned)N + idx[e], 1);
   }
 }
 
@@ -86,8 +86,8 @@ __global__ __launch_bounds__(1024) void csr_scan_kernel(const int32_t* __restric
 __global__ void csr_fill_kernel(const int32_t* __restrict__ idx, int N, int k, int64_t Me,
                                 const int32_t* __restrict__ off, int32_t* __restrict__ cur, int32_t* __restrict__ rev) {
   GRID_STRIDE(e, Me) {
-    const int64_t g = e / k;
-    const int64_t tgt = (g / N) * N + idx[e];
+    const unsigned g = (unsigned)e / (unsigned)k;
+    const unsigned tgt = (g / (unsigned)N) * (unsigned)N + idx[e];
     const int pos = off[tgt] + atomicAdd(cur + tgt, 1);
     rev[pos] = (int32_t)e;
   }
