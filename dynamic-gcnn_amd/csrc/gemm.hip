@@ -22,6 +22,10 @@
 #include "common.h"
 #include <stdlib.h>
 
+#ifndef DGCNN_ABLATE
+#define DGCNN_ABLATE 0   // experiments only: 1 = no prefetch/LDS refill, 2 = +no barrier, 3 = +no operand reads
+#endif
+
 namespace {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
@@ -326,15 +330,15 @@ __global__ __launch_bounds__(NT) void gemm_kernel(GemmP p) {
 #pragma unroll 1
   for (int kt = 0; kt < nk; ++kt) {
     const int buf = kt & 1;
-    const bool more = (kt + 1 < nk);
+    const bool more = (DGCNN_ABLATE >= 1) ? false : (kt + 1 < nk);
     if (more) {
 #pragma unroll
       for (int i = 0; i < NVA; ++i) ra[i] = fetch_a(i, kbeg + (kt + 1) * BK);
 #pragma unroll
       for (int i = 0; i < NVB; ++i) rb[i] = fetch_b(i, kbeg + (kt + 1) * BK);
     }
-    const float* as = As + buf * BK * SA + lh * SA + a_off;
-    const float* bs = Bs + buf * BK * SB + lh * SB + b_off;
+    const float* as = As + ((DGCNN_ABLATE >= 1) ? 0 : buf) * BK * SA + lh * SA + a_off;
+    const float* bs = Bs + ((DGCNN_ABLATE >= 1) ? 0 : buf) * BK * SB + lh * SB + b_off;
     // operand reads run one k-pair ahead of the MFMAs (two register sets, static indices); the
     // sched_barriers pin "issue next reads -> MFMAs of the current pair" so the LDS latency of pair
     // s+1 hides under the 8 MFMAs of pair s (hipcc otherwise sinks each read next to its use).
@@ -376,7 +380,7 @@ __global__ __launch_bounds__(NT) void gemm_kernel(GemmP p) {
 #pragma unroll
       for (int i = 0; i < NVB; ++i) store_b(buf ^ 1, i, rb[i]);
     }
-    __syncthreads();
+    if (DGCNN_ABLATE < 2) __syncthreads();
   }
 
   // ---- epilogue.  C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)

@@ -13,7 +13,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdgcnn_hip.so")
+LIB_PATH = os.environ.get("DGCNN_HIP_LIB") or os.path.join(_HERE, "libdgcnn_hip.so")   # env override: experiments
 STAT_SLOTS = 32
 
 c_int, c_i64, c_f32, c_f64, c_vp, c_sz, c_u64 = (ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_double,

@@ -1,0 +1,57 @@
+#!/usr/bin/env python
+"""Times one training micro-step (fwd+bwd+Adam) on the other BASELINE.json configs (fp32 path) on
+one GPU, and checks that the loss is finite and that every layer's k-NN graph contains self.
+These are parity-test shapes, not bench lines (bench.py reports configs[1])."""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "dynamic-gcnn_amd"))
+import numpy as np
+import torch
+import dgcnn
+
+CONFIGS = [
+    ("configs[0] B=2 N=512 k=10, 1 EdgeConv", dict(MODEL_NAME="dgcnn", EDGE_CONV_LAYERS=1, EDGE_CONV_FILTERS=64, KVALUE=10), 2, 512, 3),
+    ("configs[1] B=24 N=2048 k=20, 3 EdgeConv (64,64,128)", dict(MODEL_NAME="dgcnn", EDGE_CONV_LAYERS=3, EDGE_CONV_FILTERS=[64, 64, 128], KVALUE=20), 24, 2048, 3),
+    ("configs[2] B=8 N=16384 k=40 residual x6 (fp32 path)", dict(MODEL_NAME="residual-dgcnn", EDGE_CONV_LAYERS=6, EDGE_CONV_FILTERS=64, KVALUE=40), 8, 16384, 3),
+    ("configs[4] per-GPU B=8 N=65536 k=20, 3 EdgeConv", dict(MODEL_NAME="dgcnn", EDGE_CONV_LAYERS=3, EDGE_CONV_FILTERS=[64, 64, 128], KVALUE=20), 8, 65536, 3),
+]
+
+
+def main():
+    for name, cfg, B, N, C in CONFIGS:
+        flags = dgcnn.DGCNN_FLAGS(NUM_CLASS=2, FC_LAYERS=2, FC_FILTERS=[512, 256], TRAIN=True, NUM_CHANNEL=C, **cfg)
+        tv = dgcnn.trainval(flags).initialize()
+        rng = np.random.default_rng(0)
+        pts = torch.from_numpy(rng.random((B, N, C), dtype=np.float32)).cuda()
+        lab = torch.from_numpy(rng.integers(0, 2, (B, N)).astype(np.int32)).cuda()
+        idx = dgcnn.ops.k_nn(pts, int(flags.KVALUE))
+        assert bool(((idx == torch.arange(N, device="cuda", dtype=torch.int32)[None, :, None]).sum(-1) == 1).all())
+
+        def step():
+            tv.zero_gradients(None)
+            r = tv.accum_gradient(None, [pts], [lab])
+            tv.apply_gradient(None)
+            return r
+        for _ in range(2):
+            r = step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        n = 3
+        for _ in range(n):
+            r = step()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / n
+        loss = float(r[2])
+        assert np.isfinite(loss)
+        print("%-58s %9.2f ms/step  %9.1f clouds/s  loss %.4f  peak mem %.1f GB" % (
+            name, dt * 1e3, B / dt, loss, torch.cuda.max_memory_allocated() / 2**30), flush=True)
+        del tv
+        torch.cuda.empty_cache()
+        torch.cuda.reset_peak_memory_stats()
+
+
+if __name__ == "__main__":
+    main()
