@@ -23,7 +23,7 @@
 #include <stdlib.h>
 
 #ifndef DGCNN_ABLATE
-#define DGCNN_ABLATE 0   // experiments only: 1 = no prefetch/LDS refill, 2 = +no barrier, 3 = +no operand reads
+#define DGCNN_ABLATE 0   // experiments only: 1 = no prefetch/LDS refill, 2 = +no barrier, 3 = prefetch but no LDS refill, 4 = LDS refill of stale registers, no prefetch
 #endif
 
 namespace {
@@ -327,18 +327,28 @@ __global__ __launch_bounds__(NT) void gemm_kernel(GemmP p) {
 
   const int a_off = wr * (BM / 2) + l31;
   const int b_off = wc * (BN / 2) + l31;
+  int knext = 0;
+  auto prefetch_slot = [&](int sl, bool more) {     // one prefetch load per MFMA group (slots 0..NVA+NVB-1)
+    // VEC: unconditional (addresses are clamped into the operand, so the extra fetch after the last
+    // tile is harmless) -- a branch here would split the block and make hipcc drain vmcnt(0) per load
+    if ((!VEC && !more) || DGCNN_ABLATE == 4) return;
+#pragma unroll
+    for (int i = 0; i < NVA; ++i)
+      if (sl == i) ra[i] = fetch_a(i, knext);
+#pragma unroll
+    for (int i = 0; i < NVB; ++i)
+      if (sl == NVA + i) rb[i] = fetch_b(i, knext);
+  };
 #pragma unroll 1
   for (int kt = 0; kt < nk; ++kt) {
     const int buf = kt & 1;
-    const bool more = (DGCNN_ABLATE >= 1) ? false : (kt + 1 < nk);
-    if (more) {
-#pragma unroll
-      for (int i = 0; i < NVA; ++i) ra[i] = fetch_a(i, kbeg + (kt + 1) * BK);
-#pragma unroll
-      for (int i = 0; i < NVB; ++i) rb[i] = fetch_b(i, kbeg + (kt + 1) * BK);
-    }
-    const float* as = As + ((DGCNN_ABLATE >= 1) ? 0 : buf) * BK * SA + lh * SA + a_off;
-    const float* bs = Bs + ((DGCNN_ABLATE >= 1) ? 0 : buf) * BK * SB + lh * SB + b_off;
+    const bool more = (DGCNN_ABLATE == 1 || DGCNN_ABLATE == 2) ? false : (kt + 1 < nk);
+    knext = kbeg + (kt + 1) * BK;
+    // The prefetch of tile kt+1 is NOT issued up front: its NVA+NVB loads (and their address VALU) are
+    // slotted one per MFMA group below, so they issue in the shadow of this wave's own MFMAs
+    // (measured: up-front prefetch costs 15 % of the MFMA rate, profiles/r01_gemm_ablation.txt).
+    const float* as = As + ((DGCNN_ABLATE >= 1 && DGCNN_ABLATE != 4) ? 0 : buf) * BK * SA + lh * SA + a_off;
+    const float* bs = Bs + ((DGCNN_ABLATE >= 1 && DGCNN_ABLATE != 4) ? 0 : buf) * BK * SB + lh * SB + b_off;
     // operand reads run one k-pair ahead of the MFMAs (two register sets, static indices); the
     // sched_barriers pin "issue next reads -> MFMAs of the current pair" so the LDS latency of pair
     // s+1 hides under the 8 MFMAs of pair s (hipcc otherwise sinks each read next to its use).
@@ -359,6 +369,7 @@ __global__ __launch_bounds__(NT) void gemm_kernel(GemmP p) {
 #pragma unroll
         for (int j = 0; j < TN; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[i], b0[j], acc[i][j], 0, 0, 0);
+      prefetch_slot(s, more);
       __builtin_amdgcn_sched_barrier(0);
       if (s + 2 < BK / 2) {
 #pragma unroll
@@ -372,9 +383,16 @@ __global__ __launch_bounds__(NT) void gemm_kernel(GemmP p) {
 #pragma unroll
         for (int j = 0; j < TN; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[i], b1[j], acc[i][j], 0, 0, 0);
+      prefetch_slot(s + 1, more);
       __builtin_amdgcn_sched_barrier(0);
     }
-    if (more) {
+    if (DGCNN_ABLATE == 3) {   // keep the loads alive without writing LDS
+#pragma unroll
+      for (int i = 0; i < NVA; ++i) asm volatile("" ::"v"(ra[i].x), "v"(ra[i].w));
+#pragma unroll
+      for (int i = 0; i < NVB; ++i) asm volatile("" ::"v"(rb[i].x), "v"(rb[i].w));
+    }
+    if (more && DGCNN_ABLATE != 3) {
 #pragma unroll
       for (int i = 0; i < NVA; ++i) store_a(buf ^ 1, i, ra[i]);
 #pragma unroll
