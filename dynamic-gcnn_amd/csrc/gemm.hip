@@ -55,9 +55,136 @@ struct GemmP {
 };
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+#if DGCNN_ABLATE == 5   // experiment: prefetch by LDS-DMA into a dummy LDS area (results are garbage)
+#define LD4(ptr) (__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ptr), (__attribute__((address_space(3))) void*)(smem + (threadIdx.x >> 6) * 256), 16, 0, 0), make_float4(0.f, 0.f, 0.f, 0.f))
+#else
+#define LD4(ptr) ld4(ptr)
+#endif
 
 __device__ __forceinline__ float4 sub4(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
 __device__ __forceinline__ int imin(int a, int b) { return a < b ? a : b; }
+
+// ---- shared epilogue.  C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+template <int EPI, int BM, int BN, bool VEC, int TM, int TN>
+__device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[TM][TN], float* smem, int m0, int n0,
+                                              int mt, int z, int t, int wr, int wc, int l31, int lh) {
+  const int colw = n0 + wc * (BN / 2) + l31;
+  const int roww = m0 + wr * (BM / 2) + 4 * lh;
+  if (EPI == E_SCATTER) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = roww + i * 32 + (r & 3) + 8 * (r >> 2);
+        if (row < p.M) {
+          const int nb = (row / (p.knn * p.npts)) * p.npts + p.idx[row];
+          float* d = p.dx + (int64_t)nb * p.lddx;
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            const int col = colw + j * 32;
+            if (col < p.N) atomicAdd(d + col, acc[i][j][r]);
+          }
+        }
+      }
+    return;
+  }
+
+  // ---- E_STORE: accumulators -> LDS (64 block rows at a time) -> coalesced float4 row stores.
+  // Keeps the epilogue at one global_store_dwordx4 per 4 outputs, lets the read-modify-write
+  // (beta) and the per-cloud bias be float4 loads, and needs no per-row pointer registers.
+  float* tile = smem;                       // [64][BN]
+  constexpr int QV = BN / 4;                // float4 per row
+  constexpr int RSTEP = NT / QV;            // rows covered per pass of the 256 threads
+  const int c4 = (t % QV) * 4;
+  const int rr0 = t / QV;
+  const int gcol = n0 + c4;
+  const bool col_ok = gcol < p.N;
+  const bool has_beta = (p.beta != 0.f);
+  const bool has_gb = (p.gbias != nullptr);
+  const bool split = (p.splits > 1);
+  float* outp = split ? (p.partial + (int64_t)z * p.M * p.N) : p.C;
+  const int64_t ldo = split ? (int64_t)p.N : p.ldc;
+  const bool vec_st = VEC && p.cvec && (gcol + 3 < p.N);
+  const int rlast = imin(m0 + BM, p.M) - 1;
+  const bool gb_uniform = has_gb && ((m0 / p.rpg) == (rlast / p.rpg));
+  float gbu[4] = {0.f, 0.f, 0.f, 0.f};
+  if (gb_uniform && col_ok) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      if (gcol + q < p.N) gbu[q] = p.gbias[(int64_t)(m0 / p.rpg) * p.ldgbias + gcol + q];
+  }
+  float cs[4] = {0.f, 0.f, 0.f, 0.f}, cq[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        tile[(wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * BN + wc * (BN / 2) + j * 32 + l31] = acc[i][j][r];
+    __syncthreads();
+#pragma unroll
+    for (int q0 = 0; q0 < 64 / RSTEP; ++q0) {
+      const int rl = rr0 + q0 * RSTEP;
+      const int grow = m0 + (rl >> 5) * (BM / 2) + i * 32 + (rl & 31);
+      if (grow < p.M && col_ok) {
+        const float4 tv = *reinterpret_cast<const float4*>(&tile[rl * BN + c4]);
+        float v[4] = {tv.x, tv.y, tv.z, tv.w};
+        float* dst = outp + (int64_t)grow * ldo + gcol;
+        if (!split) {
+          if (has_gb) {
+            if (gb_uniform) {
+#pragma unroll
+              for (int q = 0; q < 4; ++q) v[q] += gbu[q];
+            } else {
+              const float* gb = p.gbias + (int64_t)(grow / p.rpg) * p.ldgbias + gcol;
+#pragma unroll
+              for (int q = 0; q < 4; ++q)
+                if (gcol + q < p.N) v[q] += gb[q];
+            }
+          }
+          if (has_beta) {
+            if (vec_st) {
+              const float4 o = *reinterpret_cast<const float4*>(dst);
+              v[0] += p.beta * o.x; v[1] += p.beta * o.y; v[2] += p.beta * o.z; v[3] += p.beta * o.w;
+            } else {
+#pragma unroll
+              for (int q = 0; q < 4; ++q)
+                if (gcol + q < p.N) v[q] += p.beta * dst[q];
+            }
+          }
+        }
+        if (vec_st) {
+          *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) { cs[q] += v[q]; cq[q] += v[q] * v[q]; }
+        } else {
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            if (gcol + q < p.N) { dst[q] = v[q]; cs[q] += v[q]; cq[q] += v[q] * v[q]; }
+        }
+      }
+    }
+  }
+  if (p.stats && !split) {
+    __syncthreads();
+    float* red = smem;  // [2][BN]
+    for (int e = t; e < 2 * BN; e += NT) red[e] = 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      atomicAdd(&red[c4 + q], cs[q]);
+      atomicAdd(&red[BN + c4 + q], cq[q]);
+    }
+    __syncthreads();
+    const int slot = mt % DGCNN_STAT_SLOTS;
+    for (int e = t; e < 2 * BN; e += NT) {
+      const int which = e / BN, c = n0 + (e % BN);
+      if (c < p.N) atomicAdd(p.stats + ((int64_t)slot * 2 + which) * p.N + c, (double)red[e]);
+    }
+  }
+}
+
 
 // VEC = every operand is float4-loadable (16-B aligned, leading dimensions and the contiguous
 // extent multiples of 4).  Then each prefetch is ONE unconditional global_load_dwordx4 from a
@@ -138,19 +265,19 @@ __global__ __launch_bounds__(NT) void gemm_kernel(GemmP p) {
       if (ASRC == A_ROW) {
         const int kc = k0 + 4 * (t & 3);
         oka[i] = a_ok[i] && (kc < kend);
-        v = ld4(a_ptr[i] + imin(kc, kend - 4));
+        v = LD4(a_ptr[i] + imin(kc, kend - 4));
       } else if (ASRC == A_EDGE) {
         const int kc = k0 + 4 * (t & 3);
         const int C = p.cch;
         oka[i] = a_ok[i] && (kc < kend);
         const int kcc = imin(kc, kend - 4);
         if (k0 + BK <= C) {                       // wave-uniform: the whole k-chunk is centre features
-          v = ld4(a_ptr[i] + kcc);
+          v = LD4(a_ptr[i] + kcc);
         } else {
           const bool cen = kcc < C;
           const int col = cen ? kcc : kcc - C;
-          const float4 xc = ld4(a_ptr[i] + col);
-          const float4 xn = ld4((cen ? a_ptr[i] : a_ptr2[i]) + col);
+          const float4 xc = LD4(a_ptr[i] + col);
+          const float4 xn = LD4((cen ? a_ptr[i] : a_ptr2[i]) + col);
           const float4 df = sub4(xn, xc);
           v = cen ? xc : df;
         }
@@ -158,7 +285,7 @@ __global__ __launch_bounds__(NT) void gemm_kernel(GemmP p) {
         const int kk = k0 + t / (BM / 4) + i * (1024 / BM);
         const int m = m0 + (t % (BM / 4)) * 4;
         oka[i] = (kk < kend) && (m < p.M);
-        v = ld4(p.A + (int64_t)imin(kk, kend - 1) * p.lda + imin(m, p.M - 4));
+        v = LD4(p.A + (int64_t)imin(kk, kend - 1) * p.lda + imin(m, p.M - 4));
       } else {  // A_EDGE_T: element (m = channel of E, kk = edge row)
         const int er = k0 + t / (BM / 4) + i * (1024 / BM);
         const int m = m0 + (t % (BM / 4)) * 4;
@@ -172,8 +299,8 @@ __global__ __launch_bounds__(NT) void gemm_kernel(GemmP p) {
         const int mc = imin(m, p.M - 4);
         const bool cen = mc < C;
         const int col = cen ? mc : mc - C;
-        const float4 xc = ld4(pc + col);
-        const float4 xn = ld4((cen ? pc : pn) + col);
+        const float4 xc = LD4(pc + col);
+        const float4 xn = LD4((cen ? pc : pn) + col);
         const float4 df = sub4(xn, xc);
         v = cen ? xc : df;
       }
@@ -240,12 +367,12 @@ __global__ __launch_bounds__(NT) void gemm_kernel(GemmP p) {
         const int kk = k0 + t / (BN / 4) + i * (1024 / BN);
         const int n = n0 + (t % (BN / 4)) * 4;
         okb[i] = (kk < kend) && (n < p.N);
-        v = ld4(p.B + (int64_t)imin(kk, kend - 1) * p.ldb + imin(n, p.N - 4));
+        v = LD4(p.B + (int64_t)imin(kk, kend - 1) * p.ldb + imin(n, p.N - 4));
       } else {
         const int n = n0 + (t >> 2) + 64 * i;
         const int kc = k0 + 4 * (t & 3);
         okb[i] = (n < p.N) && (kc < kend);
-        v = ld4(p.B + (int64_t)imin(n, p.N - 1) * p.ldb + imin(kc, kend - 4));
+        v = LD4(p.B + (int64_t)imin(n, p.N - 1) * p.ldb + imin(kc, kend - 4));
       }
       return v;
     }
@@ -392,7 +519,8 @@ __global__ __launch_bounds__(NT) void gemm_kernel(GemmP p) {
 #pragma unroll
       for (int i = 0; i < NVB; ++i) asm volatile("" ::"v"(rb[i].x), "v"(rb[i].w));
     }
-    if (more && DGCNN_ABLATE != 3) {
+    if (DGCNN_ABLATE == 5) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (more && DGCNN_ABLATE != 3 && DGCNN_ABLATE != 5) {
 #pragma unroll
       for (int i = 0; i < NVA; ++i) store_a(buf ^ 1, i, ra[i]);
 #pragma unroll
@@ -401,122 +529,212 @@ __global__ __launch_bounds__(NT) void gemm_kernel(GemmP p) {
     if (DGCNN_ABLATE < 2) __syncthreads();
   }
 
-  // ---- epilogue.  C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-  const int colw = n0 + wc * (BN / 2) + l31;
-  const int roww = m0 + wr * (BM / 2) + 4 * lh;
-  if (EPI == E_SCATTER) {
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = roww + i * 32 + (r & 3) + 8 * (r >> 2);
-        if (row < p.M) {
-          const int nb = (row / (p.knn * p.npts)) * p.npts + p.idx[row];
-          float* d = p.dx + (int64_t)nb * p.lddx;
-#pragma unroll
-          for (int j = 0; j < TN; ++j) {
-            const int col = colw + j * 32;
-            if (col < p.N) atomicAdd(d + col, acc[i][j][r]);
-          }
-        }
-      }
-    return;
-  }
+  gemm_epilogue<EPI, BM, BN, VEC, TM, TN>(p, acc, smem, m0, n0, mt, z, t, wr, wc, l31, lh);
+}
 
-  // ---- E_STORE: accumulators -> LDS (64 block rows at a time) -> coalesced float4 row stores.
-  // Keeps the epilogue at one global_store_dwordx4 per 4 outputs, lets the read-modify-write
-  // (beta) and the per-cloud bias be float4 loads, and needs no per-row pointer registers.
-  float* tile = smem;                       // [64][BN]
-  constexpr int QV = BN / 4;                // float4 per row
-  constexpr int RSTEP = NT / QV;            // rows covered per pass of the 256 threads
-  const int c4 = (t % QV) * 4;
-  const int rr0 = t / QV;
-  const int gcol = n0 + c4;
-  const bool col_ok = gcol < p.N;
-  const bool has_beta = (p.beta != 0.f);
-  const bool has_gb = (p.gbias != nullptr);
-  const bool split = (p.splits > 1);
-  float* outp = split ? (p.partial + (int64_t)z * p.M * p.N) : p.C;
-  const int64_t ldo = split ? (int64_t)p.N : p.ldc;
-  const bool vec_st = VEC && p.cvec && (gcol + 3 < p.N);
-  const int rlast = imin(m0 + BM, p.M) - 1;
-  const bool gb_uniform = has_gb && ((m0 / p.rpg) == (rlast / p.rpg));
-  float gbu[4] = {0.f, 0.f, 0.f, 0.f};
-  if (gb_uniform && col_ok) {
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-      if (gcol + q < p.N) gbu[q] = p.gbias[(int64_t)(m0 / p.rpg) * p.ldgbias + gcol + q];
+// ------------------------------------------------------------------------------------------------
+// LDS-DMA variant (plain A_ROW/A_COL x B_ROW/B_COL, K % 16 == 0, float4-aligned operands).
+// The register-staged kernel above tops out at ~103 TFLOP/s; ablations (profiles/r01_gemm_ablation.txt)
+// show the MFMA + operand-read loop alone runs at 128 and that the loss is the global_load ->
+// VGPR -> ds_write staging itself (placement of the loads does not matter), while
+// `global_load_lds_dwordx4` (data never touches VGPRs) costs a third of it.  So here BOTH tiles are
+// filled by LDS-DMA, one tile ahead, into a double buffer; one vmcnt(0) + barrier per k-step.
+//   k-major sources ([k][m] / [k][n]): the LDS image is the k-major tile itself (lane-linear rows),
+//     operands are read with conflict-free ds_read_b32 as before.
+//   row-major sources (k contiguous): DMA cannot transpose, so the LDS image is [row][4 chunks of
+//     16 B] with the chunk index XOR-swizzled by (row>>2)&3 (done on the SOURCE address, the image
+//     stays lane-linear); a lane reads one chunk with ds_read_b128 -- the 16 lanes of every
+//     b128 service group then hit 16 distinct 16-B slots (conflict-free) -- and picks its k = 2s+h
+//     element with one v_cndmask per MFMA operand.  Lanes 4r..4r+3 still fetch one contiguous 64-B
+//     row segment, so global coalescing is unchanged.
+// Out-of-range rows / columns are fetched from clamped (valid) addresses: they only feed output
+// rows / columns that the epilogue never stores.
+// One LDS-DMA piece: 64 lanes x 16 B from per-lane global addresses to LDS [m0, m0 + 1 KiB).
+// Inline asm on purpose: with the builtin hipcc counts the DMA as a pending LDS write and drains
+// vmcnt(0) before the next ds_read of the OTHER buffer (no overlap at all); the asm form is invisible
+// to its waitcnt pass and is waited for by hand (vmcnt(0) right before the k-step barrier).
+__device__ __forceinline__ void dma16(const float* gsrc, unsigned lds_byte) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(gsrc), "s"(lds_byte)
+               : "memory");
+}
+
+template <int ASRC, int BSRC, int EPI, int BN>
+__global__ __launch_bounds__(NT) void gemm_dma_kernel(GemmP p) {
+  constexpr int BM = 128;
+  constexpr bool A_T = (ASRC == A_ROW);
+  constexpr bool B_T = (BSRC == B_COL);
+  constexpr int TM = 2;
+  constexpr int TN = BN / 64;
+  constexpr int AF = BM * BK;               // floats per A tile
+  constexpr int BF = BN * BK;
+  constexpr int BUF = AF + BF;
+  constexpr int SMEM_F = (2 * BUF > 64 * BN) ? 2 * BUF : 64 * BN;
+  __shared__ __attribute__((aligned(16))) float smem[SMEM_F];
+
+  const int t = threadIdx.x;
+  const int lane = t & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wr = wv >> 1, wc = wv & 1;
+  const int l31 = lane & 31, lh = lane >> 5;
+
+  const int id = blockIdx.x;
+  int mt, nt;
+  if (p.xcd_group) {
+    mt = ((id >> 3) / p.ntiles) * 8 + (id & 7);
+    nt = (id >> 3) % p.ntiles;
+  } else {
+    mt = id / p.ntiles;
+    nt = id % p.ntiles;
   }
-  float cs[4] = {0.f, 0.f, 0.f, 0.f}, cq[4] = {0.f, 0.f, 0.f, 0.f};
+  if (mt >= p.mtiles) return;
+  const int m0 = mt * BM;
+  const int n0 = nt * BN;
+  const int z = blockIdx.z;
+  const int kbeg = z * p.kchunk;
+  const int kend = (kbeg + p.kchunk < p.K) ? (kbeg + p.kchunk) : p.K;
+  const int nk = (kend - kbeg) / BK;
+
+  // ---- per-lane DMA sources (k offset added per tile) ----
+  // row-major tile of R rows: instr j covers rows 16j..16j+15; lane -> (row 16j + lane/4, slot lane%4)
+  // k-major tile of width W: instr j covers floats [256j, 256j+256) of the [16][W] image
+  constexpr int NIA = AF / 256 / 4;          // DMA instructions per wave for A (8 instr / 4 waves)
+  constexpr int NIB = BF / 256 / 4;          // BN=128: 2, BN=64: 1
+  const float* asrc[NIA];
+  int64_t astep;                             // source advance per k-tile (floats)
 #pragma unroll
-  for (int i = 0; i < TM; ++i) {
-    __syncthreads();
+  for (int q = 0; q < NIA; ++q) {
+    const int j = wv + 4 * q;
+    if (A_T) {
+      const int r = 16 * j + (lane >> 2);
+      const int c = (lane & 3) ^ ((r >> 2) & 3);
+      asrc[q] = p.A + (int64_t)imin(m0 + r, p.M - 1) * p.lda + kbeg + 4 * c;
+    } else {
+      const int flat = 256 * j + 4 * lane;
+      const int kk = flat / BM, mm = flat % BM;
+      asrc[q] = p.A + (int64_t)(kbeg + kk) * p.lda + imin(m0 + mm, p.M - 4);
+    }
+  }
+  astep = A_T ? (int64_t)BK : (int64_t)BK * p.lda;
+  const float* bsrc[NIB];
+  int64_t bstep;
+#pragma unroll
+  for (int q = 0; q < NIB; ++q) {
+    const int j = wv + 4 * q;
+    if (B_T) {
+      const int r = 16 * j + (lane >> 2);
+      const int c = (lane & 3) ^ ((r >> 2) & 3);
+      bsrc[q] = p.B + (int64_t)imin(n0 + r, p.N - 1) * p.ldb + kbeg + 4 * c;
+    } else {
+      const int flat = 256 * j + 4 * lane;
+      const int kk = flat / BN, nn = flat % BN;
+      bsrc[q] = p.B + (int64_t)(kbeg + kk) * p.ldb + imin(n0 + nn, p.N - 4);
+    }
+  }
+  bstep = B_T ? (int64_t)BK : (int64_t)BK * p.ldb;
+
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)smem;   // LDS byte offset of smem
+  auto dma_tile = [&](int kt, int buf) {     // kt clamped by the caller: always a valid tile
+    const unsigned ab = lds0 + 4u * (unsigned)(buf * BUF);
+    const unsigned bb = ab + 4u * AF;
+#pragma unroll
+    for (int q = 0; q < NIA; ++q)
+      dma16(asrc[q] + (int64_t)kt * astep, __builtin_amdgcn_readfirstlane(ab + 1024u * (unsigned)(wv + 4 * q)));
+#pragma unroll
+    for (int q = 0; q < NIB; ++q)
+      dma16(bsrc[q] + (int64_t)kt * bstep, __builtin_amdgcn_readfirstlane(bb + 1024u * (unsigned)(wv + 4 * q)));
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
 #pragma unroll
     for (int j = 0; j < TN; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r)
-        tile[(wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * BN + wc * (BN / 2) + j * 32 + l31] = acc[i][j][r];
-    __syncthreads();
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // ---- operand read offsets (floats, relative to the tile base) ----
+  int a_row[TM], a_swz[TM], b_row[TN], b_swz[TN];
 #pragma unroll
-    for (int q0 = 0; q0 < 64 / RSTEP; ++q0) {
-      const int rl = rr0 + q0 * RSTEP;
-      const int grow = m0 + (rl >> 5) * (BM / 2) + i * 32 + (rl & 31);
-      if (grow < p.M && col_ok) {
-        const float4 tv = *reinterpret_cast<const float4*>(&tile[rl * BN + c4]);
-        float v[4] = {tv.x, tv.y, tv.z, tv.w};
-        float* dst = outp + (int64_t)grow * ldo + gcol;
-        if (!split) {
-          if (has_gb) {
-            if (gb_uniform) {
+  for (int i = 0; i < TM; ++i) {
+    const int r = wr * 64 + i * 32 + l31;
+    a_row[i] = A_T ? r * 16 : r;
+    a_swz[i] = (r >> 2) & 3;
+  }
 #pragma unroll
-              for (int q = 0; q < 4; ++q) v[q] += gbu[q];
-            } else {
-              const float* gb = p.gbias + (int64_t)(grow / p.rpg) * p.ldgbias + gcol;
+  for (int j = 0; j < TN; ++j) {
+    const int r = wc * (BN / 2) + j * 32 + l31;
+    b_row[j] = B_T ? r * 16 : r;
+    b_swz[j] = (r >> 2) & 3;
+  }
+
+  if (nk > 0) dma_tile(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  // operands of k-chunk c (k = 4c..4c+3  ->  MFMA steps s = 2c, 2c+1)
+  auto read_chunk = [&](const float* ab, const float* bb, int c, float (&av)[TM][2], float (&bv)[TN][2]) {
 #pragma unroll
-              for (int q = 0; q < 4; ++q)
-                if (gcol + q < p.N) v[q] += gb[q];
-            }
-          }
-          if (has_beta) {
-            if (vec_st) {
-              const float4 o = *reinterpret_cast<const float4*>(dst);
-              v[0] += p.beta * o.x; v[1] += p.beta * o.y; v[2] += p.beta * o.z; v[3] += p.beta * o.w;
-            } else {
-#pragma unroll
-              for (int q = 0; q < 4; ++q)
-                if (gcol + q < p.N) v[q] += p.beta * dst[q];
-            }
-          }
-        }
-        if (vec_st) {
-          *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
-#pragma unroll
-          for (int q = 0; q < 4; ++q) { cs[q] += v[q]; cq[q] += v[q] * v[q]; }
-        } else {
-#pragma unroll
-          for (int q = 0; q < 4; ++q)
-            if (gcol + q < p.N) { dst[q] = v[q]; cs[q] += v[q]; cq[q] += v[q] * v[q]; }
-        }
+    for (int i = 0; i < TM; ++i) {
+      if (A_T) {
+        const float4 v = *reinterpret_cast<const float4*>(ab + a_row[i] + ((c ^ a_swz[i]) << 2));
+        av[i][0] = lh ? v.y : v.x;
+        av[i][1] = lh ? v.w : v.z;
+      } else {
+        av[i][0] = ab[(4 * c + lh) * BM + a_row[i]];
+        av[i][1] = ab[(4 * c + 2 + lh) * BM + a_row[i]];
       }
     }
-  }
-  if (p.stats && !split) {
-    __syncthreads();
-    float* red = smem;  // [2][BN]
-    for (int e = t; e < 2 * BN; e += NT) red[e] = 0.f;
-    __syncthreads();
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      atomicAdd(&red[c4 + q], cs[q]);
-      atomicAdd(&red[BN + c4 + q], cq[q]);
+    for (int j = 0; j < TN; ++j) {
+      if (B_T) {
+        const float4 v = *reinterpret_cast<const float4*>(bb + b_row[j] + ((c ^ b_swz[j]) << 2));
+        bv[j][0] = lh ? v.y : v.x;
+        bv[j][1] = lh ? v.w : v.z;
+      } else {
+        bv[j][0] = bb[(4 * c + lh) * BN + b_row[j]];
+        bv[j][1] = bb[(4 * c + 2 + lh) * BN + b_row[j]];
+      }
     }
+  };
+  auto mma_chunk = [&](float (&av)[TM][2], float (&bv)[TN][2]) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][u], bv[j][u], acc[i][j], 0, 0, 0);
+  };
+
+#pragma unroll 1
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    dma_tile((kt + 1 < nk) ? kt + 1 : kt, buf ^ 1);      // unconditional: no branch in the loop body
+    const float* ab = smem + buf * BUF;
+    const float* bb = ab + AF;
+    float av0[TM][2], bv0[TN][2], av1[TM][2], bv1[TN][2];
+    read_chunk(ab, bb, 0, av0, bv0);
+    read_chunk(ab, bb, 1, av1, bv1);
+    __builtin_amdgcn_sched_barrier(0);
+    mma_chunk(av0, bv0);
+    __builtin_amdgcn_sched_barrier(0);
+    read_chunk(ab, bb, 2, av0, bv0);
+    __builtin_amdgcn_sched_barrier(0);
+    mma_chunk(av1, bv1);
+    __builtin_amdgcn_sched_barrier(0);
+    read_chunk(ab, bb, 3, av1, bv1);
+    __builtin_amdgcn_sched_barrier(0);
+    mma_chunk(av0, bv0);
+    __builtin_amdgcn_sched_barrier(0);
+    mma_chunk(av1, bv1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    const int slot = mt % DGCNN_STAT_SLOTS;
-    for (int e = t; e < 2 * BN; e += NT) {
-      const int which = e / BN, c = n0 + (e % BN);
-      if (c < p.N) atomicAdd(p.stats + ((int64_t)slot * 2 + which) * p.N + c, (double)red[e]);
-    }
   }
+
+  gemm_epilogue<EPI, BM, BN, true, TM, TN>(p, acc, smem, m0, n0, mt, z, t, wr, wc, l31, lh);
 }
 
 // C (+)= sum over splits of the partial tiles.  64 consecutive elements x 16 split-lanes per block
@@ -664,6 +882,12 @@ inline int tile_m(int M, int N, int splits) {
   return 128;
 }
 
+inline int gemm_dma_env() {
+  static int v = -2;
+  if (v == -2) { const char* e = getenv("DGCNN_GEMM_DMA"); v = e ? atoi(e) : 1; }   // 0 = register-staged kernel (A/B switch)
+  return v;
+}
+
 template <int ASRC, int BSRC, int EPI>
 int launch(GemmP& p, hipStream_t st, const char* what) {
   const int bn = (p.N <= 64) ? 64 : 128;
@@ -675,7 +899,18 @@ int launch(GemmP& p, hipStream_t st, const char* what) {
     if (p.splits > 1) p.cvec = (p.N % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.partial) & 15) == 0);
     else p.cvec = (p.ldc % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.C) & 15) == 0);
   }
-  if (p.bm == 256) launch_bm<ASRC, BSRC, EPI, 256>(p, st, vec, bn);
+  constexpr bool dma_kind = (ASRC == A_ROW || ASRC == A_COL) && EPI == E_STORE;
+  if (dma_kind && vec && p.K % BK == 0 && p.kchunk % BK == 0 && p.bm == 128 && gemm_dma_env()) {
+    p.mtiles = (int)dg::cdiv(p.M, 128);
+    p.ntiles = (int)dg::cdiv(p.N, bn);
+    p.xcd_group = (p.ntiles > 1 && p.mtiles >= 16 && p.splits == 1) ? 1 : 0;
+    const unsigned gx = p.xcd_group ? (unsigned)(dg::cdiv(p.mtiles, 8) * 8 * p.ntiles) : (unsigned)(p.mtiles * p.ntiles);
+    dim3 grid(gx, 1, (unsigned)p.splits);
+    if constexpr (dma_kind) {
+      if (bn == 64) hipLaunchKernelGGL((gemm_dma_kernel<ASRC, BSRC, EPI, 64>), grid, dim3(NT), 0, st, p);
+      else hipLaunchKernelGGL((gemm_dma_kernel<ASRC, BSRC, EPI, 128>), grid, dim3(NT), 0, st, p);
+    }
+  } else if (p.bm == 256) launch_bm<ASRC, BSRC, EPI, 256>(p, st, vec, bn);
   else if (p.bm == 192 && (ASRC == A_ROW || ASRC == A_EDGE)) launch_bm<ASRC, BSRC, EPI, (ASRC == A_ROW || ASRC == A_EDGE) ? 192 : 128>(p, st, vec, bn);
   else { p.bm = 128; launch_bm<ASRC, BSRC, EPI, 128>(p, st, vec, bn); }
   int rc = dg::check_launch(what);
