@@ -675,30 +675,33 @@ __global__ __launch_bounds__(NT) void gemm_dma_kernel(GemmP p) {
   __syncthreads();
 
   // operands of k-chunk c (k = 4c..4c+3  ->  MFMA steps s = 2c, 2c+1)
-  auto read_chunk = [&](const float* ab, const float* bb, int c, float (&av)[TM][2], float (&bv)[TN][2]) {
+  // raw LDS reads of k-chunk c (k = 4c..4c+3 -> MFMA steps s = 2c, 2c+1) ...
+  auto load_chunk = [&](const float* ab, const float* bb, int c, float4 (&va)[TM], float4 (&vb)[TN]) {
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
-      if (A_T) {
-        const float4 v = *reinterpret_cast<const float4*>(ab + a_row[i] + ((c ^ a_swz[i]) << 2));
-        av[i][0] = lh ? v.y : v.x;
-        av[i][1] = lh ? v.w : v.z;
-      } else {
-        av[i][0] = ab[(4 * c + lh) * BM + a_row[i]];
-        av[i][1] = ab[(4 * c + 2 + lh) * BM + a_row[i]];
-      }
+      if (A_T) va[i] = *reinterpret_cast<const float4*>(ab + a_row[i] + ((c ^ a_swz[i]) << 2));
+      else va[i] = make_float4(ab[(4 * c + lh) * BM + a_row[i]], 0.f, ab[(4 * c + 2 + lh) * BM + a_row[i]], 0.f);
     }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-      if (B_T) {
-        const float4 v = *reinterpret_cast<const float4*>(bb + b_row[j] + ((c ^ b_swz[j]) << 2));
-        bv[j][0] = lh ? v.y : v.x;
-        bv[j][1] = lh ? v.w : v.z;
-      } else {
-        bv[j][0] = bb[(4 * c + lh) * BN + b_row[j]];
-        bv[j][1] = bb[(4 * c + 2 + lh) * BN + b_row[j]];
-      }
+      if (B_T) vb[j] = *reinterpret_cast<const float4*>(bb + b_row[j] + ((c ^ b_swz[j]) << 2));
+      else vb[j] = make_float4(bb[(4 * c + lh) * BN + b_row[j]], 0.f, bb[(4 * c + 2 + lh) * BN + b_row[j]], 0.f);
     }
   };
+  // ... the k = 2s + h pick (one v_cndmask per operand for row-major images) ...
+  auto select_chunk = [&](const float4 (&va)[TM], const float4 (&vb)[TN], float (&av)[TM][2], float (&bv)[TN][2]) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      av[i][0] = (A_T && lh) ? va[i].y : va[i].x;
+      av[i][1] = (A_T && lh) ? va[i].w : va[i].z;
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      bv[j][0] = (B_T && lh) ? vb[j].y : vb[j].x;
+      bv[j][1] = (B_T && lh) ? vb[j].w : vb[j].z;
+    }
+  };
+  // ... and its 2 x TM x TN MFMAs
   auto mma_chunk = [&](float (&av)[TM][2], float (&bv)[TN][2]) {
 #pragma unroll
     for (int u = 0; u < 2; ++u)
@@ -715,21 +718,31 @@ __global__ __launch_bounds__(NT) void gemm_dma_kernel(GemmP p) {
     dma_tile((kt + 1 < nk) ? kt + 1 : kt, buf ^ 1);      // unconditional: no branch in the loop body
     const float* ab = smem + buf * BUF;
     const float* bb = ab + AF;
+    // software pipeline (pinned with sched_barriers): the raw reads of chunk c+2 and the selects of
+    // chunk c+1 are issued behind the MFMAs of chunk c, so neither LDS latency nor the v_cndmasks
+    // sit in front of an MFMA group
+    float4 ra0[TM], rb0[TN], ra1[TM], rb1[TN];
     float av0[TM][2], bv0[TN][2], av1[TM][2], bv1[TN][2];
-    read_chunk(ab, bb, 0, av0, bv0);
-    read_chunk(ab, bb, 1, av1, bv1);
+    load_chunk(ab, bb, 0, ra0, rb0);
+    load_chunk(ab, bb, 1, ra1, rb1);
+    select_chunk(ra0, rb0, av0, bv0);
     __builtin_amdgcn_sched_barrier(0);
-    mma_chunk(av0, bv0);
+    mma_chunk(av0, bv0);                      // chunk 0
     __builtin_amdgcn_sched_barrier(0);
-    read_chunk(ab, bb, 2, av0, bv0);
+    load_chunk(ab, bb, 2, ra0, rb0);
+    select_chunk(ra1, rb1, av1, bv1);
     __builtin_amdgcn_sched_barrier(0);
-    mma_chunk(av1, bv1);
+    mma_chunk(av1, bv1);                      // chunk 1
     __builtin_amdgcn_sched_barrier(0);
-    read_chunk(ab, bb, 3, av1, bv1);
+    load_chunk(ab, bb, 3, ra1, rb1);
+    select_chunk(ra0, rb0, av0, bv0);
     __builtin_amdgcn_sched_barrier(0);
-    mma_chunk(av0, bv0);
+    mma_chunk(av0, bv0);                      // chunk 2
     __builtin_amdgcn_sched_barrier(0);
-    mma_chunk(av1, bv1);
+    select_chunk(ra1, rb1, av1, bv1);
+    __builtin_amdgcn_sched_barrier(0);
+    mma_chunk(av1, bv1);                      // chunk 3
+    __builtin_amdgcn_sched_barrier(0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   }
