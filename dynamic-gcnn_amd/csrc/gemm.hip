@@ -534,11 +534,12 @@ __global__ __launch_bounds__(NT) void gemm_kernel(GemmP p) {
 
 // ------------------------------------------------------------------------------------------------
 // LDS-DMA variant (plain A_ROW/A_COL x B_ROW/B_COL, K % 16 == 0, float4-aligned operands).
-// The register-staged kernel above tops out at ~103 TFLOP/s; ablations (profiles/r01_gemm_ablation.txt)
-// show the MFMA + operand-read loop alone runs at 128 and that the loss is the global_load ->
-// VGPR -> ds_write staging itself (placement of the loads does not matter), while
-// `global_load_lds_dwordx4` (data never touches VGPRs) costs a third of it.  So here BOTH tiles are
-// filled by LDS-DMA, one tile ahead, into a double buffer; one vmcnt(0) + barrier per k-step.
+// EXPERIMENT, off by default (DGCNN_GEMM_DMA=1): BOTH tiles are filled by LDS-DMA, one tile ahead, into
+// a double buffer; one vmcnt(0) + barrier per k-step.  Measured equal to the register-staged kernel
+// (104 vs 102-104 TFLOP/s on FC0): what looked like a 20 % staging cost in the ablations
+// (profiles/r01_gemm_ablation.txt) was data-dependent clocking -- a pure-MFMA loop sustains 155 TFLOP/s
+// on static operands but 138 on changing random ones (profiles/ubench/mfma_peak.hip), so both
+// kernels sit at ~75-80 % of the realistic matrix-pipe rate.
 //   k-major sources ([k][m] / [k][n]): the LDS image is the k-major tile itself (lane-linear rows),
 //     operands are read with conflict-free ds_read_b32 as before.
 //   row-major sources (k contiguous): DMA cannot transpose, so the LDS image is [row][4 chunks of
@@ -897,7 +898,7 @@ inline int tile_m(int M, int N, int splits) {
 
 inline int gemm_dma_env() {
   static int v = -2;
-  if (v == -2) { const char* e = getenv("DGCNN_GEMM_DMA"); v = e ? atoi(e) : 1; }   // 0 = register-staged kernel (A/B switch)
+  if (v == -2) { const char* e = getenv("DGCNN_GEMM_DMA"); v = e ? atoi(e) : 0; }   // 1 = LDS-DMA staged kernel (A/B switch; measured equal)
   return v;
 }
 
