@@ -81,6 +81,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--kernel-table", action="store_true", help="print per-kernel event timings to stderr")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for the "
+                    "single-GPU-box sanity run of the N>1 logic, with --same-device)")
+    ap.add_argument("--same-device", action="store_true", help="all ranks on cuda:0 (sanity runs only)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -89,13 +92,18 @@ def main():
     if args.gpus != world and world == 1 and args.gpus > 1:
         raise SystemExit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d bench.py ...`"
                          % (args.gpus, args.gpus))
+    if args.same_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=args.backend, rank=rank, world_size=world)
 
     import dgcnn
     from dgcnn import _hip as H
@@ -146,6 +154,13 @@ def main():
         tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
+        # replicas must hold identical parameters after identical Adam steps on the all-reduced gradient
+        chk = torch.stack([dgcnn.ctx().flat_param.double().sum(), dgcnn.ctx().flat_param.double().abs().sum()])
+        lo, hi = chk.clone(), chk.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        if not torch.equal(lo, hi):
+            raise SystemExit("replicas diverged: parameter checksums differ across ranks")
 
     if rank == 0:
         is_gemm = dominant.startswith("gemm") or dominant.startswith("knn")
