@@ -230,65 +230,47 @@ __global__ __launch_bounds__(256, (knn_min_waves<CP, KC>())) void knn_kernel(con
 // product, no wider accumulation; MI355X_MICROARCH.md "Matrix cores"): feeding c = 2s, 2s+1 at step
 // s reproduces the normative chain exactly -- the bit-exact tests against oracle/knn_oracle.c run on
 // this kernel.  The matrix pipe does the 2*N^2*C flops; the VALU is left for the selection.
-//
-// Register-streamed: a pre-pass writes the points de-interleaved, Xp[row][h][s] = X[row][2s+h]
-// (h = lane>>5), so the MFMA A operand of lane (i = lane&31, h) for all CP/2 steps is ONE contiguous
-// run of CP/2 floats of candidate row i: each wave pulls its 32-candidate tile straight from L2 into
-// VGPRs with float4 loads -- no LDS staging and NO workgroup barrier in the main loop (the first
-// version staged tiles through LDS: 28 % MFMA-busy, waves mostly parked at the per-tile barrier).
-// The loads of tile t+1 are issued as soon as the MFMAs of tile t have consumed the registers and
-// land during the selection phase.
+//   A operand = candidates (k-major LDS tile [c][cand], one conflict-free ds_read_b32 per step),
 //   B operand = this wave's 32 query rows, resident in CP/2 VGPRs for the whole kernel.
 //   D layout: lane l holds query row (l & 31) and candidates (r&3) + 8(r>>2) + 4(l>>5), r = 0..15:
 //   two lanes per row, each with its own register-resident sorted list over its candidate subset.
-// Block = 64 query rows x 2 interleaved candidate streams (4 waves); 4 lists per row merged via LDS.
-template <int CP>
-__global__ void knn_pack_kernel(const float* __restrict__ x, int64_t ldx, int64_t rows, int C,
-                                float* __restrict__ xp) {
-  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // one output float each
-  if (e >= rows * CP) return;
-  const int64_t r = e / CP;
-  const int o = (int)(e % CP);
-  const int h = o / (CP / 2), s = o % (CP / 2);
-  const int c = 2 * s + h;
-  xp[e] = (c < C) ? x[r * ldx + c] : 0.0f;
-}
-
+// Block = 64 query rows x 2 candidate halves (4 waves); 64-candidate LDS tiles, double buffered, next
+// tile prefetched into registers under the MFMAs; 4 lists per row merged through LDS.
 template <int CP, int KC>
-constexpr int knn_mfma_waves() {   // x_q + tile (CP/2 each) + list (2 KC) + accumulator (16) + ~40
-  return (CP + 2 * KC + 56 <= 100) ? 4 : 2;   // (the compiler needs ~230 VGPRs at CP=64, KC=20: 2 waves/SIMD)
-}
-
-template <int CP, int KC>
-__global__ __launch_bounds__(256, (knn_mfma_waves<CP, KC>())) void knn_mfma_kernel(const float* __restrict__ xp, const float* __restrict__ sq,
-                                                          int N, int k, int32_t* __restrict__ idx) {
+__global__ __launch_bounds__(256, 2) void knn_mfma_kernel(const float* __restrict__ x, const float* __restrict__ sq,
+                                                          int N, int C, int64_t ldx, int k, int vec_ok,
+                                                          int32_t* __restrict__ idx) {
   using f32x16 = __attribute__((ext_vector_type(16))) float;
-  constexpr int NS = CP / 2;                 // MFMA steps per tile = floats per lane per tile
+  constexpr int TJM = 64;                    // candidates per LDS tile: 32 per candidate-half wave
+  constexpr int ST = TJM + 2;                // k-major candidate tile [CP][ST]
+  constexpr int TILE_F = CP * ST;
   constexpr int DQ_F = 16 * 256;
   constexpr int MERGE_F = ROWS * KC * 2;
-  constexpr int WORK_F = DQ_F + 4 * 32;
+  constexpr int WORK_F = 2 * TILE_F + DQ_F + 2 * TJM;
   constexpr int SH = (WORK_F > MERGE_F ? WORK_F : MERGE_F);
+  constexpr int NV = (TJM * (CP / 4)) / 256;  // float4 staged per thread per tile
+  static_assert(NV >= 1, "tile too small");
   __shared__ __attribute__((aligned(16))) float smem[SH];
-  float* dq = smem;
-  float* sjw = smem + DQ_F + (threadIdx.x >> 6) * 32;   // this wave's 32 candidate norms
+  float* dq = smem + 2 * TILE_F;
+  float* sjs = smem + 2 * TILE_F + DQ_F;     // [2][TJM]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int w = tid >> 6;
   const int l31 = lane & 31, h = lane >> 5;
   const int qg = w & 1;                      // which 32 query rows of the block
-  const int cs = w >> 1;                     // candidate tiles t = cs, cs + 2, ...
+  const int cs = w >> 1;                     // which 32 candidates of every 64-candidate tile
   const int b = blockIdx.y;
   const int row = blockIdx.x * ROWS + qg * 32 + l31;
-  const float* xb = xp + (int64_t)b * N * CP;
+  const float* xb = x + (int64_t)b * N * ldx;
   const float* sqb = sq + (int64_t)b * N;
   const int rowc = row < N ? row : N - 1;
 
-  float bq[NS];                              // B operand: x_q[row][2s + h], contiguous in the packed layout
+  float bq[CP / 2];                          // B operand: x_q[row][2s + h]
 #pragma unroll
-  for (int s4 = 0; s4 < NS; s4 += 4) {
-    const float4 v = *reinterpret_cast<const float4*>(xb + (int64_t)rowc * CP + h * NS + s4);
-    bq[s4] = v.x; bq[s4 + 1] = v.y; bq[s4 + 2] = v.z; bq[s4 + 3] = v.w;
+  for (int s2 = 0; s2 < CP / 2; ++s2) {
+    const int c = 2 * s2 + h;
+    bq[s2] = (c < C) ? xb[(int64_t)rowc * ldx + c] : 0.0f;
   }
   const float si = sqb[rowc];
 
@@ -300,61 +282,124 @@ __global__ __launch_bounds__(256, (knn_mfma_waves<CP, KC>())) void knn_mfma_kern
     jl[t] = 0x7fffffff;
   }
 
-  float areg[NS];
-  float sjv;
-  auto fetch = [&](int j0) {                 // candidate j0 + l31 (clamped), this lane's half of its features
-    const int j = j0 + l31;
-    const int jc = j < N ? j : N - 1;
-    const float* src = xb + (int64_t)jc * CP + h * NS;
+  // ---- candidate tiles: global -> registers one tile ahead, transposed ([c][cand]) into the other
+  // LDS buffer after the current tile's MFMAs; one barrier per tile ----
+  float4 pre[NV];
+  float pre_s = INFINITY;
+  auto fetch = [&](int j0) {
 #pragma unroll
-    for (int s4 = 0; s4 < NS; s4 += 4) {
-      const float4 v = *reinterpret_cast<const float4*>(src + s4);
-      areg[s4] = v.x; areg[s4 + 1] = v.y; areg[s4 + 2] = v.z; areg[s4 + 3] = v.w;
+    for (int i = 0; i < NV; ++i) {
+      const int e = tid + 256 * i;
+      const int r = e / (CP / 4);
+      const int c4 = (e % (CP / 4)) * 4;
+      const int j = j0 + r;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (j < N) {
+        const float* src = xb + (int64_t)j * ldx + c4;
+        if (vec_ok && c4 + 3 < C) {
+          v = *reinterpret_cast<const float4*>(src);
+        } else {
+          if (c4 + 0 < C) v.x = src[0];
+          if (c4 + 1 < C) v.y = src[1];
+          if (c4 + 2 < C) v.z = src[2];
+          if (c4 + 3 < C) v.w = src[3];
+        }
+      }
+      pre[i] = v;
     }
-    sjv = (j < N) ? sqb[jc] : INFINITY;     // out-of-range candidates can never be selected
+    if (tid < TJM) pre_s = (j0 + tid < N) ? sqb[j0 + tid] : INFINITY;
+  };
+  auto stash = [&](int buf) {
+    float* d = smem + buf * TILE_F;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int e = tid + 256 * i;
+      const int r = e / (CP / 4);
+      const int c4 = (e % (CP / 4)) * 4;
+      d[(c4 + 0) * ST + r] = pre[i].x;
+      d[(c4 + 1) * ST + r] = pre[i].y;
+      d[(c4 + 2) * ST + r] = pre[i].z;
+      d[(c4 + 3) * ST + r] = pre[i].w;
+    }
+    if (tid < TJM) sjs[buf * TJM + tid] = pre_s;
   };
 
-  const int nt = (N + 31) / 32;
-  if (cs < nt) fetch(32 * cs);
-#pragma unroll 1
-  for (int t = cs; t < nt; t += 2) {
-    const int j0 = 32 * t;
-    f32x16 acc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-#pragma unroll
-    for (int s2 = 0; s2 < NS; ++s2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[s2], bq[s2], acc, 0, 0, 0);
-    sjw[l31] = sjv;                          // both halves write the same value; wave-private, no barrier
-    fetch(32 * ((t + 2 < nt) ? t + 2 : t));  // registers are free again: next tile flies during the selection
-                                             // (unconditional: a branch here costs ~60 VGPRs of phi copies)
+  const int nt = (N + TJM - 1) / TJM;
+  fetch(0);
+  stash(0);
+  __syncthreads();
 
-    // ---- distances of this lane's 16 candidates; park them, flag the ones that beat the k-th ----
-    const float thr = dl[KC - 1];
-    unsigned mask = 0u;
+#pragma unroll 1
+  for (int t = 0; t < nt; ++t) {
+    const int buf = t & 1;
+    const int j0 = t * TJM;
+    if (t + 1 < nt) fetch(j0 + TJM);
+    const int cbase = cs * 32;
+    if (j0 + cbase < N) {                    // wave-uniform
+      const float* xsT = smem + buf * TILE_F;
+      f32x16 acc;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int i = (r & 3) + 8 * (r >> 2) + 4 * h;
-      const float tt = si + sjw[i];
-      const float tp = 2.0f * acc[r];
-      const float d = tt - tp;
-      dq[r * 256 + tid] = d;
-      mask |= (unsigned)sel_i(m_flt(d, thr), 1 << r, 0);
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+      const float* ap = xsT + h * ST + cbase + l31;
+      {
+        // A operands are read in batches of BQ one batch ahead of the MFMAs that consume them
+        // (sched_barriers pin the order), so the LDS latency hides under the dependent MFMA chain.
+        constexpr int NS = CP / 2;
+        constexpr int BQ = (NS >= 16) ? 8 : NS / 2;
+        float av0[BQ], av1[BQ];
+#pragma unroll
+        for (int q = 0; q < BQ; ++q) av0[q] = ap[2 * q * ST];
+#pragma unroll
+        for (int s2 = 0; s2 < NS; s2 += 2 * BQ) {
+#pragma unroll
+          for (int q = 0; q < BQ; ++q) av1[q] = ap[2 * (s2 + BQ + q) * ST];
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int q = 0; q < BQ; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[q], bq[s2 + q], acc, 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+          if (s2 + 2 * BQ < NS) {
+#pragma unroll
+            for (int q = 0; q < BQ; ++q) av0[q] = ap[2 * (s2 + 2 * BQ + q) * ST];
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int q = 0; q < BQ; ++q)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[q], bq[s2 + BQ + q], acc, 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+
+      // ---- distances of this lane's 16 candidates; park them, flag the ones that beat the k-th ----
+      const float thr = dl[KC - 1];
+      const float* sj = sjs + buf * TJM + cbase;
+      unsigned mask = 0u;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int i = (r & 3) + 8 * (r >> 2) + 4 * h;
+        const float tt = si + sj[i];
+        const float tp = 2.0f * acc[r];
+        const float d = tt - tp;
+        dq[r * 256 + tid] = d;
+        mask |= (unsigned)sel_i(m_flt(d, thr), 1 << r, 0);
+      }
+      // drain: the parked distance of the NEXT surviving candidate is fetched before the insert of
+      // the current one (LDS round trip hidden behind ~90 VALU ops)
+      int g = __builtin_ctz(mask | 0x80000000u) & 15;
+      float dcur = dq[g * 256 + tid];
+      while (__any(mask != 0u)) {
+        const lmask_t live = m_ine((int)mask, 0);
+        const int gc = g;
+        mask &= mask - 1u;
+        g = __builtin_ctz(mask | 0x80000000u) & 15;
+        const float dnext = dq[g * 256 + tid];
+        const float d = sel_f(live, dcur, INFINITY);
+        const int i = (gc & 3) + 8 * (gc >> 2) + 4 * h;
+        list_insert<KC, false>(dl, jl, d, j0 + cbase + i);
+        dcur = dnext;
+      }
     }
-    // drain: every iteration each lane pops ITS lowest surviving candidate (ascending j, which the tie
-    // rule needs); the parked distance of the next one is fetched before the insert of the current
-    int g = __builtin_ctz(mask | 0x80000000u) & 15;
-    float dcur = dq[g * 256 + tid];
-    while (__any(mask != 0u)) {
-      const lmask_t live = m_ine((int)mask, 0);
-      const int gc = g;
-      mask &= mask - 1u;
-      g = __builtin_ctz(mask | 0x80000000u) & 15;
-      const float dnext = dq[g * 256 + tid];
-      const float d = sel_f(live, dcur, INFINITY);
-      const int i = (gc & 3) + 8 * (gc >> 2) + 4 * h;
-      list_insert<KC, false>(dl, jl, d, j0 + i);
-      dcur = dnext;
-    }
+    if (t + 1 < nt) stash(buf ^ 1);
+    __syncthreads();
   }
 
   // ---- merge: 4 lists per query row (2 lane halves x 2 candidate halves) -> lanes 0..31 of waves 0,1 ----
@@ -403,16 +448,12 @@ bool knn_force_valu() {
 }
 
 template <int CP, int KC>
-void launch_knn(const float* x, float* ws, int B, int N, int C, int64_t ldx, int k, int vec_ok,
+void launch_knn(const float* x, const float* sq, int B, int N, int C, int64_t ldx, int k, int vec_ok,
                 int32_t* idx, hipStream_t st) {
-  const float* sq = ws;
   dim3 grid((unsigned)dg::cdiv(N, ROWS), (unsigned)B);
   if constexpr (CP >= 16 && CP <= 64) {
     if (!knn_force_valu()) {
-      float* xp = ws + (int64_t)B * N;
-      const int64_t n = (int64_t)B * N * CP;
-      hipLaunchKernelGGL((knn_pack_kernel<CP>), dim3((unsigned)dg::cdiv(n, 256)), dim3(256), 0, st, x, ldx, (int64_t)B * N, C, xp);
-      hipLaunchKernelGGL((knn_mfma_kernel<CP, KC>), grid, dim3(256), 0, st, xp, sq, N, k, idx);
+      hipLaunchKernelGGL((knn_mfma_kernel<CP, KC>), grid, dim3(256), 0, st, x, sq, N, C, ldx, k, vec_ok, idx);
       return;
     }
   }
@@ -420,12 +461,12 @@ void launch_knn(const float* x, float* ws, int B, int N, int C, int64_t ldx, int
 }
 
 template <int CP>
-int dispatch_k(const float* x, float* ws, int B, int N, int C, int64_t ldx, int k, int vec_ok,
+int dispatch_k(const float* x, const float* sq, int B, int N, int C, int64_t ldx, int k, int vec_ok,
                int32_t* idx, hipStream_t st) {
-  if (k <= 8) launch_knn<CP, 8>(x, ws, B, N, C, ldx, k, vec_ok, idx, st);
-  else if (k <= 20) launch_knn<CP, 20>(x, ws, B, N, C, ldx, k, vec_ok, idx, st);
-  else if (k <= 40) launch_knn<CP, 40>(x, ws, B, N, C, ldx, k, vec_ok, idx, st);
-  else launch_knn<CP, 64>(x, ws, B, N, C, ldx, k, vec_ok, idx, st);
+  if (k <= 8) launch_knn<CP, 8>(x, sq, B, N, C, ldx, k, vec_ok, idx, st);
+  else if (k <= 20) launch_knn<CP, 20>(x, sq, B, N, C, ldx, k, vec_ok, idx, st);
+  else if (k <= 40) launch_knn<CP, 40>(x, sq, B, N, C, ldx, k, vec_ok, idx, st);
+  else launch_knn<CP, 64>(x, sq, B, N, C, ldx, k, vec_ok, idx, st);
   return dg::check_launch("dgcnn_knn_f32");
 }
 
@@ -437,15 +478,11 @@ extern "C" int dgcnn_knn_force_valu(int on) {   // A/B switch (tests): 1 = VALU 
   return prev;
 }
 
-// scratch: B*N squared norms + (MFMA path) the de-interleaved copy of the points padded to 64 channels
-extern "C" int64_t dgcnn_knn_workspace_bytes(int B, int N, int C) {
-  const int64_t cp = (C <= 4 || C > 64) ? 0 : (C <= 16 ? 16 : 64);
-  return (int64_t)sizeof(float) * B * N * (1 + cp);
-}
+extern "C" int dgcnn_knn_workspace_bytes(int B, int N) { return (int)sizeof(float) * B * N; }
 
 extern "C" int dgcnn_knn_f32(const float* x, int B, int N, int C, int64_t ldx, int k, int32_t* idx,
-                             float* ws, void* stream) {
-  DG_REQUIRE(x && idx && ws, DGCNN_EINVAL, "dgcnn_knn_f32: null pointer");
+                             float* sq_ws, void* stream) {
+  DG_REQUIRE(x && idx && sq_ws, DGCNN_EINVAL, "dgcnn_knn_f32: null pointer");
   DG_REQUIRE(B > 0 && N > 0 && C > 0 && ldx >= C, DGCNN_EINVAL, "dgcnn_knn_f32: bad shape B=%d N=%d C=%d", B, N, C);
   DG_REQUIRE(k > 0 && k <= N, DGCNN_EINVAL,
              "dgcnn_knn_f32: k=%d must be in [1, N=%d] (tf.nn.top_k raises otherwise)", k, N);
@@ -453,10 +490,10 @@ extern "C" int dgcnn_knn_f32(const float* x, int B, int N, int C, int64_t ldx, i
   DG_REQUIRE(C <= 128, DGCNN_EUNSUP, "dgcnn_knn_f32: C=%d > 128 unsupported", C);
   hipStream_t st = (hipStream_t)stream;
   const int64_t rows = (int64_t)B * N;
-  hipLaunchKernelGGL(sqnorm_kernel, dim3((unsigned)dg::cdiv(rows, 256)), dim3(256), 0, st, x, ldx, rows, C, ws);
+  hipLaunchKernelGGL(sqnorm_kernel, dim3((unsigned)dg::cdiv(rows, 256)), dim3(256), 0, st, x, ldx, rows, C, sq_ws);
   const int vec_ok = (ldx % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
-  if (C <= 4) return dispatch_k<4>(x, ws, B, N, C, ldx, k, vec_ok, idx, st);
-  if (C <= 16) return dispatch_k<16>(x, ws, B, N, C, ldx, k, vec_ok, idx, st);
-  if (C <= 64) return dispatch_k<64>(x, ws, B, N, C, ldx, k, vec_ok, idx, st);
-  return dispatch_k<128>(x, ws, B, N, C, ldx, k, vec_ok, idx, st);
+  if (C <= 4) return dispatch_k<4>(x, sq_ws, B, N, C, ldx, k, vec_ok, idx, st);
+  if (C <= 16) return dispatch_k<16>(x, sq_ws, B, N, C, ldx, k, vec_ok, idx, st);
+  if (C <= 64) return dispatch_k<64>(x, sq_ws, B, N, C, ldx, k, vec_ok, idx, st);
+  return dispatch_k<128>(x, sq_ws, B, N, C, ldx, k, vec_ok, idx, st);
 }

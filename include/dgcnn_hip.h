@@ -42,15 +42,14 @@ const char* dgcnn_last_error(void);
  * idx[b][i][0..k) = the k smallest D_ij = (s_i + s_j) - 2 <x_i,x_j> of row i (self included),
  * ascending, ties -> lower j.  Arithmetic order is normative (oracle/knn_oracle.c): bit-exact.
  * x: (B,N,C) with row stride ldx.  No (B,N,N) matrix is ever written to HBM.
- * ws: caller scratch of dgcnn_knn_workspace_bytes(B,N,C) bytes (the s_i of ops.py:14 and, for
- * C > 4, a de-interleaved copy of the points that the MFMA kernel streams into registers). */
-int64_t dgcnn_knn_workspace_bytes(int B, int N, int C);
+ * sq_ws: caller scratch of dgcnn_knn_workspace_bytes(B,N) bytes (the s_i of ops.py:14). */
+int dgcnn_knn_workspace_bytes(int B, int N);
 /* A/B switch: 1 = distances by VALU fmaf chains for every C (exact by construction), 0 (default) =
  * v_mfma_f32_32x32x2_f32 for C > 4 (bit-identical on gfx950; the tests compare both).  Returns the
  * previous setting. */
 int dgcnn_knn_force_valu(int on);
 int dgcnn_knn_f32(const float* x, int B, int N, int C, int64_t ldx, int k, int32_t* idx,
-                  float* ws, void* stream);
+                  float* sq_ws, void* stream);
 
 /* ---- K2: dgcnn/ops.py:21-40 edges (gather + tile + sub + concat) ------------------------
  * E[b][i][m][0..C) = x_i ; E[b][i][m][C..2C) = x_{idx[b][i][m]} - x_i.                    */
