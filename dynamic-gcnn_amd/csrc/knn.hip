@@ -93,11 +93,10 @@ __global__ __launch_bounds__(256, (knn_min_waves<CP, KC>())) void knn_kernel(con
   constexpr int DQ_F = PERW * 256;           // per-lane distance slots of the current 32 candidates
   constexpr int MERGE_F = ROWS * KC * 2;
   constexpr int SH = (TILE_F + DQ_F > MERGE_F ? TILE_F + DQ_F : MERGE_F);
-  __shared__ __attribute__((aligned(16))) float smem[SH + TJ + WAVES * ROWS];
+  __shared__ __attribute__((aligned(16))) float smem[SH + TJ];
   float* xs = smem;
   float* dq = smem + TILE_F;
   float* sjs = smem + SH;
-  volatile float* thrw = smem + SH + TJ;     // [4 waves][64 rows]: each wave's k-th distance so far
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -121,7 +120,6 @@ __global__ __launch_bounds__(256, (knn_min_waves<CP, KC>())) void knn_kernel(con
     jl[t] = 0x7fffffff;
   }
 
-  thrw[tid] = INFINITY;
 #pragma unroll 1
   for (int j0 = 0; j0 < N; j0 += TJ) {
     __syncthreads();
@@ -155,11 +153,7 @@ __global__ __launch_bounds__(256, (knn_min_waves<CP, KC>())) void knn_kernel(con
     // the channel loop is fully unrolled so x_i stays in registers, fenced every 16 channels so
     // the scheduler cannot hoist every LDS read).  Each lane parks d in its LDS slot and keeps a
     // 32-bit mask of the candidates that beat its current k-th distance. ----
-    // the row's candidates are split over the 4 waves' lists: beat the own list's k-th strictly and do
-    // not exceed the tightest k-th of the other three (see knn_mfma_kernel)
     const float thr = dl[KC - 1];
-    const float thr_x = fminf(fminf(thrw[((w + 1) & 3) * ROWS + lane], thrw[((w + 2) & 3) * ROWS + lane]),
-                              thrw[((w + 3) & 3) * ROWS + lane]);
     unsigned mask = 0u;
 #pragma unroll 1
     for (int g = 0; g < PERW; g += 2) {
@@ -181,8 +175,8 @@ __global__ __launch_bounds__(256, (knn_min_waves<CP, KC>())) void knn_kernel(con
       const float d0 = t0 - tp0, d1 = t1 - tp1;
       dq[g * 256 + tid] = d0;
       dq[(g + 1) * 256 + tid] = d1;
-      mask |= (unsigned)sel_i(m_flt(d0, thr) & ~m_flt(thr_x, d0), (int)(1u << g), 0);
-      mask |= (unsigned)sel_i(m_flt(d1, thr) & ~m_flt(thr_x, d1), (int)(2u << g), 0);
+      mask |= (unsigned)sel_i(m_flt(d0, thr), (int)(1u << g), 0);
+      mask |= (unsigned)sel_i(m_flt(d1, thr), (int)(2u << g), 0);
     }
     // ---- phase B: drain.  Every iteration each lane pops ITS lowest surviving candidate (ascending
     // j, which the tie rule needs) and all lanes run one insert: max-over-lanes(popcount) inserts
@@ -194,7 +188,6 @@ __global__ __launch_bounds__(256, (knn_min_waves<CP, KC>())) void knn_kernel(con
       mask &= mask - 1u;
       list_insert<KC, false>(dl, jl, d, j0 + w * PERW + g);
     }
-    thrw[w * ROWS + lane] = dl[KC - 1];
   }
 
   // ---- merge the 4 per-wave lists into wave 0 through LDS (lexicographic (d, j)) ----
@@ -253,14 +246,13 @@ __global__ __launch_bounds__(256, 2) void knn_mfma_kernel(const float* __restric
   constexpr int TILE_F = CP * ST;
   constexpr int DQ_F = 16 * 256;
   constexpr int MERGE_F = ROWS * KC * 2;
-  constexpr int WORK_F = 2 * TILE_F + DQ_F + 2 * TJM + 2 * ROWS;
+  constexpr int WORK_F = 2 * TILE_F + DQ_F + 2 * TJM;
   constexpr int SH = (WORK_F > MERGE_F ? WORK_F : MERGE_F);
   constexpr int NV = (TJM * (CP / 4)) / 256;  // float4 staged per thread per tile
   static_assert(NV >= 1, "tile too small");
   __shared__ __attribute__((aligned(16))) float smem[SH];
   float* dq = smem + 2 * TILE_F;
   float* sjs = smem + 2 * TILE_F + DQ_F;     // [2][TJM]
-  volatile float* thrw = smem + 2 * TILE_F + DQ_F + 2 * TJM;   // [2 candidate halves][64 rows]: k-th distance so far
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -335,7 +327,6 @@ __global__ __launch_bounds__(256, 2) void knn_mfma_kernel(const float* __restric
   const int nt = (N + TJM - 1) / TJM;
   fetch(0);
   stash(0);
-  if (tid < 2 * ROWS) thrw[tid] = INFINITY;
   __syncthreads();
 
 #pragma unroll 1
@@ -379,13 +370,7 @@ __global__ __launch_bounds__(256, 2) void knn_mfma_kernel(const float* __restric
       }
 
       // ---- distances of this lane's 16 candidates; park them, flag the ones that beat the k-th ----
-      // A row's candidates are split over 4 lists (2 lane halves x 2 waves).  Any list that already
-      // holds KC entries bounds the row's global k-th distance, so a candidate must beat its own list's
-      // k-th (strictly: own candidates arrive in ascending j) AND not exceed the tightest k-th of the
-      // other three lists (<=: ties are decided later by index).  Exact, and ~3x fewer inserts.
       const float thr = dl[KC - 1];
-      const float thr_pair = __shfl_xor(thr, 32);
-      const float thr_x = fminf(thr_pair, thrw[(cs ^ 1) * ROWS + qg * 32 + l31]);
       const float* sj = sjs + buf * TJM + cbase;
       unsigned mask = 0u;
 #pragma unroll
@@ -395,8 +380,7 @@ __global__ __launch_bounds__(256, 2) void knn_mfma_kernel(const float* __restric
         const float tp = 2.0f * acc[r];
         const float d = tt - tp;
         dq[r * 256 + tid] = d;
-        const lmask_t pass = m_flt(d, thr) & ~m_flt(thr_x, d);      // d < thr  &&  !(thr_x < d)
-        mask |= (unsigned)sel_i(pass, 1 << r, 0);
+        mask |= (unsigned)sel_i(m_flt(d, thr), 1 << r, 0);
       }
       // drain: the parked distance of the NEXT surviving candidate is fetched before the insert of
       // the current one (LDS round trip hidden behind ~90 VALU ops)
@@ -412,11 +396,6 @@ __global__ __launch_bounds__(256, 2) void knn_mfma_kernel(const float* __restric
         const int i = (gc & 3) + 8 * (gc >> 2) + 4 * h;
         list_insert<KC, false>(dl, jl, d, j0 + cbase + i);
         dcur = dnext;
-      }
-      {
-        const float mine = dl[KC - 1];
-        const float both = fminf(mine, __shfl_xor(mine, 32));
-        if (h == 0) thrw[cs * ROWS + qg * 32 + l31] = both;
       }
     }
     if (t + 1 < nt) stash(buf ^ 1);
