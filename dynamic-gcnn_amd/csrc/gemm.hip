@@ -52,6 +52,8 @@ struct GemmP {
   int splits; int kchunk; float* partial;
   int avec, bvec;
   int mtiles, ntiles, xcd_group, bm, cvec;
+  int edge_nbr;   // A_EDGE / A_EDGE_T rows are the raw neighbour features x_j (K or M = C) instead of [x_i, x_j - x_i]
+  int gbvec;      // per-group bias rows are float4-loadable
 };
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
@@ -138,9 +140,14 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[TM][
               for (int q = 0; q < 4; ++q) v[q] += gbu[q];
             } else {
               const float* gb = p.gbias + (int64_t)(grow / p.rpg) * p.ldgbias + gcol;
+              if (p.gbvec && gcol + 3 < p.N) {
+                const float4 g4 = *reinterpret_cast<const float4*>(gb);
+                v[0] += g4.x; v[1] += g4.y; v[2] += g4.z; v[3] += g4.w;
+              } else {
 #pragma unroll
-              for (int q = 0; q < 4; ++q)
-                if (gcol + q < p.N) v[q] += gb[q];
+                for (int q = 0; q < 4; ++q)
+                  if (gcol + q < p.N) v[q] += gb[q];
+              }
             }
           }
           if (has_beta) {
@@ -271,7 +278,9 @@ __global__ __launch_bounds__(NT) void gemm_kernel(GemmP p) {
         const int C = p.cch;
         oka[i] = a_ok[i] && (kc < kend);
         const int kcc = imin(kc, kend - 4);
-        if (k0 + BK <= C) {                       // wave-uniform: the whole k-chunk is centre features
+        if (p.edge_nbr) {                         // wave-uniform: A rows are the neighbour rows themselves
+          v = LD4(a_ptr2[i] + kcc);
+        } else if (k0 + BK <= C) {                // wave-uniform: the whole k-chunk is centre features
           v = LD4(a_ptr[i] + kcc);
         } else {
           const bool cen = kcc < C;
@@ -297,12 +306,16 @@ __global__ __launch_bounds__(NT) void gemm_kernel(GemmP p) {
         const float* pc = p.x + (int64_t)g * p.ldx;
         const float* pn = p.x + (int64_t)nb * p.ldx;
         const int mc = imin(m, p.M - 4);
-        const bool cen = mc < C;
-        const int col = cen ? mc : mc - C;
-        const float4 xc = LD4(pc + col);
-        const float4 xn = LD4((cen ? pc : pn) + col);
-        const float4 df = sub4(xn, xc);
-        v = cen ? xc : df;
+        if (p.edge_nbr) {
+          v = LD4(pn + mc);
+        } else {
+          const bool cen = mc < C;
+          const int col = cen ? mc : mc - C;
+          const float4 xc = LD4(pc + col);
+          const float4 xn = LD4((cen ? pc : pn) + col);
+          const float4 df = sub4(xn, xc);
+          v = cen ? xc : df;
+        }
       }
       return v;
     }
@@ -324,7 +337,7 @@ __global__ __launch_bounds__(NT) void gemm_kernel(GemmP p) {
         for (int q = 0; q < 4; ++q) {
           const int c = kc + q;
           e[q] = 0.f;
-          if (c < kend) e[q] = (c < C) ? a_ptr[i][c] : (a_ptr2[i][c - C] - a_ptr[i][c - C]);
+          if (c < kend) e[q] = p.edge_nbr ? a_ptr2[i][c] : ((c < C) ? a_ptr[i][c] : (a_ptr2[i][c - C] - a_ptr[i][c - C]));
         }
         v = make_float4(e[0], e[1], e[2], e[3]);
       }
@@ -352,7 +365,7 @@ __global__ __launch_bounds__(NT) void gemm_kernel(GemmP p) {
         for (int q = 0; q < 4; ++q) {
           const int c = m + q;
           e[q] = 0.f;
-          if (c < p.M) e[q] = (c < C) ? pc[c] : (pn[c - C] - pc[c - C]);
+          if (c < p.M) e[q] = p.edge_nbr ? pn[c] : ((c < C) ? pc[c] : (pn[c - C] - pc[c - C]));
         }
         v = make_float4(e[0], e[1], e[2], e[3]);
       }
@@ -793,7 +806,7 @@ template <int CC>
 __global__ __launch_bounds__(256) void edge_wgrad_smallc_kernel(const float* __restrict__ x, int64_t ldx,
                                                                 const int32_t* __restrict__ idx,
                                                                 const float* __restrict__ dY, int64_t Me, int npts,
-                                                                int knn, int C, int F, int chunk,
+                                                                int knn, int C, int F, int chunk, int nbr_only,
                                                                 float* __restrict__ partial) {
   constexpr int FB = 4;                       // F <= 256
   __shared__ float sh[4][2 * CC * 64];
@@ -825,8 +838,8 @@ __global__ __launch_bounds__(256) void edge_wgrad_smallc_kernel(const float* __r
       for (int c = 0; c < CC; ++c) {
         const float xc = (c < C) ? x[gg[u] * ldx + c] : 0.f;
         const float xn = (c < C) ? x[nn[u] * ldx + c] : 0.f;
-        ev[u][c] = xc;
-        ev[u][CC + c] = xn - xc;
+        ev[u][c] = nbr_only ? xn : xc;               // nbr_only: the C rows are x_j itself
+        ev[u][CC + c] = nbr_only ? 0.f : xn - xc;
       }
     float dv[4][FB];
 #pragma unroll
@@ -843,7 +856,8 @@ __global__ __launch_bounds__(256) void edge_wgrad_smallc_kernel(const float* __r
 #pragma unroll
         for (int c = 0; c < 2 * CC; ++c) acc[fb][c] = fmaf(ev[u][c], dv[u][fb], acc[fb][c]);
   }
-  float* out = partial + (int64_t)blockIdx.x * 2 * C * F;
+  const int rows_out = nbr_only ? C : 2 * C;
+  float* out = partial + (int64_t)blockIdx.x * rows_out * F;
 #pragma unroll
   for (int fb = 0; fb < FB; ++fb) {
     if (64 * fb >= F) break;
@@ -858,7 +872,7 @@ __global__ __launch_bounds__(256) void edge_wgrad_smallc_kernel(const float* __r
         for (int c = 0; c < 2 * CC; ++c) {
           const float v = (sh[0][c * 64 + fl] + sh[1][c * 64 + fl]) + (sh[2][c * 64 + fl] + sh[3][c * 64 + fl]);
           const int cr = (c < CC) ? c : (C + (c - CC));     // row of dW0: centre rows 0..C-1, diff rows C..2C-1
-          if ((c < CC ? c : c - CC) < C) out[(int64_t)cr * F + f] = v;
+          if ((c < CC ? c : c - CC) < C && cr < rows_out) out[(int64_t)cr * F + f] = v;
         }
       }
     }
@@ -982,6 +996,7 @@ extern "C" int dgcnn_gemm_f32(int transA, int transB, int M, int N, int K,
   p.gbias = gbias; p.ldgbias = ldgbias; p.rpg = rows_per_group > 0 ? rows_per_group : 1;
   p.stats = stats;
   p.splits = 1; p.kchunk = K;
+  p.gbvec = gbias && (ldgbias % 4 == 0) && aligned16(gbias);
   p.avec = (lda % 4 == 0) && aligned16(A);
   p.bvec = (ldb % 4 == 0) && aligned16(B);
   hipStream_t st = (hipStream_t)stream;
@@ -1033,7 +1048,7 @@ extern "C" int dgcnn_edge_mlp_wgrad_f32(const float* x, int64_t ldx, const int32
     DG_REQUIRE(ws && ws_bytes >= need, DGCNN_ENOSPC, "dgcnn_edge_mlp_wgrad_f32: workspace too small (%zu < %zu)", ws_bytes, need);
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL((edge_wgrad_smallc_kernel<4>), dim3((unsigned)nblk), dim3(256), 0, st, x, ldx, idx, dY, Me, N, k,
-                       C, F, chunk, reinterpret_cast<float*>(ws));
+                       C, F, chunk, 0, reinterpret_cast<float*>(ws));
     int rc0 = dg::check_launch("dgcnn_edge_mlp_wgrad_f32(small C)");
     if (rc0) return rc0;
     const int64_t n = (int64_t)2 * C * F;
@@ -1062,4 +1077,60 @@ extern "C" int dgcnn_edge_mlp_dgrad_scatter_f32(const float* dY, const float* W0
   p.bvec = (F % 4 == 0) && aligned16(p.B);
   p.bm = tile_m(p.M, p.N, 1);
   return launch<A_ROW, B_COL, E_SCATTER>(p, (hipStream_t)stream, "dgcnn_edge_mlp_dgrad_scatter_f32");
+}
+
+// ---- conv0 in factored form.  E W0 = x_i (W0[:C] - W0[C:]) + x_j W0[C:]: the centre term U = X (Wa - Wb)
+// is a per-POINT GEMM the host issues once; what remains per EDGE is the (B*N*k) x C GEMM of the
+// gathered neighbour rows with W0[C:], plus U[point] added in the epilogue as a per-group bias
+// (rows_per_group = k).  Half the per-edge flops of the literal form and a pure gather in the loader.
+extern "C" int dgcnn_edge_nbr_gemm_f32(const float* x, int64_t ldx, const int32_t* idx, const float* Wb,
+                                       const float* U, int64_t ldu, int B, int N, int C, int k, int F,
+                                       float* Y, double* stats, void* stream) {
+  DG_REQUIRE(x && idx && Wb && U && Y, DGCNN_EINVAL, "dgcnn_edge_nbr_gemm_f32: null pointer");
+  DG_REQUIRE(B > 0 && N > 0 && C > 0 && k > 0 && F > 0, DGCNN_EINVAL, "dgcnn_edge_nbr_gemm_f32: bad shape");
+  const int64_t Me = (int64_t)B * N * k;
+  DG_REQUIRE(Me < (1ll << 31), DGCNN_EUNSUP, "dgcnn_edge_nbr_gemm_f32: B*N*k >= 2^31");
+  GemmP p = {};
+  p.x = x; p.ldx = ldx; p.idx = idx; p.npts = N; p.cch = C; p.knn = k; p.edge_nbr = 1;
+  p.B = Wb; p.ldb = F; p.C = Y; p.ldc = F;
+  p.M = (int)Me; p.N = F; p.K = C; p.beta = 0.f;
+  p.gbias = U; p.ldgbias = ldu; p.rpg = k; p.gbvec = (ldu % 4 == 0) && aligned16(U);
+  p.stats = stats; p.splits = 1; p.kchunk = p.K;
+  p.avec = (C % 4 == 0) && (ldx % 4 == 0) && aligned16(x);
+  p.bvec = (F % 4 == 0) && aligned16(Wb);
+  p.bm = tile_m(p.M, p.N, 1);
+  return launch<A_EDGE, B_ROW, E_STORE>(p, (hipStream_t)stream, "dgcnn_edge_nbr_gemm_f32");
+}
+
+/* dWb[C][F] (+)= sum over edges of x_j^T dY (the per-edge half of conv0's wgrad in factored form) */
+extern "C" int dgcnn_edge_nbr_wgrad_f32(const float* x, int64_t ldx, const int32_t* idx, const float* dY,
+                                        int B, int N, int C, int k, int F, float* dWb, float beta,
+                                        void* ws, size_t ws_bytes, void* stream) {
+  DG_REQUIRE(x && idx && dY && dWb, DGCNN_EINVAL, "dgcnn_edge_nbr_wgrad_f32: null pointer");
+  const int64_t Me = (int64_t)B * N * k;
+  DG_REQUIRE(Me < (1ll << 31), DGCNN_EUNSUP, "dgcnn_edge_nbr_wgrad_f32: B*N*k >= 2^31");
+  if (C <= 4 && F <= 256) {
+    const int nblk = (int)(Me < 1024 * 64 ? dg::cdiv(Me, 64) : 1024);
+    const int chunk = (int)dg::cdiv(Me, nblk);
+    const size_t need = (size_t)nblk * C * F * sizeof(float);
+    DG_REQUIRE(ws && ws_bytes >= need, DGCNN_ENOSPC, "dgcnn_edge_nbr_wgrad_f32: workspace too small (%zu < %zu)", ws_bytes, need);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL((edge_wgrad_smallc_kernel<4>), dim3((unsigned)nblk), dim3(256), 0, st, x, ldx, idx, dY, Me, N, k,
+                       C, F, chunk, 1, reinterpret_cast<float*>(ws));
+    int rc0 = dg::check_launch("dgcnn_edge_nbr_wgrad_f32(small C)");
+    if (rc0) return rc0;
+    const int64_t n = (int64_t)C * F;
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)dg::cdiv(n, 64)), dim3(64 * RL), 0, st,
+                       reinterpret_cast<const float*>(ws), nblk, C, F, dWb, (int64_t)F, beta);
+    return dg::check_launch("dgcnn_edge_nbr_wgrad_f32(small C reduce)");
+  }
+  GemmP p = {};
+  p.x = x; p.ldx = ldx; p.idx = idx; p.npts = N; p.cch = C; p.knn = k; p.edge_nbr = 1;
+  p.B = dY; p.ldb = F; p.C = dWb; p.ldc = F;
+  p.M = C; p.N = F; p.K = (int)Me; p.beta = beta; p.rpg = 1;
+  p.avec = (C % 4 == 0) && (ldx % 4 == 0) && aligned16(x);
+  p.bvec = (F % 4 == 0) && aligned16(dY);
+  int rc = plan_splits(p, ws, ws_bytes, "dgcnn_edge_nbr_wgrad_f32");
+  if (rc) return rc;
+  return launch<A_EDGE_T, B_ROW, E_STORE>(p, (hipStream_t)stream, "dgcnn_edge_nbr_wgrad_f32");
 }

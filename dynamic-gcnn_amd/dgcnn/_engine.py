@@ -27,6 +27,7 @@ from . import _hip as H
 BN_EPS = 1e-3          # slim.batch_norm default epsilon [TF1-lib]
 DROPOUT_KEEP = 0.7     # tf.nn.dropout(net, 0.7): dgcnn/model.py:91
 WS_BYTES = 256 << 20
+EDGE_MLP_LITERAL = False  # True: conv0 as the literal (B*N*k) x 2C GEMM over E = [x_i, x_j - x_i] (A/B switch)
 SCATTER_ATOMICS = False  # True: dx_j += dY W^T by fp32 atomics in the GEMM epilogue (A/B switch)
 
 
@@ -347,9 +348,24 @@ def edge_conv_block(x, B, N, k, num_filters, relu1=True, outs=None, net2=None):
     idx = knn(x, B, N, k)                                               # ops.py:8-19
     Y = torch.empty((R * k, F), dtype=torch.float32, device=x.device)
     st = c.stats(F)
-    H.call("dgcnn_edge_mlp_f32", x.data_ptr(), H.ld2(x), idx.data_ptr(), W0.data_ptr(), B, N, C, k, F,
-           Y.data_ptr(), st.data_ptr(), tag="gemm_kernel<A_EDGE,B_ROW,STORE,%d,%d>" % (_tile_m(R * k, F), 64 if F <= 64 else 128),
-           work=2.0 * R * k * 2 * C * F)                                # ops.py:21-52 (gather fused)
+    literal = EDGE_MLP_LITERAL
+    wd = None
+    if literal:
+        H.call("dgcnn_edge_mlp_f32", x.data_ptr(), H.ld2(x), idx.data_ptr(), W0.data_ptr(), B, N, C, k, F,
+               Y.data_ptr(), st.data_ptr(), tag="gemm_kernel<A_EDGE,B_ROW,STORE,%d,%d>" % (_tile_m(R * k, F), 64 if F <= 64 else 128),
+               work=2.0 * R * k * 2 * C * F)                            # ops.py:21-52 (gather fused)
+    else:
+        # factored conv0: E W0 = x_i (W0[:C]-W0[C:]) + x_j W0[C:].  Centre term once per point (U), the
+        # per-edge (B*N*k) x C GEMM gathers the neighbour rows and adds U[point] in its epilogue.
+        wd = torch.empty((C, F), dtype=torch.float32, device=x.device)
+        H.call("dgcnn_copy2d_f32", W0[:C].data_ptr(), F, wd.data_ptr(), F, C, F, 0)
+        H.call("dgcnn_axpby_f32", W0[C:].data_ptr(), -1.0, wd.data_ptr(), 1.0, C * F)
+        U = torch.empty((R, F), dtype=torch.float32, device=x.device)
+        gemm(x, wd, U)
+        H.call("dgcnn_edge_nbr_gemm_f32", x.data_ptr(), H.ld2(x), idx.data_ptr(), W0[C:].data_ptr(), U.data_ptr(), F,
+               B, N, C, k, F, Y.data_ptr(), st.data_ptr(),
+               tag="gemm_kernel<A_EDGE,B_ROW,STORE,%d,%d>" % (_tile_m(R * k, F), 64 if F <= 64 else 128),
+               work=2.0 * R * k * C * F)                                # ops.py:21-52 (gather fused)
     mean, rstd = bn_finalize(st, F, R * k)                              # ops.py:53
     if outs is None:
         mm = c.new_buffer(R, 2 * F)
@@ -374,7 +390,8 @@ def edge_conv_block(x, B, N, k, num_filters, relu1=True, outs=None, net2=None):
                    mx.data_ptr(), H.ld2(mx), cnt.data_ptr(), red.data_ptr(),
                    tag="bn_bwd_reduce_kernel", work=4.0 * (R * k * F + 2 * R * F))
             dx = c.grad(x)
-            dysum = torch.empty((R, F), dtype=torch.float32, device=x.device) if dx is not None else None
+            need_sum = (dx is not None) or not literal
+            dysum = torch.empty((R, F), dtype=torch.float32, device=x.device) if need_sum else None
             H.call("dgcnn_bn_bwd_apply_f32", Y.data_ptr(), R, k, F, mean.data_ptr(), rstd.data_ptr(), beta0.data_ptr(),
                    1, dmx.data_ptr(), H.ld2(dmx), dmn.data_ptr(), H.ld2(dmn), mx.data_ptr(), H.ld2(mx), cnt.data_ptr(),
                    red.data_ptr(), Y.data_ptr(),
@@ -382,16 +399,31 @@ def edge_conv_block(x, B, N, k, num_filters, relu1=True, outs=None, net2=None):
                    tag="bn_bwd_apply_kernel", work=4.0 * (2 * R * k * F + 3 * R * F))
             dY = Y
             ws = c.workspace()
-            H.call("dgcnn_edge_mlp_wgrad_f32", x.data_ptr(), H.ld2(x), idx.data_ptr(), dY.data_ptr(), B, N, C, k, F,
-                   c.var_grads[w0name].data_ptr(), 1.0, ws.data_ptr(), ws.numel(),
-                   tag=("edge_wgrad_smallc_kernel" if C <= 4 else "gemm_kernel<A_EDGE_T,B_ROW,STORE,128,%d>" % (64 if F <= 64 else 128)),
-                   work=2.0 * R * k * 2 * C * F)
+            dW0 = c.var_grads[w0name]
+            if literal:
+                H.call("dgcnn_edge_mlp_wgrad_f32", x.data_ptr(), H.ld2(x), idx.data_ptr(), dY.data_ptr(), B, N, C, k, F,
+                       dW0.data_ptr(), 1.0, ws.data_ptr(), ws.numel(),
+                       tag=("edge_wgrad_smallc_kernel" if C <= 4 else "gemm_kernel<A_EDGE_T,B_ROW,STORE,128,%d>" % (64 if F <= 64 else 128)),
+                       work=2.0 * R * k * 2 * C * F)
+            else:
+                # dW0[C:] += sum_e x_j^T dY  -  X^T dYsum ;  dW0[:C] += X^T dYsum   (W0[:C]-W0[C:] and W0[C:] are the
+                # factors of the forward: d(Wa-Wb) = X^T dYsum, dWb = edge part)
+                H.call("dgcnn_edge_nbr_wgrad_f32", x.data_ptr(), H.ld2(x), idx.data_ptr(), dY.data_ptr(), B, N, C, k, F,
+                       dW0[C:].data_ptr(), 1.0, ws.data_ptr(), ws.numel(),
+                       tag=("edge_wgrad_smallc_kernel" if C <= 4 else "gemm_kernel<A_EDGE_T,B_ROW,STORE,128,%d>" % (64 if F <= 64 else 128)),
+                       work=2.0 * R * k * C * F)
+                dwd = torch.empty((C, F), dtype=torch.float32, device=x.device)
+                gemm(x, dysum, dwd, transA=True)
+                H.call("dgcnn_axpby_f32", dwd.data_ptr(), 1.0, dW0[:C].data_ptr(), 1.0, C * F)
+                H.call("dgcnn_axpby_f32", dwd.data_ptr(), -1.0, dW0[C:].data_ptr(), 1.0, C * F)
             if dx is not None:
                 # E = [x_i, x_j - x_i]  =>  dx_i += (sum_m dY) (W0[:C]-W0[C:])^T ; dx_j += dY W0[C:]^T
-                wd = torch.empty((C, F), dtype=torch.float32, device=x.device)
-                H.call("dgcnn_copy2d_f32", W0[:C].data_ptr(), F, wd.data_ptr(), F, C, F, 0)
-                H.call("dgcnn_axpby_f32", W0[C:].data_ptr(), -1.0, wd.data_ptr(), 1.0, C * F)
-                gemm(dysum, wd, dx, transB=True, beta=1.0)
+                wdb = wd
+                if wdb is None:
+                    wdb = torch.empty((C, F), dtype=torch.float32, device=x.device)
+                    H.call("dgcnn_copy2d_f32", W0[:C].data_ptr(), F, wdb.data_ptr(), F, C, F, 0)
+                    H.call("dgcnn_axpby_f32", W0[C:].data_ptr(), -1.0, wdb.data_ptr(), 1.0, C * F)
+                gemm(dysum, wdb, dx, transB=True, beta=1.0)
                 if SCATTER_ATOMICS or F % 4 != 0:
                     H.call("dgcnn_edge_mlp_dgrad_scatter_f32", dY.data_ptr(), W0.data_ptr(), idx.data_ptr(), B, N, C, k,
                            F, dx.data_ptr(), H.ld2(dx),

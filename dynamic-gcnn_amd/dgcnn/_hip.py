@@ -32,6 +32,9 @@ PROTOTYPES = {
     "dgcnn_edge_mlp_wgrad_f32": [c_vp, c_i64, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_f32,
                                  c_vp, c_sz, c_vp],
     "dgcnn_edge_mlp_dgrad_scatter_f32": [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_i64, c_vp],
+    "dgcnn_edge_nbr_gemm_f32": [c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp],
+    "dgcnn_edge_nbr_wgrad_f32": [c_vp, c_i64, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_f32,
+                                 c_vp, c_sz, c_vp],
     "dgcnn_edge_csr_build": [c_vp, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp],
     "dgcnn_edge_gather_sum_f32": [c_vp, c_vp, c_vp, c_i64, c_int, c_vp, c_vp],
     "dgcnn_gemm_f32": [c_int, c_int, c_int, c_int, c_int, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_f32,

@@ -75,6 +75,19 @@ int dgcnn_edge_mlp_dgrad_scatter_f32(const float* dY, const float* W0, const int
                                      int B, int N, int C, int k, int F, float* dx, int64_t lddx,
                                      void* stream);
 
+/* conv0 in FACTORED form (what dgcnn.ops.edge_conv issues): E W0 = x_i (W0[:C]-W0[C:]) + x_j W0[C:].
+ * The centre term U[point] = X (Wa-Wb) is one per-point dgcnn_gemm_f32; per edge remains the
+ * (B*N*k) x C GEMM of the gathered neighbour rows with Wb = W0[C:], with U added per group of k rows
+ * in the epilogue (+ BN column statistics): half the per-edge flops, identical result up to fp32
+ * rounding (tests compare both forms).                                                          */
+int dgcnn_edge_nbr_gemm_f32(const float* x, int64_t ldx, const int32_t* idx, const float* Wb,
+                            const float* U, int64_t ldu, int B, int N, int C, int k, int F,
+                            float* Y, double* stats, void* stream);
+/* dWb[C][F] (+)= sum_e x_j(e)^T dY[e]; the host adds X^T (sum_m dY) for the centre half.        */
+int dgcnn_edge_nbr_wgrad_f32(const float* x, int64_t ldx, const int32_t* idx, const float* dY,
+                             int B, int N, int C, int k, int F, float* dWb, float beta,
+                             void* ws, size_t ws_bytes, void* stream);
+
 /* Deterministic-shape alternative to the scatter: bucket the edges by target once (transposed
  * adjacency: off[B*N+1], rev[B*N*k]; cnt_ws = 2*B*N int32 scratch) ...                         */
 int dgcnn_edge_csr_build(const int32_t* idx, int B, int N, int k, int32_t* cnt_ws, int32_t* off,

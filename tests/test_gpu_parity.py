@@ -264,6 +264,40 @@ def test_edge_conv_forward_backward(dg, B, N, C, k, F):
         np.testing.assert_allclose(host(c.var_grads[n]), g_ref[key], rtol=1e-3, atol=scale(g_ref[key]), err_msg=n)
 
 
+def test_edge_mlp_factored_equals_literal(dg):
+    """conv0 is issued in factored form (x_i (Wa-Wb) per point + x_j Wb per edge); the literal
+    (B*N*k) x 2C GEMM over E = [x_i, x_j - x_i] stays behind a switch.  Same outputs and gradients."""
+    from dgcnn import _engine as E
+    rng = np.random.default_rng(21)
+    B, N, C, k, F = 2, 192, 64, 12, 64
+    pts = rng.normal(size=(B, N, C)).astype(np.float32)
+    W = {"conv0/weights": rng.normal(0, 0.3, (2 * C, F)).astype(np.float32), "conv0/BatchNorm/beta": rng.normal(0, 0.2, F).astype(np.float32),
+         "conv1/weights": rng.normal(0, 0.3, (2 * F, 64)).astype(np.float32), "conv1/BatchNorm/beta": rng.normal(0, 0.2, 64).astype(np.float32)}
+    res = {}
+    for literal in (True, False):
+        dg.reset()
+        c = dg.ctx()
+        E.EDGE_MLP_LITERAL = literal
+        try:
+            c.begin_step()
+            c.recording = True
+            x = c.new_buffer(B * N, C)
+            x.copy_(dev(pts.reshape(B * N, C)))
+            for n, v in W.items():
+                c.get_variable(n, v.shape)
+            _set_vars(dg, W)
+            outs = dg.ops.edge_conv(x.view(B, N, C), k, F, True)
+            for t in outs:
+                v, _, _ = E.as2d(t)
+                c.grad(v).fill_(0.01)
+            c.backward()
+            res[literal] = [host(t).copy() for t in outs] + [host(c.grad(x)).copy()] + [host(c.var_grads[n]).copy() for n in W]
+        finally:
+            E.EDGE_MLP_LITERAL = False
+    for a, b in zip(res[True], res[False]):
+        np.testing.assert_allclose(a, b, rtol=2e-3, atol=2e-4 * max(1.0, float(np.abs(a).max())))
+
+
 # ------------------------------------------------------------------------------------------
 # model.build: logits within 1e-3 of the oracle (north_star), all three MODEL_NAMEs
 # ------------------------------------------------------------------------------------------
