@@ -1,36 +1,100 @@
-"""Configuration object with the attribute names the reference's DGCNN_FLAGS carries
-(dgcnn/flags.py:9-45).  Only what the hot path reads is interpreted here (model.py:11-18,27;
-trainval.py:17,26,31,47); the argparse CLI, IO and checkpoint flags are out of scope."""
+"""Configuration object with the attribute names (and CLI option names) of the reference's
+DGCNN_FLAGS (dgcnn/flags.py:6-167).
+
+Two ways in: keyword construction / `update(dict)` from Python (what the tests and bench use), or
+`parse_args(argv)` with the reference's subcommands `train | inference | iotest` and its long/short
+option names, e.g.
+
+    python dynamic-gcnn_amd/bin/dgcnn.py train -io synthetic -bs 24 -mbs 24 -np 2048 -ecf 64,64,128 -it 100
+
+Differences from the reference: DEBUG defaults to False (the debug prints are host syncs), IO_TYPE
+defaults to 'synthetic' (h5/larcv readers are not shipped), `--gpus` lists TOWERS of this process
+(one process per GPU is the scaling axis; CUDA_VISIBLE_DEVICES is left alone).
+"""
 from __future__ import annotations
+
+import argparse
+import time
+
+# (attribute, short option, type, default, parsers, help) -- one row per reference option (flags.py:49-123)
+_BOOL = lambda s: str(s).lower() in ("1", "y", "yes", "t", "true", "on")
+_OPTIONS = [
+    ("KVALUE", "-kv", int, 20, "tif", "K value"),
+    ("DEBUG", "-db", _BOOL, False, "tif", "extra verbose mode"),
+    ("LOG_DIR", "-ld", str, "", "tif", "log dir"),
+    ("SHUFFLE", "-sh", _BOOL, 1, "tif", "shuffle the data entries"),
+    ("GPUS", None, str, "0", "tif", "towers run by this process (comma-separated integers)"),
+    ("EDGE_CONV_LAYERS", "-ecl", int, 3, "tif", "number of edge-convolution layers"),
+    ("EDGE_CONV_FILTERS", "-ecf", str, "64", "tif", "filters in edge-convolution layers"),
+    ("FC_LAYERS", "-fcl", int, 2, "tif", "number of fully-connected layers"),
+    ("FC_FILTERS", "-fcf", str, "512,256", "tif", "filters in fully-connected layers"),
+    ("NUM_CLASS", "-nc", int, 2, "tif", "number of classes"),
+    ("NUM_POINT", "-np", int, 2048, "tif", "point number"),
+    ("ITERATION", "-it", int, 10000, "tif", "iterations to run"),
+    ("BATCH_SIZE", "-bs", int, 1, "tif", "global batch size of one weight update"),
+    ("MINIBATCH_SIZE", "-mbs", int, 1, "tif", "clouds per tower per micro-step"),
+    ("REPORT_STEP", "-rs", int, 100, "tif", "period (steps) to print loss and accuracy"),
+    ("MODEL_NAME", "-mn", str, "dgcnn", "tif", "model name identifier"),
+    ("MODEL_PATH", "-mp", str, "", "tif", "checkpoint to restore (<prefix>-<iteration>)"),
+    ("IO_TYPE", "-io", str, "synthetic", "tif", "IO handler type: synthetic | npz"),
+    ("INPUT_FILE", "-if", str, "", "tif", "comma-separated input file list"),
+    ("OUTPUT_FILE", "-of", str, "", "tif", "output file name"),
+    ("DATA_KEY", "-dkey", str, "data", "tif", "keyword to fetch data from file"),
+    ("LABEL_KEY", "-lkey", str, "label", "tif", "keyword to fetch label from file"),
+    ("SEED", "-sd", int, -1, "t", "seed for random number generators"),
+    ("WEIGHT_PREFIX", "-wp", str, "./weights/snapshot", "t", "prefix for snapshots of weights"),
+    ("LEARNING_RATE", "-lr", float, 0.001, "t", "initial learning rate"),
+    ("SUMMARY_STEP", "-ss", int, 20, "t", "period (steps) to store a summary line"),
+    ("CHECKPOINT_STEP", "-chks", int, 500, "t", "period (steps) to store a snapshot of weights"),
+    ("CHECKPOINT_NUM", "-chkn", int, 10, "t", "number of latest checkpoints to keep"),
+    ("CHECKPOINT_HOUR", "-chkh", float, 0.4, "t", "accepted for compatibility; unused"),
+    ("WEIGHT_KEY", "-wkey", str, "", "tf", "keyword to fetch weight from file"),
+]
 
 
 class DGCNN_FLAGS(object):
-    # flags for model (flags.py:9-17)
-    NUM_CLASS = 2
-    MODEL_NAME = "dgcnn"
     TRAIN = True
-    KVALUE = 20
-    DEBUG = False
-    EDGE_CONV_LAYERS = 3
-    EDGE_CONV_FILTERS = 64
-    FC_LAYERS = 2
-    FC_FILTERS = [512, 256]
-    # flags for train/inference (flags.py:20-33)
-    SEED = 1
-    LEARNING_RATE = 0.001
-    GPUS = [0]
-    MINIBATCH_SIZE = 1
-    NUM_POINT = 2048
-    NUM_CHANNEL = 3
-    BATCH_SIZE = 1
-    WEIGHT_KEY = ""
+    NUM_CHANNEL = -1
+    NUM_ENTRIES = 64          # io_synthetic only
 
     def __init__(self, **kw):
+        for name, _, _, default, _, _ in _OPTIONS:
+            setattr(self, name, default)
+        self.SEED = 1         # library default; the CLI default stays -1 (= time based) as in flags.py:20
+        self.NUM_CHANNEL = 3
         self.update(kw)
 
+    # ------------------------------------------------------------------ flags.py:124-148
+    def _build_parsers(self):
+        parser = argparse.ArgumentParser(description="Edge-GCNN Configuration Flags")
+        sub = parser.add_subparsers(title="Modules", description="Valid subcommands", dest="script")
+        for key, name in (("t", "train"), ("i", "inference"), ("f", "iotest")):
+            p = sub.add_parser(name)
+            for attr, short, typ, default, where, text in _OPTIONS:
+                if key in where:
+                    names = ([short] if short else []) + ["--" + attr.lower()]
+                    p.add_argument(*names, type=typ, default=default, help="%s [default: %s]" % (text, default))
+        return parser
+
+    def parse_args(self, argv=None, run=True):
+        from . import main_funcs
+        args = vars(self._build_parsers().parse_args(argv))
+        script = args.pop("script")
+        if script is None:
+            raise SystemExit("usage: dgcnn.py {train,inference,iotest} [options]")
+        self.update(args)
+        print("\n\n-- CONFIG --")
+        for name in sorted(vars(self)):
+            print("%s = %r" % (name, getattr(self, name)))
+        if run:
+            getattr(main_funcs, script)(self)
+        return script
+
     def update(self, args):
-        """flags.py:150-167: upper-case the keys, split comma lists."""
+        """flags.py:150-167: upper-case the keys, split the comma lists, resolve a negative seed."""
         for name, value in args.items():
+            if name in ("func", "script"):
+                continue
             setattr(self, name.upper(), value)
         for key in ("EDGE_CONV_FILTERS", "FC_FILTERS"):
             v = getattr(self, key)
@@ -38,4 +102,8 @@ class DGCNN_FLAGS(object):
                 setattr(self, key, [int(a) for a in v.split(",")] if "," in v else int(v))
         if isinstance(self.GPUS, str):
             self.GPUS = [int(g) for g in self.GPUS.split(",")]
+        if isinstance(self.INPUT_FILE, str):
+            self.INPUT_FILE = [f for f in self.INPUT_FILE.split(",") if f]
+        if int(self.SEED) < 0:
+            self.SEED = int(time.time())
         return self

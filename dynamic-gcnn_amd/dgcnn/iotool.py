@@ -1,0 +1,191 @@
+"""Batch sources either side of the hot path (reference dgcnn/iotool.py:6-287).
+
+Same protocol as the reference's `io_base` (iotool.py:6-32): `initialize()`, `next()` ->
+`(idx, data, label, weight)` with data (BATCH_SIZE, N, C) float32, `store(idx, softmax)`,
+`finalize()`, `num_entries()`, `num_channels()`, `batch_size()`.  The file formats differ on
+purpose: LArCV/ROOT and h5py/PyTables are absent from this image (out of scope), so
+the sources here are
+
+  IO_TYPE 'npz'        arrays DATA_KEY / LABEL_KEY / WEIGHT_KEY of one or more .npz files, the same
+                       dense (entries, N, C) / (entries, N) layout io_h5 reads (iotool.py:212-231);
+                       OUTPUT_FILE collects data / softmax / label rows like io_h5.store.
+  IO_TYPE 'h5'         the reference's HDF5 layout through h5py when that module is importable (it is
+                       optional, as in the reference README); otherwise NotImplementedError.
+  IO_TYPE 'synthetic'  seeded clouds of the benchmark's shape; labels are a deterministic function of
+                       position so that a training loop has something to learn.
+
+'larcv' raises NotImplementedError with the reason.  Entry order follows iotool.py:262-279:
+SHUFFLE draws BATCH_SIZE distinct entries per call, otherwise a cursor wraps around the file.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+
+class io_base(object):
+
+    def __init__(self, flags):
+        self._flags = flags
+        self._batch_size = int(flags.BATCH_SIZE)
+        self._num_entries = -1
+        self._num_channels = -1
+        self._data = self._label = self._weight = None
+        self._cursor = 0
+        seed = int(getattr(flags, "SEED", -1))
+        self._rng = np.random.RandomState(seed if seed >= 0 else None)
+
+    def batch_size(self, size=None):
+        if size is None:
+            return self._batch_size
+        self._batch_size = int(size)
+
+    def num_entries(self):
+        return self._num_entries
+
+    def num_channels(self):
+        return self._num_channels
+
+    def initialize(self):
+        raise NotImplementedError
+
+    def store(self, idx, softmax):
+        raise NotImplementedError
+
+    def finalize(self):
+        pass
+
+    # entry selection shared by the dense sources (iotool.py:262-279)
+    def _draw(self):
+        n, bs = self._num_entries, self._batch_size
+        if getattr(self._flags, "SHUFFLE", 0):
+            if bs <= n:
+                return self._rng.permutation(n)[:bs]
+            return self._rng.randint(0, n, size=bs)
+        idx = (self._cursor + np.arange(bs)) % n
+        self._cursor = int(idx[-1] + 1) % n
+        return idx
+
+    def next(self):
+        idx = self._draw()
+        pick = lambda a: None if a is None else a[idx, ...]
+        return idx, pick(self._data), pick(self._label), pick(self._weight)
+
+
+class io_npz(io_base):
+
+    def __init__(self, flags):
+        super(io_npz, self).__init__(flags)
+        self._out = None
+
+    # container access; io_h5 overrides these two
+    def _open(self, path):
+        return np.load(path)
+
+    def _write(self, path, arrays):
+        np.savez_compressed(path, **arrays)
+
+    def initialize(self):
+        f = self._flags
+        files = f.INPUT_FILE if isinstance(f.INPUT_FILE, (list, tuple)) else str(f.INPUT_FILE).split(",")
+        parts = {"data": [], "label": [], "weight": []}
+        for path in files:
+            with self._open(path) as z:
+                parts["data"].append(np.asarray(z[f.DATA_KEY], np.float32))
+                if getattr(f, "LABEL_KEY", ""):
+                    parts["label"].append(np.asarray(z[f.LABEL_KEY], np.int32))
+                if getattr(f, "WEIGHT_KEY", ""):
+                    parts["weight"].append(np.asarray(z[f.WEIGHT_KEY], np.float32))
+        cat = lambda v: np.concatenate(v, axis=0) if v else None
+        self._data, self._label, self._weight = cat(parts["data"]), cat(parts["label"]), cat(parts["weight"])
+        if self._data is None or self._data.ndim != 3:
+            raise ValueError("'%s' must hold (entries, points, channels), got %s"
+                             % (f.DATA_KEY, None if self._data is None else self._data.shape))
+        for name, a in (("label", self._label), ("weight", self._weight)):
+            if a is not None and a.shape != self._data.shape[:2]:
+                raise ValueError("%s shape %s does not match data %s" % (name, a.shape, self._data.shape))
+        self._num_entries, _, self._num_channels = self._data.shape
+        self._cursor = 0
+        if getattr(f, "OUTPUT_FILE", ""):
+            self._out = {"idx": [], "data": [], "softmax": [], "label": []}
+
+    def store(self, idx, softmax):
+        if self._out is None:
+            raise NotImplementedError
+        idx = int(idx)
+        if idx >= self._num_entries:
+            raise ValueError
+        self._out["idx"].append(idx)
+        self._out["data"].append(self._data[idx])
+        self._out["softmax"].append(np.asarray(softmax, np.float32))
+        if self._label is not None:
+            self._out["label"].append(self._label[idx])
+
+    def finalize(self):
+        if self._out is not None and self._out["idx"]:
+            out = {"idx": "idx", "data": self._flags.DATA_KEY, "softmax": "softmax",
+                   "label": getattr(self._flags, "LABEL_KEY", "") or "label"}
+            self._write(self._flags.OUTPUT_FILE, {out[k]: np.stack(v) for k, v in self._out.items() if v})
+        self._out = None
+
+
+class io_h5(io_npz):
+    """HDF5 flavour of the same dense layout (iotool.py:199-280): datasets DATA_KEY (entries, N, C),
+    LABEL_KEY / WEIGHT_KEY (entries, N).  Needs h5py, which is optional: without it the factory raises
+    NotImplementedError naming the missing module.  Output is written with h5py too (the reference
+    uses PyTables earrays for the same three datasets, iotool.py:233-245)."""
+
+    def __init__(self, flags):
+        super(io_h5, self).__init__(flags)
+        try:
+            import h5py
+        except ImportError as e:
+            raise NotImplementedError("IO_TYPE 'h5' needs h5py (%s); convert the file to .npz (same dense arrays) "
+                                      "and use IO_TYPE 'npz'" % e)
+        self._h5 = h5py
+
+    def _open(self, path):
+        return self._h5.File(path, "r")
+
+    def _write(self, path, arrays):
+        with self._h5.File(path, "w") as f:
+            for name, a in arrays.items():
+                f.create_dataset(name, data=a, compression="gzip", compression_opts=5)
+
+
+class io_synthetic(io_base):
+    """NUM_ENTRIES (default 64) clouds of NUM_POINT points, NUM_CHANNEL (default 3) channels, uniform
+    in the unit cube; label = which side of a tilted plane a point lies on (NUM_CLASS bands)."""
+
+    def initialize(self):
+        f = self._flags
+        n = int(getattr(f, "NUM_ENTRIES", 64))
+        npt = int(f.NUM_POINT)
+        ch = int(f.NUM_CHANNEL) if int(getattr(f, "NUM_CHANNEL", -1)) > 0 else 3
+        g = np.random.RandomState(20180801)
+        self._data = g.random_sample((n, npt, ch)).astype(np.float32)
+        score = self._data[..., :3].mean(-1) if ch >= 3 else self._data[..., 0]
+        self._label = np.minimum((score * int(f.NUM_CLASS)).astype(np.int32), int(f.NUM_CLASS) - 1)
+        self._weight = np.ones((n, npt), np.float32) if getattr(f, "WEIGHT_KEY", "") else None
+        self._num_entries, self._num_channels = n, ch
+        self._cursor = 0
+        self._stored = {}
+
+    def store(self, idx, softmax):
+        if int(idx) >= self._num_entries:
+            raise ValueError
+        self._stored[int(idx)] = np.asarray(softmax, np.float32)
+
+
+def io_factory(flags):
+    """iotool.py:282-287."""
+    kind = getattr(flags, "IO_TYPE", "")
+    if kind == "npz":
+        return io_npz(flags)
+    if kind == "synthetic":
+        return io_synthetic(flags)
+    if kind == "h5":
+        return io_h5(flags)
+    if kind == "larcv":
+        raise NotImplementedError("IO_TYPE 'larcv' needs LArCV/ROOT, which this build does not bind; export the "
+                                  "sparse3d voxels as dense (entries, N, C) arrays and use IO_TYPE 'npz' or 'h5'")
+    raise NotImplementedError("unknown IO_TYPE '%s'" % kind)

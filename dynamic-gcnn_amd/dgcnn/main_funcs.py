@@ -1,0 +1,314 @@
+"""Run loops around the hot path: the caller side of dgcnn/trainval (reference dgcnn/main_funcs.py:9-306).
+
+Same entry points and log formats as the reference -- `train(flags)`, `inference(flags)`,
+`iotest(flags)`, `prepare(flags)`, `train_loop`, `inference_loop`, `iteration_from_filename`,
+`round_decimals`; `train_log-%07d.csv` / `inference_log-%07d.csv` with the reference's columns;
+checkpoints `<WEIGHT_PREFIX>-<iteration>` every CHECKPOINT_STEP with at most CHECKPOINT_NUM kept --
+re-thought for one process per GPU:
+
+  * BATCH_SIZE is the GLOBAL batch of one optimizer step.  Every replica draws the same batch from
+    its data source (same SEED), keeps clouds [lo,hi) = parallel.shard_bounds(BATCH_SIZE, rank, world)
+    and walks them in micro-steps of MINIBATCH_SIZE x len(GPUS) clouds (main_funcs.py:146-164).  One
+    all-reduce per optimizer step happens inside trainer.apply_gradient.
+  * loss / accuracy in the log are means over micro-steps and, for N>1, over replicas.
+  * rank 0 alone writes CSV lines, stdout reports, checkpoints and stored softmax.
+  * no tf.Session / TensorBoard: `handlers.sess` stays None and SUMMARY_STEP summaries go to a second
+    CSV (`summary-%07d.csv`: iter,accuracy,loss) instead of an event file.
+"""
+from __future__ import annotations
+
+import datetime
+import glob
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+from . import parallel
+from .iotool import io_factory
+from .trainval import trainval
+
+TRAIN_COLUMNS = ("iter,epoch,titer,ttrain,tio,tsave,tsummary,"
+                 "tsumiter,tsumtrain,tsumio,tsumsave,tsumsummary,loss,accuracy")
+INFERENCE_COLUMNS = "iter,epoch,titer,tinference,tio,tsumiter,tsuminference,tsumio,loss,accuracy"
+
+
+def round_decimals(val, digits):
+    scale = 10.0 ** digits
+    return int(val * scale + 0.5) / scale
+
+
+def iteration_from_filename(file_name):
+    """main_funcs.py:13-14 (an optional .npz extension is ignored)."""
+    stem = file_name[:-4] if file_name.endswith(".npz") else file_name
+    return int(stem.split("-")[-1])
+
+
+class Saver(object):
+    """The slice of tf.train.Saver the loops use (main_funcs.py:83-84,91,183): save with a
+    global_step suffix, keep the newest `max_to_keep`, restore by name."""
+
+    def __init__(self, max_to_keep=10):
+        self._keep = int(max_to_keep)
+        self._written = []
+
+    def save(self, trainer, prefix, global_step):
+        name = trainer.save(prefix, global_step)
+        if trainer._rank == 0:
+            self._written.append(name)
+            while self._keep > 0 and len(self._written) > self._keep:
+                old = self._written.pop(0) + ".npz"
+                if os.path.exists(old):
+                    os.remove(old)
+            with open(os.path.join(os.path.dirname(name) or ".", "checkpoint"), "w") as f:
+                f.write('model_checkpoint_path: "%s"\n' % os.path.basename(name))
+        return name
+
+    def restore(self, trainer, path):
+        trainer.restore(path)
+        return iteration_from_filename(path)
+
+
+class Handlers(object):
+    sess = None
+    data_io = None
+    csv_logger = None
+    weight_io = None
+    train_logger = None
+    trainer = None
+    iteration = 0
+    rank = 0
+    world = 1
+
+
+def iotest(flags):
+    io = io_factory(flags)
+    io.initialize()
+    seen, total = 0, io.num_entries()
+    while seen < total:
+        idx, data, label, weight = io.next()
+        print("%d/%d ... %s %s%s%s" % (seen, total, idx, data[0].shape,
+                                      "" if label is None else " %s" % (label[0].shape,),
+                                      "" if weight is None else " %s" % (weight[0].shape,)))
+        seen += len(data)
+    io.finalize()
+
+
+def train(flags):
+    flags.TRAIN = True
+    handlers = prepare(flags)
+    train_loop(flags, handlers)
+    return handlers
+
+
+def inference(flags):
+    flags.TRAIN = False
+    handlers = prepare(flags)
+    inference_loop(flags, handlers)
+    return handlers
+
+
+def _per_step(flags, world):
+    return int(flags.MINIBATCH_SIZE) * len(flags.GPUS) * world
+
+
+def prepare(flags):
+    h = Handlers()
+    dist, h.rank, h.world = parallel.dist_state()
+    if dist is not None and h.world > 1:          # one seed for all replicas: same batches, same dropout stream
+        box = [int(flags.SEED)]
+        dist.broadcast_object_list(box, src=0)
+        flags.SEED = box[0]
+    if int(flags.BATCH_SIZE) % _per_step(flags, h.world):
+        sys.stderr.write("--batch_size (%d) must be a multiple of replicas (%d) * --gpus (%d) * --minibatch_size (%d)\n"
+                         % (flags.BATCH_SIZE, h.world, len(flags.GPUS), flags.MINIBATCH_SIZE))
+        sys.exit(1)
+
+    h.data_io = io_factory(flags)
+    h.data_io.initialize()
+    flags.NUM_CHANNEL = h.data_io.num_channels()
+
+    h.trainer = trainval(flags)
+    h.trainer.initialize()
+    h.weight_io = Saver(max_to_keep=getattr(flags, "CHECKPOINT_NUM", 10))
+
+    h.iteration = 0
+    loaded = 0
+    if getattr(flags, "MODEL_PATH", ""):
+        loaded = h.weight_io.restore(h.trainer, flags.MODEL_PATH)
+        if flags.TRAIN:
+            h.iteration = loaded + 1
+
+    if getattr(flags, "LOG_DIR", "") and h.rank == 0:
+        if not os.path.exists(flags.LOG_DIR):
+            os.makedirs(flags.LOG_DIR)
+        stem = "train_log" if flags.TRAIN else "inference_log"
+        h.csv_logger = open("%s/%s-%07d.csv" % (flags.LOG_DIR, stem, loaded), "w")
+        if flags.TRAIN:
+            h.train_logger = open("%s/summary-%07d.csv" % (flags.LOG_DIR, loaded), "w")
+            h.train_logger.write("iter,accuracy,loss\n")
+    return h
+
+
+def _micro_batches(flags, h, data, label, weight):
+    """Yield (data_v, label_v, weight_v) tower lists covering this replica's share of the batch."""
+    lo, hi = parallel.shard_bounds(int(flags.BATCH_SIZE), h.rank, h.world)
+    mbs = int(flags.MINIBATCH_SIZE)
+    at = lo
+    while at < hi:
+        dv, lv, wv = [], None if label is None else [], None if weight is None else []
+        for _ in flags.GPUS:
+            dv.append(data[at:at + mbs])
+            if lv is not None:
+                lv.append(label[at:at + mbs])
+            if wv is not None:
+                wv.append(weight[at:at + mbs])
+            at += mbs
+        yield dv, lv, wv
+
+
+def _replica_mean(h, values):
+    """Mean over micro-steps (device scalars, one sync) and over replicas."""
+    if not values:
+        return -1.0
+    t = torch.stack([torch.as_tensor(v, dtype=torch.float32).reshape(()) for v in values]).mean()
+    dist, _, world = parallel.dist_state()
+    if dist is not None and world > 1:
+        t = t.clone()
+        dist.all_reduce(t)
+        t = t / world
+    return float(t)
+
+
+def train_loop(flags, h):
+    if h.csv_logger:
+        h.csv_logger.write(TRAIN_COLUMNS + "\n")
+    tsum = dict(iter=0.0, train=0.0, io=0.0, save=0.0, summary=0.0)
+    while h.iteration < int(flags.ITERATION):
+        it = h.iteration
+        stamp = datetime.datetime.fromtimestamp(time.time()).strftime("%Y-%m-%d %H:%M:%S")
+        t_iter = time.time()
+        report = bool(flags.REPORT_STEP) and (it + 1) % flags.REPORT_STEP == 0
+        summarize = bool(getattr(flags, "SUMMARY_STEP", 0)) and h.train_logger is not None and \
+            (it + 1) % flags.SUMMARY_STEP == 0
+        checkpoint = bool(getattr(flags, "CHECKPOINT_STEP", 0)) and (it + 1) % flags.CHECKPOINT_STEP == 0
+
+        t0 = time.time()
+        idx, data, label, weight = h.data_io.next()
+        t_io = time.time() - t0
+
+        t0 = time.time()
+        losses, accs = [], []
+        h.trainer.zero_gradients(h.sess)
+        for dv, lv, wv in _micro_batches(flags, h, data, label, weight):
+            res = h.trainer.accum_gradient(h.sess, dv, lv, wv, summary=summarize)
+            accs.append(res[1])
+            losses.append(res[2])
+        h.trainer.apply_gradient(h.sess)
+        loss, acc = _replica_mean(h, losses), _replica_mean(h, accs)     # syncs: ttrain is device time too
+        t_train = time.time() - t0
+
+        t0 = time.time()
+        if summarize:
+            h.train_logger.write("%d,%g,%g\n" % (it, acc, loss))
+        t_summary = time.time() - t0
+
+        t0 = time.time()
+        if checkpoint:
+            h.weight_io.save(h.trainer, flags.WEIGHT_PREFIX, global_step=it)
+        t_save = time.time() - t0
+
+        epoch = it * float(flags.BATCH_SIZE) / h.data_io.num_entries()
+        t_spent = time.time() - t_iter
+        for k, v in (("iter", t_spent), ("train", t_train), ("io", t_io), ("save", t_save), ("summary", t_summary)):
+            tsum[k] += v
+        if h.csv_logger:
+            h.csv_logger.write("%d,%g,%g,%g,%g,%g,%g,%g,%g,%g,%g,%g,%g,%g\n" % (
+                it, epoch, t_spent, t_train, t_io, t_save, t_summary,
+                tsum["iter"], tsum["train"], tsum["io"], tsum["save"], tsum["summary"], loss, acc))
+        if report and h.rank == 0:
+            mem = torch.cuda.max_memory_allocated() if torch.cuda.is_available() else 0
+            print("Iteration %d (epoch %g) @ %s ... train time fraction %g%% max mem. %g ... loss %g accuracy %g"
+                  % (it, round_decimals(epoch, 2), stamp, round_decimals(t_train / t_spent * 100.0, 2), mem,
+                     round_decimals(loss, 4), round_decimals(acc, 4)))
+            sys.stdout.flush()
+            if h.csv_logger:
+                h.csv_logger.flush()
+            if h.train_logger:
+                h.train_logger.flush()
+        h.iteration += 1
+
+    for f in (h.train_logger, h.csv_logger):
+        if f:
+            f.close()
+    h.data_io.finalize()
+
+
+def inference_loop(flags, h):
+    if h.csv_logger:
+        h.csv_logger.write(INFERENCE_COLUMNS + "\n")
+    tsum = dict(iter=0.0, inference=0.0, io=0.0)
+    has_label = bool(getattr(flags, "LABEL_KEY", ""))
+    lo, _ = parallel.shard_bounds(int(flags.BATCH_SIZE), h.rank, h.world)
+    while h.iteration < int(flags.ITERATION):
+        it = h.iteration
+        stamp = datetime.datetime.fromtimestamp(time.time()).strftime("%Y-%m-%d %H:%M:%S")
+        t_iter = time.time()
+        report = bool(flags.REPORT_STEP) and (it + 1) % flags.REPORT_STEP == 0
+
+        t0 = time.time()
+        idx, data, label, weight = h.data_io.next()
+        if not has_label:
+            label = weight = None
+        t_io = time.time() - t0
+
+        t0 = time.time()
+        softmax, losses, accs = [], [], []
+        for dv, lv, wv in _micro_batches(flags, h, data, label, weight):
+            res = h.trainer.inference(h.sess, dv, lv, wv)
+            if has_label:
+                softmax += [s.clone() for s in res[:-2]]      # the engine reuses its buffers every step
+                accs.append(res[-2])
+                losses.append(res[-1])
+            else:
+                softmax += [s.clone() for s in res]
+        loss, acc = _replica_mean(h, losses), _replica_mean(h, accs)
+        if not has_label:
+            torch.cuda.synchronize()
+        t_inf = time.time() - t0
+
+        if getattr(flags, "OUTPUT_FILE", "") and h.world == 1:
+            at = lo
+            for tower in softmax:
+                for row in tower.cpu().numpy():
+                    h.data_io.store(idx[at], row)
+                    at += 1
+
+        epoch = it * float(flags.BATCH_SIZE) / h.data_io.num_entries()
+        t_spent = time.time() - t_iter
+        for k, v in (("iter", t_spent), ("inference", t_inf), ("io", t_io)):
+            tsum[k] += v
+        if h.csv_logger:
+            h.csv_logger.write("%d,%g,%g,%g,%g,%g,%g,%g,%g,%g\n" % (
+                it, epoch, t_spent, t_inf, t_io, tsum["iter"], tsum["inference"], tsum["io"], loss, acc))
+        if report and h.rank == 0:
+            mem = torch.cuda.max_memory_allocated() if torch.cuda.is_available() else 0
+            print("Iteration %d (epoch %g) @ %s ... inference time fraction %g%% max mem. %g ... loss %g accuracy %g"
+                  % (it, round_decimals(epoch, 2), stamp, round_decimals(t_inf / t_spent * 100.0, 2), mem,
+                     round_decimals(loss, 4), round_decimals(acc, 4)))
+            sys.stdout.flush()
+            if h.csv_logger:
+                h.csv_logger.flush()
+        h.iteration += 1
+
+    if h.csv_logger:
+        h.csv_logger.close()
+    h.data_io.finalize()
+
+
+def latest_checkpoint(prefix):
+    """Newest `<prefix>-<iter>` on disk (by iteration), or '' -- convenience for resuming."""
+    names = [p[:-4] for p in glob.glob(prefix + "-*.npz") if p[len(prefix) + 1:-4].isdigit()]
+    return max(names, key=iteration_from_filename) if names else ""

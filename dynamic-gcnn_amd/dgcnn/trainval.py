@@ -12,7 +12,9 @@ in the reference.  `sess` arguments are accepted and ignored.
 from __future__ import annotations
 
 import math
+import os
 
+import numpy as np
 import torch
 
 from . import _engine as E
@@ -177,3 +179,73 @@ class trainval(object):
         H.call("dgcnn_adam_f32", c.flat_param.data_ptr(), g.data_ptr(), c.flat_m.data_ptr(), c.flat_v.data_ptr(),
                g.numel(), lr_t, b1, b2, eps)
         return None
+
+    # ------------------------------------------------------------------ main_funcs.py:83-94,181-185
+    def state_dict(self):
+        """Host copy of everything tf.train.Saver would write for this graph: the trainable variables
+        under their TF names, Adam's two slots per variable (`<name>/Adam`, `<name>/Adam_1`) and the
+        beta power accumulators."""
+        c = self._ctx
+        out = {}
+        off = 0
+        m, v = c.flat_m.cpu().numpy(), c.flat_v.cpu().numpy()
+        for name, var in c.vars.items():
+            n = var.numel()
+            out[name] = var.detach().cpu().numpy().copy()
+            out[name + "/Adam"] = m[off:off + n].reshape(tuple(var.shape)).copy()
+            out[name + "/Adam_1"] = v[off:off + n].reshape(tuple(var.shape)).copy()
+            off += n
+        out["beta1_power"] = np.float32(0.9 ** (c.adam_t + 1))      # TF: beta^(t+1) after t updates
+        out["beta2_power"] = np.float32(0.999 ** (c.adam_t + 1))
+        out["adam_step"] = np.int64(c.adam_t)
+        out["dropout_step"] = np.int64(c.step_seed)           # position in the dropout mask stream
+        return out
+
+    def load_state_dict(self, state, strict=True):
+        c = self._ctx
+        missing = [n for n in c.vars if n not in state]
+        if missing and strict:
+            raise KeyError("checkpoint lacks variables: %s" % ", ".join(missing[:4]))
+        m = np.zeros(c.flat_param.numel(), np.float32)
+        v = np.zeros_like(m)
+        p = c.flat_param.cpu().numpy().copy()
+        off = 0
+        for name, var in c.vars.items():
+            n = var.numel()
+            if name in state:
+                a = np.asarray(state[name], np.float32)
+                if a.shape != tuple(var.shape):
+                    raise ValueError("checkpoint variable %s has shape %s, graph wants %s"
+                                     % (name, a.shape, tuple(var.shape)))
+                p[off:off + n] = a.reshape(-1)
+                if name + "/Adam" in state:
+                    m[off:off + n] = np.asarray(state[name + "/Adam"], np.float32).reshape(-1)
+                    v[off:off + n] = np.asarray(state[name + "/Adam_1"], np.float32).reshape(-1)
+            off += n
+        c.flat_param.copy_(torch.from_numpy(p))
+        c.flat_m.copy_(torch.from_numpy(m))
+        c.flat_v.copy_(torch.from_numpy(v))
+        c.adam_t = int(state["adam_step"]) if "adam_step" in state else 0
+        c.step_seed = int(state["dropout_step"]) if "dropout_step" in state else 0
+        return self
+
+    def save(self, prefix, global_step):
+        """`weight_io.save(sess, WEIGHT_PREFIX, global_step=iteration)` (main_funcs.py:183): writes
+        `<prefix>-<global_step>.npz` (rank 0 only; replicas hold identical state) and returns the
+        checkpoint name WITHOUT extension, the form MODEL_PATH / iteration_from_filename expect."""
+        name = "%s-%d" % (prefix, int(global_step))
+        if self._rank == 0:
+            d = os.path.dirname(name)
+            if d and not os.path.isdir(d):
+                os.makedirs(d)
+            tmp = name + ".tmp.npz"
+            np.savez(tmp, **self.state_dict())
+            os.replace(tmp, name + ".npz")
+        return name
+
+    def restore(self, path):
+        """`weight_io.restore(sess, MODEL_PATH)` (main_funcs.py:91): every rank reads the file."""
+        fn = path if path.endswith(".npz") else path + ".npz"
+        with np.load(fn) as z:
+            self.load_state_dict({k: z[k] for k in z.files})
+        return self
