@@ -221,7 +221,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
     const float* __restrict__ rstd, const float* __restrict__ beta, int relu,
     const float* __restrict__ dmax, int64_t lddmax, const float* __restrict__ dmean, int64_t lddmean,
     const float* __restrict__ mx_in, int64_t ldmx, const float* __restrict__ cnt_in,
-    const double* __restrict__ red, float* dY, float* __restrict__ dYsum, int fv_shift) {
+    const double* __restrict__ red, float* dY, float* __restrict__ dYsum, int64_t lddysum, int fv_shift) {
   const int FV = F / V;
   const int64_t items = R * FV;
   const float invk = 1.0f / (float)k;
@@ -269,7 +269,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
       }
       Vec<V>::st(dy + (int64_t)m * F, o);
     }
-    if (dYsum) Vec<V>::st(dYsum + r * F + f, acc);
+    if (dYsum) Vec<V>::st(dYsum + r * lddysum + f, acc);
   }
 }
 
@@ -352,21 +352,22 @@ extern "C" int dgcnn_bn_bwd_apply_f32(const float* Y, int64_t R, int k, int F,
                                       const float* mean, const float* rstd, const float* beta, int relu,
                                       const float* dmax, int64_t lddmax, const float* dmean, int64_t lddmean,
                                       const float* mx_in, int64_t ldmx, const float* cnt_in,
-                                      double* red, float* dY, float* dYsum, float* dbeta, float dbeta_beta,
-                                      void* stream) {
+                                      double* red, float* dY, float* dYsum, int64_t lddysum, float* dbeta,
+                                      float dbeta_beta, void* stream) {
   DG_REQUIRE(Y && mean && rstd && beta && dmax && red && dY, DGCNN_EINVAL, "dgcnn_bn_bwd_apply_f32: null pointer");
   DG_REQUIRE(R > 0 && k > 0 && F > 0, DGCNN_EINVAL, "dgcnn_bn_bwd_apply_f32: bad shape");
+  DG_REQUIRE(!dYsum || lddysum >= F, DGCNN_EINVAL, "dgcnn_bn_bwd_apply_f32: lddysum < F");
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)dg::cdiv(F, 128)), dim3(128), 0, st, red, F, dbeta,
                      dbeta_beta);
   const bool vec = (F % 4 == 0) && (lddmax % 4 == 0) && a16(Y) && a16(dY) && a16(dmax) && a16(mean) && a16(rstd) &&
-                   a16(beta) && (!dmean || ((lddmean % 4 == 0) && a16(dmean))) && (!dYsum || a16(dYsum)) &&
+                   a16(beta) && (!dmean || ((lddmean % 4 == 0) && a16(dmean))) && (!dYsum || (a16(dYsum) && lddysum % 4 == 0)) &&
                    (!mx_in || ((ldmx % 4 == 0) && a16(mx_in) && a16(cnt_in)));
   if (vec)
     hipLaunchKernelGGL((bn_bwd_apply_kernel<4>), dim3(grid_for(R * (F / 4))), dim3(256), 0, st, Y, R, k, F, mean, rstd,
-                       beta, relu, dmax, lddmax, dmean, lddmean, mx_in, ldmx, cnt_in, red, dY, dYsum, shift_of(F / 4));
+                       beta, relu, dmax, lddmax, dmean, lddmean, mx_in, ldmx, cnt_in, red, dY, dYsum, lddysum, shift_of(F / 4));
   else
     hipLaunchKernelGGL((bn_bwd_apply_kernel<1>), dim3(grid_for(R * F)), dim3(256), 0, st, Y, R, k, F, mean, rstd, beta,
-                       relu, dmax, lddmax, dmean, lddmean, mx_in, ldmx, cnt_in, red, dY, dYsum, shift_of(F));
+                       relu, dmax, lddmax, dmean, lddmean, mx_in, ldmx, cnt_in, red, dY, dYsum, lddysum, shift_of(F));
   return dg::check_launch("dgcnn_bn_bwd_apply_f32");
 }

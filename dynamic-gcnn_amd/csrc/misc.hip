@@ -97,7 +97,7 @@ __global__ void csr_fill_kernel(const int32_t* __restrict__ idx, int N, int k, i
 // (a wave covers whole 256-B rows), 4 rows in flight.
 __global__ __launch_bounds__(256) void csr_gather_sum_kernel(const float* __restrict__ dY, const int32_t* __restrict__ off,
                                                              const int32_t* __restrict__ rev, int64_t R, int F,
-                                                             float* __restrict__ S) {
+                                                             float* __restrict__ S, int64_t lds) {
   const int FV = F / 4;
   GRID_STRIDE(it, R * FV) {
     const int64_t j = it / FV;
@@ -119,7 +119,93 @@ __global__ __launch_bounds__(256) void csr_gather_sum_kernel(const float* __rest
       const float4 v = *reinterpret_cast<const float4*>(dY + (int64_t)rev[p] * F + f);
       a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
     }
-    *reinterpret_cast<float4*>(S + j * F + f) = a;
+    *reinterpret_cast<float4*>(S + j * lds + f) = a;
+  }
+}
+
+// ---- conv0 of an EdgeConv layer without an edge-level GEMM.  The 1x1 convolution is linear, so for the
+// edge (i, j):  [x_i, x_j - x_i] W0 = x_i (Wa - Wb) + x_j Wb = U[i] + V[j]  with  [U | V] = X [Wa-Wb | Wb]
+// ONE point-level GEMM (k times fewer MACs than the edge-level product of dgcnn/ops.py:47-52).  What is
+// left per edge is a gather-add, bound by the HBM write of Y (the V rows of a cloud live in L2):
+//   Y[e][:] = V[cloud(e)*N + idx[e]][:] + U[e / k][:]   (+ BatchNorm column sums of Y)
+// Lanes: F/4 float4 lanes per edge row, RP = 256/(F/4) rows per pass, 4 passes in flight.  XCD x (blockIdx % 8)
+// sweeps the x-th eighth of the edge rows with all its blocks side by side, so the clouds an XCD's L2
+// holds at any moment are few.
+__global__ __launch_bounds__(256) void edge_gather_add_kernel(const float* __restrict__ V, int64_t ldv,
+                                                              const float* __restrict__ U, int64_t ldu,
+                                                              const int32_t* __restrict__ idx, unsigned rows,
+                                                              unsigned npts, unsigned knn, int F,
+                                                              float* __restrict__ Y, double* __restrict__ stats) {
+  __shared__ float red[2 * 1024];
+  const int FV = F >> 2;
+  const unsigned RP = 256u / (unsigned)FV;
+  const int t = threadIdx.x;
+  const bool active = (unsigned)t < RP * (unsigned)FV;
+  const unsigned r = (unsigned)t / (unsigned)FV;
+  const int f = (t % FV) * 4;
+  const unsigned xcd = blockIdx.x & 7, l = blockIdx.x >> 3, nl = gridDim.x >> 3;
+  const unsigned per = (rows + 7) / 8;
+  const unsigned xbeg = xcd * per;
+  const unsigned xend = (xbeg + per < rows) ? (xbeg + per) : rows;
+  float cs[4] = {0.f, 0.f, 0.f, 0.f}, cq[4] = {0.f, 0.f, 0.f, 0.f};
+  if (active) {
+    const unsigned step = nl * RP;
+    for (unsigned e0 = xbeg + l * RP + r; e0 < xend; e0 += 4 * step) {
+      float4 v[4], u[4];
+      bool ok[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const unsigned e = e0 + q * step;
+        ok[q] = e < xend;
+        const unsigned ec = ok[q] ? e : e0;
+        const unsigned i = ec / knn;
+        const unsigned b = i / npts;
+        v[q] = *reinterpret_cast<const float4*>(V + ((int64_t)b * npts + idx[ec]) * ldv + f);
+        u[q] = *reinterpret_cast<const float4*>(U + (int64_t)i * ldu + f);
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (ok[q]) {
+          const float4 y = make_float4(v[q].x + u[q].x, v[q].y + u[q].y, v[q].z + u[q].z, v[q].w + u[q].w);
+          *reinterpret_cast<float4*>(Y + (int64_t)(e0 + q * step) * F + f) = y;
+          cs[0] += y.x; cs[1] += y.y; cs[2] += y.z; cs[3] += y.w;
+          cq[0] += y.x * y.x; cq[1] += y.y * y.y; cq[2] += y.z * y.z; cq[3] += y.w * y.w;
+        }
+    }
+  }
+  if (!stats) return;
+  for (int e = t; e < 2 * F; e += 256) red[e] = 0.f;
+  __syncthreads();
+  if (active) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      atomicAdd(&red[f + q], cs[q]);
+      atomicAdd(&red[F + f + q], cq[q]);
+    }
+  }
+  __syncthreads();
+  const int slot = blockIdx.x % DGCNN_STAT_SLOTS;
+  for (int e = t; e < 2 * F; e += 256)
+    atomicAdd(stats + ((int64_t)slot * 2 + e / F) * F + (e % F), (double)red[e]);
+}
+
+// Wcat = [Wa - Wb | Wb] (C x 2F) from W0 = [Wa ; Wb] (2C x F), and the matching gradient fold
+//   dWa += dWcat[:, :F] ;  dWb += dWcat[:, F:] - dWcat[:, :F]
+__global__ void edge_weight_split_kernel(const float* __restrict__ W0, int C, int F, float* __restrict__ Wcat) {
+  GRID_STRIDE(i, (int64_t)C * F) {
+    const int c = (int)(i / F), f = (int)(i % F);
+    const float wa = W0[(int64_t)c * F + f], wb = W0[(int64_t)(C + c) * F + f];
+    Wcat[(int64_t)c * 2 * F + f] = wa - wb;
+    Wcat[(int64_t)c * 2 * F + F + f] = wb;
+  }
+}
+
+__global__ void edge_wgrad_combine_kernel(const float* __restrict__ dWcat, int C, int F, float* __restrict__ dW0) {
+  GRID_STRIDE(i, (int64_t)C * F) {
+    const int c = (int)(i / F), f = (int)(i % F);
+    const float du = dWcat[(int64_t)c * 2 * F + f], dv = dWcat[(int64_t)c * 2 * F + F + f];
+    dW0[(int64_t)c * F + f] += du;
+    dW0[(int64_t)(C + c) * F + f] += dv - du;
   }
 }
 
@@ -323,11 +409,43 @@ extern "C" int dgcnn_edge_csr_build(const int32_t* idx, int B, int N, int k, int
 }
 
 extern "C" int dgcnn_edge_gather_sum_f32(const float* dY, const int32_t* off, const int32_t* rev, int64_t R, int F,
-                                         float* S, void* stream) {
+                                         float* S, int64_t lds, void* stream) {
   DG_REQUIRE(dY && off && rev && S && R > 0 && F > 0 && F % 4 == 0, DGCNN_EINVAL, "dgcnn_edge_gather_sum_f32: bad args");
+  DG_REQUIRE(lds >= F && lds % 4 == 0 && (reinterpret_cast<uintptr_t>(S) & 15) == 0, DGCNN_EINVAL,
+             "dgcnn_edge_gather_sum_f32: S must be 16-byte aligned with lds %% 4 == 0");
   unsigned g = grid1d(R * (F / 4));
-  hipLaunchKernelGGL(csr_gather_sum_kernel, dim3(g), dim3(256), 0, ST, dY, off, rev, R, F, S);
+  hipLaunchKernelGGL(csr_gather_sum_kernel, dim3(g), dim3(256), 0, ST, dY, off, rev, R, F, S, lds);
   return dg::check_launch("dgcnn_edge_gather_sum_f32");
+}
+
+extern "C" int dgcnn_edge_gather_add_f32(const float* V, int64_t ldv, const float* U, int64_t ldu, const int32_t* idx,
+                                         int B, int N, int k, int F, float* Y, double* stats, void* stream) {
+  DG_REQUIRE(V && U && idx && Y && B > 0 && N > 0 && k > 0 && F > 0, DGCNN_EINVAL, "dgcnn_edge_gather_add_f32: bad args");
+  DG_REQUIRE(F % 4 == 0 && F <= 1024, DGCNN_EUNSUP, "dgcnn_edge_gather_add_f32: F must be a multiple of 4, <= 1024 (got %d)", F);
+  const int64_t rows = (int64_t)B * N * k;
+  DG_REQUIRE(rows < (1ll << 31), DGCNN_EUNSUP, "dgcnn_edge_gather_add_f32: B*N*k >= 2^31");
+  auto a16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+  DG_REQUIRE(a16(V) && a16(U) && a16(Y) && ldv % 4 == 0 && ldu % 4 == 0 && ldv >= F && ldu >= F, DGCNN_EINVAL,
+             "dgcnn_edge_gather_add_f32: V, U, Y must be 16-byte aligned with leading dimensions %% 4 == 0");
+  const unsigned rp = 256u / (unsigned)(F / 4);
+  int64_t g = dg::cdiv(dg::cdiv(rows, 8), (int64_t)rp * 4);      // blocks per XCD so that each thread makes >= 1 trip
+  if (g > 256) g = 256;                                          // 2048 blocks = 8 per CU
+  if (g < 1) g = 1;
+  hipLaunchKernelGGL(edge_gather_add_kernel, dim3((unsigned)g * 8), dim3(256), 0, ST, V, ldv, U, ldu, idx, (unsigned)rows,
+                     (unsigned)N, (unsigned)k, F, Y, stats);
+  return dg::check_launch("dgcnn_edge_gather_add_f32");
+}
+
+extern "C" int dgcnn_edge_weight_split_f32(const float* W0, int C, int F, float* Wcat, void* stream) {
+  DG_REQUIRE(W0 && Wcat && C > 0 && F > 0, DGCNN_EINVAL, "dgcnn_edge_weight_split_f32: bad args");
+  hipLaunchKernelGGL(edge_weight_split_kernel, dim3(grid1d((int64_t)C * F)), dim3(256), 0, ST, W0, C, F, Wcat);
+  return dg::check_launch("dgcnn_edge_weight_split_f32");
+}
+
+extern "C" int dgcnn_edge_wgrad_combine_f32(const float* dWcat, int C, int F, float* dW0, void* stream) {
+  DG_REQUIRE(dWcat && dW0 && C > 0 && F > 0, DGCNN_EINVAL, "dgcnn_edge_wgrad_combine_f32: bad args");
+  hipLaunchKernelGGL(edge_wgrad_combine_kernel, dim3(grid1d((int64_t)C * F)), dim3(256), 0, ST, dWcat, C, F, dW0);
+  return dg::check_launch("dgcnn_edge_wgrad_combine_f32");
 }
 
 extern "C" int dgcnn_global_max_f32(const float* x, int64_t ldx, int B, int N, int F, float* out, int32_t* arg,

@@ -28,6 +28,7 @@ BN_EPS = 1e-3          # slim.batch_norm default epsilon [TF1-lib]
 DROPOUT_KEEP = 0.7     # tf.nn.dropout(net, 0.7): dgcnn/model.py:91
 WS_BYTES = 256 << 20
 EDGE_MLP_LITERAL = False  # True: conv0 as the literal (B*N*k) x 2C GEMM over E = [x_i, x_j - x_i] (A/B switch)
+EDGE_MLP_NBR_GEMM = False  # True: factored conv0 with an edge-level neighbour GEMM instead of point-level GEMM + gather-add
 SCATTER_ATOMICS = False  # True: dx_j += dY W^T by fp32 atomics in the GEMM epilogue (A/B switch)
 
 
@@ -313,7 +314,7 @@ def conv_bn_act(x, leaf_scope, num_outputs, relu=True, out=None, out2=None, gbia
             H.call("dgcnn_bn_bwd_reduce_f32", T.data_ptr(), R, 1, F, mean.data_ptr(), rstd.data_ptr(), beta.data_ptr(),
                    int(relu), dout.data_ptr(), H.ld2(dout), 0, 0, 0, 0, 0, red.data_ptr())
             H.call("dgcnn_bn_bwd_apply_f32", T.data_ptr(), R, 1, F, mean.data_ptr(), rstd.data_ptr(), beta.data_ptr(),
-                   int(relu), dout.data_ptr(), H.ld2(dout), 0, 0, 0, 0, 0, red.data_ptr(), T.data_ptr(), 0,
+                   int(relu), dout.data_ptr(), H.ld2(dout), 0, 0, 0, 0, 0, red.data_ptr(), T.data_ptr(), 0, 0,
                    c.var_grads[bname].data_ptr(), 1.0)
             dT = T
             dWx = c.var_grads[wname] if w_rows is None else c.var_grads[wname][w_rows[0]:w_rows[1]]
@@ -349,14 +350,27 @@ def edge_conv_block(x, B, N, k, num_filters, relu1=True, outs=None, net2=None):
     Y = torch.empty((R * k, F), dtype=torch.float32, device=x.device)
     st = c.stats(F)
     literal = EDGE_MLP_LITERAL
-    wd = None
+    gather = (not literal) and (not EDGE_MLP_NBR_GEMM) and F % 4 == 0 and F <= 1024
+    wd = wcat = None
     if literal:
         H.call("dgcnn_edge_mlp_f32", x.data_ptr(), H.ld2(x), idx.data_ptr(), W0.data_ptr(), B, N, C, k, F,
                Y.data_ptr(), st.data_ptr(), tag="gemm_kernel<A_EDGE,B_ROW,STORE,%d,%d>" % (_tile_m(R * k, F), 64 if F <= 64 else 128),
                work=2.0 * R * k * 2 * C * F)                            # ops.py:21-52 (gather fused)
+    elif gather:
+        # conv0 is linear: E W0 = x_i (Wa-Wb) + x_j Wb = U[i] + V[j] with [U | V] = X [Wa-Wb | Wb] -- ONE
+        # point-level GEMM (k times fewer MACs than the edge tensor product), then a per-edge gather-add
+        # bound by the HBM write of Y, which also takes the BatchNorm column sums.
+        wcat = torch.empty((C, 2 * F), dtype=torch.float32, device=x.device)
+        H.call("dgcnn_edge_weight_split_f32", W0.data_ptr(), C, F, wcat.data_ptr())
+        UV = torch.empty((R, 2 * F), dtype=torch.float32, device=x.device)
+        gemm(x, wcat, UV)
+        H.call("dgcnn_edge_gather_add_f32", UV[:, F:].data_ptr(), 2 * F, UV.data_ptr(), 2 * F, idx.data_ptr(),
+               B, N, k, F, Y.data_ptr(), st.data_ptr(),
+               tag="edge_gather_add_kernel", work=4.0 * (R * k * F + 2 * R * F) + 4.0 * R * k)   # ops.py:21-52
+        del UV
     else:
-        # factored conv0: E W0 = x_i (W0[:C]-W0[C:]) + x_j W0[C:].  Centre term once per point (U), the
-        # per-edge (B*N*k) x C GEMM gathers the neighbour rows and adds U[point] in its epilogue.
+        # factored conv0, edge-level form (kept for odd F and as a cross-check): centre term once per point
+        # (U); the per-edge (B*N*k) x C GEMM gathers the neighbour rows and adds U[point] in its epilogue.
         wd = torch.empty((C, F), dtype=torch.float32, device=x.device)
         H.call("dgcnn_copy2d_f32", W0[:C].data_ptr(), F, wd.data_ptr(), F, C, F, 0)
         H.call("dgcnn_axpby_f32", W0[C:].data_ptr(), -1.0, wd.data_ptr(), 1.0, C * F)
@@ -391,15 +405,39 @@ def edge_conv_block(x, B, N, k, num_filters, relu1=True, outs=None, net2=None):
                    tag="bn_bwd_reduce_kernel", work=4.0 * (R * k * F + 2 * R * F))
             dx = c.grad(x)
             need_sum = (dx is not None) or not literal
-            dysum = torch.empty((R, F), dtype=torch.float32, device=x.device) if need_sum else None
+            dUV = dysum = None
+            if gather:
+                dUV = torch.empty((R, 2 * F), dtype=torch.float32, device=x.device)    # [dU | dV]
+                dysum = dUV[:, :F]
+            elif need_sum:
+                dysum = torch.empty((R, F), dtype=torch.float32, device=x.device)
             H.call("dgcnn_bn_bwd_apply_f32", Y.data_ptr(), R, k, F, mean.data_ptr(), rstd.data_ptr(), beta0.data_ptr(),
                    1, dmx.data_ptr(), H.ld2(dmx), dmn.data_ptr(), H.ld2(dmn), mx.data_ptr(), H.ld2(mx), cnt.data_ptr(),
                    red.data_ptr(), Y.data_ptr(),
-                   H._p(dysum), c.var_grads[b0name].data_ptr(), 1.0,
+                   H._p(dysum), 0 if dysum is None else H.ld2(dysum), c.var_grads[b0name].data_ptr(), 1.0,
                    tag="bn_bwd_apply_kernel", work=4.0 * (2 * R * k * F + 3 * R * F))
             dY = Y
             ws = c.workspace()
             dW0 = c.var_grads[w0name]
+
+            def incoming_sum(S):
+                # tf.gather^T as a gather: bucket edges by target, then every point sums its incoming dY rows
+                cws = torch.empty(2 * R, dtype=torch.int32, device=x.device)
+                off = torch.empty(R + 1, dtype=torch.int32, device=x.device)
+                rev = torch.empty(R * k, dtype=torch.int32, device=x.device)
+                H.call("dgcnn_edge_csr_build", idx.data_ptr(), B, N, k, cws.data_ptr(), off.data_ptr(), rev.data_ptr())
+                H.call("dgcnn_edge_gather_sum_f32", dY.data_ptr(), off.data_ptr(), rev.data_ptr(), R, F, S.data_ptr(),
+                       H.ld2(S), tag="csr_gather_sum_kernel", work=4.0 * (R * k * F + R * F))
+
+            if gather:
+                # dU = sum_m dY, dV = sum of incoming dY;  dWcat = X^T [dU|dV],  dx += [dU|dV] Wcat^T
+                incoming_sum(dUV[:, F:])
+                dwcat = torch.empty((C, 2 * F), dtype=torch.float32, device=x.device)
+                gemm(x, dUV, dwcat, transA=True)
+                H.call("dgcnn_edge_wgrad_combine_f32", dwcat.data_ptr(), C, F, dW0.data_ptr())
+                if dx is not None:
+                    gemm(dUV, wcat, dx, transB=True, beta=1.0)
+                return
             if literal:
                 H.call("dgcnn_edge_mlp_wgrad_f32", x.data_ptr(), H.ld2(x), idx.data_ptr(), dY.data_ptr(), B, N, C, k, F,
                        dW0.data_ptr(), 1.0, ws.data_ptr(), ws.numel(),
@@ -430,14 +468,8 @@ def edge_conv_block(x, B, N, k, num_filters, relu1=True, outs=None, net2=None):
                            tag="gemm_kernel<A_ROW,B_COL,SCATTER,%d,%d>" % (_tile_m(R * k, C), 64 if C <= 64 else 128),
                            work=2.0 * R * k * C * F)
                 else:
-                    # tf.gather^T as a gather: bucket edges by target, sum incoming dY rows, one small GEMM
-                    cws = torch.empty(2 * R, dtype=torch.int32, device=x.device)
-                    off = torch.empty(R + 1, dtype=torch.int32, device=x.device)
-                    rev = torch.empty(R * k, dtype=torch.int32, device=x.device)
-                    H.call("dgcnn_edge_csr_build", idx.data_ptr(), B, N, k, cws.data_ptr(), off.data_ptr(), rev.data_ptr())
                     S = torch.empty((R, F), dtype=torch.float32, device=x.device)
-                    H.call("dgcnn_edge_gather_sum_f32", dY.data_ptr(), off.data_ptr(), rev.data_ptr(), R, F, S.data_ptr(),
-                           tag="csr_gather_sum_kernel", work=4.0 * (R * k * F + R * F))
+                    incoming_sum(S)
                     gemm(S, W0[C:], dx, transB=True, beta=1.0)
         c.tape.append(bwd)
 

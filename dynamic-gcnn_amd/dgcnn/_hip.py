@@ -36,7 +36,10 @@ PROTOTYPES = {
     "dgcnn_edge_nbr_wgrad_f32": [c_vp, c_i64, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_f32,
                                  c_vp, c_sz, c_vp],
     "dgcnn_edge_csr_build": [c_vp, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp],
-    "dgcnn_edge_gather_sum_f32": [c_vp, c_vp, c_vp, c_i64, c_int, c_vp, c_vp],
+    "dgcnn_edge_gather_sum_f32": [c_vp, c_vp, c_vp, c_i64, c_int, c_vp, c_i64, c_vp],
+    "dgcnn_edge_weight_split_f32": [c_vp, c_int, c_int, c_vp, c_vp],
+    "dgcnn_edge_gather_add_f32": [c_vp, c_i64, c_vp, c_i64, c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp],
+    "dgcnn_edge_wgrad_combine_f32": [c_vp, c_int, c_int, c_vp, c_vp],
     "dgcnn_gemm_f32": [c_int, c_int, c_int, c_int, c_int, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_f32,
                        c_vp, c_i64, c_int, c_vp, c_vp, c_sz, c_vp],
     "dgcnn_bn_finalize_f32": [c_vp, c_int, c_f64, c_f32, c_vp, c_vp, c_vp],
@@ -45,7 +48,7 @@ PROTOTYPES = {
     "dgcnn_bn_bwd_reduce_f32": [c_vp, c_i64, c_int, c_int, c_vp, c_vp, c_vp, c_int, c_vp, c_i64, c_vp, c_i64,
                                 c_vp, c_i64, c_vp, c_vp, c_vp],
     "dgcnn_bn_bwd_apply_f32": [c_vp, c_i64, c_int, c_int, c_vp, c_vp, c_vp, c_int, c_vp, c_i64, c_vp, c_i64,
-                               c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_f32, c_vp],
+                               c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_f32, c_vp],
     "dgcnn_global_max_f32": [c_vp, c_i64, c_int, c_int, c_int, c_vp, c_vp, c_vp],
     "dgcnn_global_max_bwd_f32": [c_vp, c_vp, c_int, c_int, c_int, c_vp, c_i64, c_vp],
     "dgcnn_group_colsum_f32": [c_vp, c_i64, c_int, c_int, c_int, c_vp, c_vp],

@@ -95,7 +95,21 @@ int dgcnn_edge_csr_build(const int32_t* idx, int B, int N, int k, int32_t* cnt_w
 /* ... then S[j][:] = sum over incoming edges e of dY[e][:] (tf.gather^T as a gather); the host
  * finishes with a plain GEMM dx += S W0[C:2C]^T.                                              */
 int dgcnn_edge_gather_sum_f32(const float* dY, const int32_t* off, const int32_t* rev, int64_t R, int F,
-                              float* S, void* stream);
+                              float* S, int64_t lds, void* stream);
+
+/* ---- conv0 of an EdgeConv layer (ops.py:47-52) as point-level GEMM + per-edge gather-add ---------
+ * The convolution is linear: [x_i, x_j - x_i] W0 = x_i (Wa - Wb) + x_j Wb with W0 = [Wa ; Wb].  So
+ *   Wcat = [Wa - Wb | Wb]              (C x 2F)    dgcnn_edge_weight_split_f32
+ *   [U | V] = X Wcat                   (B*N x 2F)  dgcnn_gemm_f32   (k times fewer MACs than the edge tensor product)
+ *   Y[b,i,m,:] = V[b, idx[b,i,m], :] + U[b,i,:]    dgcnn_edge_gather_add_f32 (+ BN column sums of Y into stats)
+ * backward: dU = sum_m dY (dgcnn_bn_bwd_apply_f32's dYsum), dV = dgcnn_edge_gather_sum_f32(dY);
+ *   dWcat = X^T [dU | dV], dX += [dU | dV] Wcat^T (dgcnn_gemm_f32), then
+ *   dW0[:C] += dWcat[:, :F] ; dW0[C:] += dWcat[:, F:] - dWcat[:, :F]     dgcnn_edge_wgrad_combine_f32
+ * F %% 4 == 0, F <= 1024, 16-byte aligned rows.                                                  */
+int dgcnn_edge_weight_split_f32(const float* W0, int C, int F, float* Wcat, void* stream);
+int dgcnn_edge_gather_add_f32(const float* V, int64_t ldv, const float* U, int64_t ldu, const int32_t* idx,
+                              int B, int N, int k, int F, float* Y, double* stats, void* stream);
+int dgcnn_edge_wgrad_combine_f32(const float* dWcat, int C, int F, float* dW0, void* stream);
 
 /* ---- plain fp32 MFMA GEMM: every other slim.conv2d 1x1 (ops.py:62-70,125-133,153-160;
  * model.py:46-53,65-72,94-101) and their dgrad / wgrad --------------------------------------
@@ -134,8 +148,8 @@ int dgcnn_bn_bwd_apply_f32(const float* Y, int64_t R, int k, int F,
                            const float* mean, const float* rstd, const float* beta, int relu,
                            const float* dmax, int64_t lddmax, const float* dmean, int64_t lddmean,
                            const float* mx_in, int64_t ldmx, const float* cnt_in,
-                           double* red, float* dY, float* dYsum, float* dbeta, float dbeta_beta,
-                           void* stream);
+                           double* red, float* dY, float* dYsum, int64_t lddysum, float* dbeta,
+                           float dbeta_beta, void* stream);
 
 /* ---- head helpers (model.py:76-91) and residual add (ops.py:134) -------------------------- */
 /* max_pool_v2 over the N points of each cloud: out[b][f] = max_i x[b][i][f], arg[b][f] = first i */

@@ -264,20 +264,22 @@ def test_edge_conv_forward_backward(dg, B, N, C, k, F):
         np.testing.assert_allclose(host(c.var_grads[n]), g_ref[key], rtol=1e-3, atol=scale(g_ref[key]), err_msg=n)
 
 
-def test_edge_mlp_factored_equals_literal(dg):
-    """conv0 is issued in factored form (x_i (Wa-Wb) per point + x_j Wb per edge); the literal
-    (B*N*k) x 2C GEMM over E = [x_i, x_j - x_i] stays behind a switch.  Same outputs and gradients."""
+@pytest.mark.parametrize("B,N,C,k,F", [(2, 192, 64, 12, 64), (2, 160, 3, 9, 48), (1, 256, 64, 20, 128)])
+def test_edge_mlp_three_forms_agree(dg, B, N, C, k, F):
+    """conv0 is issued as point-level GEMM [U|V] = X [Wa-Wb | Wb] + per-edge gather-add (default); the
+    edge-level factored GEMM and the literal (B*N*k) x 2C GEMM over E = [x_i, x_j - x_i] stay behind
+    switches.  Same outputs and gradients from all three."""
     from dgcnn import _engine as E
     rng = np.random.default_rng(21)
-    B, N, C, k, F = 2, 192, 64, 12, 64
     pts = rng.normal(size=(B, N, C)).astype(np.float32)
     W = {"conv0/weights": rng.normal(0, 0.3, (2 * C, F)).astype(np.float32), "conv0/BatchNorm/beta": rng.normal(0, 0.2, F).astype(np.float32),
          "conv1/weights": rng.normal(0, 0.3, (2 * F, 64)).astype(np.float32), "conv1/BatchNorm/beta": rng.normal(0, 0.2, 64).astype(np.float32)}
     res = {}
-    for literal in (True, False):
+    for form in ("literal", "nbr_gemm", "gather"):
         dg.reset()
         c = dg.ctx()
-        E.EDGE_MLP_LITERAL = literal
+        E.EDGE_MLP_LITERAL = form == "literal"
+        E.EDGE_MLP_NBR_GEMM = form == "nbr_gemm"
         try:
             c.begin_step()
             c.recording = True
@@ -291,11 +293,57 @@ def test_edge_mlp_factored_equals_literal(dg):
                 v, _, _ = E.as2d(t)
                 c.grad(v).fill_(0.01)
             c.backward()
-            res[literal] = [host(t).copy() for t in outs] + [host(c.grad(x)).copy()] + [host(c.var_grads[n]).copy() for n in W]
+            res[form] = [host(t).copy() for t in outs] + [host(c.grad(x)).copy()] + [host(c.var_grads[n]).copy() for n in W]
         finally:
             E.EDGE_MLP_LITERAL = False
-    for a, b in zip(res[True], res[False]):
-        np.testing.assert_allclose(a, b, rtol=2e-3, atol=2e-4 * max(1.0, float(np.abs(a).max())))
+            E.EDGE_MLP_NBR_GEMM = False
+    for form in ("nbr_gemm", "gather"):
+        for a, b in zip(res["literal"], res[form]):
+            np.testing.assert_allclose(a, b, rtol=2e-3, atol=2e-4 * max(1.0, float(np.abs(a).max())), err_msg=form)
+
+
+@pytest.mark.parametrize("B,N,k,F,ld", [(2, 100, 7, 64, 128), (3, 64, 20, 128, 256), (1, 130, 5, 48, 100), (2, 50, 3, 4, 8)])
+def test_edge_gather_add_and_weight_fold(dg, B, N, k, F, ld):
+    """Y[b,i,m] = V[b, idx[b,i,m]] + U[b,i] with BatchNorm column sums; Wcat = [Wa-Wb | Wb] and its
+    gradient fold (the pieces that replace the edge-level GEMM of ops.py:47-52)."""
+    from dgcnn import _hip as H
+    rng = np.random.default_rng(F + k)
+    UV = rng.normal(size=(B * N, ld)).astype(np.float32)
+    idx = rng.integers(0, N, (B, N, k)).astype(np.int32)
+    d_uv, d_idx = dev(UV), dev(idx)
+    Y = torch.full((B * N * k, F), float("nan"), device="cuda")
+    st = torch.zeros((H.STAT_SLOTS if hasattr(H, "STAT_SLOTS") else 32, 2, F), dtype=torch.float64, device="cuda")
+    H.call("dgcnn_edge_gather_add_f32", d_uv[:, F:].data_ptr(), ld, d_uv.data_ptr(), ld, d_idx.data_ptr(), B, N, k, F,
+           Y.data_ptr(), st.data_ptr())
+    U, V = UV[:, :F].reshape(B, N, F), UV[:, F:2 * F].reshape(B, N, F)
+    ref = V[np.arange(B)[:, None, None], idx] + U[:, :, None, :]
+    got = host(Y).reshape(B, N, k, F)
+    np.testing.assert_array_equal(got, ref)                                  # one fp32 add per element: exact
+    s = host(st).sum(0)
+    r64 = ref.astype(np.float64).reshape(-1, F)
+    np.testing.assert_allclose(s[0], r64.sum(0), rtol=1e-5, atol=1e-3)       # fp32 partials per thread, fp64 across
+    np.testing.assert_allclose(s[1], (r64 ** 2).sum(0), rtol=1e-5, atol=1e-3)
+    # no stats requested
+    H.call("dgcnn_edge_gather_add_f32", d_uv[:, F:].data_ptr(), ld, d_uv.data_ptr(), ld, d_idx.data_ptr(), B, N, k, F,
+           Y.data_ptr(), 0)
+    np.testing.assert_array_equal(host(Y).reshape(B, N, k, F), ref)
+
+    C = 5
+    W0 = rng.normal(size=(2 * C, F)).astype(np.float32)
+    wcat = torch.empty((C, 2 * F), device="cuda")
+    H.call("dgcnn_edge_weight_split_f32", dev(W0).data_ptr(), C, F, wcat.data_ptr())
+    np.testing.assert_array_equal(host(wcat), np.concatenate([W0[:C] - W0[C:], W0[C:]], axis=1))
+    dwcat = rng.normal(size=(C, 2 * F)).astype(np.float32)
+    acc = rng.normal(size=(2 * C, F)).astype(np.float32)
+    d_acc = dev(acc)
+    H.call("dgcnn_edge_wgrad_combine_f32", dev(dwcat).data_ptr(), C, F, d_acc.data_ptr())
+    want = acc.copy()
+    want[:C] += dwcat[:, :F]
+    want[C:] += dwcat[:, F:] - dwcat[:, :F]
+    np.testing.assert_array_equal(host(d_acc), want)
+    with pytest.raises(H.HipError):
+        H.call("dgcnn_edge_gather_add_f32", d_uv[:, F:].data_ptr(), ld, d_uv.data_ptr(), ld, d_idx.data_ptr(), B, N, k, 6,
+               Y.data_ptr(), 0)
 
 
 # ------------------------------------------------------------------------------------------
