@@ -29,4 +29,10 @@ inline int check_launch(const char* what) {
 
 static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// gemm_x3.hip: arithmetic of the plain GEMMs (0 native fp32 MFMA, 6 / 9 = partial products of the exact
+// three-way bf16 split on the bf16 matrix pipe) and its launcher (pv = GemmP*, tiles already planned)
+int gemm_arith();
+void set_gemm_arith(int v);
+void launch_gemm_x3(int asrc, int bsrc, void* pv, hipStream_t st, int bn, int np);
+
 }  // namespace dg

@@ -1,0 +1,177 @@
+// gemm_common.h -- what the GEMM kernel families share: the launch descriptor, the operand-source /
+// epilogue kinds and the accumulator epilogue (32x32 MFMA C/D layout is the same for every input type).
+#pragma once
+#include "common.h"
+#include <stdlib.h>
+
+#ifndef DGCNN_ABLATE
+#define DGCNN_ABLATE 0   // experiments only: 1 = no prefetch/LDS refill, 2 = +no barrier, 3 = prefetch but no LDS refill, 4 = LDS refill of stale registers, no prefetch
+#endif
+
+namespace {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+enum { A_ROW = 0, A_COL = 1, A_EDGE = 2, A_EDGE_T = 3 };
+enum { B_ROW = 0, B_COL = 1 };
+enum { E_STORE = 0, E_SCATTER = 1 };
+
+constexpr int BK = 16;
+constexpr int NT = 256;
+
+struct GemmP {
+  const float* A; int64_t lda;
+  const float* B; int64_t ldb;
+  float* C; int64_t ldc;
+  int M, N, K;
+  float beta;
+  const float* gbias; int64_t ldgbias; int rpg;
+  double* stats;
+  // edge sources / scatter
+  const float* x; int64_t ldx; const int32_t* idx; int npts; int cch; int knn;
+  float* dx; int64_t lddx;
+  // split-K
+  int splits; int kchunk; float* partial;
+  int avec, bvec;
+  int mtiles, ntiles, xcd_group, bm, cvec;
+  int edge_nbr;   // A_EDGE / A_EDGE_T rows are the raw neighbour features x_j (K or M = C) instead of [x_i, x_j - x_i]
+  int gbvec;      // per-group bias rows are float4-loadable
+};
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+#if DGCNN_ABLATE == 5   // experiment: prefetch by LDS-DMA into a dummy LDS area (results are garbage)
+#define LD4(ptr) (__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ptr), (__attribute__((address_space(3))) void*)(smem + (threadIdx.x >> 6) * 256), 16, 0, 0), make_float4(0.f, 0.f, 0.f, 0.f))
+#else
+#define LD4(ptr) ld4(ptr)
+#endif
+
+__device__ __forceinline__ float4 sub4(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
+__device__ __forceinline__ int imin(int a, int b) { return a < b ? a : b; }
+
+// ---- shared epilogue.  C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+template <int EPI, int BM, int BN, bool VEC, int TM, int TN>
+__device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[TM][TN], float* smem, int m0, int n0,
+                                              int mt, int z, int t, int wr, int wc, int l31, int lh) {
+  const int colw = n0 + wc * (BN / 2) + l31;
+  const int roww = m0 + wr * (BM / 2) + 4 * lh;
+  if (EPI == E_SCATTER) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = roww + i * 32 + (r & 3) + 8 * (r >> 2);
+        if (row < p.M) {
+          const int nb = (row / (p.knn * p.npts)) * p.npts + p.idx[row];
+          float* d = p.dx + (int64_t)nb * p.lddx;
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            const int col = colw + j * 32;
+            if (col < p.N) atomicAdd(d + col, acc[i][j][r]);
+          }
+        }
+      }
+    return;
+  }
+
+  // ---- E_STORE: accumulators -> LDS (64 block rows at a time) -> coalesced float4 row stores.
+  // Keeps the epilogue at one global_store_dwordx4 per 4 outputs, lets the read-modify-write
+  // (beta) and the per-cloud bias be float4 loads, and needs no per-row pointer registers.
+  float* tile = smem;                       // [64][BN]
+  constexpr int QV = BN / 4;                // float4 per row
+  constexpr int RSTEP = NT / QV;            // rows covered per pass of the 256 threads
+  const int c4 = (t % QV) * 4;
+  const int rr0 = t / QV;
+  const int gcol = n0 + c4;
+  const bool col_ok = gcol < p.N;
+  const bool has_beta = (p.beta != 0.f);
+  const bool has_gb = (p.gbias != nullptr);
+  const bool split = (p.splits > 1);
+  float* outp = split ? (p.partial + (int64_t)z * p.M * p.N) : p.C;
+  const int64_t ldo = split ? (int64_t)p.N : p.ldc;
+  const bool vec_st = VEC && p.cvec && (gcol + 3 < p.N);
+  const int rlast = imin(m0 + BM, p.M) - 1;
+  const bool gb_uniform = has_gb && ((m0 / p.rpg) == (rlast / p.rpg));
+  float gbu[4] = {0.f, 0.f, 0.f, 0.f};
+  if (gb_uniform && col_ok) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      if (gcol + q < p.N) gbu[q] = p.gbias[(int64_t)(m0 / p.rpg) * p.ldgbias + gcol + q];
+  }
+  float cs[4] = {0.f, 0.f, 0.f, 0.f}, cq[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        tile[(wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * BN + wc * (BN / 2) + j * 32 + l31] = acc[i][j][r];
+    __syncthreads();
+#pragma unroll
+    for (int q0 = 0; q0 < 64 / RSTEP; ++q0) {
+      const int rl = rr0 + q0 * RSTEP;
+      const int grow = m0 + (rl >> 5) * (BM / 2) + i * 32 + (rl & 31);
+      if (grow < p.M && col_ok) {
+        const float4 tv = *reinterpret_cast<const float4*>(&tile[rl * BN + c4]);
+        float v[4] = {tv.x, tv.y, tv.z, tv.w};
+        float* dst = outp + (int64_t)grow * ldo + gcol;
+        if (!split) {
+          if (has_gb) {
+            if (gb_uniform) {
+#pragma unroll
+              for (int q = 0; q < 4; ++q) v[q] += gbu[q];
+            } else {
+              const float* gb = p.gbias + (int64_t)(grow / p.rpg) * p.ldgbias + gcol;
+              if (p.gbvec && gcol + 3 < p.N) {
+                const float4 g4 = *reinterpret_cast<const float4*>(gb);
+                v[0] += g4.x; v[1] += g4.y; v[2] += g4.z; v[3] += g4.w;
+              } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                  if (gcol + q < p.N) v[q] += gb[q];
+              }
+            }
+          }
+          if (has_beta) {
+            if (vec_st) {
+              const float4 o = *reinterpret_cast<const float4*>(dst);
+              v[0] += p.beta * o.x; v[1] += p.beta * o.y; v[2] += p.beta * o.z; v[3] += p.beta * o.w;
+            } else {
+#pragma unroll
+              for (int q = 0; q < 4; ++q)
+                if (gcol + q < p.N) v[q] += p.beta * dst[q];
+            }
+          }
+        }
+        if (vec_st) {
+          *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) { cs[q] += v[q]; cq[q] += v[q] * v[q]; }
+        } else {
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            if (gcol + q < p.N) { dst[q] = v[q]; cs[q] += v[q]; cq[q] += v[q] * v[q]; }
+        }
+      }
+    }
+  }
+  if (p.stats && !split) {
+    __syncthreads();
+    float* red = smem;  // [2][BN]
+    for (int e = t; e < 2 * BN; e += NT) red[e] = 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      atomicAdd(&red[c4 + q], cs[q]);
+      atomicAdd(&red[BN + c4 + q], cq[q]);
+    }
+    __syncthreads();
+    const int slot = mt % DGCNN_STAT_SLOTS;
+    for (int e = t; e < 2 * BN; e += NT) {
+      const int which = e / BN, c = n0 + (e % BN);
+      if (c < p.N) atomicAdd(p.stats + ((int64_t)slot * 2 + which) * p.N + c, (double)red[e]);
+    }
+  }
+}
+
+}  // namespace

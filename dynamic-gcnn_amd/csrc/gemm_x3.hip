@@ -1,0 +1,359 @@
+// gemm_x3.hip -- fp32 GEMM on the bf16 matrix pipe by exact operand splitting (gfx950).
+//
+// v_mfma_f32_32x32x2_f32 runs at the fp32 VECTOR rate (157 TFLOP/s peak, 1/16 of the bf16 MFMA rate).
+// Every fp32 value is EXACTLY the sum of three bf16 values:
+//     a = a1 + a2 + a3,   a1 = bf16(a), a2 = bf16(a - a1), a3 = bf16(a - a1 - a2)      (8 + 8 + 8 significand bits)
+// so a*b = sum_ij a_i*b_j, each partial product exact in fp32, accumulated in the fp32 MFMA accumulator:
+//     NP = 9  all nine partial products: nothing is dropped, only the fp32 accumulation rounds
+//             (as it does in the native kernel)                               -> 9/16 of the native MFMA time
+//     NP = 6  drops a2*b3, a3*b2, a3*b3 (<= 2^-23 |a*b| together, the size of ONE fp32 rounding of the
+//             product -- what an unfused multiply-add chain commits anyway)    -> 6/16 of the native MFMA time
+// Inputs, outputs and accumulators stay fp32; tests/test_gpu_parity.py::test_gemm_split_accuracy measures
+// the error of both against an fp64 product next to the native fp32-MFMA kernel (profiles/r01_gemm_arith.txt).
+// Inf/NaN inputs produce NaN (Inf - Inf in the split); the path's activations are finite.
+//
+// Kernel: block tile 128 x BN (BN in {64,128}) x 32, 256 threads = 2x2 waves, each wave 64 x BN/2 as
+// 32x32x16 bf16 MFMA tiles.  Waves 0-1 fetch the A slab, waves 2-3 the B slab (8 global_load_dwordx4
+// each, two slabs ahead, in registers); under the MFMAs of the current slab the 32 values per thread fetched
+// for the next one are split into packed bf16 registers, and between the two barriers of a k-step only the
+// 12 ds_write_b128 into the three bf16 planes remain (LDS image: struct Img).  A lane's MFMA operand (8
+// consecutive k of one row) is one ds_read_b128 per plane.  Epilogue shared with the native kernel
+// (gemm_common.h).
+#include "gemm_common.h"
+#include <type_traits>
+
+#ifndef DGCNN_GEMM_ARITH_DEFAULT
+#define DGCNN_GEMM_ARITH_DEFAULT 6
+#endif
+
+namespace {
+
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+
+constexpr int XK = 32;            // k per slab
+enum { KCONTIG = 0, KSTRIDED = 1 };
+
+// LDS image of one bf16 plane of a TILE x 32 operand slab: [4 chunks of 8 k][row'][16 B], where the tile
+// row r sits at row' = (r & 3) * (TILE/4 + 4) + (r >> 2).  With that permutation
+//   * an MFMA operand read (ds_read_b128, lanes = 32 consecutive tile rows, serviced in the hardware's four
+//     16-lane groups) touches 16 distinct 16-byte slots,
+//   * the transposing store of a k-strided source (a lane owns tile rows 4q..4q+3; 8 consecutive lanes store
+//     rows 4q+e) and the store of a k-contiguous source (8 lanes = 2 rows x 4 chunks; chunk stride = 80 mod
+//     128 bytes) are conflict-free too (ds_write_b128: 8-lane groups, 32 banks).
+template <int TILE>
+struct Img {
+  static constexpr int RS = TILE / 4 + 4;
+  static constexpr unsigned CS = (TILE == 128 ? 141u : 77u) * 16u;    // chunk stride, = 80 (mod 128)
+  static constexpr unsigned PB = 4u * CS;                              // bytes per plane
+  static __device__ __forceinline__ unsigned at(int r, int chunk) {
+    return (unsigned)chunk * CS + (unsigned)(((r & 3) * RS + (r >> 2)) << 4);
+  }
+};
+
+__device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {
+  unsigned r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+  return r;
+}
+
+// (x0, x1) -> packed bf16 pairs of the three split terms (x0 in the low half)
+__device__ __forceinline__ void split_pair(float x0, float x1, unsigned& h, unsigned& m, unsigned& l) {
+  h = cvt_pk_bf16(x0, x1);
+  const float r0 = x0 - __uint_as_float(h << 16);
+  const float r1 = x1 - __uint_as_float(h & 0xffff0000u);
+  m = cvt_pk_bf16(r0, r1);
+  const float s0 = r0 - __uint_as_float(m << 16);
+  const float s1 = r1 - __uint_as_float(m & 0xffff0000u);
+  l = cvt_pk_bf16(s0, s1);
+}
+
+struct Packed { uint4 h, m, l; };   // one 8-k chunk of one row, three planes
+
+__device__ __forceinline__ Packed split8(float v0, float v1, float v2, float v3, float v4, float v5, float v6, float v7) {
+  Packed o;
+  split_pair(v0, v1, o.h.x, o.m.x, o.l.x);
+  split_pair(v2, v3, o.h.y, o.m.y, o.l.y);
+  split_pair(v4, v5, o.h.z, o.m.z, o.l.z);
+  split_pair(v6, v7, o.h.w, o.m.w, o.l.w);
+  return o;
+}
+
+__device__ __forceinline__ float4 keep(bool c, float4 v) { return c ? v : make_float4(0.f, 0.f, 0.f, 0.f); }
+
+// One operand slab (TILE rows x 32 k) staged by 128 threads (u = 0..127), 4 chunks (of 8 k, one row) each:
+//   KCONTIG  (k contiguous in memory: A[m][k], B stored [n][k]): chunk c = u&3 of rows (u>>2) + 32 j
+//   KSTRIDED (row index contiguous:   A stored [k][m], B[k][n]):  chunk c of rows 4q..4q+3; 8 loads over k
+// MASK = false: the block is interior and every slab is full -- no clamps, no predicates.
+template <int KIND, int TILE>
+struct Stage {
+  static constexpr int NC = (KIND == KCONTIG) ? TILE / 32 : 4;    // chunks per thread
+  const float* p[4];
+  int64_t ld;
+  unsigned rok;
+  int c, r0;
+  bool on;
+
+  __device__ __forceinline__ void init(const float* base, int64_t ld_, int row0, int nrows, int u, int kbeg) {
+    ld = ld_;
+    rok = 0;
+    if (KIND == KCONTIG) {
+      on = true;
+      c = u & 3;
+      r0 = u >> 2;
+#pragma unroll
+      for (int j = 0; j < NC; ++j) {
+        const int row = row0 + r0 + 32 * j;
+        if (row < nrows) rok |= 1u << j;
+        p[j] = base + (int64_t)imin(row, nrows - 1) * ld + (kbeg + 8 * c);
+      }
+    } else {
+      constexpr int QN = TILE / 4;
+      on = u < QN * 4;
+      c = (u / QN) & 3;
+      r0 = 4 * (u % QN);
+      const int row = row0 + r0;
+      if (row < nrows) rok = 1u;
+      p[0] = base + imin(row, nrows - 4) + (int64_t)(kbeg + 8 * c) * ld;
+    }
+  }
+
+  // raw slab starting at k = kbeg + koff (koff a multiple of 32)
+  template <bool MASK>
+  __device__ __forceinline__ void load(float4 (&L)[8], unsigned& pm, int koff, int klen) const {
+    if (KIND == KCONTIG) {
+#pragma unroll
+      for (int j = 0; j < NC; ++j)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int kk = koff + 8 * c + 4 * h;           // relative to kbeg
+          if (MASK) {
+            if (((rok >> j) & 1u) && kk < klen) pm |= 1u << (2 * j + h);
+            L[2 * j + h] = ld4(p[j] + (imin(kk, klen - 4) - 8 * c));
+          } else {
+            L[2 * j + h] = ld4(p[j] + (koff + 4 * h));
+          }
+        }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int kk = koff + 8 * c + i;
+        if (MASK) {
+          if (rok && kk < klen) pm |= 1u << i;
+          L[i] = ld4(p[0] + (int64_t)(imin(kk, klen - 1) - 8 * c) * ld);
+        } else {
+          L[i] = ld4(p[0] + (int64_t)(koff + i) * ld);
+        }
+      }
+    }
+  }
+
+  template <bool MASK>
+  __device__ __forceinline__ void split(const float4 (&L)[8], unsigned pm, Packed (&P)[4]) const {
+    if (KIND == KCONTIG) {
+#pragma unroll
+      for (int j = 0; j < NC; ++j) {
+        const float4 a = MASK ? keep((pm >> (2 * j)) & 1u, L[2 * j]) : L[2 * j];
+        const float4 b = MASK ? keep((pm >> (2 * j + 1)) & 1u, L[2 * j + 1]) : L[2 * j + 1];
+        P[j] = split8(a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w);
+      }
+    } else {
+      float4 Z[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) Z[i] = MASK ? keep((pm >> i) & 1u, L[i]) : L[i];
+      P[0] = split8(Z[0].x, Z[1].x, Z[2].x, Z[3].x, Z[4].x, Z[5].x, Z[6].x, Z[7].x);
+      P[1] = split8(Z[0].y, Z[1].y, Z[2].y, Z[3].y, Z[4].y, Z[5].y, Z[6].y, Z[7].y);
+      P[2] = split8(Z[0].z, Z[1].z, Z[2].z, Z[3].z, Z[4].z, Z[5].z, Z[6].z, Z[7].z);
+      P[3] = split8(Z[0].w, Z[1].w, Z[2].w, Z[3].w, Z[4].w, Z[5].w, Z[6].w, Z[7].w);
+    }
+  }
+
+  __device__ __forceinline__ void write(const Packed (&P)[4], char* plane0) const {
+    using I = Img<TILE>;
+#pragma unroll
+    for (int j = 0; j < NC; ++j) {
+      const unsigned off = (KIND == KCONTIG) ? I::at(r0 + 32 * j, c) : I::at(r0 + j, c);
+      *reinterpret_cast<uint4*>(plane0 + off) = P[j].h;
+      *reinterpret_cast<uint4*>(plane0 + I::PB + off) = P[j].m;
+      *reinterpret_cast<uint4*>(plane0 + 2 * I::PB + off) = P[j].l;
+    }
+  }
+};
+
+template <int AKIND, int BKIND, int BN, int NP>
+__global__ __launch_bounds__(NT, 2) void gemm_x3_kernel(GemmP p) {
+  constexpr int BM = 128;
+  constexpr int TM = 2;
+  constexpr int TN = BN / 64;
+  using IA = Img<BM>;
+  using IB = Img<BN>;
+  constexpr unsigned LDS_BYTES = 3 * IA::PB + 3 * IB::PB;
+  constexpr unsigned EPI_BYTES = 64 * BN * 4;
+  __shared__ __attribute__((aligned(16))) char smem_raw[LDS_BYTES > EPI_BYTES ? LDS_BYTES : EPI_BYTES];
+  char* As = smem_raw;
+  char* Bs = smem_raw + 3 * IA::PB;
+
+  const int t = threadIdx.x;
+  const int lane = t & 63;
+  const int wv = t >> 6;
+  const int wr = wv >> 1, wc = wv & 1;
+  const int l31 = lane & 31, lh = lane >> 5;
+
+  const int id = blockIdx.x;
+  int mt, nt;
+  if (p.xcd_group) {
+    mt = ((id >> 3) / p.ntiles) * 8 + (id & 7);
+    nt = (id >> 3) % p.ntiles;
+  } else {
+    mt = id / p.ntiles;
+    nt = id % p.ntiles;
+  }
+  if (mt >= p.mtiles) return;
+  const int m0 = mt * BM;
+  const int n0 = nt * BN;
+  const int z = blockIdx.z;
+  const int kbeg = z * p.kchunk;
+  const int kend = (kbeg + p.kchunk < p.K) ? (kbeg + p.kchunk) : p.K;
+  const int klen = kend - kbeg;
+  const int nk = (klen + XK - 1) / XK;
+
+  // waves 0-1 stage A, waves 2-3 stage B (wave-uniform role)
+  const bool roleA = t < 128;
+  const int u = t & 127;
+  Stage<AKIND, BM> sa;
+  Stage<BKIND, BN> sb;
+  sa.init(p.A, p.lda, m0, p.M, u, kbeg);
+  sb.init(p.B, p.ldb, n0, p.N, u, kbeg);
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // operand addresses of this lane: tile row (wave base + 32 i + l31), chunk = 2*kstep + lh
+  unsigned a_off[TM], b_off[TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) a_off[i] = IA::at(wr * 64 + i * 32 + l31, lh);
+#pragma unroll
+  for (int j = 0; j < TN; ++j) b_off[j] = IB::at(wc * (BN / 2) + j * 32 + l31, lh);
+
+  auto mfma_slab = [&]() {
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      bf16x8 a[TM][3], b[TN][3];
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+          a[i][q] = *reinterpret_cast<const bf16x8*>(As + q * IA::PB + a_off[i] + 2 * s * IA::CS);
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          b[j][q] = *reinterpret_cast<const bf16x8*>(Bs + q * IB::PB + b_off[j] + 2 * s * IB::CS);
+      }
+      // partial products, largest first: (1,1) (1,2) (2,1) (2,2) (1,3) (3,1) [(2,3) (3,2) (3,3)]
+      constexpr int PA[9] = {0, 0, 1, 1, 0, 2, 1, 2, 2};
+      constexpr int PB[9] = {0, 1, 0, 1, 2, 0, 2, 1, 2};
+#pragma unroll
+      for (int q = 0; q < NP; ++q)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][PA[q]], b[j][PB[q]], acc[i][j], 0, 0, 0);
+    }
+  };
+
+  // Software pipeline, two slabs deep: while the MFMAs of slab kt read LDS, the raw registers L (slab kt+1,
+  // fetched during iteration kt-1) are split into the packed registers P, then L is refilled with slab kt+2;
+  // between the two barriers only the 12 ds_write_b128 of P remain.
+  auto run = [&](auto mask_tag) {
+    constexpr bool MASK = decltype(mask_tag)::value;
+    float4 L[8];
+    Packed P[4];
+    unsigned pm = 0;
+    auto fetch = [&](int slab) {
+      pm = 0;
+      if (roleA) sa.template load<MASK>(L, pm, slab * XK, klen);
+      else if (sb.on) sb.template load<MASK>(L, pm, slab * XK, klen);
+    };
+    auto do_split = [&]() {
+      if (roleA) sa.template split<MASK>(L, pm, P);
+      else if (sb.on) sb.template split<MASK>(L, pm, P);
+    };
+    auto do_write = [&]() {
+      if (roleA) sa.write(P, As);
+      else if (sb.on) sb.write(P, Bs);
+    };
+    fetch(0);
+    do_split();
+    do_write();
+    fetch(imin(1, nk - 1));
+    __syncthreads();
+#pragma unroll 1
+    for (int kt = 0; kt < nk; ++kt) {
+      do_split();                               // slab kt+1 (garbage-but-valid after the last one; not written)
+      fetch(imin(kt + 2, nk - 1));
+      mfma_slab();
+      __syncthreads();
+      if (kt + 1 < nk) do_write();
+      __syncthreads();
+    }
+  };
+  const bool edge = (m0 + BM > p.M) || (n0 + BN > p.N) || (klen % XK != 0);
+  if (edge) run(std::true_type{});
+  else run(std::false_type{});
+
+  gemm_epilogue<E_STORE, BM, BN, true, TM, TN>(p, acc, reinterpret_cast<float*>(smem_raw), m0, n0, mt, z, t, wr, wc, l31, lh);
+}
+
+int g_arith = -1;      // -1: not resolved yet; 0 native fp32 MFMA; 6 / 9 partial products on the bf16 pipe
+
+template <int AKIND, int BKIND>
+void launch_kind(GemmP& p, hipStream_t st, int bn, int np, dim3 grid) {
+  if (bn == 64) {
+    if (np == 9) hipLaunchKernelGGL((gemm_x3_kernel<AKIND, BKIND, 64, 9>), grid, dim3(NT), 0, st, p);
+    else hipLaunchKernelGGL((gemm_x3_kernel<AKIND, BKIND, 64, 6>), grid, dim3(NT), 0, st, p);
+  } else {
+    if (np == 9) hipLaunchKernelGGL((gemm_x3_kernel<AKIND, BKIND, 128, 9>), grid, dim3(NT), 0, st, p);
+    else hipLaunchKernelGGL((gemm_x3_kernel<AKIND, BKIND, 128, 6>), grid, dim3(NT), 0, st, p);
+  }
+}
+
+}  // namespace
+
+namespace dg {
+
+int gemm_arith() {
+  if (g_arith < 0) {
+    const char* e = getenv("DGCNN_GEMM_ARITH");      // f32 | bf16x6 | bf16x9
+    int v = DGCNN_GEMM_ARITH_DEFAULT;
+    if (e) v = (e[0] == 'f' || e[0] == '0') ? 0 : ((e[0] == '9' || (e[0] == 'b' && e[5] == '9')) ? 9 : 6);
+    g_arith = v;
+  }
+  return g_arith;
+}
+
+void set_gemm_arith(int v) { g_arith = v; }
+
+// asrc in {A_ROW, A_COL}, bsrc in {B_ROW, B_COL}; operands float4-loadable (checked by the caller).
+// p.mtiles / ntiles / xcd_group / splits / kchunk (multiple of 32 when splits > 1) are set.
+void launch_gemm_x3(int asrc, int bsrc, void* pv, hipStream_t st, int bn, int np) {
+  GemmP& p = *reinterpret_cast<GemmP*>(pv);
+  const unsigned gx = p.xcd_group ? (unsigned)(cdiv(p.mtiles, 8) * 8 * p.ntiles) : (unsigned)(p.mtiles * p.ntiles);
+  dim3 grid(gx, 1, (unsigned)p.splits);
+  if (asrc == A_ROW && bsrc == B_ROW) launch_kind<KCONTIG, KSTRIDED>(p, st, bn, np, grid);
+  else if (asrc == A_ROW && bsrc == B_COL) launch_kind<KCONTIG, KCONTIG>(p, st, bn, np, grid);
+  else launch_kind<KSTRIDED, KSTRIDED>(p, st, bn, np, grid);
+}
+
+}  // namespace dg
+
+extern "C" int dgcnn_gemm_set_arith(int mode) {
+  DG_REQUIRE(mode == 0 || mode == 6 || mode == 9, DGCNN_EINVAL, "dgcnn_gemm_set_arith: mode must be 0, 6 or 9 (got %d)", mode);
+  dg::set_gemm_arith(mode);
+  return DGCNN_OK;
+}
+
+extern "C" int dgcnn_gemm_get_arith(void) { return dg::gemm_arith(); }

@@ -258,12 +258,22 @@ def gemm(A, Bm, C, transA=False, transB=False, beta=0.0, gbias=None, rpg=0, stat
     Kb = Bm.shape[1] if transB else Bm.shape[0]
     assert K == Kb and tuple(C.shape) == (M, N), (A.shape, Bm.shape, C.shape, transA, transB)
     ws = ctx().workspace()
+    tag = None
+    if H.TIMER is not None:                  # kernel identity for bench.py's table (mirrors the C dispatch)
+        lda, ldb = H.ld2(A), H.ld2(Bm)
+        vec = (lda % 4 == 0 and ldb % 4 == 0 and A.data_ptr() % 16 == 0 and Bm.data_ptr() % 16 == 0 and
+               ((M if transA else K) % 4 == 0) and ((K if transB else N) % 4 == 0))
+        arith = H.gemm_arith()
+        bn = 64 if N <= 64 else 128
+        if vec and arith:
+            tag = "gemm_x3_kernel<%s,%s,%d,bf16x%d>" % ("KSTRIDED" if transA else "KCONTIG",
+                                                         "KCONTIG" if transB else "KSTRIDED", bn, arith)
+        else:
+            tag = "gemm_kernel<%s,%s,STORE,%d,%d>" % ("A_COL" if transA else "A_ROW", "B_COL" if transB else "B_ROW",
+                                                      _tile_m(M, N), bn)
     H.call("dgcnn_gemm_f32", int(transA), int(transB), M, N, K, A.data_ptr(), H.ld2(A), Bm.data_ptr(), H.ld2(Bm),
            C.data_ptr(), H.ld2(C), float(beta), H._p(gbias), 0 if gbias is None else H.ld2(gbias), int(rpg),
-           H._p(stats), ws.data_ptr(), ws.numel(),
-           tag="gemm_kernel<%s,%s,STORE,%d,%d>" % ("A_COL" if transA else "A_ROW", "B_COL" if transB else "B_ROW",
-                                                    _tile_m(M, N), 64 if N <= 64 else 128),
-           work=2.0 * M * N * K)
+           H._p(stats), ws.data_ptr(), ws.numel(), tag=tag, work=2.0 * M * N * K)
 
 
 def bn_finalize(stats, F, count):

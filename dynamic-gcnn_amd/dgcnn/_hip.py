@@ -40,6 +40,8 @@ PROTOTYPES = {
     "dgcnn_edge_weight_split_f32": [c_vp, c_int, c_int, c_vp, c_vp],
     "dgcnn_edge_gather_add_f32": [c_vp, c_i64, c_vp, c_i64, c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp],
     "dgcnn_edge_wgrad_combine_f32": [c_vp, c_int, c_int, c_vp, c_vp],
+    "dgcnn_gemm_set_arith": [c_int],
+    "dgcnn_gemm_get_arith": [],
     "dgcnn_gemm_f32": [c_int, c_int, c_int, c_int, c_int, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_f32,
                        c_vp, c_i64, c_int, c_vp, c_vp, c_sz, c_vp],
     "dgcnn_bn_finalize_f32": [c_vp, c_int, c_f64, c_f32, c_vp, c_vp, c_vp],
@@ -82,6 +84,18 @@ def load():
             fn.restype = ctypes.c_char_p if name == "dgcnn_last_error" else ctypes.c_int
         _lib = lib
     return _lib
+
+
+def set_gemm_arith(mode):
+    """0 = native fp32 MFMA, 6 / 9 = partial products of the exact 3-way bf16 split (include/dgcnn_hip.h)."""
+    lib = load()
+    if lib.dgcnn_gemm_set_arith(int(mode)) != 0:
+        raise ValueError(lib.dgcnn_last_error().decode())
+
+
+def gemm_arith():
+    lib = load()
+    return int(lib.dgcnn_gemm_get_arith())
 
 
 def _stream():

@@ -116,6 +116,13 @@ int dgcnn_edge_wgrad_combine_f32(const float* dWcat, int C, int F, float* dW0, v
  * C[M][N] = op(A)[M][K] op(B)[K][N] (+ beta*C) (+ gbias[row / rows_per_group][n]);
  * transA: A stored [K][M]; transB: B stored [N][K].  stats (optional): BN sums of C's columns.
  * ws is needed when the library decides to split K (transA, tall reductions).                */
+/* Arithmetic of dgcnn_gemm_f32 when its operands are float4-loadable (16-byte aligned, leading dimensions
+ * and contiguous extents multiples of 4):  0 = v_mfma_f32_32x32x2_f32 (an fmaf chain, 157 TFLOP/s peak);
+ * 6 / 9 = every fp32 operand is split EXACTLY into three bf16 terms and 6 (terms below 2^-23 |a b| dropped)
+ * or all 9 partial products run on the bf16 matrix pipe with fp32 accumulation (fp32-class results, see
+ * gemm_x3.hip).  Default 6, or $DGCNN_GEMM_ARITH = f32 | bf16x6 | bf16x9.  Process-wide.               */
+int dgcnn_gemm_set_arith(int mode);
+int dgcnn_gemm_get_arith(void);
 int dgcnn_gemm_f32(int transA, int transB, int M, int N, int K,
                    const float* A, int64_t lda, const float* B, int64_t ldb,
                    float* C, int64_t ldc, float beta,

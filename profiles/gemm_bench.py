@@ -18,21 +18,25 @@ SHAPES = [  # (name, transA, transB, M, N, K)
 
 
 def main():
+  from dgcnn import _hip as H
+  for mode in ([int(a) for a in sys.argv[1:]] or [0, 6, 9]):
+    H.set_gemm_arith(mode)
+    print("# arithmetic: %s" % {0: "native fp32 MFMA", 6: "bf16 split, 6 partial products", 9: "bf16 split, 9 partial products"}[mode])
     for name, ta, tb, M, N, K in SHAPES:
-        A = torch.randn((K, M) if ta else (M, K), device="cuda")
-        B = torch.randn((N, K) if tb else (K, N), device="cuda")
-        C = torch.zeros((M, N), device="cuda")
-        for _ in range(3):
-            E.gemm(A, B, C, transA=bool(ta), transB=bool(tb))
-        torch.cuda.synchronize()
-        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record()
-        for _ in range(10):
-            E.gemm(A, B, C, transA=bool(ta), transB=bool(tb))
-        b.record()
-        torch.cuda.synchronize()
-        ms = a.elapsed_time(b) / 10
-        print("%-18s M=%6d N=%5d K=%6d  %8.1f us  %6.1f TFLOP/s" % (name, M, N, K, ms * 1e3, 2.0 * M * N * K / ms / 1e9))
+          A = torch.randn((K, M) if ta else (M, K), device="cuda")
+          B = torch.randn((N, K) if tb else (K, N), device="cuda")
+          C = torch.zeros((M, N), device="cuda")
+          for _ in range(3):
+              E.gemm(A, B, C, transA=bool(ta), transB=bool(tb))
+          torch.cuda.synchronize()
+          a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+          a.record()
+          for _ in range(10):
+              E.gemm(A, B, C, transA=bool(ta), transB=bool(tb))
+          b.record()
+          torch.cuda.synchronize()
+          ms = a.elapsed_time(b) / 10
+          print("%-18s M=%6d N=%5d K=%6d  %8.1f us  %6.1f TFLOP/s" % (name, M, N, K, ms * 1e3, 2.0 * M * N * K / ms / 1e9))
 
 
 if __name__ == "__main__":

