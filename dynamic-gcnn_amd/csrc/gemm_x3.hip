@@ -22,6 +22,10 @@
 #include "gemm_common.h"
 #include <type_traits>
 
+#ifndef X3_ABLATE
+#define X3_ABLATE 0      // experiments only (profiles/x3_ablate.sh)
+#endif
+
 #ifndef DGCNN_GEMM_ARITH_DEFAULT
 #define DGCNN_GEMM_ARITH_DEFAULT 6
 #endif
@@ -293,12 +297,53 @@ __global__ __launch_bounds__(NT, 2) void gemm_x3_kernel(GemmP p) {
     __syncthreads();
 #pragma unroll 1
     for (int kt = 0; kt < nk; ++kt) {
+#if X3_ABLATE == 0
       do_split();                               // slab kt+1 (garbage-but-valid after the last one; not written)
       fetch(imin(kt + 2, nk - 1));
       mfma_slab();
       __syncthreads();
       if (kt + 1 < nk) do_write();
       __syncthreads();
+#elif X3_ABLATE == 1                            // experiments (wrong results): LDS reads + MFMAs only
+      mfma_slab();
+#elif X3_ABLATE == 2                            // + barriers
+      mfma_slab();
+      __syncthreads();
+      __syncthreads();
+#elif X3_ABLATE == 3                            // + fetch and LDS refill, no split (stale P)
+      fetch(imin(kt + 2, nk - 1));
+      mfma_slab();
+      asm volatile("" ::"v"(L[0].x), "v"(L[1].x), "v"(L[2].x), "v"(L[3].x), "v"(L[4].x), "v"(L[5].x), "v"(L[6].x), "v"(L[7].x));
+      __syncthreads();
+      if (kt + 1 < nk) do_write();
+      __syncthreads();
+#elif X3_ABLATE == 4                            // split but no LDS refill
+      do_split();
+      fetch(imin(kt + 2, nk - 1));
+      mfma_slab();
+      asm volatile("" ::"v"(P[0].h.x), "v"(P[1].m.y), "v"(P[2].l.z), "v"(P[3].h.w), "v"(P[0].l.x), "v"(P[1].h.y), "v"(P[2].m.z), "v"(P[3].l.w));
+      __syncthreads();
+      __syncthreads();
+#elif X3_ABLATE == 5                            // fetch only
+      fetch(imin(kt + 2, nk - 1));
+      mfma_slab();
+      asm volatile("" ::"v"(L[0].x), "v"(L[1].x), "v"(L[2].x), "v"(L[3].x), "v"(L[4].x), "v"(L[5].x), "v"(L[6].x), "v"(L[7].x));
+      __syncthreads();
+      __syncthreads();
+#elif X3_ABLATE == 6                            // fetch only, always the same slab (L1/L2 resident)
+      fetch(kt & 1);
+      mfma_slab();
+      asm volatile("" ::"v"(L[0].x), "v"(L[1].x), "v"(L[2].x), "v"(L[3].x), "v"(L[4].x), "v"(L[5].x), "v"(L[6].x), "v"(L[7].x));
+      __syncthreads();
+      __syncthreads();
+#elif X3_ABLATE == 7                            // everything, but always the same two slabs (no L2/HBM streaming)
+      do_split();
+      fetch(kt & 1);
+      mfma_slab();
+      __syncthreads();
+      if (kt + 1 < nk) do_write();
+      __syncthreads();
+#endif
     }
   };
   const bool edge = (m0 + BM > p.M) || (n0 + BN > p.N) || (klen % XK != 0);
