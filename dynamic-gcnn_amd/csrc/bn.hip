@@ -77,39 +77,121 @@ template <> struct Vec<1> {
   static __device__ __forceinline__ void st(float* p, const float (&o)[1]) { *p = o[0]; }
 };
 
+// ---- where the k rows of a point come from ------------------------------------------------------------
+// G = false: the materialised tensor Y[(r*k + m)*F + f].
+// G = true : conv0 of an EdgeConv layer, never materialised: y = V[cloud(r)*N + idx[r*k + m]][f] + U[r][f]
+//            (dgcnn_edge_gather_add_f32's formula; the same single fp32 add everywhere, so values recomputed
+//            in different kernels compare equal).  V / U are point-level (k times smaller than Y) and are
+//            served by L2 / MALL: the forward writes no edge tensor at all, the backward only dY.
+struct Src {
+  const float* Y;
+  const float* V; int64_t ldv;
+  const float* U; int64_t ldu;
+  const int32_t* idx;
+  unsigned npts;
+};
+
+constexpr int NB = 4;    // rows in flight per lane
+
+template <int V, bool G>
+struct Rows {
+  const float* base;
+  const int32_t* ip;
+  int64_t ld;
+  float u[V];
+  __device__ __forceinline__ void init(const Src& s, int64_t r, int k, int F, int f) {
+    if (G) {
+      const unsigned cloud = (unsigned)r / s.npts;
+      base = s.V + (int64_t)cloud * s.npts * s.ldv + f;
+      ip = s.idx + r * k;
+      ld = s.ldv;
+      Vec<V>::ld(s.U + r * s.ldu + f, u);
+    } else {
+      base = s.Y + (r * k) * F + f;
+      ip = nullptr;
+      ld = F;
+    }
+  }
+  // rows m .. m+NB-1 (indices past k-1 re-read row k-1; the caller ignores them)
+  __device__ __forceinline__ void load(int m, int k, float (&y)[NB][V]) const {
+    int64_t row[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      const int mm = (m + b < k) ? (m + b) : (k - 1);
+      row[b] = G ? (int64_t)ip[mm] : (int64_t)mm;
+    }
+#pragma unroll
+    for (int b = 0; b < NB; ++b) Vec<V>::ld(base + row[b] * ld, y[b]);
+    if (G) {
+#pragma unroll
+      for (int b = 0; b < NB; ++b)
+#pragma unroll
+        for (int v = 0; v < V; ++v) y[b][v] += u[v];
+    }
+  }
+};
+
+// item = (row, channel quad).  G: XCD x (blockIdx % 8) owns the x-th eighth of the rows and its blocks sweep it
+// side by side, so the clouds whose V rows an XCD's L2 holds at any moment are few.
+struct Items { int64_t base, count, first, step; };
+template <bool G>
+__device__ __forceinline__ Items items_of(int64_t R, int FV) {
+  Items it;
+  if (G) {
+    const int64_t per = (R + 7) / 8;
+    const int64_t rb = (int64_t)(blockIdx.x & 7) * per;
+    int64_t rows = R - rb;
+    rows = rows < 0 ? 0 : (rows > per ? per : rows);
+    it.base = rb * FV;
+    it.count = rows * FV;
+    it.first = (int64_t)(blockIdx.x >> 3) * blockDim.x + threadIdx.x;
+    it.step = (int64_t)(gridDim.x >> 3) * blockDim.x;
+  } else {
+    it.base = 0;
+    it.count = R * FV;
+    it.first = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    it.step = (int64_t)gridDim.x * blockDim.x;
+  }
+  return it;
+}
+
 // ---- forward: z = (y-mu)*rstd + beta; relu; max / mean over the k rows of each point ----
-template <int V>
+template <int V, bool G>
 __global__ __launch_bounds__(256) void bn_act_kreduce_kernel(
-    const float* __restrict__ Y, int64_t R, int k, int F, const float* __restrict__ mean,
+    Src src, int64_t R, int k, int F, const float* __restrict__ mean,
     const float* __restrict__ rstd, const float* __restrict__ beta, int relu,
     float* __restrict__ max_out, int64_t ldmax, float* __restrict__ mean_out, int64_t ldmean,
     float* __restrict__ out2, int64_t ldout2, float* __restrict__ cnt_out, int fv_shift) {
   const int FV = F / V;
-  const int64_t items = R * FV;
+  const Items its = items_of<G>(R, FV);
   const float invk = 1.0f / (float)k;
-  for (int64_t it = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; it < items;
-       it += (int64_t)gridDim.x * blockDim.x) {
+  for (int64_t q = its.first; q < its.count; q += its.step) {
     int64_t r;
     int fq;
-    split_item(it, FV, fv_shift, r, fq);
+    split_item(its.base + q, FV, fv_shift, r, fq);
     const int f = fq * V;
     float mu[V], rs[V], be[V], mx[V], sm[V], cn[V];
     Vec<V>::ld(mean + f, mu); Vec<V>::ld(rstd + f, rs); Vec<V>::ld(beta + f, be);
 #pragma unroll
     for (int v = 0; v < V; ++v) { mx[v] = -INFINITY; sm[v] = 0.f; cn[v] = 0.f; }
-    const float* y = Y + (r * k) * F + f;
-    for (int m = 0; m < k; ++m) {
-      float yv[V];
-      Vec<V>::ld(y + (int64_t)m * F, yv);
+    Rows<V, G> rows;
+    rows.init(src, r, k, F, f);
+    for (int m = 0; m < k; m += NB) {
+      float yv[NB][V];
+      rows.load(m, k, yv);
 #pragma unroll
-      for (int v = 0; v < V; ++v) {
-        float xh;
-        const float z = bn_z(yv[v], mu[v], rs[v], be[v], relu, xh);
-        const bool gt = z > mx[v];
-        cn[v] = gt ? 1.f : ((z == mx[v]) ? cn[v] + 1.f : cn[v]);   // ties share the max gradient (A.5)
-        mx[v] = gt ? z : mx[v];
-        sm[v] += z;
-      }
+      for (int b = 0; b < NB; ++b)
+        if (m + b < k) {
+#pragma unroll
+          for (int v = 0; v < V; ++v) {
+            float xh;
+            const float z = bn_z(yv[b][v], mu[v], rs[v], be[v], relu, xh);
+            const bool gt = z > mx[v];
+            cn[v] = gt ? 1.f : ((z == mx[v]) ? cn[v] + 1.f : cn[v]);   // ties share the max gradient (A.5)
+            mx[v] = gt ? z : mx[v];
+            sm[v] += z;
+          }
+        }
     }
     Vec<V>::st(max_out + r * ldmax + f, mx);
     if (out2) Vec<V>::st(out2 + r * ldout2 + f, mx);
@@ -126,28 +208,32 @@ __global__ __launch_bounds__(256) void bn_act_kreduce_kernel(
 template <int V>
 struct KState { float mx[V]; float cnt[V]; };
 
-template <int V>
-__device__ __forceinline__ void k_pass_max(const float* y, int k, int F, const float (&mu)[V],
+template <int V, bool G>
+__device__ __forceinline__ void k_pass_max(const Rows<V, G>& rows, int k, const float (&mu)[V],
                                            const float (&rs)[V], const float (&be)[V], int relu,
                                            KState<V>& st) {
 #pragma unroll
   for (int v = 0; v < V; ++v) { st.mx[v] = -INFINITY; st.cnt[v] = 0.f; }
-  for (int m = 0; m < k; ++m) {
-    float yv[V];
-    Vec<V>::ld(y + (int64_t)m * F, yv);
+  for (int m = 0; m < k; m += NB) {
+    float yv[NB][V];
+    rows.load(m, k, yv);
 #pragma unroll
-    for (int v = 0; v < V; ++v) {
-      float xh;
-      const float z = bn_z(yv[v], mu[v], rs[v], be[v], relu, xh);
-      if (z > st.mx[v]) { st.mx[v] = z; st.cnt[v] = 1.f; }
-      else if (z == st.mx[v]) st.cnt[v] += 1.f;
-    }
+    for (int b = 0; b < NB; ++b)
+      if (m + b < k) {
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+          float xh;
+          const float z = bn_z(yv[b][v], mu[v], rs[v], be[v], relu, xh);
+          if (z > st.mx[v]) { st.mx[v] = z; st.cnt[v] = 1.f; }
+          else if (z == st.mx[v]) st.cnt[v] += 1.f;
+        }
+      }
   }
 }
 
-template <int V>
+template <int V, bool G>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
-    const float* __restrict__ Y, int64_t R, int k, int F, const float* __restrict__ mean,
+    Src src, int64_t R, int k, int F, const float* __restrict__ mean,
     const float* __restrict__ rstd, const float* __restrict__ beta, int relu,
     const float* __restrict__ dmax, int64_t lddmax, const float* __restrict__ dmean, int64_t lddmean,
     const float* __restrict__ mx_in, int64_t ldmx, const float* __restrict__ cnt_in, double* __restrict__ red,
@@ -156,17 +242,16 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
   for (int e = threadIdx.x; e < 2 * F; e += blockDim.x) lred[e] = 0.f;
   __syncthreads();
   const int FV = F / V;
-  const int64_t items = R * FV;
+  const Items its = items_of<G>(R, FV);
   const float invk = 1.0f / (float)k;
   int curf = -1;
   float s0[V], s1[V];
 #pragma unroll
   for (int v = 0; v < V; ++v) { s0[v] = 0.f; s1[v] = 0.f; }
-  for (int64_t it = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; it < items;
-       it += (int64_t)gridDim.x * blockDim.x) {
+  for (int64_t q = its.first; q < its.count; q += its.step) {
     int64_t r;
     int fq;
-    split_item(it, FV, fv_shift, r, fq);
+    split_item(its.base + q, FV, fv_shift, r, fq);
     const int f = fq * V;
     if (f != curf) {
       if (curf >= 0) {
@@ -178,31 +263,36 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
     float mu[V], rs[V], be[V], dmx[V], dmn[V];
     Vec<V>::ld(mean + f, mu); Vec<V>::ld(rstd + f, rs); Vec<V>::ld(beta + f, be);
     Vec<V>::ld(dmax + r * lddmax + f, dmx);
-    const float* y = Y + (r * k) * F + f;
+    Rows<V, G> rows;
+    rows.init(src, r, k, F, f);
     KState<V> st;
     if (dmean) {
       Vec<V>::ld(dmean + r * lddmean + f, dmn);
-      if (mx_in) {                 // forward kept (max, #ties): Y is read once
+      if (mx_in) {                 // forward kept (max, #ties): the rows are read once
         Vec<V>::ld(mx_in + r * ldmx + f, st.mx);
         Vec<V>::ld(cnt_in + r * F + f, st.cnt);
       } else {
-        k_pass_max<V>(y, k, F, mu, rs, be, relu, st);
+        k_pass_max<V, G>(rows, k, mu, rs, be, relu, st);
       }
     }
-    for (int m = 0; m < k; ++m) {
-      float yv[V];
-      Vec<V>::ld(y + (int64_t)m * F, yv);
+    for (int m = 0; m < k; m += NB) {
+      float yv[NB][V];
+      rows.load(m, k, yv);
 #pragma unroll
-      for (int v = 0; v < V; ++v) {
-        float xh;
-        const float z = bn_z(yv[v], mu[v], rs[v], be[v], relu, xh);
-        float dz;
-        if (dmean) dz = ((z == st.mx[v]) ? dmx[v] / st.cnt[v] : 0.f) + dmn[v] * invk;
-        else dz = dmx[v];
-        if (relu && !(z > 0.f)) dz = 0.f;
-        s0[v] += dz;
-        s1[v] += dz * xh;
-      }
+      for (int b = 0; b < NB; ++b)
+        if (m + b < k) {
+#pragma unroll
+          for (int v = 0; v < V; ++v) {
+            float xh;
+            const float z = bn_z(yv[b][v], mu[v], rs[v], be[v], relu, xh);
+            float dz;
+            if (dmean) dz = ((z == st.mx[v]) ? dmx[v] / st.cnt[v] : 0.f) + dmn[v] * invk;
+            else dz = dmx[v];
+            if (relu && !(z > 0.f)) dz = 0.f;
+            s0[v] += dz;
+            s1[v] += dz * xh;
+          }
+        }
     }
   }
   if (curf >= 0) {
@@ -215,22 +305,21 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
     atomicAdd(red + (int64_t)slot * 2 * F + e, (double)lred[e]);
 }
 
-template <int V>
+template <int V, bool G>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
-    const float* Y, int64_t R, int k, int F, const float* __restrict__ mean,
+    Src src, int64_t R, int k, int F, const float* __restrict__ mean,
     const float* __restrict__ rstd, const float* __restrict__ beta, int relu,
     const float* __restrict__ dmax, int64_t lddmax, const float* __restrict__ dmean, int64_t lddmean,
     const float* __restrict__ mx_in, int64_t ldmx, const float* __restrict__ cnt_in,
     const double* __restrict__ red, float* dY, float* __restrict__ dYsum, int64_t lddysum, int fv_shift) {
   const int FV = F / V;
-  const int64_t items = R * FV;
+  const Items its = items_of<G>(R, FV);
   const float invk = 1.0f / (float)k;
   const double inv_cnt = 1.0 / ((double)R * (double)k);
-  for (int64_t it = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; it < items;
-       it += (int64_t)gridDim.x * blockDim.x) {
+  for (int64_t q = its.first; q < its.count; q += its.step) {
     int64_t r;
     int fq;
-    split_item(it, FV, fv_shift, r, fq);
+    split_item(its.base + q, FV, fv_shift, r, fq);
     const int f = fq * V;
     float mu[V], rs[V], be[V], dmx[V], dmn[V], c1[V], c2[V], acc[V];
     Vec<V>::ld(mean + f, mu); Vec<V>::ld(rstd + f, rs); Vec<V>::ld(beta + f, be);
@@ -241,33 +330,39 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
       c2[v] = (float)(red[F + f + v] * inv_cnt);
       acc[v] = 0.f;
     }
-    const float* y = Y + (r * k) * F + f;
+    Rows<V, G> rows;
+    rows.init(src, r, k, F, f);
     float* dy = dY + (r * k) * F + f;
     KState<V> st;
     if (dmean) {
       Vec<V>::ld(dmean + r * lddmean + f, dmn);
-      if (mx_in) {                 // forward kept (max, #ties): Y is read once
+      if (mx_in) {                 // forward kept (max, #ties): the rows are read once
         Vec<V>::ld(mx_in + r * ldmx + f, st.mx);
         Vec<V>::ld(cnt_in + r * F + f, st.cnt);
       } else {
-        k_pass_max<V>(y, k, F, mu, rs, be, relu, st);
+        k_pass_max<V, G>(rows, k, mu, rs, be, relu, st);
       }
     }
-    for (int m = 0; m < k; ++m) {
-      float yv[V], o[V];
-      Vec<V>::ld(y + (int64_t)m * F, yv);
+    for (int m = 0; m < k; m += NB) {
+      float yv[NB][V];
+      rows.load(m, k, yv);                 // all NB rows are in registers before the first store (dY may be Y)
 #pragma unroll
-      for (int v = 0; v < V; ++v) {
-        float xh;
-        const float z = bn_z(yv[v], mu[v], rs[v], be[v], relu, xh);
-        float dz;
-        if (dmean) dz = ((z == st.mx[v]) ? dmx[v] / st.cnt[v] : 0.f) + dmn[v] * invk;
-        else dz = dmx[v];
-        if (relu && !(z > 0.f)) dz = 0.f;
-        o[v] = rs[v] * (dz - c1[v] - xh * c2[v]);
-        acc[v] += o[v];
-      }
-      Vec<V>::st(dy + (int64_t)m * F, o);
+      for (int b = 0; b < NB; ++b)
+        if (m + b < k) {
+          float o[V];
+#pragma unroll
+          for (int v = 0; v < V; ++v) {
+            float xh;
+            const float z = bn_z(yv[b][v], mu[v], rs[v], be[v], relu, xh);
+            float dz;
+            if (dmean) dz = ((z == st.mx[v]) ? dmx[v] / st.cnt[v] : 0.f) + dmn[v] * invk;
+            else dz = dmx[v];
+            if (relu && !(z > 0.f)) dz = 0.f;
+            o[v] = rs[v] * (dz - c1[v] - xh * c2[v]);
+            acc[v] += o[v];
+          }
+          Vec<V>::st(dy + (int64_t)(m + b) * F, o);
+        }
     }
     if (dYsum) Vec<V>::st(dYsum + r * lddysum + f, acc);
   }
@@ -297,6 +392,105 @@ inline unsigned grid_reduce(int64_t items) {
   return (unsigned)g;
 }
 
+inline Src dense_src(const float* Y) { Src s = {}; s.Y = Y; return s; }
+
+inline Src edge_src(const float* V, int64_t ldv, const float* U, int64_t ldu, const int32_t* idx, int N) {
+  Src s = {};
+  s.V = V; s.ldv = ldv; s.U = U; s.ldu = ldu; s.idx = idx; s.npts = (unsigned)N;
+  return s;
+}
+
+inline unsigned grid8(unsigned g) { return (g + 7u) & ~7u; }     // XCD-aware item mapping needs a multiple of 8
+
+// shared argument checks of the gather-sourced (edge) variants
+int check_edge(const char* what, const float* V, int64_t ldv, const float* U, int64_t ldu, const int32_t* idx,
+               int B, int N, int k, int F) {
+  DG_REQUIRE(V && U && idx, DGCNN_EINVAL, "%s: null pointer", what);
+  DG_REQUIRE(B > 0 && N > 0 && k > 0 && F > 0, DGCNN_EINVAL, "%s: bad shape", what);
+  DG_REQUIRE(F % 4 == 0, DGCNN_EUNSUP, "%s: F must be a multiple of 4 (got %d)", what, F);
+  DG_REQUIRE((int64_t)B * N * k < (1ll << 31), DGCNN_EUNSUP, "%s: B*N*k >= 2^31", what);
+  DG_REQUIRE(a16(V) && a16(U) && ldv % 4 == 0 && ldu % 4 == 0 && ldv >= F && ldu >= F, DGCNN_EINVAL,
+             "%s: V, U must be 16-byte aligned with leading dimensions %% 4 == 0", what);
+  return DGCNN_OK;
+}
+
+template <bool G>
+int launch_act_kreduce(const char* what, Src src, int64_t R, int k, int F, const float* mean, const float* rstd,
+                       const float* beta, int relu, float* max_out, int64_t ldmax, float* mean_out, int64_t ldmean,
+                       float* out2, int64_t ldout2, float* cnt_out, hipStream_t st) {
+  DG_REQUIRE(mean && rstd && beta && max_out, DGCNN_EINVAL, "%s: null pointer", what);
+  const bool vec = (F % 4 == 0) && (ldmax % 4 == 0) && (G || a16(src.Y)) && a16(max_out) && a16(mean) && a16(rstd) &&
+                   a16(beta) && (!mean_out || ((ldmean % 4 == 0) && a16(mean_out))) &&
+                   (!out2 || ((ldout2 % 4 == 0) && a16(out2))) && (!cnt_out || a16(cnt_out));
+  if (G) {
+    DG_REQUIRE(vec, DGCNN_EINVAL, "%s: outputs must be 16-byte aligned with leading dimensions %% 4 == 0", what);
+    hipLaunchKernelGGL((bn_act_kreduce_kernel<4, true>), dim3(grid8(grid_for(R * (F / 4)))), dim3(256), 0, st, src, R, k, F,
+                       mean, rstd, beta, relu, max_out, ldmax, mean_out, ldmean, out2, ldout2, cnt_out, shift_of(F / 4));
+  } else if (vec) {
+    hipLaunchKernelGGL((bn_act_kreduce_kernel<4, false>), dim3(grid_for(R * (F / 4))), dim3(256), 0, st, src, R, k, F, mean,
+                       rstd, beta, relu, max_out, ldmax, mean_out, ldmean, out2, ldout2, cnt_out, shift_of(F / 4));
+  } else {
+    hipLaunchKernelGGL((bn_act_kreduce_kernel<1, false>), dim3(grid_for(R * F)), dim3(256), 0, st, src, R, k, F, mean, rstd,
+                       beta, relu, max_out, ldmax, mean_out, ldmean, out2, ldout2, cnt_out, shift_of(F));
+  }
+  return dg::check_launch(what);
+}
+
+template <bool G>
+int launch_bwd_reduce(const char* what, Src src, int64_t R, int k, int F, const float* mean, const float* rstd,
+                      const float* beta, int relu, const float* dmax, int64_t lddmax, const float* dmean,
+                      int64_t lddmean, const float* mx_in, int64_t ldmx, const float* cnt_in, double* red,
+                      hipStream_t st) {
+  DG_REQUIRE(mean && rstd && beta && dmax && red, DGCNN_EINVAL, "%s: null pointer", what);
+  DG_REQUIRE(F <= 8192, DGCNN_EINVAL, "%s: F > 8192", what);
+  DG_REQUIRE(!mx_in || cnt_in, DGCNN_EINVAL, "%s: mx_in needs cnt_in", what);
+  const bool vec = (F % 4 == 0) && (lddmax % 4 == 0) && (G || a16(src.Y)) && a16(dmax) && a16(mean) && a16(rstd) &&
+                   a16(beta) && (!dmean || ((lddmean % 4 == 0) && a16(dmean))) &&
+                   (!mx_in || ((ldmx % 4 == 0) && a16(mx_in) && a16(cnt_in)));
+  const size_t sh = (size_t)2 * F * sizeof(float);
+  if (G) {
+    DG_REQUIRE(vec, DGCNN_EINVAL, "%s: operands must be 16-byte aligned with leading dimensions %% 4 == 0", what);
+    hipLaunchKernelGGL((bn_bwd_reduce_kernel<4, true>), dim3(grid8(grid_reduce(R * (F / 4)))), dim3(256), sh, st, src, R, k,
+                       F, mean, rstd, beta, relu, dmax, lddmax, dmean, lddmean, mx_in, ldmx, cnt_in, red, shift_of(F / 4));
+  } else if (vec) {
+    hipLaunchKernelGGL((bn_bwd_reduce_kernel<4, false>), dim3(grid_reduce(R * (F / 4))), dim3(256), sh, st, src, R, k, F,
+                       mean, rstd, beta, relu, dmax, lddmax, dmean, lddmean, mx_in, ldmx, cnt_in, red, shift_of(F / 4));
+  } else {
+    hipLaunchKernelGGL((bn_bwd_reduce_kernel<1, false>), dim3(grid_reduce(R * F)), dim3(256), sh, st, src, R, k, F, mean,
+                       rstd, beta, relu, dmax, lddmax, dmean, lddmean, mx_in, ldmx, cnt_in, red, shift_of(F));
+  }
+  return dg::check_launch(what);
+}
+
+template <bool G>
+int launch_bwd_apply(const char* what, Src src, int64_t R, int k, int F, const float* mean, const float* rstd,
+                     const float* beta, int relu, const float* dmax, int64_t lddmax, const float* dmean,
+                     int64_t lddmean, const float* mx_in, int64_t ldmx, const float* cnt_in, double* red, float* dY,
+                     float* dYsum, int64_t lddysum, float* dbeta, float dbeta_beta, hipStream_t st) {
+  DG_REQUIRE(mean && rstd && beta && dmax && red && dY, DGCNN_EINVAL, "%s: null pointer", what);
+  DG_REQUIRE(!dYsum || lddysum >= F, DGCNN_EINVAL, "%s: lddysum < F", what);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)dg::cdiv(F, 128)), dim3(128), 0, st, red, F, dbeta,
+                     dbeta_beta);
+  const bool vec = (F % 4 == 0) && (lddmax % 4 == 0) && (G || a16(src.Y)) && a16(dY) && a16(dmax) && a16(mean) &&
+                   a16(rstd) && a16(beta) && (!dmean || ((lddmean % 4 == 0) && a16(dmean))) &&
+                   (!dYsum || (a16(dYsum) && lddysum % 4 == 0)) &&
+                   (!mx_in || ((ldmx % 4 == 0) && a16(mx_in) && a16(cnt_in)));
+  if (G) {
+    DG_REQUIRE(vec, DGCNN_EINVAL, "%s: operands must be 16-byte aligned with leading dimensions %% 4 == 0", what);
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<4, true>), dim3(grid8(grid_for(R * (F / 4)))), dim3(256), 0, st, src, R, k, F,
+                       mean, rstd, beta, relu, dmax, lddmax, dmean, lddmean, mx_in, ldmx, cnt_in, red, dY, dYsum, lddysum,
+                       shift_of(F / 4));
+  } else if (vec) {
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<4, false>), dim3(grid_for(R * (F / 4))), dim3(256), 0, st, src, R, k, F, mean,
+                       rstd, beta, relu, dmax, lddmax, dmean, lddmean, mx_in, ldmx, cnt_in, red, dY, dYsum, lddysum,
+                       shift_of(F / 4));
+  } else {
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<1, false>), dim3(grid_for(R * F)), dim3(256), 0, st, src, R, k, F, mean, rstd,
+                       beta, relu, dmax, lddmax, dmean, lddmean, mx_in, ldmx, cnt_in, red, dY, dYsum, lddysum, shift_of(F));
+  }
+  return dg::check_launch(what);
+}
+
 }  // namespace
 
 extern "C" int dgcnn_bn_finalize_f32(const double* stats, int F, double count, float eps,
@@ -311,19 +505,10 @@ extern "C" int dgcnn_bn_act_kreduce_f32(const float* Y, int64_t R, int k, int F,
                                         const float* mean, const float* rstd, const float* beta, int relu,
                                         float* max_out, int64_t ldmax, float* mean_out, int64_t ldmean,
                                         float* out2, int64_t ldout2, float* cnt_out, void* stream) {
-  DG_REQUIRE(Y && mean && rstd && beta && max_out, DGCNN_EINVAL, "dgcnn_bn_act_kreduce_f32: null pointer");
+  DG_REQUIRE(Y, DGCNN_EINVAL, "dgcnn_bn_act_kreduce_f32: null pointer");
   DG_REQUIRE(R > 0 && k > 0 && F > 0, DGCNN_EINVAL, "dgcnn_bn_act_kreduce_f32: bad shape");
-  const bool vec = (F % 4 == 0) && (ldmax % 4 == 0) && a16(Y) && a16(max_out) && a16(mean) && a16(rstd) && a16(beta) &&
-                   (!mean_out || ((ldmean % 4 == 0) && a16(mean_out))) && (!out2 || ((ldout2 % 4 == 0) && a16(out2))) &&
-                   (!cnt_out || a16(cnt_out));
-  hipStream_t st = (hipStream_t)stream;
-  if (vec)
-    hipLaunchKernelGGL((bn_act_kreduce_kernel<4>), dim3(grid_for(R * (F / 4))), dim3(256), 0, st, Y, R, k, F, mean,
-                       rstd, beta, relu, max_out, ldmax, mean_out, ldmean, out2, ldout2, cnt_out, shift_of(F / 4));
-  else
-    hipLaunchKernelGGL((bn_act_kreduce_kernel<1>), dim3(grid_for(R * F)), dim3(256), 0, st, Y, R, k, F, mean, rstd,
-                       beta, relu, max_out, ldmax, mean_out, ldmean, out2, ldout2, cnt_out, shift_of(F));
-  return dg::check_launch("dgcnn_bn_act_kreduce_f32");
+  return launch_act_kreduce<false>("dgcnn_bn_act_kreduce_f32", dense_src(Y), R, k, F, mean, rstd, beta, relu, max_out,
+                                   ldmax, mean_out, ldmean, out2, ldout2, cnt_out, (hipStream_t)stream);
 }
 
 extern "C" int dgcnn_bn_bwd_reduce_f32(const float* Y, int64_t R, int k, int F,
@@ -331,21 +516,10 @@ extern "C" int dgcnn_bn_bwd_reduce_f32(const float* Y, int64_t R, int k, int F,
                                        const float* dmax, int64_t lddmax, const float* dmean, int64_t lddmean,
                                        const float* mx_in, int64_t ldmx, const float* cnt_in,
                                        double* red, void* stream) {
-  DG_REQUIRE(Y && mean && rstd && beta && dmax && red, DGCNN_EINVAL, "dgcnn_bn_bwd_reduce_f32: null pointer");
-  DG_REQUIRE(R > 0 && k > 0 && F > 0 && F <= 8192, DGCNN_EINVAL, "dgcnn_bn_bwd_reduce_f32: bad shape");
-  const bool vec = (F % 4 == 0) && (lddmax % 4 == 0) && a16(Y) && a16(dmax) && a16(mean) && a16(rstd) && a16(beta) &&
-                   (!dmean || ((lddmean % 4 == 0) && a16(dmean))) &&
-                   (!mx_in || ((ldmx % 4 == 0) && a16(mx_in) && a16(cnt_in)));
-  DG_REQUIRE(!mx_in || cnt_in, DGCNN_EINVAL, "dgcnn_bn_bwd_reduce_f32: mx_in needs cnt_in");
-  hipStream_t st = (hipStream_t)stream;
-  const size_t sh = (size_t)2 * F * sizeof(float);
-  if (vec)
-    hipLaunchKernelGGL((bn_bwd_reduce_kernel<4>), dim3(grid_reduce(R * (F / 4))), dim3(256), sh, st, Y, R, k, F, mean,
-                       rstd, beta, relu, dmax, lddmax, dmean, lddmean, mx_in, ldmx, cnt_in, red, shift_of(F / 4));
-  else
-    hipLaunchKernelGGL((bn_bwd_reduce_kernel<1>), dim3(grid_reduce(R * F)), dim3(256), sh, st, Y, R, k, F, mean, rstd,
-                       beta, relu, dmax, lddmax, dmean, lddmean, mx_in, ldmx, cnt_in, red, shift_of(F));
-  return dg::check_launch("dgcnn_bn_bwd_reduce_f32");
+  DG_REQUIRE(Y, DGCNN_EINVAL, "dgcnn_bn_bwd_reduce_f32: null pointer");
+  DG_REQUIRE(R > 0 && k > 0 && F > 0, DGCNN_EINVAL, "dgcnn_bn_bwd_reduce_f32: bad shape");
+  return launch_bwd_reduce<false>("dgcnn_bn_bwd_reduce_f32", dense_src(Y), R, k, F, mean, rstd, beta, relu, dmax, lddmax,
+                                  dmean, lddmean, mx_in, ldmx, cnt_in, red, (hipStream_t)stream);
 }
 
 extern "C" int dgcnn_bn_bwd_apply_f32(const float* Y, int64_t R, int k, int F,
@@ -354,20 +528,49 @@ extern "C" int dgcnn_bn_bwd_apply_f32(const float* Y, int64_t R, int k, int F,
                                       const float* mx_in, int64_t ldmx, const float* cnt_in,
                                       double* red, float* dY, float* dYsum, int64_t lddysum, float* dbeta,
                                       float dbeta_beta, void* stream) {
-  DG_REQUIRE(Y && mean && rstd && beta && dmax && red && dY, DGCNN_EINVAL, "dgcnn_bn_bwd_apply_f32: null pointer");
+  DG_REQUIRE(Y, DGCNN_EINVAL, "dgcnn_bn_bwd_apply_f32: null pointer");
   DG_REQUIRE(R > 0 && k > 0 && F > 0, DGCNN_EINVAL, "dgcnn_bn_bwd_apply_f32: bad shape");
-  DG_REQUIRE(!dYsum || lddysum >= F, DGCNN_EINVAL, "dgcnn_bn_bwd_apply_f32: lddysum < F");
-  hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)dg::cdiv(F, 128)), dim3(128), 0, st, red, F, dbeta,
-                     dbeta_beta);
-  const bool vec = (F % 4 == 0) && (lddmax % 4 == 0) && a16(Y) && a16(dY) && a16(dmax) && a16(mean) && a16(rstd) &&
-                   a16(beta) && (!dmean || ((lddmean % 4 == 0) && a16(dmean))) && (!dYsum || (a16(dYsum) && lddysum % 4 == 0)) &&
-                   (!mx_in || ((ldmx % 4 == 0) && a16(mx_in) && a16(cnt_in)));
-  if (vec)
-    hipLaunchKernelGGL((bn_bwd_apply_kernel<4>), dim3(grid_for(R * (F / 4))), dim3(256), 0, st, Y, R, k, F, mean, rstd,
-                       beta, relu, dmax, lddmax, dmean, lddmean, mx_in, ldmx, cnt_in, red, dY, dYsum, lddysum, shift_of(F / 4));
-  else
-    hipLaunchKernelGGL((bn_bwd_apply_kernel<1>), dim3(grid_for(R * F)), dim3(256), 0, st, Y, R, k, F, mean, rstd, beta,
-                       relu, dmax, lddmax, dmean, lddmean, mx_in, ldmx, cnt_in, red, dY, dYsum, lddysum, shift_of(F));
-  return dg::check_launch("dgcnn_bn_bwd_apply_f32");
+  return launch_bwd_apply<false>("dgcnn_bn_bwd_apply_f32", dense_src(Y), R, k, F, mean, rstd, beta, relu, dmax, lddmax,
+                                 dmean, lddmean, mx_in, ldmx, cnt_in, red, dY, dYsum, lddysum, dbeta, dbeta_beta,
+                                 (hipStream_t)stream);
+}
+
+// ---- the same three passes over the never-materialised conv0 output  y = V[neighbour] + U[point] ----
+extern "C" int dgcnn_edge_bn_act_kreduce_f32(const float* V, int64_t ldv, const float* U, int64_t ldu,
+                                             const int32_t* idx, int B, int N, int k, int F,
+                                             const float* mean, const float* rstd, const float* beta, int relu,
+                                             float* max_out, int64_t ldmax, float* mean_out, int64_t ldmean,
+                                             float* cnt_out, void* stream) {
+  int rc = check_edge("dgcnn_edge_bn_act_kreduce_f32", V, ldv, U, ldu, idx, B, N, k, F);
+  if (rc) return rc;
+  return launch_act_kreduce<true>("dgcnn_edge_bn_act_kreduce_f32", edge_src(V, ldv, U, ldu, idx, N), (int64_t)B * N, k, F,
+                                  mean, rstd, beta, relu, max_out, ldmax, mean_out, ldmean, nullptr, 0, cnt_out,
+                                  (hipStream_t)stream);
+}
+
+extern "C" int dgcnn_edge_bn_bwd_reduce_f32(const float* V, int64_t ldv, const float* U, int64_t ldu,
+                                            const int32_t* idx, int B, int N, int k, int F,
+                                            const float* mean, const float* rstd, const float* beta, int relu,
+                                            const float* dmax, int64_t lddmax, const float* dmean, int64_t lddmean,
+                                            const float* mx_in, int64_t ldmx, const float* cnt_in,
+                                            double* red, void* stream) {
+  int rc = check_edge("dgcnn_edge_bn_bwd_reduce_f32", V, ldv, U, ldu, idx, B, N, k, F);
+  if (rc) return rc;
+  return launch_bwd_reduce<true>("dgcnn_edge_bn_bwd_reduce_f32", edge_src(V, ldv, U, ldu, idx, N), (int64_t)B * N, k, F,
+                                 mean, rstd, beta, relu, dmax, lddmax, dmean, lddmean, mx_in, ldmx, cnt_in, red,
+                                 (hipStream_t)stream);
+}
+
+extern "C" int dgcnn_edge_bn_bwd_apply_f32(const float* V, int64_t ldv, const float* U, int64_t ldu,
+                                           const int32_t* idx, int B, int N, int k, int F,
+                                           const float* mean, const float* rstd, const float* beta, int relu,
+                                           const float* dmax, int64_t lddmax, const float* dmean, int64_t lddmean,
+                                           const float* mx_in, int64_t ldmx, const float* cnt_in,
+                                           double* red, float* dY, float* dYsum, int64_t lddysum, float* dbeta,
+                                           float dbeta_beta, void* stream) {
+  int rc = check_edge("dgcnn_edge_bn_bwd_apply_f32", V, ldv, U, ldu, idx, B, N, k, F);
+  if (rc) return rc;
+  return launch_bwd_apply<true>("dgcnn_edge_bn_bwd_apply_f32", edge_src(V, ldv, U, ldu, idx, N), (int64_t)B * N, k, F, mean,
+                                rstd, beta, relu, dmax, lddmax, dmean, lddmean, mx_in, ldmx, cnt_in, red, dY, dYsum,
+                                lddysum, dbeta, dbeta_beta, (hipStream_t)stream);
 }

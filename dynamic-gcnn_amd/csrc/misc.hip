@@ -167,7 +167,7 @@ __global__ __launch_bounds__(256) void edge_gather_add_kernel(const float* __res
       for (int q = 0; q < 4; ++q)
         if (ok[q]) {
           const float4 y = make_float4(v[q].x + u[q].x, v[q].y + u[q].y, v[q].z + u[q].z, v[q].w + u[q].w);
-          *reinterpret_cast<float4*>(Y + (int64_t)(e0 + q * step) * F + f) = y;
+          if (Y) *reinterpret_cast<float4*>(Y + (int64_t)(e0 + q * step) * F + f) = y;
           cs[0] += y.x; cs[1] += y.y; cs[2] += y.z; cs[3] += y.w;
           cq[0] += y.x * y.x; cq[1] += y.y * y.y; cq[2] += y.z * y.z; cq[3] += y.w * y.w;
         }
@@ -420,12 +420,12 @@ extern "C" int dgcnn_edge_gather_sum_f32(const float* dY, const int32_t* off, co
 
 extern "C" int dgcnn_edge_gather_add_f32(const float* V, int64_t ldv, const float* U, int64_t ldu, const int32_t* idx,
                                          int B, int N, int k, int F, float* Y, double* stats, void* stream) {
-  DG_REQUIRE(V && U && idx && Y && B > 0 && N > 0 && k > 0 && F > 0, DGCNN_EINVAL, "dgcnn_edge_gather_add_f32: bad args");
+  DG_REQUIRE(V && U && idx && (Y || stats) && B > 0 && N > 0 && k > 0 && F > 0, DGCNN_EINVAL, "dgcnn_edge_gather_add_f32: bad args");
   DG_REQUIRE(F % 4 == 0 && F <= 1024, DGCNN_EUNSUP, "dgcnn_edge_gather_add_f32: F must be a multiple of 4, <= 1024 (got %d)", F);
   const int64_t rows = (int64_t)B * N * k;
   DG_REQUIRE(rows < (1ll << 31), DGCNN_EUNSUP, "dgcnn_edge_gather_add_f32: B*N*k >= 2^31");
   auto a16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
-  DG_REQUIRE(a16(V) && a16(U) && a16(Y) && ldv % 4 == 0 && ldu % 4 == 0 && ldv >= F && ldu >= F, DGCNN_EINVAL,
+  DG_REQUIRE(a16(V) && a16(U) && (!Y || a16(Y)) && ldv % 4 == 0 && ldu % 4 == 0 && ldv >= F && ldu >= F, DGCNN_EINVAL,
              "dgcnn_edge_gather_add_f32: V, U, Y must be 16-byte aligned with leading dimensions %% 4 == 0");
   const unsigned rp = 256u / (unsigned)(F / 4);
   int64_t g = dg::cdiv(dg::cdiv(rows, 8), (int64_t)rp * 4);      // blocks per XCD so that each thread makes >= 1 trip

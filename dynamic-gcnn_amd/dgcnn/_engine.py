@@ -28,6 +28,8 @@ BN_EPS = 1e-3          # slim.batch_norm default epsilon [TF1-lib]
 DROPOUT_KEEP = 0.7     # tf.nn.dropout(net, 0.7): dgcnn/model.py:91
 WS_BYTES = 256 << 20
 EDGE_MLP_LITERAL = False  # True: conv0 as the literal (B*N*k) x 2C GEMM over E = [x_i, x_j - x_i] (A/B switch)
+EDGE_MATERIALIZE_Y = False  # True: gather-add writes the (B*N*k, F) conv0 output and BatchNorm streams it (A/B switch);
+                            # False: the BatchNorm passes recompute y = V[neighbour] + U[point] (no edge tensor in the forward)
 EDGE_MLP_NBR_GEMM = False  # True: factored conv0 with an edge-level neighbour GEMM instead of point-level GEMM + gather-add
 SCATTER_ATOMICS = False  # True: dx_j += dY W^T by fp32 atomics in the GEMM epilogue (A/B switch)
 
@@ -357,11 +359,12 @@ def edge_conv_block(x, B, N, k, num_filters, relu1=True, outs=None, net2=None):
         w0name, W0 = c.get_variable("weights", (2 * C, F))
         b0name, beta0 = c.get_variable("BatchNorm/beta", (F,))
     idx = knn(x, B, N, k)                                               # ops.py:8-19
-    Y = torch.empty((R * k, F), dtype=torch.float32, device=x.device)
     st = c.stats(F)
     literal = EDGE_MLP_LITERAL
     gather = (not literal) and (not EDGE_MLP_NBR_GEMM) and F % 4 == 0 and F <= 1024
-    wd = wcat = None
+    virtual = gather and not EDGE_MATERIALIZE_Y          # conv0 output never written: recomputed from (V, U, idx)
+    Y = None if virtual else torch.empty((R * k, F), dtype=torch.float32, device=x.device)
+    wd = wcat = UV = None
     if literal:
         H.call("dgcnn_edge_mlp_f32", x.data_ptr(), H.ld2(x), idx.data_ptr(), W0.data_ptr(), B, N, C, k, F,
                Y.data_ptr(), st.data_ptr(), tag="gemm_kernel<A_EDGE,B_ROW,STORE,%d,%d>" % (_tile_m(R * k, F), 64 if F <= 64 else 128),
@@ -375,9 +378,10 @@ def edge_conv_block(x, B, N, k, num_filters, relu1=True, outs=None, net2=None):
         UV = torch.empty((R, 2 * F), dtype=torch.float32, device=x.device)
         gemm(x, wcat, UV)
         H.call("dgcnn_edge_gather_add_f32", UV[:, F:].data_ptr(), 2 * F, UV.data_ptr(), 2 * F, idx.data_ptr(),
-               B, N, k, F, Y.data_ptr(), st.data_ptr(),
-               tag="edge_gather_add_kernel", work=4.0 * (R * k * F + 2 * R * F) + 4.0 * R * k)   # ops.py:21-52
-        del UV
+               B, N, k, F, H._p(Y), st.data_ptr(),
+               tag="edge_gather_add_kernel", work=4.0 * ((0 if virtual else R * k * F) + 2 * R * F) + 4.0 * R * k)   # ops.py:21-52
+        if not virtual:
+            UV = None
     else:
         # factored conv0, edge-level form (kept for odd F and as a cross-check): centre term once per point
         # (U); the per-edge (B*N*k) x C GEMM gathers the neighbour rows and adds U[point] in its epilogue.
@@ -398,9 +402,15 @@ def edge_conv_block(x, B, N, k, num_filters, relu1=True, outs=None, net2=None):
         mm, net_out = outs
     mx, mn = mm[:, :F], mm[:, F:]
     cnt = torch.empty((R, F), dtype=torch.float32, device=x.device) if c.recording else None   # ties of the max
-    H.call("dgcnn_bn_act_kreduce_f32", Y.data_ptr(), R, k, F, mean.data_ptr(), rstd.data_ptr(), beta0.data_ptr(), 1,
-           mx.data_ptr(), H.ld2(mx), mn.data_ptr(), H.ld2(mn), 0, 0, H._p(cnt),
-           tag="bn_act_kreduce_kernel", work=4.0 * (R * k * F + 2 * R * F))   # ops.py:54-58
+    if virtual:
+        esrc = (UV[:, F:].data_ptr(), 2 * F, UV.data_ptr(), 2 * F, idx.data_ptr(), B, N, k, F)
+        H.call("dgcnn_edge_bn_act_kreduce_f32", *esrc, mean.data_ptr(), rstd.data_ptr(), beta0.data_ptr(), 1,
+               mx.data_ptr(), H.ld2(mx), mn.data_ptr(), H.ld2(mn), H._p(cnt),
+               tag="bn_act_kreduce_kernel<edge>", work=4.0 * (4 * R * F) + 4.0 * R * k)   # ops.py:54-58
+    else:
+        H.call("dgcnn_bn_act_kreduce_f32", Y.data_ptr(), R, k, F, mean.data_ptr(), rstd.data_ptr(), beta0.data_ptr(), 1,
+               mx.data_ptr(), H.ld2(mx), mn.data_ptr(), H.ld2(mn), 0, 0, H._p(cnt),
+               tag="bn_act_kreduce_kernel", work=4.0 * (R * k * F + 2 * R * F))   # ops.py:54-58
 
     if c.recording:
         def bwd():
@@ -409,10 +419,17 @@ def edge_conv_block(x, B, N, k, num_filters, relu1=True, outs=None, net2=None):
                 return
             dmx, dmn = dmm[:, :F], dmm[:, F:]
             red = c.stats(F)
-            H.call("dgcnn_bn_bwd_reduce_f32", Y.data_ptr(), R, k, F, mean.data_ptr(), rstd.data_ptr(),
-                   beta0.data_ptr(), 1, dmx.data_ptr(), H.ld2(dmx), dmn.data_ptr(), H.ld2(dmn),
-                   mx.data_ptr(), H.ld2(mx), cnt.data_ptr(), red.data_ptr(),
-                   tag="bn_bwd_reduce_kernel", work=4.0 * (R * k * F + 2 * R * F))
+            if virtual:
+                assert UV is not None          # esrc holds raw pointers into UV: this reference keeps it alive
+                H.call("dgcnn_edge_bn_bwd_reduce_f32", *esrc, mean.data_ptr(), rstd.data_ptr(),
+                       beta0.data_ptr(), 1, dmx.data_ptr(), H.ld2(dmx), dmn.data_ptr(), H.ld2(dmn),
+                       mx.data_ptr(), H.ld2(mx), cnt.data_ptr(), red.data_ptr(),
+                       tag="bn_bwd_reduce_kernel<edge>", work=4.0 * (6 * R * F) + 4.0 * R * k)
+            else:
+                H.call("dgcnn_bn_bwd_reduce_f32", Y.data_ptr(), R, k, F, mean.data_ptr(), rstd.data_ptr(),
+                       beta0.data_ptr(), 1, dmx.data_ptr(), H.ld2(dmx), dmn.data_ptr(), H.ld2(dmn),
+                       mx.data_ptr(), H.ld2(mx), cnt.data_ptr(), red.data_ptr(),
+                       tag="bn_bwd_reduce_kernel", work=4.0 * (R * k * F + 2 * R * F))
             dx = c.grad(x)
             need_sum = (dx is not None) or not literal
             dUV = dysum = None
@@ -421,12 +438,20 @@ def edge_conv_block(x, B, N, k, num_filters, relu1=True, outs=None, net2=None):
                 dysum = dUV[:, :F]
             elif need_sum:
                 dysum = torch.empty((R, F), dtype=torch.float32, device=x.device)
-            H.call("dgcnn_bn_bwd_apply_f32", Y.data_ptr(), R, k, F, mean.data_ptr(), rstd.data_ptr(), beta0.data_ptr(),
-                   1, dmx.data_ptr(), H.ld2(dmx), dmn.data_ptr(), H.ld2(dmn), mx.data_ptr(), H.ld2(mx), cnt.data_ptr(),
-                   red.data_ptr(), Y.data_ptr(),
-                   H._p(dysum), 0 if dysum is None else H.ld2(dysum), c.var_grads[b0name].data_ptr(), 1.0,
-                   tag="bn_bwd_apply_kernel", work=4.0 * (2 * R * k * F + 3 * R * F))
-            dY = Y
+            if virtual:
+                dY = torch.empty((R * k, F), dtype=torch.float32, device=x.device)
+                H.call("dgcnn_edge_bn_bwd_apply_f32", *esrc, mean.data_ptr(), rstd.data_ptr(), beta0.data_ptr(),
+                       1, dmx.data_ptr(), H.ld2(dmx), dmn.data_ptr(), H.ld2(dmn), mx.data_ptr(), H.ld2(mx), cnt.data_ptr(),
+                       red.data_ptr(), dY.data_ptr(),
+                       H._p(dysum), 0 if dysum is None else H.ld2(dysum), c.var_grads[b0name].data_ptr(), 1.0,
+                       tag="bn_bwd_apply_kernel<edge>", work=4.0 * (R * k * F + 7 * R * F) + 4.0 * R * k)
+            else:
+                H.call("dgcnn_bn_bwd_apply_f32", Y.data_ptr(), R, k, F, mean.data_ptr(), rstd.data_ptr(), beta0.data_ptr(),
+                       1, dmx.data_ptr(), H.ld2(dmx), dmn.data_ptr(), H.ld2(dmn), mx.data_ptr(), H.ld2(mx), cnt.data_ptr(),
+                       red.data_ptr(), Y.data_ptr(),
+                       H._p(dysum), 0 if dysum is None else H.ld2(dysum), c.var_grads[b0name].data_ptr(), 1.0,
+                       tag="bn_bwd_apply_kernel", work=4.0 * (2 * R * k * F + 3 * R * F))
+                dY = Y
             ws = c.workspace()
             dW0 = c.var_grads[w0name]
 

@@ -40,6 +40,13 @@ PROTOTYPES = {
     "dgcnn_edge_weight_split_f32": [c_vp, c_int, c_int, c_vp, c_vp],
     "dgcnn_edge_gather_add_f32": [c_vp, c_i64, c_vp, c_i64, c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp],
     "dgcnn_edge_wgrad_combine_f32": [c_vp, c_int, c_int, c_vp, c_vp],
+    "dgcnn_edge_bn_act_kreduce_f32": [c_vp, c_i64, c_vp, c_i64, c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp,
+                                      c_int, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp],
+    "dgcnn_edge_bn_bwd_reduce_f32": [c_vp, c_i64, c_vp, c_i64, c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp,
+                                     c_int, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp],
+    "dgcnn_edge_bn_bwd_apply_f32": [c_vp, c_i64, c_vp, c_i64, c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp,
+                                    c_int, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp,
+                                    c_f32, c_vp],
     "dgcnn_gemm_set_arith": [c_int],
     "dgcnn_gemm_get_arith": [],
     "dgcnn_gemm_f32": [c_int, c_int, c_int, c_int, c_int, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_f32,

@@ -110,6 +110,29 @@ int dgcnn_edge_weight_split_f32(const float* W0, int C, int F, float* Wcat, void
 int dgcnn_edge_gather_add_f32(const float* V, int64_t ldv, const float* U, int64_t ldu, const int32_t* idx,
                               int B, int N, int k, int F, float* Y, double* stats, void* stream);
 int dgcnn_edge_wgrad_combine_f32(const float* dWcat, int C, int F, float* dW0, void* stream);
+/* Y may be NULL in dgcnn_edge_gather_add_f32 (column sums only).  The three BatchNorm passes below are
+ * dgcnn_bn_act_kreduce_f32 / _bwd_reduce_f32 / _bwd_apply_f32 with the k rows of point (b,i) RECOMPUTED as
+ * V[b, idx[b,i,m], :] + U[b,i,:] instead of read from a (B*N*k, F) tensor: the forward then writes no edge
+ * tensor to HBM at all and the backward only dY (which the transposed-adjacency sum needs).  Same argument
+ * meaning as their dense counterparts (see below); dY is (B*N*k, F) dense.                           */
+int dgcnn_edge_bn_act_kreduce_f32(const float* V, int64_t ldv, const float* U, int64_t ldu,
+                                  const int32_t* idx, int B, int N, int k, int F,
+                                  const float* mean, const float* rstd, const float* beta, int relu,
+                                  float* max_out, int64_t ldmax, float* mean_out, int64_t ldmean,
+                                  float* cnt_out, void* stream);
+int dgcnn_edge_bn_bwd_reduce_f32(const float* V, int64_t ldv, const float* U, int64_t ldu,
+                                 const int32_t* idx, int B, int N, int k, int F,
+                                 const float* mean, const float* rstd, const float* beta, int relu,
+                                 const float* dmax, int64_t lddmax, const float* dmean, int64_t lddmean,
+                                 const float* mx_in, int64_t ldmx, const float* cnt_in,
+                                 double* red, void* stream);
+int dgcnn_edge_bn_bwd_apply_f32(const float* V, int64_t ldv, const float* U, int64_t ldu,
+                                const int32_t* idx, int B, int N, int k, int F,
+                                const float* mean, const float* rstd, const float* beta, int relu,
+                                const float* dmax, int64_t lddmax, const float* dmean, int64_t lddmean,
+                                const float* mx_in, int64_t ldmx, const float* cnt_in,
+                                double* red, float* dY, float* dYsum, int64_t lddysum, float* dbeta,
+                                float dbeta_beta, void* stream);
 
 /* ---- plain fp32 MFMA GEMM: every other slim.conv2d 1x1 (ops.py:62-70,125-133,153-160;
  * model.py:46-53,65-72,94-101) and their dgrad / wgrad --------------------------------------

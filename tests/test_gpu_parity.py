@@ -310,21 +310,23 @@ def test_edge_conv_forward_backward(dg, B, N, C, k, F):
 
 
 @pytest.mark.parametrize("B,N,C,k,F", [(2, 192, 64, 12, 64), (2, 160, 3, 9, 48), (1, 256, 64, 20, 128)])
-def test_edge_mlp_three_forms_agree(dg, B, N, C, k, F):
-    """conv0 is issued as point-level GEMM [U|V] = X [Wa-Wb | Wb] + per-edge gather-add (default); the
-    edge-level factored GEMM and the literal (B*N*k) x 2C GEMM over E = [x_i, x_j - x_i] stay behind
-    switches.  Same outputs and gradients from all three."""
+def test_edge_mlp_forms_agree(dg, B, N, C, k, F):
+    """conv0 is issued as point-level GEMM [U|V] = X [Wa-Wb | Wb] and its (B*N*k, F) output is never written:
+    the BatchNorm passes recompute V[neighbour] + U[point] (default).  Materialising it with the gather-add
+    kernel, the edge-level factored GEMM and the literal (B*N*k) x 2C GEMM over E = [x_i, x_j - x_i] stay
+    behind switches.  Same outputs and gradients from all four."""
     from dgcnn import _engine as E
     rng = np.random.default_rng(21)
     pts = rng.normal(size=(B, N, C)).astype(np.float32)
     W = {"conv0/weights": rng.normal(0, 0.3, (2 * C, F)).astype(np.float32), "conv0/BatchNorm/beta": rng.normal(0, 0.2, F).astype(np.float32),
          "conv1/weights": rng.normal(0, 0.3, (2 * F, 64)).astype(np.float32), "conv1/BatchNorm/beta": rng.normal(0, 0.2, 64).astype(np.float32)}
     res = {}
-    for form in ("literal", "nbr_gemm", "gather"):
+    for form in ("literal", "nbr_gemm", "gather_y", "gather"):
         dg.reset()
         c = dg.ctx()
         E.EDGE_MLP_LITERAL = form == "literal"
         E.EDGE_MLP_NBR_GEMM = form == "nbr_gemm"
+        E.EDGE_MATERIALIZE_Y = form == "gather_y"
         try:
             c.begin_step()
             c.recording = True
@@ -342,9 +344,76 @@ def test_edge_mlp_three_forms_agree(dg, B, N, C, k, F):
         finally:
             E.EDGE_MLP_LITERAL = False
             E.EDGE_MLP_NBR_GEMM = False
-    for form in ("nbr_gemm", "gather"):
+            E.EDGE_MATERIALIZE_Y = False
+    for a, b in zip(res["gather_y"][:3], res["gather"][:3]):      # same y = V + U, written or recomputed: same forward
+        np.testing.assert_allclose(a, b, rtol=0, atol=1e-5)       # (up to the fp64-atomic order of the BN sums)
+    for form in ("nbr_gemm", "gather_y", "gather"):
         for a, b in zip(res["literal"], res[form]):
             np.testing.assert_allclose(a, b, rtol=2e-3, atol=2e-4 * max(1.0, float(np.abs(a).max())), err_msg=form)
+
+
+@pytest.mark.parametrize("B,N,k,F", [(2, 100, 7, 64), (3, 64, 20, 128), (1, 130, 5, 48), (2, 50, 1, 8), (9, 40, 6, 16)])
+def test_edge_bn_passes_equal_dense_passes(dg, B, N, k, F):
+    """dgcnn_edge_bn_* recompute y = V[idx] + U instead of reading Y: against the dense kernels on the
+    materialised Y the forward outputs and dY are bit-identical and the reductions agree to fp64 round-off."""
+    from dgcnn import _hip as H
+    rng = np.random.default_rng(B * 100 + F)
+    R = B * N
+    UV = dev(rng.normal(size=(R, 2 * F)).astype(np.float32))
+    idx = dev(rng.integers(0, N, (B, N, k)).astype(np.int32))
+    e = (UV[:, F:].data_ptr(), 2 * F, UV.data_ptr(), 2 * F, idx.data_ptr(), B, N, k, F)
+    Y = torch.empty((R * k, F), device="cuda")
+    H.call("dgcnn_edge_gather_add_f32", *e, Y.data_ptr(), 0)
+    mean, rstd, beta = (dev(rng.normal(0, 0.3, F).astype(np.float32)), dev((0.5 + rng.random(F)).astype(np.float32)),
+                        dev(rng.normal(0, 0.3, F).astype(np.float32)))
+    outs = []
+    for edge in (False, True):
+        mm = torch.zeros((R, 2 * F + 4), device="cuda")                  # max | mean inside a wider buffer
+        mx, mn = mm[:, :F], mm[:, F:2 * F]
+        cnt = torch.zeros((R, F), device="cuda")
+        if edge:
+            H.call("dgcnn_edge_bn_act_kreduce_f32", *e, mean.data_ptr(), rstd.data_ptr(), beta.data_ptr(), 1,
+                   mx.data_ptr(), H.ld2(mx), mn.data_ptr(), H.ld2(mn), cnt.data_ptr())
+        else:
+            H.call("dgcnn_bn_act_kreduce_f32", Y.data_ptr(), R, k, F, mean.data_ptr(), rstd.data_ptr(), beta.data_ptr(), 1,
+                   mx.data_ptr(), H.ld2(mx), mn.data_ptr(), H.ld2(mn), 0, 0, cnt.data_ptr())
+        outs.append((host(mm).copy(), host(cnt).copy()))
+    np.testing.assert_array_equal(outs[0][0], outs[1][0])
+    np.testing.assert_array_equal(outs[0][1], outs[1][1])
+    assert outs[0][1].min() >= 1 and outs[0][1].max() <= k
+    mx = dev(outs[0][0][:, :F].copy())
+    cnt = dev(outs[0][1])
+    dmx, dmn = dev(rng.normal(size=(R, F)).astype(np.float32)), dev(rng.normal(size=(R, F)).astype(np.float32))
+    reds, dys = [], []
+    for edge in (False, True):
+        red = torch.zeros((H.STAT_SLOTS, 2, F), dtype=torch.float64, device="cuda")
+        args = (mean.data_ptr(), rstd.data_ptr(), beta.data_ptr(), 1, dmx.data_ptr(), F, dmn.data_ptr(), F,
+                mx.data_ptr(), F, cnt.data_ptr())
+        if edge:
+            H.call("dgcnn_edge_bn_bwd_reduce_f32", *e, *args, red.data_ptr())
+        else:
+            H.call("dgcnn_bn_bwd_reduce_f32", Y.data_ptr(), R, k, F, *args, red.data_ptr())
+        reds.append(host(red).sum(0))
+    np.testing.assert_allclose(reds[0], reds[1], rtol=1e-6, atol=1e-4)
+    red0 = torch.zeros((H.STAT_SLOTS, 2, F), dtype=torch.float64, device="cuda")
+    red0[0] = dev(reds[0])
+    for edge in (False, True):
+        red = red0.clone()
+        dY = torch.empty((R * k, F), device="cuda")
+        dsum = torch.zeros((R, F + 4), device="cuda")
+        dbeta = torch.zeros(F, device="cuda")
+        tail = (red.data_ptr(), dY.data_ptr(), dsum.data_ptr(), F + 4, dbeta.data_ptr(), 0.0)
+        if edge:
+            H.call("dgcnn_edge_bn_bwd_apply_f32", *e, *args, *tail)
+        else:
+            H.call("dgcnn_bn_bwd_apply_f32", Y.data_ptr(), R, k, F, *args, *tail)
+        dys.append((host(dY).copy(), host(dsum).copy(), host(dbeta).copy()))
+    for a, b in zip(dys[0], dys[1]):
+        np.testing.assert_array_equal(a, b)
+    assert np.abs(dys[0][1][:, F:]).max() == 0
+    with pytest.raises(H.HipError):
+        H.call("dgcnn_edge_bn_bwd_reduce_f32", UV[:, F:].data_ptr(), 2 * F, UV.data_ptr(), 2 * F, idx.data_ptr(), B, N, k, 6,
+               *args, red0.data_ptr())
 
 
 @pytest.mark.parametrize("B,N,k,F,ld", [(2, 100, 7, 64, 128), (3, 64, 20, 128, 256), (1, 130, 5, 48, 100), (2, 50, 3, 4, 8)])
@@ -372,6 +441,11 @@ def test_edge_gather_add_and_weight_fold(dg, B, N, k, F, ld):
     H.call("dgcnn_edge_gather_add_f32", d_uv[:, F:].data_ptr(), ld, d_uv.data_ptr(), ld, d_idx.data_ptr(), B, N, k, F,
            Y.data_ptr(), 0)
     np.testing.assert_array_equal(host(Y).reshape(B, N, k, F), ref)
+    # no Y requested: column sums only
+    st.zero_()
+    H.call("dgcnn_edge_gather_add_f32", d_uv[:, F:].data_ptr(), ld, d_uv.data_ptr(), ld, d_idx.data_ptr(), B, N, k, F,
+           0, st.data_ptr())
+    np.testing.assert_allclose(host(st).sum(0)[0], r64.sum(0), rtol=1e-5, atol=1e-3)
 
     C = 5
     W0 = rng.normal(size=(2 * C, F)).astype(np.float32)
