@@ -243,9 +243,24 @@ __global__ __launch_bounds__(NT, 2) void gemm_x3_kernel(GemmP p) {
 #pragma unroll
   for (int j = 0; j < TN; ++j) b_off[j] = IB::at(wc * (BN / 2) + j * 32 + l31, lh);
 
+#if X3_ABLATE == 8 || X3_ABLATE == 9
+  bf16x8 a[TM][3], b[TN][3];     // experiments: operands read once (8: random-ish data, 9: zeros), MFMAs only
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) a[i][q][e] = (X3_ABLATE == 9) ? (__bf16)0.f : (__bf16)(float)(p.A[(t * 8 + e + q * 2048 + i * 77) & 0xffff]);
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) b[j][q][e] = (X3_ABLATE == 9) ? (__bf16)0.f : (__bf16)(float)(p.B[(t * 8 + e + q * 2048 + j * 131) & 0xffff]);
+  }
+#endif
   auto mfma_slab = [&]() {
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
+#if !(X3_ABLATE == 8 || X3_ABLATE == 9)
       bf16x8 a[TM][3], b[TN][3];
 #pragma unroll
       for (int q = 0; q < 3; ++q) {
@@ -256,6 +271,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_x3_kernel(GemmP p) {
         for (int j = 0; j < TN; ++j)
           b[j][q] = *reinterpret_cast<const bf16x8*>(Bs + q * IB::PB + b_off[j] + 2 * s * IB::CS);
       }
+#endif
       // partial products, largest first: (1,1) (1,2) (2,1) (2,2) (1,3) (3,1) [(2,3) (3,2) (3,3)]
       constexpr int PA[9] = {0, 0, 1, 1, 0, 2, 1, 2, 2};
       constexpr int PB[9] = {0, 1, 0, 1, 2, 0, 2, 1, 2};
@@ -304,7 +320,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_x3_kernel(GemmP p) {
       __syncthreads();
       if (kt + 1 < nk) do_write();
       __syncthreads();
-#elif X3_ABLATE == 1                            // experiments (wrong results): LDS reads + MFMAs only
+#elif X3_ABLATE == 1 || X3_ABLATE == 8 || X3_ABLATE == 9   // experiments (wrong results): LDS reads + MFMAs only / MFMAs only
       mfma_slab();
 #elif X3_ABLATE == 2                            // + barriers
       mfma_slab();

@@ -4,6 +4,7 @@
 // residual add+relu (ops.py:134), strided copies (tf.concat), softmax / CE / accuracy
 // (trainval.py:39-52), gradient accumulation and Adam (trainval.py:17,75-80).
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -90,6 +91,60 @@ __global__ void csr_fill_kernel(const int32_t* __restrict__ idx, int N, int k, i
     const unsigned tgt = (g / (unsigned)N) * (unsigned)N + idx[e];
     const int pos = off[tgt] + atomicAdd(cur + tgt, 1);
     rev[pos] = (int32_t)e;
+  }
+}
+
+// The same counting sort with the histogram and the cursors in LDS (LDS atomics instead of ~2 N k global ones):
+// block (g, b) owns the targets [g*T, (g+1)*T) of cloud b, scans all N*k neighbour indices of the cloud twice
+// (they are L2-resident: 4 N k bytes) and keeps only its own range.  Used when T fits in LDS.
+__global__ __launch_bounds__(1024) void csr_cloud_kernel(const int32_t* __restrict__ idx, int N, int k, int T,
+                                                         int32_t* __restrict__ off, int32_t* __restrict__ rev) {
+  extern __shared__ int sh[];          // [T] histogram -> cursors, [1024] scan partials, [1] edges below the range
+  int* hist = sh;
+  int* part = sh + T;
+  int* below = part + 1024;
+  const int b = blockIdx.y, g = blockIdx.x, t = threadIdx.x;
+  const int t0 = g * T, t1 = (t0 + T < N) ? (t0 + T) : N;
+  const int Me = N * k;
+  const int32_t* ib = idx + (int64_t)b * Me;
+  for (int i = t; i < T; i += 1024) hist[i] = 0;
+  if (t == 0) *below = 0;
+  __syncthreads();
+  int lo = 0;
+  for (int e = t; e < Me; e += 1024) {
+    const int j = ib[e];
+    if (j < t0) ++lo;
+    else if (j < t1) atomicAdd(&hist[j - t0], 1);
+  }
+  for (int d = 32; d > 0; d >>= 1) lo += __shfl_down(lo, d, 64);
+  if ((t & 63) == 0 && lo) atomicAdd(below, lo);
+  __syncthreads();
+  // exclusive scan of hist[0..T): per-thread slices, Hillis-Steele over the 1024 slice sums
+  const int per = (T + 1023) / 1024;
+  const int s0 = t * per, s1 = (s0 + per < T) ? (s0 + per) : T;
+  int sum = 0;
+  for (int i = s0; i < s1; ++i) sum += hist[i];
+  part[t] = sum;
+  __syncthreads();
+  for (int d = 1; d < 1024; d <<= 1) {
+    const int v = (t >= d) ? part[t - d] : 0;
+    __syncthreads();
+    part[t] += v;
+    __syncthreads();
+  }
+  int run = *below + part[t] - sum;                 // position inside the cloud of this slice's first bucket
+  const int64_t cb = (int64_t)b * Me;
+  for (int i = s0; i < s1; ++i) {
+    const int c = hist[i];
+    if (t0 + i < N) off[(int64_t)b * N + t0 + i] = (int32_t)(cb + run);
+    hist[i] = run;                                  // becomes the bucket's cursor
+    run += c;
+  }
+  if (b == gridDim.y - 1 && g == gridDim.x - 1 && t == 1023) off[(int64_t)gridDim.y * N] = (int32_t)((int64_t)gridDim.y * Me);
+  __syncthreads();
+  for (int e = t; e < Me; e += 1024) {
+    const int j = ib[e];
+    if (j >= t0 && j < t1) rev[cb + atomicAdd(&hist[j - t0], 1)] = (int32_t)(cb + e);
   }
 }
 
@@ -401,7 +456,20 @@ extern "C" int dgcnn_edge_csr_build(const int32_t* idx, int B, int N, int k, int
   DG_REQUIRE(idx && cnt_ws && off && rev && B > 0 && N > 0 && k > 0, DGCNN_EINVAL, "dgcnn_edge_csr_build: bad args");
   const int64_t Me = (int64_t)B * N * k;
   DG_REQUIRE(Me < (1ll << 31), DGCNN_EUNSUP, "dgcnn_edge_csr_build: B*N*k >= 2^31");
-  hipMemsetAsync(cnt_ws, 0, sizeof(int32_t) * 2 * (size_t)B * N, ST);      // [counts | cursors]
+  {
+    // LDS variant: split every cloud's targets over G blocks so that ~256 blocks run and a range fits in LDS
+    int G = 1;
+    while (G < 64 && ((int64_t)B * G < 256 || dg::cdiv(N, G) > 12288) && dg::cdiv(N, G * 2) >= 64) G *= 2;
+    const int T = (int)dg::cdiv(N, G);
+    static int use_lds = -1;
+    if (use_lds < 0) { const char* e = getenv("DGCNN_CSR_GLOBAL"); use_lds = (e && e[0] == '1') ? 0 : 1; }   // A/B switch
+    if (use_lds && T <= 12288) {     // <= 52 KB of dynamic LDS
+      const size_t sh = sizeof(int) * ((size_t)T + 1024 + 1);
+      hipLaunchKernelGGL(csr_cloud_kernel, dim3((unsigned)dg::cdiv(N, T), (unsigned)B), dim3(1024), sh, ST, idx, N, k, T, off, rev);
+      return dg::check_launch("dgcnn_edge_csr_build");
+    }
+  }
+  (void)hipMemsetAsync(cnt_ws, 0, sizeof(int32_t) * 2 * (size_t)B * N, ST);      // [counts | cursors]
   hipLaunchKernelGGL(csr_count_kernel, dim3(grid1d(Me)), dim3(256), 0, ST, idx, N, k, Me, cnt_ws);
   hipLaunchKernelGGL(csr_scan_kernel, dim3((unsigned)B), dim3(1024), 0, ST, cnt_ws, N, k, off);
   hipLaunchKernelGGL(csr_fill_kernel, dim3(grid1d(Me)), dim3(256), 0, ST, idx, N, k, Me, off, cnt_ws + (size_t)B * N, rev);

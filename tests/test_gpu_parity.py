@@ -416,6 +416,36 @@ def test_edge_bn_passes_equal_dense_passes(dg, B, N, k, F):
                *args, red0.data_ptr())
 
 
+@pytest.mark.parametrize("B,N,k", [(2, 100, 7), (24, 2048, 20), (1, 40000, 3), (3, 64, 1), (5, 777, 13), (1, 70000, 2)])
+def test_edge_csr_build_and_incoming_sum(dg, B, N, k):
+    """Transposed adjacency (who points at me): off is the exclusive prefix of the in-degrees, bucket j of rev
+    holds exactly the edges whose neighbour is j (any order), and the gather-sum over it equals tf.gather^T."""
+    from dgcnn import _hip as H
+    rng = np.random.default_rng(N + k)
+    idx = rng.integers(0, N, (B, N, k)).astype(np.int32)
+    idx[0, :, 0] = 0 if N < 1000 else idx[0, :, 0]                      # a very popular target
+    d_idx = dev(idx)
+    R = B * N
+    cws = torch.zeros(2 * R, dtype=torch.int32, device="cuda")
+    off = torch.full((R + 1,), -1, dtype=torch.int32, device="cuda")
+    rev = torch.full((R * k,), -1, dtype=torch.int32, device="cuda")
+    H.call("dgcnn_edge_csr_build", d_idx.data_ptr(), B, N, k, cws.data_ptr(), off.data_ptr(), rev.data_ptr())
+    tgt = (idx.reshape(B, N * k).astype(np.int64) + (np.arange(B) * N)[:, None]).reshape(-1)     # global target of every edge
+    deg = np.bincount(tgt, minlength=R)
+    want_off = np.concatenate([[0], np.cumsum(deg)])
+    np.testing.assert_array_equal(host(off), want_off)
+    r = host(rev).astype(np.int64)
+    assert np.array_equal(np.sort(r), np.arange(R * k))                 # a permutation of the edges
+    np.testing.assert_array_equal(tgt[r], np.repeat(np.arange(R), deg))  # bucket j holds only edges pointing at j
+    F = 8
+    dY = rng.normal(size=(R * k, F)).astype(np.float32)
+    S = torch.empty((R, F), device="cuda")
+    H.call("dgcnn_edge_gather_sum_f32", dev(dY).data_ptr(), off.data_ptr(), rev.data_ptr(), R, F, S.data_ptr(), F)
+    want = np.zeros((R, F))
+    np.add.at(want, tgt, dY.astype(np.float64))
+    np.testing.assert_allclose(host(S), want, rtol=1e-5, atol=1e-4)
+
+
 @pytest.mark.parametrize("B,N,k,F,ld", [(2, 100, 7, 64, 128), (3, 64, 20, 128, 256), (1, 130, 5, 48, 100), (2, 50, 3, 4, 8)])
 def test_edge_gather_add_and_weight_fold(dg, B, N, k, F, ld):
     """Y[b,i,m] = V[b, idx[b,i,m]] + U[b,i] with BatchNorm column sums; Wcat = [Wa-Wb | Wb] and its
@@ -559,7 +589,7 @@ def test_model_logits_and_gradients(dg, cfg):
         err = np.abs(g - ref)
         # (summation orders are not run-to-run deterministic -- fp64 stat atomics, CSR fill order -- so WHICH
         # decisions flip varies: allow 0.1 % of the elements up to 1e-1 of the scale, the rest 2e-2)
-        assert (err <= 2e-2 * scale + 2e-2 * np.abs(ref)).mean() >= 0.999, n
+        assert (err > 2e-2 * scale + 2e-2 * np.abs(ref)).sum() <= max(2, 1e-3 * err.size), n      # (2 elements of a small tensor)
         assert err.max() <= 1e-1 * scale, n
         assert np.linalg.norm(g - ref) <= 2e-2 * max(np.linalg.norm(ref), 1e-6), n
 
