@@ -171,7 +171,7 @@ def main():
         if is_gemm:
             achieved = work / secs / 1e12          # algorithmic fp32 flops (2 M N K per GEMM)
             peak, note = PEAK_F32_MFMA_TFLOPS, "fp32 MFMA dense peak"
-            if dominant.startswith("gemm_x3"):
+            if dominant.startswith("gemm_x3"):      # gemm_x3_kernel / gemm_x3w2_kernel
                 # fp32 GEMM computed as NP exact bf16 partial products on the bf16 matrix pipe (gemm_x3.hip):
                 # the ceiling for ALGORITHMIC fp32 flops is the bf16 dense peak / NP
                 nprod = int(dominant.rstrip(">").split("bf16x")[1])

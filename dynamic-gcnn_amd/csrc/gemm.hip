@@ -759,8 +759,8 @@ int launch(GemmP& p, hipStream_t st, const char* what) {
   }
   constexpr bool dma_kind = (ASRC == A_ROW || ASRC == A_COL) && EPI == E_STORE;
   if (dma_kind && vec && dg::gemm_arith() != 0) {          // bf16-split kernel (gemm_x3.hip)
-    p.bm = 128;
-    p.mtiles = (int)dg::cdiv(p.M, 128);
+    p.bm = dg::x3_tile_m(p.M, p.N);
+    p.mtiles = (int)dg::cdiv(p.M, p.bm);
     p.ntiles = (int)dg::cdiv(p.N, bn);
     p.xcd_group = (p.ntiles > 1 && p.mtiles >= 16 && p.splits == 1) ? 1 : 0;
     dg::launch_gemm_x3(ASRC, BSRC, &p, st, bn, dg::gemm_arith());
@@ -794,8 +794,10 @@ inline bool aligned16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 
 int plan_splits(GemmP& p, void* ws, size_t ws_bytes, const char* what) {
   const int bn = (p.N <= 64) ? 64 : 128;
   p.bm = 128;
-  const int64_t tiles = dg::cdiv(p.M, p.bm) * dg::cdiv(p.N, bn);
-  int64_t s = dg::cdiv(1024, tiles);
+  // the 256-row bf16-split kernel runs one 768-thread workgroup per CU: aim at 2 rounds of 256 workgroups
+  const bool big = dg::gemm_arith() != 0 && p.avec && p.bvec && dg::x3_tile_m(p.M, p.N) == 256;
+  const int64_t tiles = dg::cdiv(p.M, big ? 256 : 128) * dg::cdiv(p.N, bn);
+  int64_t s = dg::cdiv(big ? 512 : 1024, tiles);
   const int64_t maxs = p.K / 256 > 0 ? p.K / 256 : 1;
   if (s > maxs) s = maxs;
   if (s < 1) s = 1;

@@ -49,11 +49,12 @@ __device__ __forceinline__ float4 sub4(float4 a, float4 b) { return make_float4(
 __device__ __forceinline__ int imin(int a, int b) { return a < b ? a : b; }
 
 // ---- shared epilogue.  C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-template <int EPI, int BM, int BN, bool VEC, int TM, int TN>
+// WR = wave rows of the block (each wave owns BM/WR rows as TM 32-row tiles), NTH = threads taking part.
+template <int EPI, int BM, int BN, bool VEC, int TM, int TN, int WR = 2, int NTH = NT>
 __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[TM][TN], float* smem, int m0, int n0,
                                               int mt, int z, int t, int wr, int wc, int l31, int lh) {
   const int colw = n0 + wc * (BN / 2) + l31;
-  const int roww = m0 + wr * (BM / 2) + 4 * lh;
+  const int roww = m0 + wr * (BM / WR) + 4 * lh;
   if (EPI == E_SCATTER) {
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -76,9 +77,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[TM][
   // ---- E_STORE: accumulators -> LDS (64 block rows at a time) -> coalesced float4 row stores.
   // Keeps the epilogue at one global_store_dwordx4 per 4 outputs, lets the read-modify-write
   // (beta) and the per-cloud bias be float4 loads, and needs no per-row pointer registers.
-  float* tile = smem;                       // [64][BN]
+  float* tile = smem;                       // [WR*32][BN]
   constexpr int QV = BN / 4;                // float4 per row
-  constexpr int RSTEP = NT / QV;            // rows covered per pass of the 256 threads
+  constexpr int RSTEP = NTH / QV;           // rows covered per pass of the NTH threads
   const int c4 = (t % QV) * 4;
   const int rr0 = t / QV;
   const int gcol = n0 + c4;
@@ -108,9 +109,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[TM][
         tile[(wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * BN + wc * (BN / 2) + j * 32 + l31] = acc[i][j][r];
     __syncthreads();
 #pragma unroll
-    for (int q0 = 0; q0 < 64 / RSTEP; ++q0) {
+    for (int q0 = 0; q0 < (WR * 32) / RSTEP; ++q0) {
       const int rl = rr0 + q0 * RSTEP;
-      const int grow = m0 + (rl >> 5) * (BM / 2) + i * 32 + (rl & 31);
+      const int grow = m0 + (rl >> 5) * (BM / WR) + i * 32 + (rl & 31);
       if (grow < p.M && col_ok) {
         const float4 tv = *reinterpret_cast<const float4*>(&tile[rl * BN + c4]);
         float v[4] = {tv.x, tv.y, tv.z, tv.w};
@@ -158,7 +159,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[TM][
   if (p.stats && !split) {
     __syncthreads();
     float* red = smem;  // [2][BN]
-    for (int e = t; e < 2 * BN; e += NT) red[e] = 0.f;
+    for (int e = t; e < 2 * BN; e += NTH) red[e] = 0.f;
     __syncthreads();
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -167,7 +168,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[TM][
     }
     __syncthreads();
     const int slot = mt % DGCNN_STAT_SLOTS;
-    for (int e = t; e < 2 * BN; e += NT) {
+    for (int e = t; e < 2 * BN; e += NTH) {
       const int which = e / BN, c = n0 + (e % BN);
       if (c < p.N) atomicAdd(p.stats + ((int64_t)slot * 2 + which) * p.N + c, (double)red[e]);
     }

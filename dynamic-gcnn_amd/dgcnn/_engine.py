@@ -268,8 +268,11 @@ def gemm(A, Bm, C, transA=False, transB=False, beta=0.0, gbias=None, rpg=0, stat
         arith = H.gemm_arith()
         bn = 64 if N <= 64 else 128
         if vec and arith:
-            tag = "gemm_x3_kernel<%s,%s,%d,bf16x%d>" % ("KSTRIDED" if transA else "KCONTIG",
-                                                         "KCONTIG" if transB else "KSTRIDED", bn, arith)
+            kinds = ("KSTRIDED" if transA else "KCONTIG", "KCONTIG" if transB else "KSTRIDED")
+            if M > 128 and N > 64:           # dg::x3_tile_m: 256 x 128 wave-specialised kernel
+                tag = "gemm_x3w2_kernel<%s,%s,bf16x%d>" % (kinds + (arith,))
+            else:
+                tag = "gemm_x3_kernel<%s,%s,%d,bf16x%d>" % (kinds + (bn, arith))
         else:
             tag = "gemm_kernel<%s,%s,STORE,%d,%d>" % ("A_COL" if transA else "A_ROW", "B_COL" if transB else "B_ROW",
                                                       _tile_m(M, N), bn)

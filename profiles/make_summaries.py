@@ -28,6 +28,10 @@ def tag_of(name):
     if m:
         return "gemm_kernel<%s,%s,%s,%s,%s>" % (AS[int(m.group(1))], BS[int(m.group(2))], EP[int(m.group(3))],
                                                   m.group(4), m.group(5))
+    m = re.match(r"gemm_x3w2_kernel<(\d), (\d), (\d+)>", n)
+    if m:
+        kinds = {0: "KCONTIG", 1: "KSTRIDED"}
+        return "gemm_x3w2_kernel<%s,%s,bf16x%s>" % (kinds[int(m.group(1))], kinds[int(m.group(2))], m.group(3))
     m = re.match(r"gemm_x3_kernel<(\d), (\d), (\d+), (\d+)>", n)
     if m:
         kinds = {0: "KCONTIG", 1: "KSTRIDED"}
