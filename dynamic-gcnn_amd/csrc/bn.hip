@@ -91,7 +91,10 @@ struct Src {
   unsigned npts;
 };
 
-constexpr int NB = 4;    // rows in flight per lane
+#ifndef BN_NB
+#define BN_NB 4
+#endif
+constexpr int NB = BN_NB;    // rows in flight per lane
 
 template <int V, bool G>
 struct Rows {

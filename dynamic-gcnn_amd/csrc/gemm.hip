@@ -845,6 +845,12 @@ extern "C" int dgcnn_gemm_f32(int transA, int transB, int M, int N, int K,
     return launch<A_COL, B_ROW, E_STORE>(p, st, "dgcnn_gemm_f32(TN)");
   }
   p.bm = tile_m(M, N, 1);
+  // a handful of output tiles with a long reduction (per-cloud rows: M = B): split K so the chip is not idle
+  if (!gbias && !stats && ws && K >= 512 && dg::cdiv(M, 128) * dg::cdiv(N, 128) <= 32) {
+    int rc = plan_splits(p, ws, ws_bytes, "dgcnn_gemm_f32");
+    if (rc) return rc;
+    p.bm = 128;
+  }
   if (transB) return launch<A_ROW, B_COL, E_STORE>(p, st, "dgcnn_gemm_f32(NT)");
   return launch<A_ROW, B_ROW, E_STORE>(p, st, "dgcnn_gemm_f32(NN)");
 }

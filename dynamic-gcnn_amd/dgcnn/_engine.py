@@ -376,10 +376,19 @@ def edge_conv_block(x, B, N, k, num_filters, relu1=True, outs=None, net2=None):
         # conv0 is linear: E W0 = x_i (Wa-Wb) + x_j Wb = U[i] + V[j] with [U | V] = X [Wa-Wb | Wb] -- ONE
         # point-level GEMM (k times fewer MACs than the edge tensor product), then a per-edge gather-add
         # bound by the HBM write of Y, which also takes the BatchNorm column sums.
-        wcat = torch.empty((C, 2 * F), dtype=torch.float32, device=x.device)
+        # C = 3 (raw coordinates): pad the reduction dimension to 4 with a zero column / zero weight row so that
+        # the point-level GEMMs take the float4 path (the generic scalar kernel costs ~10x more on them)
+        Cp = (C + 3) // 4 * 4
+        xg = x
+        if Cp != C:
+            xg = torch.zeros((R, Cp), dtype=torch.float32, device=x.device)
+            H.call("dgcnn_copy2d_f32", x.data_ptr(), H.ld2(x), xg.data_ptr(), Cp, R, C, 0)
+            wcat = torch.zeros((Cp, 2 * F), dtype=torch.float32, device=x.device)
+        else:
+            wcat = torch.empty((C, 2 * F), dtype=torch.float32, device=x.device)
         H.call("dgcnn_edge_weight_split_f32", W0.data_ptr(), C, F, wcat.data_ptr())
         UV = torch.empty((R, 2 * F), dtype=torch.float32, device=x.device)
-        gemm(x, wcat, UV)
+        gemm(xg, wcat, UV)
         H.call("dgcnn_edge_gather_add_f32", UV[:, F:].data_ptr(), 2 * F, UV.data_ptr(), 2 * F, idx.data_ptr(),
                B, N, k, F, H._p(Y), st.data_ptr(),
                tag="edge_gather_add_kernel", work=4.0 * ((0 if virtual else R * k * F) + 2 * R * F) + 4.0 * R * k)   # ops.py:21-52
@@ -470,11 +479,11 @@ def edge_conv_block(x, B, N, k, num_filters, relu1=True, outs=None, net2=None):
             if gather:
                 # dU = sum_m dY, dV = sum of incoming dY;  dWcat = X^T [dU|dV],  dx += [dU|dV] Wcat^T
                 incoming_sum(dUV[:, F:])
-                dwcat = torch.empty((C, 2 * F), dtype=torch.float32, device=x.device)
-                gemm(x, dUV, dwcat, transA=True)
+                dwcat = torch.empty((Cp, 2 * F), dtype=torch.float32, device=x.device)
+                gemm(xg, dUV, dwcat, transA=True)
                 H.call("dgcnn_edge_wgrad_combine_f32", dwcat.data_ptr(), C, F, dW0.data_ptr())
                 if dx is not None:
-                    gemm(dUV, wcat, dx, transB=True, beta=1.0)
+                    gemm(dUV, wcat[:C], dx, transB=True, beta=1.0)
                 return
             if literal:
                 H.call("dgcnn_edge_mlp_wgrad_f32", x.data_ptr(), H.ld2(x), idx.data_ptr(), dY.data_ptr(), B, N, C, k, F,
