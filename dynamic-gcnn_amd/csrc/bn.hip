@@ -115,21 +115,23 @@ struct Rows {
       ld = F;
     }
   }
-  // rows m .. m+NB-1 (indices past k-1 re-read row k-1; the caller ignores them)
+  // rows m .. m+NB-1.  Gathered rows: no control flow, indices past k-1 re-read row k-1 (the caller ignores
+  // them).  Dense rows (mostly k = 1): rows past k-1 are skipped (k, m are wave-uniform: scalar branches).
   __device__ __forceinline__ void load(int m, int k, float (&y)[NB][V]) const {
-    int64_t row[NB];
+    if constexpr (G) {
+      int64_t row[NB];
 #pragma unroll
-    for (int b = 0; b < NB; ++b) {
-      const int mm = (m + b < k) ? (m + b) : (k - 1);
-      row[b] = G ? (int64_t)ip[mm] : (int64_t)mm;
-    }
+      for (int b = 0; b < NB; ++b) row[b] = (int64_t)ip[(m + b < k) ? (m + b) : (k - 1)];
 #pragma unroll
-    for (int b = 0; b < NB; ++b) Vec<V>::ld(base + row[b] * ld, y[b]);
-    if (G) {
+      for (int b = 0; b < NB; ++b) Vec<V>::ld(base + row[b] * ld, y[b]);
 #pragma unroll
       for (int b = 0; b < NB; ++b)
 #pragma unroll
         for (int v = 0; v < V; ++v) y[b][v] += u[v];
+    } else {
+#pragma unroll
+      for (int b = 0; b < NB; ++b)
+        if (m + b < k) Vec<V>::ld(base + (int64_t)(m + b) * ld, y[b]);
     }
   }
 };
@@ -371,6 +373,141 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
   }
 }
 
+// ---- k = 1 (per-point layers: conv1, shortcut, merged, FC, Final): column-fixed streaming kernels -------------
+// A thread keeps ONE channel quad for its whole life (mean / rstd / beta / the backward constants live in
+// registers) and walks rows with 4 independent row loads in flight; block = (256 / FVB rows) x FVB quads,
+// blockIdx.y = chunk of 256 quads when F > 1024.  The generic kernels above reload the three parameter quads
+// per item, which for k = 1 is most of their load instructions.
+struct K1Map {
+  int f; int64_t r0, rstep; bool on;
+};
+__device__ __forceinline__ K1Map k1_map(int F, int FVB, int RP) {
+  K1Map m;
+  const int t = threadIdx.x;
+  const int fq = blockIdx.y * 256 + (t % FVB);
+  m.f = fq * 4;
+  m.on = (t < RP * FVB) && (m.f < F);
+  m.r0 = (int64_t)blockIdx.x * RP + t / FVB;
+  m.rstep = (int64_t)gridDim.x * RP;
+  return m;
+}
+
+__global__ __launch_bounds__(256) void bn1_act_kernel(const float* __restrict__ T, int64_t R, int F, int FVB, int RP,
+                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                      const float* __restrict__ beta, int relu,
+                                                      float* __restrict__ out, int64_t ldo, float* __restrict__ out2,
+                                                      int64_t ldo2, float* __restrict__ cnt_out) {
+  const K1Map m = k1_map(F, FVB, RP);
+  if (!m.on) return;
+  float mu[4], rs[4], be[4];
+  Vec<4>::ld(mean + m.f, mu); Vec<4>::ld(rstd + m.f, rs); Vec<4>::ld(beta + m.f, be);
+  const float one[4] = {1.f, 1.f, 1.f, 1.f};
+  for (int64_t r = m.r0; r < R; r += 4 * m.rstep) {
+    float y[4][4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const int64_t rr = r + b * m.rstep;
+      if (rr < R) Vec<4>::ld(T + rr * F + m.f, y[b]);
+    }
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const int64_t rr = r + b * m.rstep;
+      if (rr < R) {
+        float z[4];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) { float xh; z[v] = bn_z(y[b][v], mu[v], rs[v], be[v], relu, xh); }
+        Vec<4>::st(out + rr * ldo + m.f, z);
+        if (out2) Vec<4>::st(out2 + rr * ldo2 + m.f, z);
+        if (cnt_out) Vec<4>::st(cnt_out + rr * F + m.f, one);
+      }
+    }
+  }
+}
+
+// APPLY = false: column sums of dz and dz*xhat into red;  APPLY = true: dT = rstd (dz - c1 - xhat c2) (in place ok)
+template <bool APPLY>
+__global__ __launch_bounds__(256) void bn1_bwd_kernel(const float* T, int64_t R, int F, int FVB, int RP,
+                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                      const float* __restrict__ beta, int relu,
+                                                      const float* __restrict__ dout, int64_t lddo,
+                                                      double* __restrict__ red, float* dT, float* __restrict__ dsum,
+                                                      int64_t lddsum) {
+  extern __shared__ float lred[];   // reduce only: [2][min(F,1024)]
+  const K1Map m = k1_map(F, FVB, RP);
+  const int fbase = blockIdx.y * 1024;
+  const int fw = (F - fbase < 1024) ? (F - fbase) : 1024;
+  if (!APPLY) {
+    for (int e = threadIdx.x; e < 2 * fw; e += 256) lred[e] = 0.f;
+    __syncthreads();
+  }
+  float mu[4] = {0, 0, 0, 0}, rs[4] = {0, 0, 0, 0}, be[4] = {0, 0, 0, 0}, c1[4] = {0, 0, 0, 0}, c2[4] = {0, 0, 0, 0};
+  float s0[4] = {0, 0, 0, 0}, s1[4] = {0, 0, 0, 0};
+  if (m.on) {
+    Vec<4>::ld(mean + m.f, mu); Vec<4>::ld(rstd + m.f, rs); Vec<4>::ld(beta + m.f, be);
+    if (APPLY) {
+      const double inv_cnt = 1.0 / (double)R;
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        c1[v] = (float)(red[m.f + v] * inv_cnt);
+        c2[v] = (float)(red[F + m.f + v] * inv_cnt);
+      }
+    }
+    for (int64_t r = m.r0; r < R; r += 4 * m.rstep) {
+      float y[4][4], d[4][4];
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const int64_t rr = r + b * m.rstep;
+        if (rr < R) { Vec<4>::ld(T + rr * F + m.f, y[b]); Vec<4>::ld(dout + rr * lddo + m.f, d[b]); }
+      }
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const int64_t rr = r + b * m.rstep;
+        if (rr < R) {
+          float o[4];
+#pragma unroll
+          for (int v = 0; v < 4; ++v) {
+            float xh;
+            const float z = bn_z(y[b][v], mu[v], rs[v], be[v], relu, xh);
+            float dz = d[b][v];
+            if (relu && !(z > 0.f)) dz = 0.f;
+            if (APPLY) o[v] = rs[v] * (dz - c1[v] - xh * c2[v]);
+            else { s0[v] += dz; s1[v] += dz * xh; }
+          }
+          if (APPLY) {
+            Vec<4>::st(dT + rr * F + m.f, o);
+            if (dsum) Vec<4>::st(dsum + rr * lddsum + m.f, o);
+          }
+        }
+      }
+    }
+  }
+  if (!APPLY) {
+    if (m.on) {
+#pragma unroll
+      for (int v = 0; v < 4; ++v) { atomicAdd(&lred[m.f - fbase + v], s0[v]); atomicAdd(&lred[fw + m.f - fbase + v], s1[v]); }
+    }
+    __syncthreads();
+    const int slot = blockIdx.x % SLOTS;
+    for (int e = threadIdx.x; e < 2 * fw; e += 256) {
+      const int which = e / fw, c = fbase + (e % fw);
+      atomicAdd(red + ((int64_t)slot * 2 + which) * F + c, (double)lred[e]);
+    }
+  }
+}
+
+struct K1Grid { dim3 grid; int FVB, RP; };
+inline K1Grid k1_grid(int64_t R, int F, int max_blocks) {
+  K1Grid g;
+  const int FV = F / 4;
+  g.FVB = FV < 256 ? FV : 256;
+  g.RP = 256 / g.FVB;
+  int64_t gx = dg::cdiv(R, (int64_t)g.RP * 4);             // >= 4 rows per thread
+  if (gx > max_blocks) gx = max_blocks;
+  if (gx < 1) gx = 1;
+  g.grid = dim3((unsigned)gx, (unsigned)dg::cdiv(FV, 256));
+  return g;
+}
+
 inline unsigned grid_for(int64_t items) {
   int64_t g = dg::cdiv(items, 256);
   if (g > 256 * 16) g = 256 * 16;
@@ -429,6 +566,10 @@ int launch_act_kreduce(const char* what, Src src, int64_t R, int k, int F, const
     DG_REQUIRE(vec, DGCNN_EINVAL, "%s: outputs must be 16-byte aligned with leading dimensions %% 4 == 0", what);
     hipLaunchKernelGGL((bn_act_kreduce_kernel<4, true>), dim3(grid8(grid_for(R * (F / 4)))), dim3(256), 0, st, src, R, k, F,
                        mean, rstd, beta, relu, max_out, ldmax, mean_out, ldmean, out2, ldout2, cnt_out, shift_of(F / 4));
+  } else if (vec && k == 1 && !mean_out) {
+    const K1Grid g = k1_grid(R, F, 4096);
+    hipLaunchKernelGGL(bn1_act_kernel, g.grid, dim3(256), 0, st, src.Y, R, F, g.FVB, g.RP, mean, rstd, beta, relu, max_out,
+                       ldmax, out2, ldout2, cnt_out);
   } else if (vec) {
     hipLaunchKernelGGL((bn_act_kreduce_kernel<4, false>), dim3(grid_for(R * (F / 4))), dim3(256), 0, st, src, R, k, F, mean,
                        rstd, beta, relu, max_out, ldmax, mean_out, ldmean, out2, ldout2, cnt_out, shift_of(F / 4));
@@ -455,6 +596,11 @@ int launch_bwd_reduce(const char* what, Src src, int64_t R, int k, int F, const 
     DG_REQUIRE(vec, DGCNN_EINVAL, "%s: operands must be 16-byte aligned with leading dimensions %% 4 == 0", what);
     hipLaunchKernelGGL((bn_bwd_reduce_kernel<4, true>), dim3(grid8(grid_reduce(R * (F / 4)))), dim3(256), sh, st, src, R, k,
                        F, mean, rstd, beta, relu, dmax, lddmax, dmean, lddmean, mx_in, ldmx, cnt_in, red, shift_of(F / 4));
+  } else if (vec && k == 1 && !dmean) {
+    const K1Grid g = k1_grid(R, F, 2048);
+    const size_t sh1 = sizeof(float) * 2 * (size_t)(F < 1024 ? F : 1024);
+    hipLaunchKernelGGL((bn1_bwd_kernel<false>), g.grid, dim3(256), sh1, st, src.Y, R, F, g.FVB, g.RP, mean, rstd, beta, relu,
+                       dmax, lddmax, red, (float*)nullptr, (float*)nullptr, (int64_t)0);
   } else if (vec) {
     hipLaunchKernelGGL((bn_bwd_reduce_kernel<4, false>), dim3(grid_reduce(R * (F / 4))), dim3(256), sh, st, src, R, k, F,
                        mean, rstd, beta, relu, dmax, lddmax, dmean, lddmean, mx_in, ldmx, cnt_in, red, shift_of(F / 4));
@@ -483,6 +629,10 @@ int launch_bwd_apply(const char* what, Src src, int64_t R, int k, int F, const f
     hipLaunchKernelGGL((bn_bwd_apply_kernel<4, true>), dim3(grid8(grid_for(R * (F / 4)))), dim3(256), 0, st, src, R, k, F,
                        mean, rstd, beta, relu, dmax, lddmax, dmean, lddmean, mx_in, ldmx, cnt_in, red, dY, dYsum, lddysum,
                        shift_of(F / 4));
+  } else if (vec && k == 1 && !dmean) {
+    const K1Grid g = k1_grid(R, F, 4096);
+    hipLaunchKernelGGL((bn1_bwd_kernel<true>), g.grid, dim3(256), 0, st, src.Y, R, F, g.FVB, g.RP, mean, rstd, beta, relu,
+                       dmax, lddmax, red, dY, dYsum, lddysum);
   } else if (vec) {
     hipLaunchKernelGGL((bn_bwd_apply_kernel<4, false>), dim3(grid_for(R * (F / 4))), dim3(256), 0, st, src, R, k, F, mean,
                        rstd, beta, relu, dmax, lddmax, dmean, lddmean, mx_in, ldmx, cnt_in, red, dY, dYsum, lddysum,

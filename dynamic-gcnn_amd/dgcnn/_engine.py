@@ -314,7 +314,8 @@ def conv_bn_act(x, leaf_scope, num_outputs, relu=True, out=None, out2=None, gbia
     if out is None:
         out = c.new_buffer(R, F)
     H.call("dgcnn_bn_act_kreduce_f32", T.data_ptr(), R, 1, F, mean.data_ptr(), rstd.data_ptr(), beta.data_ptr(),
-           int(relu), out.data_ptr(), H.ld2(out), 0, 0, H._p(out2), 0 if out2 is None else H.ld2(out2), 0)
+           int(relu), out.data_ptr(), H.ld2(out), 0, 0, H._p(out2), 0 if out2 is None else H.ld2(out2), 0,
+           tag="bn_act_kreduce_kernel<k=1>", work=4.0 * R * F * (2 if out2 is None else 3))
 
     if c.recording:
         def bwd():
@@ -327,10 +328,11 @@ def conv_bn_act(x, leaf_scope, num_outputs, relu=True, out=None, out2=None, gbia
                     H.call("dgcnn_copy2d_f32", d2.data_ptr(), H.ld2(d2), dout.data_ptr(), H.ld2(dout), R, F, 1)
             red = c.stats(F)
             H.call("dgcnn_bn_bwd_reduce_f32", T.data_ptr(), R, 1, F, mean.data_ptr(), rstd.data_ptr(), beta.data_ptr(),
-                   int(relu), dout.data_ptr(), H.ld2(dout), 0, 0, 0, 0, 0, red.data_ptr())
+                   int(relu), dout.data_ptr(), H.ld2(dout), 0, 0, 0, 0, 0, red.data_ptr(),
+                   tag="bn_bwd_reduce_kernel<k=1>", work=4.0 * R * F * 2)
             H.call("dgcnn_bn_bwd_apply_f32", T.data_ptr(), R, 1, F, mean.data_ptr(), rstd.data_ptr(), beta.data_ptr(),
                    int(relu), dout.data_ptr(), H.ld2(dout), 0, 0, 0, 0, 0, red.data_ptr(), T.data_ptr(), 0, 0,
-                   c.var_grads[bname].data_ptr(), 1.0)
+                   c.var_grads[bname].data_ptr(), 1.0, tag="bn_bwd_apply_kernel<k=1>", work=4.0 * R * F * 3)
             dT = T
             dWx = c.var_grads[wname] if w_rows is None else c.var_grads[wname][w_rows[0]:w_rows[1]]
             gemm(x, dT, dWx, transA=True, beta=1.0)                    # dW += x^T dT
