@@ -3,6 +3,7 @@
 // backward.  All HBM-bound: one float4 column-quad per lane so that a
 // wave reads whole 256-B feature rows, k rows per point streamed with k independent loads.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -381,7 +382,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
 struct K1Map {
   int f; int64_t r0, rstep; bool on;
 };
-__device__ __forceinline__ K1Map k1_map(int F, int FVB, int RP) {
+__device__ __forceinline__ K1Map k1_map(int F, int FVB, int RP) {   // RP = blockDim.x / FVB
   K1Map m;
   const int t = threadIdx.x;
   const int fq = blockIdx.y * 256 + (t % FVB);
@@ -437,7 +438,7 @@ __global__ __launch_bounds__(256) void bn1_bwd_kernel(const float* T, int64_t R,
   const int fbase = blockIdx.y * 1024;
   const int fw = (F - fbase < 1024) ? (F - fbase) : 1024;
   if (!APPLY) {
-    for (int e = threadIdx.x; e < 2 * fw; e += 256) lred[e] = 0.f;
+    for (int e = threadIdx.x; e < 2 * fw; e += blockDim.x) lred[e] = 0.f;
     __syncthreads();
   }
   float mu[4] = {0, 0, 0, 0}, rs[4] = {0, 0, 0, 0}, be[4] = {0, 0, 0, 0}, c1[4] = {0, 0, 0, 0}, c2[4] = {0, 0, 0, 0};
@@ -488,7 +489,7 @@ __global__ __launch_bounds__(256) void bn1_bwd_kernel(const float* T, int64_t R,
     }
     __syncthreads();
     const int slot = blockIdx.x % SLOTS;
-    for (int e = threadIdx.x; e < 2 * fw; e += 256) {
+    for (int e = threadIdx.x; e < 2 * fw; e += blockDim.x) {
       const int which = e / fw, c = fbase + (e % fw);
       atomicAdd(red + ((int64_t)slot * 2 + which) * F + c, (double)lred[e]);
     }
@@ -496,11 +497,11 @@ __global__ __launch_bounds__(256) void bn1_bwd_kernel(const float* T, int64_t R,
 }
 
 struct K1Grid { dim3 grid; int FVB, RP; };
-inline K1Grid k1_grid(int64_t R, int F, int max_blocks) {
+inline K1Grid k1_grid(int64_t R, int F, int max_blocks, int threads = 256) {
   K1Grid g;
   const int FV = F / 4;
   g.FVB = FV < 256 ? FV : 256;
-  g.RP = 256 / g.FVB;
+  g.RP = threads / g.FVB;
   int64_t gx = dg::cdiv(R, (int64_t)g.RP * 4);             // >= 4 rows per thread
   if (gx > max_blocks) gx = max_blocks;
   if (gx < 1) gx = 1;
@@ -597,7 +598,11 @@ int launch_bwd_reduce(const char* what, Src src, int64_t R, int k, int F, const 
     hipLaunchKernelGGL((bn_bwd_reduce_kernel<4, true>), dim3(grid8(grid_reduce(R * (F / 4)))), dim3(256), sh, st, src, R, k,
                        F, mean, rstd, beta, relu, dmax, lddmax, dmean, lddmean, mx_in, ldmx, cnt_in, red, shift_of(F / 4));
   } else if (vec && k == 1 && !dmean) {
-    const K1Grid g = k1_grid(R, F, 2048);
+    static int mb = -1;
+    if (mb < 0) { const char* e = getenv("DGCNN_BN1_RED_BLOCKS"); mb = e ? atoi(e) : 256; }   // experiments
+    // the kernel ends with 2F double atomics per workgroup, which dominate above ~1 workgroup per CU
+    // (F = 256: 19 us at 256 workgroups, 32 us at 2048; 1024-thread workgroups are slower: profiles/bn1_bench.py)
+    const K1Grid g = k1_grid(R, F, mb);
     const size_t sh1 = sizeof(float) * 2 * (size_t)(F < 1024 ? F : 1024);
     hipLaunchKernelGGL((bn1_bwd_kernel<false>), g.grid, dim3(256), sh1, st, src.Y, R, F, g.FVB, g.RP, mean, rstd, beta, relu,
                        dmax, lddmax, red, (float*)nullptr, (float*)nullptr, (int64_t)0);
