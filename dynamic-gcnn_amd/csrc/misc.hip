@@ -278,7 +278,16 @@ __global__ __launch_bounds__(64 * RG) void global_max_kernel(const float* __rest
   int bi = 0x7fffffff;
   if (f < F) {
     const float* p = x + (int64_t)b * N * ldx + f;
-    for (int i = rg; i < N; i += RG) {
+    int i = rg;
+    for (; i + 7 * RG < N; i += 8 * RG) {            // 8 independent row loads in flight per lane
+      float v[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) v[q] = p[(int64_t)(i + q * RG) * ldx];
+#pragma unroll
+      for (int q = 0; q < 8; ++q)
+        if (v[q] > best) { best = v[q]; bi = i + q * RG; }
+    }
+    for (; i < N; i += RG) {
       const float v = p[(int64_t)i * ldx];
       if (v > best) { best = v; bi = i; }
     }
@@ -315,7 +324,15 @@ __global__ __launch_bounds__(64 * RG) void group_colsum_kernel(const float* __re
   float s = 0.f;
   if (f < F) {
     const float* p = x + (int64_t)g * rows * ldx + f;
-    for (int i = rg; i < rows; i += RG) s += p[(int64_t)i * ldx];
+    int i = rg;
+    for (; i + 7 * RG < rows; i += 8 * RG) {         // 8 independent row loads in flight per lane; same summation order
+      float v[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) v[q] = p[(int64_t)(i + q * RG) * ldx];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) s += v[q];
+    }
+    for (; i < rows; i += RG) s += p[(int64_t)i * ldx];
   }
   sv[rg][threadIdx.x & 63] = s;
   __syncthreads();
