@@ -17,6 +17,7 @@ Layout conventions (DESIGN.md "Data layout"):
 from __future__ import annotations
 
 import contextlib
+import os
 from collections import OrderedDict
 
 import numpy as np
@@ -30,6 +31,7 @@ WS_BYTES = 256 << 20
 EDGE_MLP_LITERAL = False  # True: conv0 as the literal (B*N*k) x 2C GEMM over E = [x_i, x_j - x_i] (A/B switch)
 EDGE_MATERIALIZE_Y = False  # True: gather-add writes the (B*N*k, F) conv0 output and BatchNorm streams it (A/B switch);
                             # False: the BatchNorm passes recompute y = V[neighbour] + U[point] (no edge tensor in the forward)
+WGRAD_SIDE_STREAM = os.environ.get("DGCNN_SIDE_STREAM", "1") != "0"   # weight-gradient GEMMs on a second HIP stream
 EDGE_MLP_NBR_GEMM = False  # True: factored conv0 with an edge-level neighbour GEMM instead of point-level GEMM + gather-add
 SCATTER_ATOMICS = False  # True: dx_j += dY W^T by fp32 atomics in the GEMM epilogue (A/B switch)
 
@@ -44,6 +46,9 @@ class Context(object):
         self.roots = []                  # [(buffer, [grad or None])]
         self.recording = False
         self.ws = None
+        self.ws_side = None
+        self.side = None                 # second HIP stream: weight-gradient GEMMs (nothing on the critical path needs them)
+        self.side_busy = False
         self.seed = 1
         self._rng = None
         self.stat_arena = None
@@ -59,9 +64,38 @@ class Context(object):
         return torch.device("cuda", torch.cuda.current_device())
 
     def workspace(self):
+        if torch.cuda.current_stream() == self.side and self.side is not None:
+            if self.ws_side is None or self.ws_side.device != self.device:
+                self.ws_side = torch.empty(WS_BYTES, dtype=torch.uint8, device=self.device)
+            return self.ws_side
         if self.ws is None or self.ws.device != self.device:
             self.ws = torch.empty(WS_BYTES, dtype=torch.uint8, device=self.device)
         return self.ws
+
+    @contextlib.contextmanager
+    def off_critical_path(self, *temporaries):
+        """Run the enclosed launches on the side stream, ordered after everything issued so far on the
+        current stream.  The bf16-split GEMMs run at the package power cap while the BatchNorm / gather passes
+        of the backward chain are bandwidth bound: a weight-gradient GEMM (needed only by the optimizer)
+        issued here overlaps the chain instead of stalling it.  `temporaries`: tensors allocated on the main
+        stream that the side work touches and that may be freed before the streams join."""
+        if not WGRAD_SIDE_STREAM:
+            yield
+            return
+        main = torch.cuda.current_stream()
+        if self.side is None or self.side.device != self.device:
+            self.side = torch.cuda.Stream(device=self.device)
+        self.side.wait_stream(main)
+        for t in temporaries:
+            t.record_stream(self.side)
+        self.side_busy = True
+        with torch.cuda.stream(self.side):
+            yield
+
+    def join_side(self):
+        if self.side_busy:
+            torch.cuda.current_stream().wait_stream(self.side)
+            self.side_busy = False
 
     def stats(self, F):
         """Zeroed double[SLOTS][2][F] carved from one arena that is memset once per step."""
@@ -176,6 +210,7 @@ class Context(object):
     def backward(self):
         for fn in reversed(self.tape):
             fn()
+        self.join_side()                 # before the tape's tensors are released
         self.tape = []
 
 
@@ -335,7 +370,8 @@ def conv_bn_act(x, leaf_scope, num_outputs, relu=True, out=None, out2=None, gbia
                    c.var_grads[bname].data_ptr(), 1.0, tag="bn_bwd_apply_kernel<k=1>", work=4.0 * R * F * 3)
             dT = T
             dWx = c.var_grads[wname] if w_rows is None else c.var_grads[wname][w_rows[0]:w_rows[1]]
-            gemm(x, dT, dWx, transA=True, beta=1.0)                    # dW += x^T dT
+            with c.off_critical_path():
+                gemm(x, dT, dWx, transA=True, beta=1.0)                # dW += x^T dT
             dx, bx = c.grad_w(x)
             if dx is not None:
                 gemm(dT, Wx, dx, transB=True, beta=bx)                 # dx (+)= dT W^T
@@ -482,8 +518,9 @@ def edge_conv_block(x, B, N, k, num_filters, relu1=True, outs=None, net2=None):
                 # dU = sum_m dY, dV = sum of incoming dY;  dWcat = X^T [dU|dV],  dx += [dU|dV] Wcat^T
                 incoming_sum(dUV[:, F:])
                 dwcat = torch.empty((Cp, 2 * F), dtype=torch.float32, device=x.device)
-                gemm(xg, dUV, dwcat, transA=True)
-                H.call("dgcnn_edge_wgrad_combine_f32", dwcat.data_ptr(), C, F, dW0.data_ptr())
+                with c.off_critical_path(dwcat):
+                    gemm(xg, dUV, dwcat, transA=True)
+                    H.call("dgcnn_edge_wgrad_combine_f32", dwcat.data_ptr(), C, F, dW0.data_ptr())
                 if dx is not None:
                     gemm(dUV, wcat[:C], dx, transB=True, beta=1.0)
                 return
