@@ -208,6 +208,7 @@ class Context(object):
         return self.grad(v), 1.0
 
     def backward(self):
+        self.join_side()                 # side work issued during the forward (transposed adjacency)
         for fn in reversed(self.tape):
             fn()
         self.join_side()                 # before the tape's tensors are released
@@ -462,6 +463,16 @@ def edge_conv_block(x, B, N, k, num_filters, relu1=True, outs=None, net2=None):
                mx.data_ptr(), H.ld2(mx), mn.data_ptr(), H.ld2(mn), 0, 0, H._p(cnt),
                tag="bn_act_kreduce_kernel", work=4.0 * (R * k * F + 2 * R * F))   # ops.py:54-58
 
+    csr = None
+    if c.recording and gather and WGRAD_SIDE_STREAM:
+        # the transposed adjacency depends only on idx: build it now, off the critical path, for the backward
+        cws = torch.empty(2 * R, dtype=torch.int32, device=x.device)
+        off_t = torch.empty(R + 1, dtype=torch.int32, device=x.device)
+        rev_t = torch.empty(R * k, dtype=torch.int32, device=x.device)
+        with c.off_critical_path(cws, off_t, rev_t):
+            H.call("dgcnn_edge_csr_build", idx.data_ptr(), B, N, k, cws.data_ptr(), off_t.data_ptr(), rev_t.data_ptr())
+        csr = (off_t, rev_t)
+
     if c.recording:
         def bwd():
             dmm = c.grad(mm)
@@ -507,10 +518,13 @@ def edge_conv_block(x, B, N, k, num_filters, relu1=True, outs=None, net2=None):
 
             def incoming_sum(S):
                 # tf.gather^T as a gather: bucket edges by target, then every point sums its incoming dY rows
-                cws = torch.empty(2 * R, dtype=torch.int32, device=x.device)
-                off = torch.empty(R + 1, dtype=torch.int32, device=x.device)
-                rev = torch.empty(R * k, dtype=torch.int32, device=x.device)
-                H.call("dgcnn_edge_csr_build", idx.data_ptr(), B, N, k, cws.data_ptr(), off.data_ptr(), rev.data_ptr())
+                if csr is not None:
+                    off, rev = csr                    # built on the side stream during the forward
+                else:
+                    cws = torch.empty(2 * R, dtype=torch.int32, device=x.device)
+                    off = torch.empty(R + 1, dtype=torch.int32, device=x.device)
+                    rev = torch.empty(R * k, dtype=torch.int32, device=x.device)
+                    H.call("dgcnn_edge_csr_build", idx.data_ptr(), B, N, k, cws.data_ptr(), off.data_ptr(), rev.data_ptr())
                 H.call("dgcnn_edge_gather_sum_f32", dY.data_ptr(), off.data_ptr(), rev.data_ptr(), R, F, S.data_ptr(),
                        H.ld2(S), tag="csr_gather_sum_kernel", work=4.0 * (R * k * F + R * F))
 
