@@ -627,6 +627,154 @@ __global__ __launch_bounds__(64 * RL) void reduce_partials_kernel(const float* _
   }
 }
 
+// ---- skinny products (the class dimension: Final layer, N = NUM_CLASS <= 4).  An MFMA tile would be > 95 %
+// padding and N = 2 is not float4-loadable, so these ran on the scalar generic kernel (~0.1 ms per step);
+// they are plain streaming problems.
+// NN:  C[M][N] = A[M][K] B[K][N] (+ beta C) (+ column sums), N <= 4, K % 4 == 0.  One wave per row at a time:
+//      lanes own float4 chunks of k, wave-reduce the N partial dots.
+template <int N>
+__global__ __launch_bounds__(256) void skinny_nn_kernel(const float* __restrict__ A, int64_t lda,
+                                                        const float* __restrict__ B, int64_t ldb, float* __restrict__ C,
+                                                        int64_t ldc, int M, int K, float beta, double* __restrict__ stats) {
+  extern __shared__ float bs[];                  // [K][N] then [2][N] for the statistics
+  float* red = bs + (size_t)K * N;
+  for (int e = threadIdx.x; e < K * N; e += 256) bs[e] = B[(int64_t)(e / N) * ldb + (e % N)];
+  if (threadIdx.x < 2 * N) red[threadIdx.x] = 0.f;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int nw = gridDim.x * 4;
+  float cs[N], cq[N];
+#pragma unroll
+  for (int n = 0; n < N; ++n) { cs[n] = 0.f; cq[n] = 0.f; }
+  for (int r = blockIdx.x * 4 + wv; r < M; r += nw) {
+    float acc[N];
+#pragma unroll
+    for (int n = 0; n < N; ++n) acc[n] = 0.f;
+    const float* a = A + (int64_t)r * lda;
+    for (int k4 = lane * 4; k4 < K; k4 += 256) {
+      const float4 v = ld4(a + k4);
+      const float* b = bs + k4 * N;
+#pragma unroll
+      for (int n = 0; n < N; ++n) acc[n] += v.x * b[n] + v.y * b[N + n] + v.z * b[2 * N + n] + v.w * b[3 * N + n];
+    }
+#pragma unroll
+    for (int n = 0; n < N; ++n)
+      for (int d = 32; d > 0; d >>= 1) acc[n] += __shfl_down(acc[n], d, 64);
+    if (lane == 0) {
+#pragma unroll
+      for (int n = 0; n < N; ++n) {
+        float* c = C + (int64_t)r * ldc + n;
+        const float v = (beta != 0.f) ? (acc[n] + beta * *c) : acc[n];
+        *c = v;
+        cs[n] += v;
+        cq[n] += v * v;
+      }
+    }
+  }
+  if (stats) {
+    if (lane == 0) {
+#pragma unroll
+      for (int n = 0; n < N; ++n) { atomicAdd(&red[n], cs[n]); atomicAdd(&red[N + n], cq[n]); }
+    }
+    __syncthreads();
+    if (threadIdx.x < 2 * N) {
+      const int which = threadIdx.x / N, n = threadIdx.x % N;
+      atomicAdd(stats + ((int64_t)(blockIdx.x % DGCNN_STAT_SLOTS) * 2 + which) * N + n, (double)red[threadIdx.x]);
+    }
+  }
+}
+
+// TN:  partial[z][M][N] = sum over the rows of block z of A[r][m] B[r][n]   (A stored [R][M], M % 4 == 0, N <= 4);
+//      lanes own float4 chunks of m; combined by reduce_partials_kernel.
+template <int N>
+__global__ __launch_bounds__(256) void skinny_tn_kernel(const float* __restrict__ A, int64_t lda,
+                                                        const float* __restrict__ B, int64_t ldb, int M, int R,
+                                                        float* __restrict__ part) {
+  __shared__ float sh[4][64 * 4 * 4];            // per wave: 64 lanes x 4 m x N
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int rows_per = (R + gridDim.x - 1) / gridDim.x;
+  const int r0 = blockIdx.x * rows_per, r1 = (r0 + rows_per < R) ? (r0 + rows_per) : R;
+  float* out = part + (int64_t)blockIdx.x * M * N;
+  for (int mc = 0; mc < M; mc += 256) {             // uniform trip count (barriers inside)
+    const int m4 = mc + lane * 4;
+    const bool on = m4 < M;
+    const int m4c = on ? m4 : 0;
+    float acc[4][N];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int n = 0; n < N; ++n) acc[q][n] = 0.f;
+    int r = r0 + wv;
+    for (; r + 12 < r1; r += 16) {                // 4 rows of this wave in flight
+      float4 v[4];
+      float b[4][N];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        v[i] = ld4(A + (int64_t)(r + 4 * i) * lda + m4c);
+#pragma unroll
+        for (int n = 0; n < N; ++n) b[i][n] = B[(int64_t)(r + 4 * i) * ldb + n];
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int n = 0; n < N; ++n) {
+          acc[0][n] += v[i].x * b[i][n]; acc[1][n] += v[i].y * b[i][n];
+          acc[2][n] += v[i].z * b[i][n]; acc[3][n] += v[i].w * b[i][n];
+        }
+    }
+    for (; r < r1; r += 4) {
+      const float4 v = ld4(A + (int64_t)r * lda + m4c);
+#pragma unroll
+      for (int n = 0; n < N; ++n) {
+        const float b = B[(int64_t)r * ldb + n];
+        acc[0][n] += v.x * b; acc[1][n] += v.y * b; acc[2][n] += v.z * b; acc[3][n] += v.w * b;
+      }
+    }
+    // combine the 4 waves (fixed order), write the block's partial tile
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int n = 0; n < N; ++n) sh[wv][(lane * 4 + q) * 4 + n] = acc[q][n];
+    __syncthreads();
+    if (wv == 0 && on) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int n = 0; n < N; ++n) {
+          const int e = (lane * 4 + q) * 4 + n;
+          out[(int64_t)(m4 + q) * N + n] = (sh[0][e] + sh[1][e]) + (sh[2][e] + sh[3][e]);
+        }
+    }
+  }
+}
+
+// NT with a tiny reduction:  C[M][Nc] = A[M][K] B[Nc][K]^T (+ beta C),  K <= 4, Nc % 4 == 0: elementwise.
+template <int K>
+__global__ __launch_bounds__(256) void skinny_nt_kernel(const float* __restrict__ A, int64_t lda,
+                                                        const float* __restrict__ B, int64_t ldb, float* __restrict__ C,
+                                                        int64_t ldc, int M, int Nc, float beta) {
+  const int NV = Nc / 4;
+  const int64_t items = (int64_t)M * NV;
+  for (int64_t it = (int64_t)blockIdx.x * 256 + threadIdx.x; it < items; it += (int64_t)gridDim.x * 256) {
+    const int r = (int)(it / NV), c4 = (int)(it % NV) * 4;
+    float a[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) a[k] = A[(int64_t)r * lda + k];
+    float o[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int k = 0; k < K; ++k) o[q] += a[k] * B[(int64_t)(c4 + q) * ldb + k];
+    float4* dst = reinterpret_cast<float4*>(C + (int64_t)r * ldc + c4);
+    if (beta != 0.f) {
+      const float4 old = *dst;
+      o[0] += beta * old.x; o[1] += beta * old.y; o[2] += beta * old.z; o[3] += beta * old.w;
+    }
+    *dst = make_float4(o[0], o[1], o[2], o[3]);
+  }
+}
+
 // conv0 wgrad for raw point clouds (C <= 4, i.e. 2C <= 8 rows of dW0): the MFMA tile would be 95 %
 // padding and its generic loader is scalar.  HBM-bound instead: stream dY once (coalesced 256-B
 // rows), rebuild the 2C edge features of each edge from (x, idx) -- wave-uniform, so they sit in
@@ -838,6 +986,36 @@ extern "C" int dgcnn_gemm_f32(int transA, int transB, int M, int N, int K,
   p.avec = (lda % 4 == 0) && aligned16(A);
   p.bvec = (ldb % 4 == 0) && aligned16(B);
   hipStream_t st = (hipStream_t)stream;
+  // ---- skinny shapes (class dimension): streaming kernels instead of 95 %-padded MFMA tiles
+  if (!gbias && !transA && !transB && N <= 4 && K % 4 == 0 && K <= 4096 && p.avec) {
+    const size_t sh = sizeof(float) * ((size_t)K * N + 2 * N);
+    const unsigned g = (unsigned)(dg::cdiv(M, 4) < 2048 ? dg::cdiv(M, 4) : 2048);
+#define DG_SK_NN(NN) hipLaunchKernelGGL((skinny_nn_kernel<NN>), dim3(g), dim3(256), sh, st, A, lda, B, ldb, C, ldc, M, K, beta, stats)
+    if (N == 1) DG_SK_NN(1); else if (N == 2) DG_SK_NN(2); else if (N == 3) DG_SK_NN(3); else DG_SK_NN(4);
+#undef DG_SK_NN
+    return dg::check_launch("dgcnn_gemm_f32(NN skinny)");
+  }
+  if (!gbias && !stats && transA && N <= 4 && M % 4 == 0 && M <= 4096 && p.avec && ws) {
+    int64_t nb = dg::cdiv(K, 64);                       // >= 64 rows of the reduction per block
+    if (nb > 512) nb = 512;
+    if (ws_bytes >= (size_t)nb * M * N * sizeof(float)) {
+      float* part = reinterpret_cast<float*>(ws);
+#define DG_SK_TN(NN) hipLaunchKernelGGL((skinny_tn_kernel<NN>), dim3((unsigned)nb), dim3(256), 0, st, A, lda, B, ldb, M, K, part)
+      if (N == 1) DG_SK_TN(1); else if (N == 2) DG_SK_TN(2); else if (N == 3) DG_SK_TN(3); else DG_SK_TN(4);
+#undef DG_SK_TN
+      hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)dg::cdiv((int64_t)M * N, 64)), dim3(64 * RL), 0, st, part,
+                         (int)nb, M, N, C, ldc, beta);
+      return dg::check_launch("dgcnn_gemm_f32(TN skinny)");
+    }
+  }
+  if (!gbias && !stats && transB && K <= 4 && N % 4 == 0 && ldc % 4 == 0 && aligned16(C)) {
+    const int64_t items = (int64_t)M * (N / 4);
+    const unsigned g = (unsigned)(dg::cdiv(items, 256) < 8192 ? dg::cdiv(items, 256) : 8192);
+#define DG_SK_NT(KK) hipLaunchKernelGGL((skinny_nt_kernel<KK>), dim3(g), dim3(256), 0, st, A, lda, B, ldb, C, ldc, M, N, beta)
+    if (K == 1) DG_SK_NT(1); else if (K == 2) DG_SK_NT(2); else if (K == 3) DG_SK_NT(3); else DG_SK_NT(4);
+#undef DG_SK_NT
+    return dg::check_launch("dgcnn_gemm_f32(NT skinny)");
+  }
   if (transA) {
     DG_REQUIRE(!gbias && !stats, DGCNN_EUNSUP, "dgcnn_gemm_f32: bias/stats with transA unsupported");
     int rc = plan_splits(p, ws, ws_bytes, "dgcnn_gemm_f32");

@@ -174,6 +174,37 @@ def test_gemm_tn_splitk(dg, arith, M, N, K):
     np.testing.assert_allclose(host(C), ref + 2, rtol=1e-4, atol=1e-5 * K ** 0.5 * 4)
 
 
+@pytest.mark.parametrize("M,N,K", [(1000, 2, 256), (49152, 2, 256), (130, 4, 64), (77, 1, 1024), (512, 3, 8)])
+def test_gemm_skinny_class_dimension(dg, M, N, K):
+    """The Final layer's products (N = NUM_CLASS) take dedicated streaming kernels: NN with BN sums and beta,
+    the weight gradient (TN, reduction over the rows) and the data gradient (NT, reduction length N)."""
+    from dgcnn import _engine as E
+    rng = np.random.default_rng(M + N + K)
+    A = rng.normal(size=(M, K)).astype(np.float32)
+    W = rng.normal(size=(K, N)).astype(np.float32)
+    ref = A.astype(np.float64) @ W
+    tol = dict(rtol=1e-5, atol=2e-6 * K ** 0.5 * 4 + 1e-5)
+    C = dev(np.full((M, N), 0.5, np.float32))
+    st = torch.zeros(E.H.STAT_SLOTS * 2 * N, dtype=torch.float64, device="cuda")
+    E.gemm(dev(A), dev(W), C, beta=2.0, stats=st)
+    np.testing.assert_allclose(host(C), ref + 1.0, **tol)
+    s = host(st).reshape(E.H.STAT_SLOTS, 2, N).sum(0)
+    np.testing.assert_allclose(s[0], (ref + 1.0).sum(0), rtol=1e-5, atol=1e-2)
+    np.testing.assert_allclose(s[1], ((ref + 1.0) ** 2).sum(0), rtol=1e-5, atol=1e-2)
+    # weight gradient: dW (K x N) += A^T dT
+    dT = rng.normal(size=(M, N)).astype(np.float32)
+    dW = dev(np.ones((K, N), np.float32))
+    E.gemm(dev(A), dev(dT), dW, transA=True, beta=1.0)
+    np.testing.assert_allclose(host(dW), A.astype(np.float64).T @ dT + 1.0, rtol=1e-4, atol=1e-5 * M ** 0.5 * 4)
+    # data gradient: dA (M x K) = dT W^T  (+ beta dA)
+    dA = dev(np.full((M, K), 3.0, np.float32))
+    E.gemm(dev(dT), dev(W), dA, transB=True, beta=1.0)
+    np.testing.assert_allclose(host(dA), dT.astype(np.float64) @ W.T + 3.0, rtol=1e-5, atol=1e-5)
+    dA2 = torch.empty((M, K), device="cuda")
+    E.gemm(dev(dT), dev(W), dA2, transB=True)
+    np.testing.assert_allclose(host(dA2), dT.astype(np.float64) @ W.T, rtol=1e-5, atol=1e-5)
+
+
 def test_gemm_split_accuracy(dg):
     """The bf16-split kernels (gemm_x3.hip) against the native fp32-MFMA kernel, both measured against an
     fp64 product: error relative to sum_k |a_k b_k| (the natural fp32 scale of a dot product).  All nine
