@@ -625,6 +625,34 @@ def test_model_logits_and_gradients(dg, cfg):
         assert np.linalg.norm(g - ref) <= 2e-2 * max(np.linalg.norm(ref), 1e-6), n
 
 
+def test_side_stream_does_not_change_results(dg):
+    """Weight-gradient GEMMs / the transposed adjacency run on a second HIP stream; with it switched off the
+    same gradients must come out (up to the run-to-run atomic-order noise of the BN sums)."""
+    from dgcnn import _engine as E
+    flags = dg.DGCNN_FLAGS(EDGE_CONV_LAYERS=2, EDGE_CONV_FILTERS=[64, 64], KVALUE=10, FC_FILTERS=[64, 32], NUM_CHANNEL=3,
+                           TRAIN=True, SEED=3)
+    rng = np.random.default_rng(11)
+    pts = rng.random((4, 512, 3), dtype=np.float32)
+    lab = rng.integers(0, 2, (4, 512)).astype(np.int32)
+    keep, E.DROPOUT_KEEP = E.DROPOUT_KEEP, 1.0
+    old = E.WGRAD_SIDE_STREAM
+    got = {}
+    try:
+        for side in (False, True):
+            E.WGRAD_SIDE_STREAM = side
+            tv = dg.trainval(flags).initialize()
+            for _ in range(2):                                   # two micro-steps: accumulation across joins
+                tv.accum_gradient(None, [pts], [lab])
+            got[side] = host(dg.ctx().flat_grad).copy()
+    finally:
+        E.WGRAD_SIDE_STREAM = old
+        E.DROPOUT_KEEP = keep
+    d = np.abs(got[True] - got[False])
+    scale = np.abs(got[False]).max()
+    assert np.linalg.norm(got[True] - got[False]) <= 2e-3 * np.linalg.norm(got[False]), d.max() / scale
+    assert np.abs(got[True]).sum() > 0
+
+
 def test_two_microsteps_and_adam(dg):
     """gradients are SUMMED over micro-steps (trainval.py:79), then one Adam step."""
     flags = dg.DGCNN_FLAGS(EDGE_CONV_LAYERS=1, KVALUE=6, FC_FILTERS=[32, 16], NUM_CHANNEL=3, TRAIN=True)
