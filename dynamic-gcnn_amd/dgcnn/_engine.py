@@ -32,6 +32,7 @@ EDGE_MLP_LITERAL = False  # True: conv0 as the literal (B*N*k) x 2C GEMM over E 
 EDGE_MATERIALIZE_Y = False  # True: gather-add writes the (B*N*k, F) conv0 output and BatchNorm streams it (A/B switch);
                             # False: the BatchNorm passes recompute y = V[neighbour] + U[point] (no edge tensor in the forward)
 WGRAD_SIDE_STREAM = os.environ.get("DGCNN_SIDE_STREAM", "1") != "0"   # weight-gradient GEMMs on a second HIP stream
+SIDE_STREAM_MIN_ROWS = 16384   # below this many points the side stream is not used
 EDGE_MLP_NBR_GEMM = False  # True: factored conv0 with an edge-level neighbour GEMM instead of point-level GEMM + gather-add
 SCATTER_ATOMICS = False  # True: dx_j += dY W^T by fp32 atomics in the GEMM epilogue (A/B switch)
 
@@ -73,14 +74,14 @@ class Context(object):
         return self.ws
 
     @contextlib.contextmanager
-    def off_critical_path(self, *temporaries):
+    def off_critical_path(self, *temporaries, rows=1 << 30):
         """Run the enclosed launches on the side stream, ordered after everything issued so far on the
         current stream.  The bf16-split GEMMs run at the package power cap while the BatchNorm / gather passes
         of the backward chain are bandwidth bound: a weight-gradient GEMM (needed only by the optimizer)
         issued here overlaps the chain instead of stalling it.  `temporaries`: tensors allocated on the main
         stream that the side work touches and that may be freed before the streams join."""
-        if not WGRAD_SIDE_STREAM:
-            yield
+        if not WGRAD_SIDE_STREAM or rows < SIDE_STREAM_MIN_ROWS:      # tiny problems are host-launch bound: the
+            yield                                                       # stream switches only add latency there
             return
         main = torch.cuda.current_stream()
         if self.side is None or self.side.device != self.device:
@@ -371,7 +372,7 @@ def conv_bn_act(x, leaf_scope, num_outputs, relu=True, out=None, out2=None, gbia
                    c.var_grads[bname].data_ptr(), 1.0, tag="bn_bwd_apply_kernel<k=1>", work=4.0 * R * F * 3)
             dT = T
             dWx = c.var_grads[wname] if w_rows is None else c.var_grads[wname][w_rows[0]:w_rows[1]]
-            with c.off_critical_path():
+            with c.off_critical_path(rows=R):
                 gemm(x, dT, dWx, transA=True, beta=1.0)                # dW += x^T dT
             dx, bx = c.grad_w(x)
             if dx is not None:
@@ -464,12 +465,12 @@ def edge_conv_block(x, B, N, k, num_filters, relu1=True, outs=None, net2=None):
                tag="bn_act_kreduce_kernel", work=4.0 * (R * k * F + 2 * R * F))   # ops.py:54-58
 
     csr = None
-    if c.recording and gather and WGRAD_SIDE_STREAM:
+    if c.recording and gather and WGRAD_SIDE_STREAM and R >= SIDE_STREAM_MIN_ROWS:
         # the transposed adjacency depends only on idx: build it now, off the critical path, for the backward
         cws = torch.empty(2 * R, dtype=torch.int32, device=x.device)
         off_t = torch.empty(R + 1, dtype=torch.int32, device=x.device)
         rev_t = torch.empty(R * k, dtype=torch.int32, device=x.device)
-        with c.off_critical_path(cws, off_t, rev_t):
+        with c.off_critical_path(cws, off_t, rev_t, rows=R):
             H.call("dgcnn_edge_csr_build", idx.data_ptr(), B, N, k, cws.data_ptr(), off_t.data_ptr(), rev_t.data_ptr())
         csr = (off_t, rev_t)
 
@@ -532,7 +533,7 @@ def edge_conv_block(x, B, N, k, num_filters, relu1=True, outs=None, net2=None):
                 # dU = sum_m dY, dV = sum of incoming dY;  dWcat = X^T [dU|dV],  dx += [dU|dV] Wcat^T
                 incoming_sum(dUV[:, F:])
                 dwcat = torch.empty((Cp, 2 * F), dtype=torch.float32, device=x.device)
-                with c.off_critical_path(dwcat):
+                with c.off_critical_path(dwcat, rows=R):
                     gemm(xg, dUV, dwcat, transA=True)
                     H.call("dgcnn_edge_wgrad_combine_f32", dwcat.data_ptr(), C, F, dW0.data_ptr())
                 if dx is not None:
