@@ -95,6 +95,7 @@ struct Src {
 #ifndef BN_NB
 #define BN_NB 4
 #endif
+constexpr int CNT_POS = 256;   // edge variants pack (#ties of the max) + CNT_POS * (#rows with z > 0) into cnt_out (k <= 255)
 constexpr int NB = BN_NB;    // rows in flight per lane
 
 template <int V, bool G>
@@ -176,10 +177,10 @@ __global__ __launch_bounds__(256) void bn_act_kreduce_kernel(
     int fq;
     split_item(its.base + q, FV, fv_shift, r, fq);
     const int f = fq * V;
-    float mu[V], rs[V], be[V], mx[V], sm[V], cn[V];
+    float mu[V], rs[V], be[V], mx[V], sm[V], cn[V], np[V];
     Vec<V>::ld(mean + f, mu); Vec<V>::ld(rstd + f, rs); Vec<V>::ld(beta + f, be);
 #pragma unroll
-    for (int v = 0; v < V; ++v) { mx[v] = -INFINITY; sm[v] = 0.f; cn[v] = 0.f; }
+    for (int v = 0; v < V; ++v) { mx[v] = -INFINITY; sm[v] = 0.f; cn[v] = 0.f; np[v] = 0.f; }
     Rows<V, G> rows;
     rows.init(src, r, k, F, f);
     for (int m = 0; m < k; m += NB) {
@@ -196,11 +197,16 @@ __global__ __launch_bounds__(256) void bn_act_kreduce_kernel(
             cn[v] = gt ? 1.f : ((z == mx[v]) ? cn[v] + 1.f : cn[v]);   // ties share the max gradient (A.5)
             mx[v] = gt ? z : mx[v];
             sm[v] += z;
+            if (G) np[v] += (z > 0.f) ? (float)CNT_POS : 0.f;
           }
         }
     }
     Vec<V>::st(max_out + r * ldmax + f, mx);
     if (out2) Vec<V>::st(out2 + r * ldout2 + f, mx);
+    if (G) {                       // edge variant: ties + CNT_POS x (rows with z > 0), both exact small integers
+#pragma unroll
+      for (int v = 0; v < V; ++v) cn[v] += np[v];
+    }
     if (cnt_out) Vec<V>::st(cnt_out + r * F + f, cn);
     if (mean_out) {
 #pragma unroll
@@ -277,6 +283,10 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
       if (mx_in) {                 // forward kept (max, #ties): the rows are read once
         Vec<V>::ld(mx_in + r * ldmx + f, st.mx);
         Vec<V>::ld(cnt_in + r * F + f, st.cnt);
+        if (G) {
+#pragma unroll
+          for (int v = 0; v < V; ++v) st.cnt[v] -= (float)CNT_POS * floorf(st.cnt[v] * (1.0f / CNT_POS));
+        }
       } else {
         k_pass_max<V, G>(rows, k, mu, rs, be, relu, st);
       }
@@ -345,6 +355,10 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
       if (mx_in) {                 // forward kept (max, #ties): the rows are read once
         Vec<V>::ld(mx_in + r * ldmx + f, st.mx);
         Vec<V>::ld(cnt_in + r * F + f, st.cnt);
+        if (G) {
+#pragma unroll
+          for (int v = 0; v < V; ++v) st.cnt[v] -= (float)CNT_POS * floorf(st.cnt[v] * (1.0f / CNT_POS));
+        }
       } else {
         k_pass_max<V, G>(rows, k, mu, rs, be, relu, st);
       }
@@ -496,6 +510,51 @@ __global__ __launch_bounds__(256) void bn1_bwd_kernel(const float* T, int64_t R,
   }
 }
 
+// Backward BN reduction of an EdgeConv conv0 WITHOUT touching the edges.  With relu and dz_e = [z_e = max_i]
+// dmax_i / ties_i + dmean_i / k  (zero where z_e <= 0), summing over the k rows of point i gives
+//   sum_m dz        = [max_i > 0] dmax_i + dmean_i npos_i / k
+//   sum_m dz xhat   = [max_i > 0] dmax_i (max_i - beta) + (dmean_i / k) (k mean_i - beta npos_i)
+// (xhat = z - beta where z > 0; the ties all equal max_i; k mean_i = sum of the positive z): only the forward's
+// per-point outputs (max, mean, packed ties/positives) and the incoming gradients are needed.
+__global__ __launch_bounds__(256) void edge_bwd_reduce_points_kernel(
+    const float* __restrict__ mx, int64_t ldmx, const float* __restrict__ mn, int64_t ldmn,
+    const float* __restrict__ cntpos, const float* __restrict__ dmax, int64_t lddmax,
+    const float* __restrict__ dmean, int64_t lddmean, const float* __restrict__ beta, int64_t R, int k, int F,
+    int FVB, int RP, double* __restrict__ red) {
+  extern __shared__ float lred[];
+  const K1Map m = k1_map(F, FVB, RP);
+  const int fbase = blockIdx.y * 1024;
+  const int fw = (F - fbase < 1024) ? (F - fbase) : 1024;
+  for (int e = threadIdx.x; e < 2 * fw; e += 256) lred[e] = 0.f;
+  __syncthreads();
+  if (m.on) {
+    float be[4], s0[4] = {0, 0, 0, 0}, s1[4] = {0, 0, 0, 0};
+    Vec<4>::ld(beta + m.f, be);
+    const float invk = 1.0f / (float)k, kf = (float)k;
+    for (int64_t r = m.r0; r < R; r += m.rstep) {
+      float a[4], b[4], c[4], d[4], e[4];
+      Vec<4>::ld(mx + r * ldmx + m.f, a); Vec<4>::ld(mn + r * ldmn + m.f, b); Vec<4>::ld(cntpos + r * F + m.f, c);
+      Vec<4>::ld(dmax + r * lddmax + m.f, d); Vec<4>::ld(dmean + r * lddmean + m.f, e);
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const float npos = floorf(c[v] * (1.0f / CNT_POS));
+        const float g1 = (a[v] > 0.f) ? d[v] : 0.f;
+        const float g2 = e[v] * invk;
+        s0[v] += g1 + g2 * npos;
+        s1[v] += g1 * (a[v] - be[v]) + g2 * (kf * b[v] - be[v] * npos);
+      }
+    }
+#pragma unroll
+    for (int v = 0; v < 4; ++v) { atomicAdd(&lred[m.f - fbase + v], s0[v]); atomicAdd(&lred[fw + m.f - fbase + v], s1[v]); }
+  }
+  __syncthreads();
+  const int slot = blockIdx.x % SLOTS;
+  for (int e = threadIdx.x; e < 2 * fw; e += 256) {
+    const int which = e / fw, c = fbase + (e % fw);
+    atomicAdd(red + ((int64_t)slot * 2 + which) * F + c, (double)lred[e]);
+  }
+}
+
 struct K1Grid { dim3 grid; int FVB, RP; };
 inline K1Grid k1_grid(int64_t R, int F, int max_blocks, int threads = 256) {
   K1Grid g;
@@ -550,6 +609,7 @@ int check_edge(const char* what, const float* V, int64_t ldv, const float* U, in
   DG_REQUIRE(B > 0 && N > 0 && k > 0 && F > 0, DGCNN_EINVAL, "%s: bad shape", what);
   DG_REQUIRE(F % 4 == 0, DGCNN_EUNSUP, "%s: F must be a multiple of 4 (got %d)", what, F);
   DG_REQUIRE((int64_t)B * N * k < (1ll << 31), DGCNN_EUNSUP, "%s: B*N*k >= 2^31", what);
+  DG_REQUIRE(k < CNT_POS, DGCNN_EUNSUP, "%s: k must be < %d", what, CNT_POS);
   DG_REQUIRE(a16(V) && a16(U) && ldv % 4 == 0 && ldu % 4 == 0 && ldv >= F && ldu >= F, DGCNN_EINVAL,
              "%s: V, U must be 16-byte aligned with leading dimensions %% 4 == 0", what);
   return DGCNN_OK;
@@ -717,6 +777,23 @@ extern "C" int dgcnn_edge_bn_bwd_reduce_f32(const float* V, int64_t ldv, const f
   return launch_bwd_reduce<true>("dgcnn_edge_bn_bwd_reduce_f32", edge_src(V, ldv, U, ldu, idx, N), (int64_t)B * N, k, F,
                                  mean, rstd, beta, relu, dmax, lddmax, dmean, lddmean, mx_in, ldmx, cnt_in, red,
                                  (hipStream_t)stream);
+}
+
+extern "C" int dgcnn_edge_bn_bwd_reduce_points_f32(const float* mx, int64_t ldmx, const float* mn, int64_t ldmn,
+                                                   const float* cntpos, const float* dmax, int64_t lddmax,
+                                                   const float* dmean, int64_t lddmean, const float* beta,
+                                                   int64_t R, int k, int F, double* red, void* stream) {
+  DG_REQUIRE(mx && mn && cntpos && dmax && dmean && beta && red, DGCNN_EINVAL, "dgcnn_edge_bn_bwd_reduce_points_f32: null pointer");
+  DG_REQUIRE(R > 0 && k > 0 && k < CNT_POS && F > 0 && F % 4 == 0, DGCNN_EINVAL,
+             "dgcnn_edge_bn_bwd_reduce_points_f32: bad shape (F %% 4 == 0, k < %d)", CNT_POS);
+  DG_REQUIRE(a16(mx) && a16(mn) && a16(cntpos) && a16(dmax) && a16(dmean) && a16(beta) && ldmx % 4 == 0 && ldmn % 4 == 0 &&
+                 lddmax % 4 == 0 && lddmean % 4 == 0, DGCNN_EINVAL,
+             "dgcnn_edge_bn_bwd_reduce_points_f32: operands must be 16-byte aligned with leading dimensions %% 4 == 0");
+  const K1Grid g = k1_grid(R, F, 256);
+  const size_t sh = sizeof(float) * 2 * (size_t)(F < 1024 ? F : 1024);
+  hipLaunchKernelGGL(edge_bwd_reduce_points_kernel, g.grid, dim3(256), sh, (hipStream_t)stream, mx, ldmx, mn, ldmn, cntpos,
+                     dmax, lddmax, dmean, lddmean, beta, R, k, F, g.FVB, g.RP, red);
+  return dg::check_launch("dgcnn_edge_bn_bwd_reduce_points_f32");
 }
 
 extern "C" int dgcnn_edge_bn_bwd_apply_f32(const float* V, int64_t ldv, const float* U, int64_t ldu,

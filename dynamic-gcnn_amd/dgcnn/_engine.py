@@ -32,6 +32,7 @@ EDGE_MLP_LITERAL = False  # True: conv0 as the literal (B*N*k) x 2C GEMM over E 
 EDGE_MATERIALIZE_Y = False  # True: gather-add writes the (B*N*k, F) conv0 output and BatchNorm streams it (A/B switch);
                             # False: the BatchNorm passes recompute y = V[neighbour] + U[point] (no edge tensor in the forward)
 WGRAD_SIDE_STREAM = os.environ.get("DGCNN_SIDE_STREAM", "1") != "0"   # weight-gradient GEMMs on a second HIP stream
+EDGE_BWD_REDUCE_POINTS = True   # BN backward sums of conv0 from per-point data (False: a pass over the edges)
 SIDE_STREAM_MIN_ROWS = 16384   # below this many points the side stream is not used
 EDGE_MLP_NBR_GEMM = False  # True: factored conv0 with an edge-level neighbour GEMM instead of point-level GEMM + gather-add
 SCATTER_ATOMICS = False  # True: dx_j += dY W^T by fp32 atomics in the GEMM epilogue (A/B switch)
@@ -481,7 +482,12 @@ def edge_conv_block(x, B, N, k, num_filters, relu1=True, outs=None, net2=None):
                 return
             dmx, dmn = dmm[:, :F], dmm[:, F:]
             red = c.stats(F)
-            if virtual:
+            if virtual and EDGE_BWD_REDUCE_POINTS:
+                # sum dz, sum dz*xhat from the forward's per-point outputs alone (bn.hip): no pass over the edges
+                H.call("dgcnn_edge_bn_bwd_reduce_points_f32", mx.data_ptr(), H.ld2(mx), mn.data_ptr(), H.ld2(mn),
+                       cnt.data_ptr(), dmx.data_ptr(), H.ld2(dmx), dmn.data_ptr(), H.ld2(dmn), beta0.data_ptr(), R, k, F,
+                       red.data_ptr(), tag="edge_bwd_reduce_points_kernel", work=4.0 * 5 * R * F)
+            elif virtual:
                 assert UV is not None          # esrc holds raw pointers into UV: this reference keeps it alive
                 H.call("dgcnn_edge_bn_bwd_reduce_f32", *esrc, mean.data_ptr(), rstd.data_ptr(),
                        beta0.data_ptr(), 1, dmx.data_ptr(), H.ld2(dmx), dmn.data_ptr(), H.ld2(dmn),
@@ -501,6 +507,7 @@ def edge_conv_block(x, B, N, k, num_filters, relu1=True, outs=None, net2=None):
             elif need_sum:
                 dysum = torch.empty((R, F), dtype=torch.float32, device=x.device)
             if virtual:
+                assert UV is not None          # esrc holds raw pointers into UV: this reference keeps it alive
                 dY = torch.empty((R * k, F), dtype=torch.float32, device=x.device)
                 H.call("dgcnn_edge_bn_bwd_apply_f32", *esrc, mean.data_ptr(), rstd.data_ptr(), beta0.data_ptr(),
                        1, dmx.data_ptr(), H.ld2(dmx), dmn.data_ptr(), H.ld2(dmn), mx.data_ptr(), H.ld2(mx), cnt.data_ptr(),

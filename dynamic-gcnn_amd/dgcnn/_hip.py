@@ -44,6 +44,8 @@ PROTOTYPES = {
                                       c_int, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp],
     "dgcnn_edge_bn_bwd_reduce_f32": [c_vp, c_i64, c_vp, c_i64, c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp,
                                      c_int, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp],
+    "dgcnn_edge_bn_bwd_reduce_points_f32": [c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_int,
+                                            c_int, c_vp, c_vp],
     "dgcnn_edge_bn_bwd_apply_f32": [c_vp, c_i64, c_vp, c_i64, c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp,
                                     c_int, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp,
                                     c_f32, c_vp],

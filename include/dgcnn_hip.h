@@ -126,6 +126,13 @@ int dgcnn_edge_bn_bwd_reduce_f32(const float* V, int64_t ldv, const float* U, in
                                  const float* dmax, int64_t lddmax, const float* dmean, int64_t lddmean,
                                  const float* mx_in, int64_t ldmx, const float* cnt_in,
                                  double* red, void* stream);
+/* The backward BN reduction of a relu conv0 from per-point data only (no pass over the edges): cntpos is the
+ * cnt_out of dgcnn_edge_bn_act_kreduce_f32, which for the edge variants holds (#ties of the max) + 256 * (#rows
+ * with z > 0) (k < 256); mx / mn are that call's max_out / mean_out.  Fills red like _bwd_reduce_f32.            */
+int dgcnn_edge_bn_bwd_reduce_points_f32(const float* mx, int64_t ldmx, const float* mn, int64_t ldmn,
+                                        const float* cntpos, const float* dmax, int64_t lddmax,
+                                        const float* dmean, int64_t lddmean, const float* beta,
+                                        int64_t R, int k, int F, double* red, void* stream);
 int dgcnn_edge_bn_bwd_apply_f32(const float* V, int64_t ldv, const float* U, int64_t ldu,
                                 const int32_t* idx, int B, int N, int k, int F,
                                 const float* mean, const float* rstd, const float* beta, int relu,

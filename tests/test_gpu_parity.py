@@ -410,10 +410,17 @@ def test_edge_bn_passes_equal_dense_passes(dg, B, N, k, F):
                    mx.data_ptr(), H.ld2(mx), mn.data_ptr(), H.ld2(mn), 0, 0, cnt.data_ptr())
         outs.append((host(mm).copy(), host(cnt).copy()))
     np.testing.assert_array_equal(outs[0][0], outs[1][0])
-    np.testing.assert_array_equal(outs[0][1], outs[1][1])
+    # the edge variant packs (#ties of the max) + 256 * (#rows with z > 0) into cnt_out
+    packed = outs[1][1]
+    npos, ties = np.floor(packed / 256), packed % 256
+    np.testing.assert_array_equal(outs[0][1], ties)
+    z = np.maximum((host(Y).reshape(R, k, F) - host(mean)) * host(rstd) + host(beta), 0)
+    np.testing.assert_array_equal(npos, (z > 0).sum(1))
     assert outs[0][1].min() >= 1 and outs[0][1].max() <= k
     mx = dev(outs[0][0][:, :F].copy())
+    mn = dev(outs[0][0][:, F:2 * F].copy())
     cnt = dev(outs[0][1])
+    cnt_packed = dev(packed)
     dmx, dmn = dev(rng.normal(size=(R, F)).astype(np.float32)), dev(rng.normal(size=(R, F)).astype(np.float32))
     reds, dys = [], []
     for edge in (False, True):
@@ -421,11 +428,18 @@ def test_edge_bn_passes_equal_dense_passes(dg, B, N, k, F):
         args = (mean.data_ptr(), rstd.data_ptr(), beta.data_ptr(), 1, dmx.data_ptr(), F, dmn.data_ptr(), F,
                 mx.data_ptr(), F, cnt.data_ptr())
         if edge:
-            H.call("dgcnn_edge_bn_bwd_reduce_f32", *e, *args, red.data_ptr())
+            eargs = args[:-1] + (cnt_packed.data_ptr(),)
+            H.call("dgcnn_edge_bn_bwd_reduce_f32", *e, *eargs, red.data_ptr())
         else:
             H.call("dgcnn_bn_bwd_reduce_f32", Y.data_ptr(), R, k, F, *args, red.data_ptr())
         reds.append(host(red).sum(0))
     np.testing.assert_allclose(reds[0], reds[1], rtol=1e-6, atol=1e-4)
+    # the same two sums from per-point data only (no pass over the edges)
+    red = torch.zeros((H.STAT_SLOTS, 2, F), dtype=torch.float64, device="cuda")
+    H.call("dgcnn_edge_bn_bwd_reduce_points_f32", mx.data_ptr(), F, mn.data_ptr(), F, cnt_packed.data_ptr(), dmx.data_ptr(), F,
+           dmn.data_ptr(), F, beta.data_ptr(), R, k, F, red.data_ptr())
+    rp = host(red).sum(0)
+    np.testing.assert_allclose(rp, reds[0], rtol=2e-4, atol=2e-3 * max(1.0, float(np.abs(reds[0]).max()) * 1e-2))
     red0 = torch.zeros((H.STAT_SLOTS, 2, F), dtype=torch.float64, device="cuda")
     red0[0] = dev(reds[0])
     for edge in (False, True):
@@ -435,7 +449,7 @@ def test_edge_bn_passes_equal_dense_passes(dg, B, N, k, F):
         dbeta = torch.zeros(F, device="cuda")
         tail = (red.data_ptr(), dY.data_ptr(), dsum.data_ptr(), F + 4, dbeta.data_ptr(), 0.0)
         if edge:
-            H.call("dgcnn_edge_bn_bwd_apply_f32", *e, *args, *tail)
+            H.call("dgcnn_edge_bn_bwd_apply_f32", *e, *(args[:-1] + (cnt_packed.data_ptr(),)), *tail)
         else:
             H.call("dgcnn_bn_bwd_apply_f32", Y.data_ptr(), R, k, F, *args, *tail)
         dys.append((host(dY).copy(), host(dsum).copy(), host(dbeta).copy()))
@@ -445,6 +459,9 @@ def test_edge_bn_passes_equal_dense_passes(dg, B, N, k, F):
     with pytest.raises(H.HipError):
         H.call("dgcnn_edge_bn_bwd_reduce_f32", UV[:, F:].data_ptr(), 2 * F, UV.data_ptr(), 2 * F, idx.data_ptr(), B, N, k, 6,
                *args, red0.data_ptr())
+    with pytest.raises(ValueError):
+        H.call("dgcnn_edge_bn_bwd_reduce_points_f32", mx.data_ptr(), F, mn.data_ptr(), F, cnt_packed.data_ptr(), dmx.data_ptr(), F,
+               dmn.data_ptr(), F, beta.data_ptr(), R, 256, F, red0.data_ptr())
 
 
 @pytest.mark.parametrize("B,N,k", [(2, 100, 7), (24, 2048, 20), (1, 40000, 3), (3, 64, 1), (5, 777, 13), (1, 70000, 2)])
