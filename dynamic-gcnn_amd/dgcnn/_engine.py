@@ -406,7 +406,8 @@ def edge_conv_block(x, B, N, k, num_filters, relu1=True, outs=None, net2=None):
     st = c.stats(F)
     literal = EDGE_MLP_LITERAL
     gather = (not literal) and (not EDGE_MLP_NBR_GEMM) and F % 4 == 0 and F <= 1024
-    virtual = gather and not EDGE_MATERIALIZE_Y          # conv0 output never written: recomputed from (V, U, idx)
+    virtual = gather and not EDGE_MATERIALIZE_Y and k < 256   # conv0 output never written: recomputed from (V, U, idx)
+    #                                                           (the edge BN passes pack tie / positive counts: k < 256)
     Y = None if virtual else torch.empty((R * k, F), dtype=torch.float32, device=x.device)
     wd = wcat = UV = None
     if literal:
