@@ -370,168 +370,11 @@ __global__ __launch_bounds__(NT, 2) void gemm_x3_kernel(GemmP p) {
 }
 
 // ------------------------------------------------------------------------------------------------------
-// Wave-specialised variant (default).  512 threads: waves 0-3 are CONSUMERS (2x2, 64 x BN/2 each, MFMAs and
-// operand reads only), waves 4-7 are PRODUCERS (global fetch two slabs ahead, split, LDS writes).  A
-// workgroup's waves are dealt to the SIMDs cyclically, so consumer w and producer w+4 share a SIMD: the
-// producer's VALU / VMEM / DS instructions issue in the shadow of its partner's MFMAs instead of in the same
-// in-order stream.  LDS is double buffered, ONE barrier per 32-k slab:
-//     consumers:  MFMAs on buffer kt&1                          | barrier
-//     producers:  split slab kt+1, fetch slab kt+2, write buffer (kt+1)&1 | barrier
-// Producers leave before the epilogue (finished waves do not take part in later barriers).
-template <int AKIND, int BKIND, int BN, int NP>
-__global__ __launch_bounds__(512, 2) void gemm_x3ws_kernel(GemmP p) {
-  constexpr int BM = 128;
-  constexpr int TM = 2;
-  constexpr int TN = BN / 64;
-  using IA = Img<BM>;
-  using IB = Img<BN>;
-  constexpr unsigned BUF = 3 * IA::PB + 3 * IB::PB;
-  constexpr unsigned EPI_BYTES = 64 * BN * 4;
-  static_assert(2 * BUF >= EPI_BYTES, "epilogue tile must fit");
-  __shared__ __attribute__((aligned(16))) char smem_raw[2 * BUF];
-
-  const int t = threadIdx.x;
-  const int lane = t & 63;
-  const int wv = t >> 6;
-
-  const int id = blockIdx.x;
-  int mt, nt;
-  if (p.xcd_group) {
-    mt = ((id >> 3) / p.ntiles) * 8 + (id & 7);
-    nt = (id >> 3) % p.ntiles;
-  } else {
-    mt = id / p.ntiles;
-    nt = id % p.ntiles;
-  }
-  if (mt >= p.mtiles) return;
-  const int m0 = mt * BM;
-  const int n0 = nt * BN;
-  const int z = blockIdx.z;
-  const int kbeg = z * p.kchunk;
-  const int kend = (kbeg + p.kchunk < p.K) ? (kbeg + p.kchunk) : p.K;
-  const int klen = kend - kbeg;
-  const int nk = (klen + XK - 1) / XK;
-
-  if (wv >= 4) {
-    // ------------------------------------------------------------------ producers
-    const int pt = t - 256;
-    const bool roleA = pt < 128;
-    const int u = pt & 127;
-    Stage<AKIND, BM> sa;
-    Stage<BKIND, BN> sb;
-    sa.init(p.A, p.lda, m0, p.M, u, kbeg);
-    sb.init(p.B, p.ldb, n0, p.N, u, kbeg);
-    auto run = [&](auto mask_tag) {
-      constexpr bool MASK = decltype(mask_tag)::value;
-      // Ring of DEPTH raw slabs in registers: a producer wave keeps DEPTH x 8 KB of loads in flight, which is
-      // what covers the HBM latency of the streamed operand (one slab per wave in flight tops out at ~170
-      // TFLOP/s-equivalent, profiles/r01_gemm_x3_ablation.txt).  Producers are far from the register limit.
-      constexpr int DEPTH = 3;
-      float4 L[DEPTH][8];
-      unsigned pm[DEPTH];
-      Packed P[4];
-      auto fetch = [&](float4 (&Ls)[8], unsigned& pms, int slab) {
-        pms = 0;
-        if (roleA) sa.template load<MASK>(Ls, pms, slab * XK, klen);
-        else if (sb.on) sb.template load<MASK>(Ls, pms, slab * XK, klen);
-      };
-      auto stage = [&](const float4 (&Ls)[8], unsigned pms, int buf) {
-        if (roleA) sa.template split<MASK>(Ls, pms, P);
-        else if (sb.on) sb.template split<MASK>(Ls, pms, P);
-        char* base = smem_raw + buf * BUF;
-        if (roleA) sa.write(P, base);
-        else if (sb.on) sb.write(P, base + 3 * IA::PB);
-      };
-      fetch(L[0], pm[0], 0);
-#pragma unroll
-      for (int d = 1; d < DEPTH; ++d) fetch(L[d], pm[d], imin(d, nk - 1));
-      stage(L[0], pm[0], 0);
-      fetch(L[0], pm[0], imin(DEPTH, nk - 1));
-      __syncthreads();
-      // iteration kt stages slab kt+1, held in ring slot (kt+1) % DEPTH, then refills the slot with slab kt+1+DEPTH
-#pragma unroll 1
-      for (int kt0 = 0; kt0 < nk; kt0 += DEPTH) {
-#pragma unroll
-        for (int d = 0; d < DEPTH; ++d) {
-          const int kt = kt0 + d;
-          constexpr int dummy = 0; (void)dummy;
-          if (kt < nk) {
-#if X3_ABLATE != 11
-            if (kt + 1 < nk) {
-              stage(L[(d + 1) % DEPTH], pm[(d + 1) % DEPTH], (kt + 1) & 1);
-              fetch(L[(d + 1) % DEPTH], pm[(d + 1) % DEPTH], imin(kt + 1 + DEPTH, nk - 1));
-            }
-#endif
-            __syncthreads();
-          }
-        }
-      }
-    };
-    const bool edge = (m0 + BM > p.M) || (n0 + BN > p.N) || (klen % XK != 0);
-    if (edge) run(std::true_type{});
-    else run(std::false_type{});
-    return;
-  }
-
-  // -------------------------------------------------------------------- consumers
-  const int wr = wv >> 1, wc = wv & 1;
-  const int l31 = lane & 31, lh = lane >> 5;
-  f32x16 acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-  unsigned a_off[TM], b_off[TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i) a_off[i] = IA::at(wr * 64 + i * 32 + l31, lh);
-#pragma unroll
-  for (int j = 0; j < TN; ++j) b_off[j] = 3 * IA::PB + IB::at(wc * (BN / 2) + j * 32 + l31, lh);
-
-  __syncthreads();                                 // buffer 0 is ready
-#pragma unroll 1
-  for (int kt = 0; kt < nk; ++kt) {
-#if X3_ABLATE == 12
-    __syncthreads();
-    continue;
-#endif
-    const char* base = smem_raw + (kt & 1) * BUF;
-    bf16x8 a[2][TM][3], b[2][TN][3];
-#pragma unroll
-    for (int s = 0; s < 2; ++s)
-#pragma unroll
-      for (int q = 0; q < 3; ++q) {
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-          a[s][i][q] = *reinterpret_cast<const bf16x8*>(base + q * IA::PB + a_off[i] + 2 * s * IA::CS);
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-          b[s][j][q] = *reinterpret_cast<const bf16x8*>(base + q * IB::PB + b_off[j] + 2 * s * IB::CS);
-      }
-    constexpr int PA[9] = {0, 0, 1, 1, 0, 2, 1, 2, 2};
-    constexpr int PB[9] = {0, 1, 0, 1, 2, 0, 2, 1, 2};
-#pragma unroll
-    for (int s = 0; s < 2; ++s)
-#pragma unroll
-      for (int q = 0; q < NP; ++q)
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s][i][PA[q]], b[s][j][PB[q]], acc[i][j], 0, 0, 0);
-    __syncthreads();
-  }
-
-  gemm_epilogue<E_STORE, BM, BN, true, TM, TN>(p, acc, reinterpret_cast<float*>(smem_raw), m0, n0, mt, z, t, wr, wc, l31, lh);
-}
-
-// ------------------------------------------------------------------------------------------------------
 // 256 x 128 tile, 768 threads: waves 0-7 consumers (4 x 2, 64 x 64 each), waves 8-11 producers.  Three waves
 // per SIMD (two consumers + one producer; <= 168 VGPRs).  The staging work per MFMA is 3/4 of the 128 x 128
 // tile's (a 32-k slab of A and B is 384 rows for 256 x 128 outputs instead of 256 rows for 128 x 128), and it
-// is the staging VALU / DS-write issue slots next to the MFMAs that bound these kernels
-// (profiles/r01_gemm_x3_ablation.txt): consumers alone reach the power-limited MFMA rate.
+// is the staging work next to the MFMAs that costs (profiles/r01_gemm_x3_ablation.txt): consumers alone reach the
+// power-limited MFMA rate, and a wave-specialised 128 x 128 variant was no faster than gemm_x3_kernel (removed).
 //   every producer thread stages 4 chunks of A (256 rows) and 2 chunks of B (128 rows) per slab,
 //   ring of 2 raw slabs in registers, split + write chunk by chunk (12 live registers).
 template <int KIND, int TILE>          // staged by 256 threads
@@ -768,27 +611,11 @@ __global__ __launch_bounds__(768) void gemm_x3w2_kernel(GemmP p) {
 
 int g_arith = -1;      // -1: not resolved yet; 0 native fp32 MFMA; 6 / 9 partial products on the bf16 pipe
 
-inline int x3_ws() {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("DGCNN_GEMM_X3_WS"); v = (e && e[0] == '1') ? 1 : 0; }   // A/B switch (measured slower)
-  return v;
-}
-
 template <int AKIND, int BKIND>
 void launch_kind(GemmP& p, hipStream_t st, int bn, int np, dim3 grid) {
   if (p.bm == 256) {
     if (np == 9) hipLaunchKernelGGL((gemm_x3w2_kernel<AKIND, BKIND, 9>), grid, dim3(768), 0, st, p);
     else hipLaunchKernelGGL((gemm_x3w2_kernel<AKIND, BKIND, 6>), grid, dim3(768), 0, st, p);
-    return;
-  }
-  if (x3_ws()) {
-    if (bn == 64) {
-      if (np == 9) hipLaunchKernelGGL((gemm_x3ws_kernel<AKIND, BKIND, 64, 9>), grid, dim3(512), 0, st, p);
-      else hipLaunchKernelGGL((gemm_x3ws_kernel<AKIND, BKIND, 64, 6>), grid, dim3(512), 0, st, p);
-    } else {
-      if (np == 9) hipLaunchKernelGGL((gemm_x3ws_kernel<AKIND, BKIND, 128, 9>), grid, dim3(512), 0, st, p);
-      else hipLaunchKernelGGL((gemm_x3ws_kernel<AKIND, BKIND, 128, 6>), grid, dim3(512), 0, st, p);
-    }
     return;
   }
   if (bn == 64) {
