@@ -1,15 +1,16 @@
-import os, sys
+import sys
 sys.path.insert(0, "dynamic-gcnn_amd")
 import torch, numpy as np
-import dgcnn
 from dgcnn import _engine as E
 rng = np.random.default_rng(0)
-for (B, N, C, k) in [(24, 2048, 64, 20), (24, 2048, 3, 20)]:
+for (B, N, C, k) in [(24, 2048, 64, 20), (8, 16384, 64, 40), (8, 16384, 3, 40), (8, 65536, 64, 20), (8, 65536, 3, 20)]:
     x = torch.from_numpy(np.maximum(rng.normal(size=(B * N, C)), 0).astype(np.float32)).cuda()
-    for _ in range(3): E.knn(x, B, N, k)
+    for _ in range(2): E.knn(x, B, N, k)
     torch.cuda.synchronize()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record()
-    for _ in range(20): idx = E.knn(x, B, N, k)
+    n = 5
+    for _ in range(n): idx = E.knn(x, B, N, k)
     b.record(); torch.cuda.synchronize()
-    print("knn B=%d N=%d C=%d k=%d: %.1f us  checksum %d" % (B, N, C, k, a.elapsed_time(b) / 20 * 1e3, int(idx.long().sum())))
+    ms = a.elapsed_time(b) / n
+    print("knn B=%d N=%d C=%d k=%d: %.2f ms  %.1f TFLOP/s (2 B N^2 C)" % (B, N, C, k, ms, 2.0 * B * N * N * C / ms / 1e9))
