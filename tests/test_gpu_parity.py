@@ -577,6 +577,11 @@ CONFIGS = [
     dict(MODEL_NAME="dgcnn", EDGE_CONV_LAYERS=3, EDGE_CONV_FILTERS=[64, 64, 128], KVALUE=20, B=3, N=256, C=3),
     dict(MODEL_NAME="residual-dgcnn", EDGE_CONV_LAYERS=3, EDGE_CONV_FILTERS=64, KVALUE=12, B=2, N=192, C=4),   # G8
     dict(MODEL_NAME="residual-dgcnn-nofc", EDGE_CONV_LAYERS=2, EDGE_CONV_FILTERS=64, KVALUE=8, B=2, N=128, C=3),
+    # odd shapes: filter counts that are not multiples of 4 (conv0 falls back to the edge-level factored GEMM, scalar
+    # BN / GEMM paths), ragged N, one cloud, k = 3
+    dict(MODEL_NAME="dgcnn", EDGE_CONV_LAYERS=2, EDGE_CONV_FILTERS=[6, 10], KVALUE=3, B=1, N=50, C=3),
+    # filter counts that are multiples of 4 but not powers of two (gather path with 12 / 20 float4 lanes per row), C = 4
+    dict(MODEL_NAME="dgcnn", EDGE_CONV_LAYERS=2, EDGE_CONV_FILTERS=[48, 80], KVALUE=5, B=2, N=77, C=4),
 ]
 
 
