@@ -1,5 +1,6 @@
-// misc.hip -- the small HBM-bound kernels either side of the GEMMs: edge gather (the explicit
-// dgcnn/ops.py:21-40 tensor, API/tests only -- the model path gathers inside the GEMM), global
+// misc.hip -- the HBM / L2-bound kernels either side of the GEMMs: edge gather (the explicit dgcnn/ops.py:21-40
+// tensor, API/tests only), the per-edge gather-add of conv0 (y = V[neighbour] + U[point]: statistics pass of the
+// model path, ops.py:47-53), transposed adjacency (counting sort) + incoming-edge sums (tf.gather^T), global
 // max-pool + its gradient (model.py:76-81), tf.tile^T column sums, dropout (model.py:91),
 // residual add+relu (ops.py:134), strided copies (tf.concat), softmax / CE / accuracy
 // (trainval.py:39-52), gradient accumulation and Adam (trainval.py:17,75-80).

@@ -12,7 +12,11 @@ Layout conventions (DESIGN.md "Data layout"):
   * gradients mirror the forward buffers: the gradient of a column slice is the same slice of the
     gradient of its parent buffer (found by address), zero-initialised, always accumulated into;
   * parameters, their gradient accumulators and the Adam moments live in four flat fp32 buckets
-    (one RCCL all-reduce, one fused Adam launch per step).
+    (one RCCL all-reduce, one fused Adam launch per step);
+  * conv0 of an EdgeConv layer is a point-level GEMM [U|V] = X [Wa-Wb | Wb]; its (B*N*k, F) output is never
+    written: the BatchNorm passes recompute V[neighbour] + U[point] (edge_conv_block);
+  * work that only the optimizer needs (weight-gradient GEMMs, the transposed adjacency) runs on a second
+    HIP stream (Context.off_critical_path) and joins before the tape is released.
 """
 from __future__ import annotations
 
