@@ -1,4 +1,7 @@
-// gemm.hip -- K3: fp32 MFMA (v_mfma_f32_32x32x2_f32) GEMM family for gfx950.
+// gemm.hip -- K3: fp32 MFMA (v_mfma_f32_32x32x2_f32) GEMM family for gfx950, the dgcnn_gemm_f32 dispatcher and
+// the streaming kernels for the class dimension.  Since the bf16-split kernels (gemm_x3.hip) became the default
+// arithmetic for float4-loadable operands, this family serves DGCNN_GEMM_ARITH=f32, unaligned / odd shapes and
+// the edge-level conv0 forms that the model path keeps behind switches (A_EDGE*, E_SCATTER).
 //
 // One kernel template covers every 1x1 convolution of the path and its gradients
 // (dgcnn/ops.py:47-52,62-70,125-133,153-160; dgcnn/model.py:46-53,65-72,94-101):
