@@ -647,6 +647,31 @@ def test_model_logits_and_gradients(dg, cfg):
         assert np.linalg.norm(g - ref) <= 2e-2 * max(np.linalg.norm(ref), 1e-6), n
 
 
+@pytest.mark.parametrize("ncls", [3, 4, 5, 8])
+def test_logits_other_class_counts(dg, ncls):
+    """NUM_CLASS other than 2: the class-dimension products switch between the streaming kernels (<= 4 classes)
+    and the generic / bf16-split GEMMs; logits within 1e-3 of the oracle, loss finite, one optimizer step runs."""
+    flags = dg.DGCNN_FLAGS(EDGE_CONV_LAYERS=2, EDGE_CONV_FILTERS=[32, 64], KVALUE=6, FC_LAYERS=1, FC_FILTERS=[64], NUM_CLASS=ncls,
+                           NUM_CHANNEL=3, TRAIN=False)
+    rng = np.random.default_rng(ncls)
+    B, N = 2, 160
+    pts = rng.random((B, N, 3), dtype=np.float32)
+    labels = rng.integers(0, ncls, (B, N)).astype(np.int32)
+    params = O.init_params(flags, 3, seed=2)
+    tv, res, cap = _run_model(dg, flags, pts, params, train=False, labels=labels)
+    idx_list = [cap["EdgeConv%d" % i][1] for i in range(2)]
+    logits_ref, _ = O.model_forward(pts, flags, params, idx_list=idx_list)
+    loss_ref, sm_ref, acc_ref, _ = O.softmax_xent(logits_ref, labels)
+    np.testing.assert_allclose(host(res[0]), sm_ref, rtol=0, atol=1e-3)
+    assert abs(float(res[-1]) - float(loss_ref)) < 1e-3
+    flags.TRAIN = True
+    tv2 = dg.trainval(flags).initialize()
+    tv2.zero_gradients(None)
+    r = tv2.accum_gradient(None, [pts], [labels])
+    tv2.apply_gradient(None)
+    assert np.isfinite(float(r[2])) and float(dg.ctx().flat_grad.abs().sum()) > 0
+
+
 def test_side_stream_does_not_change_results(dg):
     """Weight-gradient GEMMs / the transposed adjacency run on a second HIP stream; with it switched off the
     same gradients must come out (up to the run-to-run atomic-order noise of the BN sums)."""
