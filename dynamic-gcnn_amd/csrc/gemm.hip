@@ -941,17 +941,37 @@ int launch(GemmP& p, hipStream_t st, const char* what) {
 
 inline bool aligned16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
 
-// choose a split of the reduction dimension so that ~1024 workgroups are in flight
+// choose a split of the reduction dimension
+//   bf16-split kernels: every k-chunk is pinned to one XCD (gemm_common.h:block_tile), so the number of chunks is
+//     8 x (chunks per XCD), sized so that the chunks of an XCD fill its 32 CUs in whole rounds;
+//   native kernels: ~1024 workgroups in flight.
 int plan_splits(GemmP& p, void* ws, size_t ws_bytes, const char* what) {
   const int bn = (p.N <= 64) ? 64 : 128;
   p.bm = 128;
+  p.zmajor = 0;
+  const bool x3 = dg::gemm_arith() != 0 && p.avec && p.bvec;
   // the 256-row bf16-split kernel runs one 768-thread workgroup per CU: aim at 2 rounds of 256 workgroups
-  const bool big = dg::gemm_arith() != 0 && p.avec && p.bvec && dg::x3_tile_m(p.M, p.N) == 256;
+  const bool big = x3 && dg::x3_tile_m(p.M, p.N) == 256;
   const int64_t tiles = dg::cdiv(p.M, big ? 256 : 128) * dg::cdiv(p.N, bn);
   int64_t s = dg::cdiv(big ? 512 : 1024, tiles);
   const int64_t maxs = p.K / 256 > 0 ? p.K / 256 : 1;
   if (s > maxs) s = maxs;
   if (s < 1) s = 1;
+  static int zm_env = -1;
+  if (zm_env < 0) { const char* e = getenv("DGCNN_GEMM_ZMAJOR"); zm_env = e ? atoi(e) : 1; }   // A/B switch
+  if (x3 && zm_env && maxs >= 8) {
+    const int64_t cap = big ? 32 : 64;           // workgroups one XCD (32 CUs) runs at a time
+    double best_eff = 0.0;
+    int64_t best = 0;
+    for (int64_t R = 1; R <= 3; ++R) {           // rounds of `cap` workgroups per XCD
+      int64_t per = (cap * R) / tiles;           // k-chunks per XCD
+      if (per < 1) per = 1;
+      if (8 * per > maxs) per = maxs / 8;
+      const double eff = (double)(tiles * per) / (double)(cap * dg::cdiv(tiles * per, cap));
+      if (eff > best_eff + 0.03) { best_eff = eff; best = 8 * per; }
+    }
+    if (best >= 8) { s = best; p.zmajor = 1; }
+  }
   int64_t chunk = dg::cdiv(dg::cdiv(p.K, s), 32) * 32;     // multiple of both kernels' k-slab
   s = dg::cdiv(p.K, chunk);
   p.splits = (int)s;
@@ -964,6 +984,8 @@ int plan_splits(GemmP& p, void* ws, size_t ws_bytes, const char* what) {
       return DGCNN_ENOSPC;
     }
     p.partial = reinterpret_cast<float*>(ws);
+  } else {
+    p.zmajor = 0;
   }
   return DGCNN_OK;
 }

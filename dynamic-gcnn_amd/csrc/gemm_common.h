@@ -36,7 +36,38 @@ struct GemmP {
   int mtiles, ntiles, xcd_group, bm, cvec;
   int edge_nbr;   // A_EDGE / A_EDGE_T rows are the raw neighbour features x_j (K or M = C) instead of [x_i, x_j - x_i]
   int gbvec;      // per-group bias rows are float4-loadable
+  int zmajor;     // split-K launches of the bf16-split kernels: 1-D grid, XCD x (= block id % 8) owns the k-chunks z = x (mod 8)
 };
+
+// Block -> (mt, nt, z).  MI355X hands workgroup b to XCD b % 8 (each XCD has a private 4 MB L2).
+//   zmajor    (split-K: few output tiles, long reduction) every k-chunk z is pinned to ONE XCD: all mtiles x ntiles tiles
+//             of the chunk run there side by side (<= 32 CUs), march through k in step and share each A / B slab
+//             through that L2 -- every operand byte leaves HBM once.  (With z on the grid's z axis the tiles of a chunk
+//             landed on all 8 XCDs: the A panel was fetched once per column tile, the B panel once per row tile:
+//             3.2x the algorithmic bytes on FC0's weight gradient, profiles/r01e_pmc_hbm_bytes.txt.)
+//   xcd_group (many row panels, several column tiles) the column tiles of one A row panel share an XCD;
+//   otherwise row-major over the tiles, z from the grid.
+__device__ __forceinline__ bool block_tile(const GemmP& p, int& mt, int& nt, int& z) {
+  const int id = blockIdx.x;
+  if (p.zmajor) {
+    const int tiles = p.mtiles * p.ntiles;
+    const int j = id >> 3;
+    z = (id & 7) + 8 * (j / tiles);
+    const int tl = j % tiles;
+    mt = tl / p.ntiles;
+    nt = tl % p.ntiles;
+    return z < p.splits;
+  }
+  z = blockIdx.z;
+  if (p.xcd_group) {
+    mt = ((id >> 3) / p.ntiles) * 8 + (id & 7);
+    nt = (id >> 3) % p.ntiles;
+  } else {
+    mt = id / p.ntiles;
+    nt = id % p.ntiles;
+  }
+  return mt < p.mtiles;
+}
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 #if DGCNN_ABLATE == 5   // experiment: prefetch by LDS-DMA into a dummy LDS area (results are garbage)

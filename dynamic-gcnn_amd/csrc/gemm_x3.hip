@@ -202,19 +202,10 @@ __global__ __launch_bounds__(NT, 2) void gemm_x3_kernel(GemmP p) {
   const int wr = wv >> 1, wc = wv & 1;
   const int l31 = lane & 31, lh = lane >> 5;
 
-  const int id = blockIdx.x;
-  int mt, nt;
-  if (p.xcd_group) {
-    mt = ((id >> 3) / p.ntiles) * 8 + (id & 7);
-    nt = (id >> 3) % p.ntiles;
-  } else {
-    mt = id / p.ntiles;
-    nt = id % p.ntiles;
-  }
-  if (mt >= p.mtiles) return;
+  int mt, nt, z;
+  if (!block_tile(p, mt, nt, z)) return;
   const int m0 = mt * BM;
   const int n0 = nt * BN;
-  const int z = blockIdx.z;
   const int kbeg = z * p.kchunk;
   const int kend = (kbeg + p.kchunk < p.K) ? (kbeg + p.kchunk) : p.K;
   const int klen = kend - kbeg;
@@ -484,19 +475,10 @@ __global__ __launch_bounds__(768) void gemm_x3w2_kernel(GemmP p) {
   const int lane = t & 63;
   const int wv = t >> 6;
 
-  const int id = blockIdx.x;
-  int mt, nt;
-  if (p.xcd_group) {
-    mt = ((id >> 3) / p.ntiles) * 8 + (id & 7);
-    nt = (id >> 3) % p.ntiles;
-  } else {
-    mt = id / p.ntiles;
-    nt = id % p.ntiles;
-  }
-  if (mt >= p.mtiles) return;
+  int mt, nt, z;
+  if (!block_tile(p, mt, nt, z)) return;
   const int m0 = mt * BM;
   const int n0 = nt * BN;
-  const int z = blockIdx.z;
   const int kbeg = z * p.kchunk;
   const int kend = (kbeg + p.kchunk < p.K) ? (kbeg + p.kchunk) : p.K;
   const int klen = kend - kbeg;
@@ -656,6 +638,7 @@ void launch_gemm_x3(int asrc, int bsrc, void* pv, hipStream_t st, int bn, int np
   GemmP& p = *reinterpret_cast<GemmP*>(pv);
   const unsigned gx = p.xcd_group ? (unsigned)(cdiv(p.mtiles, 8) * 8 * p.ntiles) : (unsigned)(p.mtiles * p.ntiles);
   dim3 grid(gx, 1, (unsigned)p.splits);
+  if (p.zmajor) grid = dim3((unsigned)(cdiv(p.splits, 8) * 8 * p.mtiles * p.ntiles), 1, 1);
   if (asrc == A_ROW && bsrc == B_ROW) launch_kind<KCONTIG, KSTRIDED>(p, st, bn, np, grid);
   else if (asrc == A_ROW && bsrc == B_COL) launch_kind<KCONTIG, KCONTIG>(p, st, bn, np, grid);
   else launch_kind<KSTRIDED, KSTRIDED>(p, st, bn, np, grid);

@@ -303,7 +303,9 @@ __global__ __launch_bounds__(64 * RG) void global_max_kernel(const float* __rest
       if (v > best || (v == best && i < bi)) { best = v; bi = i; }
     }
     out[(int64_t)b * F + f] = best;
-    if (arg) arg[(int64_t)b * F + f] = bi;
+    // a column that is all NaN / -inf never updates bi: keep the backward scatter inside the cloud (row 0, like
+    // np.argmax) instead of leaving the 0x7fffffff sentinel for global_max_bwd_kernel to index with
+    if (arg) arg[(int64_t)b * F + f] = bi < N ? bi : 0;
   }
 }
 

@@ -545,7 +545,9 @@ def edge_conv_block(x, B, N, k, num_filters, relu1=True, outs=None, net2=None):
                 # dU = sum_m dY, dV = sum of incoming dY;  dWcat = X^T [dU|dV],  dx += [dU|dV] Wcat^T
                 incoming_sum(dUV[:, F:])
                 dwcat = torch.empty((Cp, 2 * F), dtype=torch.float32, device=x.device)
-                with c.off_critical_path(dwcat, rows=R):
+                # dUV / dwcat are locals of this closure allocated on the main stream: record them on the side stream,
+                # or the caching allocator may hand dUV's block to the next main-stream allocation while the side GEMM reads it
+                with c.off_critical_path(dwcat, dUV, rows=R):
                     gemm(xg, dUV, dwcat, transA=True)
                     H.call("dgcnn_edge_wgrad_combine_f32", dwcat.data_ptr(), C, F, dW0.data_ptr())
                 if dx is not None:

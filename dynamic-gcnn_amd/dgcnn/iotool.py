@@ -9,7 +9,13 @@ the sources here are
   IO_TYPE 'npz'        arrays DATA_KEY / LABEL_KEY / WEIGHT_KEY of one or more .npz files, the same
                        dense (entries, N, C) / (entries, N) layout io_h5 reads (iotool.py:212-231);
                        OUTPUT_FILE collects data / softmax / label rows like io_h5.store.
-  IO_TYPE 'h5'         the reference's HDF5 layout through h5py when that module is importable (it is
+                       RAGGED files (clouds with different point counts -- what io_larcv yields, iotool.py:76-98, and
+                       what production trains on with `-np -1 -mbs 1`, scripts/lsf/train_dgcnn.sh:28) additionally
+                       hold `<DATA_KEY>_offsets` (entries+1 int64): cloud e = rows offsets[e]:offsets[e+1] of the
+                       concatenated DATA_KEY (points, C) / LABEL_KEY (points,) / WEIGHT_KEY (points,) arrays.  Clouds
+                       with fewer than MIN_POINTS (256, iotool.py:81) points are dropped at load time; next() returns
+                       LISTS of per-cloud arrays, like io_larcv.next (iotool.py:127-150).
+  IO_TYPE 'h5'         the same two layouts as HDF5 datasets through h5py when that module is importable (it is
                        optional, as in the reference README); otherwise NotImplementedError.
   IO_TYPE 'synthetic'  seeded clouds of the benchmark's shape; labels are a deterministic function of
                        position so that a training loop has something to learn.
@@ -76,6 +82,7 @@ class io_npz(io_base):
     def __init__(self, flags):
         super(io_npz, self).__init__(flags)
         self._out = None
+        self._ragged = False
 
     # container access; io_h5 overrides these two
     def _open(self, path):
@@ -88,25 +95,76 @@ class io_npz(io_base):
         f = self._flags
         files = f.INPUT_FILE if isinstance(f.INPUT_FILE, (list, tuple)) else str(f.INPUT_FILE).split(",")
         parts = {"data": [], "label": [], "weight": []}
+        okey = f.DATA_KEY + "_offsets"
+        ragged = None
         for path in files:
             with self._open(path) as z:
-                parts["data"].append(np.asarray(z[f.DATA_KEY], np.float32))
-                if getattr(f, "LABEL_KEY", ""):
-                    parts["label"].append(np.asarray(z[f.LABEL_KEY], np.int32))
-                if getattr(f, "WEIGHT_KEY", ""):
-                    parts["weight"].append(np.asarray(z[f.WEIGHT_KEY], np.float32))
-        cat = lambda v: np.concatenate(v, axis=0) if v else None
-        self._data, self._label, self._weight = cat(parts["data"]), cat(parts["label"]), cat(parts["weight"])
-        if self._data is None or self._data.ndim != 3:
-            raise ValueError("'%s' must hold (entries, points, channels), got %s"
-                             % (f.DATA_KEY, None if self._data is None else self._data.shape))
-        for name, a in (("label", self._label), ("weight", self._weight)):
-            if a is not None and a.shape != self._data.shape[:2]:
-                raise ValueError("%s shape %s does not match data %s" % (name, a.shape, self._data.shape))
-        self._num_entries, _, self._num_channels = self._data.shape
+                names = set(z.keys())
+                is_ragged = okey in names
+                if ragged is None:
+                    ragged = is_ragged
+                elif ragged != is_ragged:
+                    raise ValueError("cannot mix dense and ragged ('%s' present) input files" % okey)
+                data = np.asarray(z[f.DATA_KEY], np.float32)
+                label = np.asarray(z[f.LABEL_KEY], np.int32) if getattr(f, "LABEL_KEY", "") else None
+                weight = np.asarray(z[f.WEIGHT_KEY], np.float32) if getattr(f, "WEIGHT_KEY", "") else None
+                if ragged:
+                    off = np.asarray(z[okey], np.int64)
+                    if data.ndim != 2 or off.ndim != 1 or off[0] != 0 or off[-1] != len(data) or (np.diff(off) < 0).any():
+                        raise ValueError("ragged file %s: '%s' must be (points, channels) and '%s' a non-decreasing "
+                                         "prefix array ending at %d" % (path, f.DATA_KEY, okey, len(data)))
+                    for name, a in (("label", label), ("weight", weight)):
+                        if a is not None and a.shape != (len(data),):
+                            raise ValueError("%s shape %s does not match the %d points of '%s'" % (name, a.shape, len(data), f.DATA_KEY))
+                    for e in range(len(off) - 1):
+                        lo, hi = int(off[e]), int(off[e + 1])
+                        if hi - lo < int(getattr(f, "MIN_POINTS", 256)):     # iotool.py:81: `if num_point < 256: continue`
+                            continue
+                        parts["data"].append(data[lo:hi])
+                        if label is not None:
+                            parts["label"].append(label[lo:hi])
+                        if weight is not None:
+                            parts["weight"].append(weight[lo:hi])
+                else:
+                    parts["data"].append(data)
+                    if label is not None:
+                        parts["label"].append(label)
+                    if weight is not None:
+                        parts["weight"].append(weight)
+        self._ragged = bool(ragged)
+        if self._ragged:
+            self._data = parts["data"]
+            self._label = parts["label"] or None
+            self._weight = parts["weight"] or None
+            if not self._data:
+                raise ValueError("no cloud with at least %d points in %s" % (int(getattr(f, "MIN_POINTS", 256)), files))
+            self._num_entries, self._num_channels = len(self._data), self._data[0].shape[1]
+        else:
+            cat = lambda v: np.concatenate(v, axis=0) if v else None
+            self._data, self._label, self._weight = cat(parts["data"]), cat(parts["label"]), cat(parts["weight"])
+            if self._data is None or self._data.ndim != 3:
+                raise ValueError("'%s' must hold (entries, points, channels), got %s"
+                                 % (f.DATA_KEY, None if self._data is None else self._data.shape))
+            for name, a in (("label", self._label), ("weight", self._weight)):
+                if a is not None and a.shape != self._data.shape[:2]:
+                    raise ValueError("%s shape %s does not match data %s" % (name, a.shape, self._data.shape))
+            self._num_entries, _, self._num_channels = self._data.shape
         self._cursor = 0
         if getattr(f, "OUTPUT_FILE", ""):
             self._out = {"idx": [], "data": [], "softmax": [], "label": []}
+
+    def next(self):
+        if not self._ragged:
+            return super(io_npz, self).next()
+        n, bs = self._num_entries, self._batch_size
+        if getattr(self._flags, "SHUFFLE", 0) and bs <= n:
+            start = int(self._rng.random_sample() * (n - bs))          # io_larcv.next: a random contiguous window
+            idx = np.arange(start, start + bs)
+        else:
+            idx = (self._cursor + np.arange(bs)) % n                     # sequential with wrap-around
+            self._cursor = int(idx[-1] + 1) % n
+        pick = lambda v: None if v is None else [v[i] for i in idx]
+        return idx, pick(self._data), pick(self._label), pick(self._weight)
 
     def store(self, idx, softmax):
         if self._out is None:
@@ -124,13 +182,21 @@ class io_npz(io_base):
         if self._out is not None and self._out["idx"]:
             out = {"idx": "idx", "data": self._flags.DATA_KEY, "softmax": "softmax",
                    "label": getattr(self._flags, "LABEL_KEY", "") or "label"}
-            self._write(self._flags.OUTPUT_FILE, {out[k]: np.stack(v) for k, v in self._out.items() if v})
+            if self._ragged:                                             # same CSR layout as the input
+                arrays = {"idx": np.asarray(self._out["idx"], np.int64),
+                          self._flags.DATA_KEY + "_offsets": np.concatenate([[0], np.cumsum([len(d) for d in self._out["data"]])]).astype(np.int64)}
+                for k in ("data", "softmax", "label"):
+                    if self._out[k]:
+                        arrays[out[k]] = np.concatenate(self._out[k], axis=0)
+                self._write(self._flags.OUTPUT_FILE, arrays)
+            else:
+                self._write(self._flags.OUTPUT_FILE, {out[k]: np.stack(v) for k, v in self._out.items() if v})
         self._out = None
 
 
 class io_h5(io_npz):
-    """HDF5 flavour of the same dense layout (iotool.py:199-280): datasets DATA_KEY (entries, N, C),
-    LABEL_KEY / WEIGHT_KEY (entries, N).  Needs h5py, which is optional: without it the factory raises
+    """HDF5 flavour of the same layouts (iotool.py:199-280): datasets DATA_KEY (entries, N, C),
+    LABEL_KEY / WEIGHT_KEY (entries, N), or the ragged form with `<DATA_KEY>_offsets`.  Needs h5py, which is optional: without it the factory raises
     NotImplementedError naming the missing module.  Output is written with h5py too (the reference
     uses PyTables earrays for the same three datasets, iotool.py:233-245)."""
 

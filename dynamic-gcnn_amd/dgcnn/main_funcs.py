@@ -152,6 +152,19 @@ def prepare(flags):
     return h
 
 
+def _tower_array(chunk, what):
+    """Rows [at, at+MINIBATCH_SIZE) of a batch as ONE array (MINIBATCH_SIZE, N, ...), the shape the reference's
+    placeholders take (trainval.py:31-35: (MINIBATCH_SIZE, None, NUM_CHANNEL)).  Dense sources hand over an array
+    slice; variable-N sources (io_larcv-like lists, iotool.py:127-150) a list of per-cloud arrays, which only stacks
+    when the clouds agree in N -- the production regime is `-mbs 1` (scripts/lsf/train_dgcnn.sh:28)."""
+    if isinstance(chunk, np.ndarray):
+        return chunk
+    if len({c.shape[0] for c in chunk}) != 1:
+        raise ValueError("clouds of %s in one micro-batch have different point counts %s: a variable-N source needs "
+                         "--minibatch_size 1" % (what, [c.shape[0] for c in chunk]))
+    return np.stack(chunk)
+
+
 def _micro_batches(flags, h, data, label, weight):
     """Yield (data_v, label_v, weight_v) tower lists covering this replica's share of the batch."""
     lo, hi = parallel.shard_bounds(int(flags.BATCH_SIZE), h.rank, h.world)
@@ -160,11 +173,11 @@ def _micro_batches(flags, h, data, label, weight):
     while at < hi:
         dv, lv, wv = [], None if label is None else [], None if weight is None else []
         for _ in flags.GPUS:
-            dv.append(data[at:at + mbs])
+            dv.append(_tower_array(data[at:at + mbs], "data"))
             if lv is not None:
-                lv.append(label[at:at + mbs])
+                lv.append(_tower_array(label[at:at + mbs], "label"))
             if wv is not None:
-                wv.append(weight[at:at + mbs])
+                wv.append(_tower_array(weight[at:at + mbs], "weight"))
             at += mbs
         yield dv, lv, wv
 
@@ -193,7 +206,8 @@ def train_loop(flags, h):
         report = bool(flags.REPORT_STEP) and (it + 1) % flags.REPORT_STEP == 0
         summarize = bool(getattr(flags, "SUMMARY_STEP", 0)) and h.train_logger is not None and \
             (it + 1) % flags.SUMMARY_STEP == 0
-        checkpoint = bool(getattr(flags, "CHECKPOINT_STEP", 0)) and (it + 1) % flags.CHECKPOINT_STEP == 0
+        checkpoint = bool(getattr(flags, "CHECKPOINT_STEP", 0)) and bool(getattr(flags, "WEIGHT_PREFIX", "")) and \
+            (it + 1) % flags.CHECKPOINT_STEP == 0                           # main_funcs.py:131: no prefix, no snapshot
 
         t0 = time.time()
         idx, data, label, weight = h.data_io.next()
@@ -279,12 +293,18 @@ def inference_loop(flags, h):
             torch.cuda.synchronize()
         t_inf = time.time() - t0
 
-        if getattr(flags, "OUTPUT_FILE", "") and h.world == 1:
-            at = lo
-            for tower in softmax:
-                for row in tower.cpu().numpy():
+        if getattr(flags, "OUTPUT_FILE", ""):
+            # every replica holds the softmax of its own shard [lo, hi) of the batch: gather the shards to rank 0,
+            # which owns the output file (main_funcs.py:264-268 stores from the one process the reference has)
+            rows = [row for tower in softmax for row in tower.cpu().numpy()]
+            if h.world > 1:
+                dist = parallel.dist_state()[0]
+                box = [None] * h.world if h.rank == 0 else None
+                dist.gather_object(rows, box, dst=0)
+                rows = [r for part in box for r in part] if h.rank == 0 else []
+            if h.rank == 0:
+                for at, row in enumerate(rows):
                     h.data_io.store(idx[at], row)
-                    at += 1
 
         epoch = it * float(flags.BATCH_SIZE) / h.data_io.num_entries()
         t_spent = time.time() - t_iter

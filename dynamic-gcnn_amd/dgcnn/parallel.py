@@ -42,9 +42,11 @@ def broadcast_(flat, dist, src=0):
 
 def allreduce_mean_(flat, dist, world):
     """flat <- mean over replicas of flat (trainval.py:64-73), in place, one collective."""
-    if dist is None or world == 1:
+    if dist is None:
         return flat
-    dist.all_reduce(flat)                                   # SUM over replicas
+    dist.all_reduce(flat)                                   # SUM over replicas (a one-rank group still issues it)
+    if world == 1:
+        return flat
     if flat.is_cuda:
         H.call("dgcnn_axpby_f32", flat.data_ptr(), 1.0 / world, flat.data_ptr(), 0.0, flat.numel())
     else:                                                   # host tensors only exist in the gloo tests

@@ -23,6 +23,9 @@ from . import model
 from . import parallel
 
 
+TF_SCOPE = "dgcnn/"       # tf.variable_scope('dgcnn', reuse=tf.AUTO_REUSE): trainval.py:29
+
+
 def param_specs(flags, num_channel):
     """[(name, shape)] in the creation order of tf.trainable_variables()."""
     from .ops import _listify
@@ -181,20 +184,40 @@ class trainval(object):
         return None
 
     # ------------------------------------------------------------------ main_funcs.py:83-94,181-185
+    def _slots(self):
+        """[(variable name, offset into the flat buckets, view)] in bucket order.  The buckets are laid out by
+        allocate_variables(param_specs(...)); a variable created lazily by get_variable outside the specs has no
+        slice in them and is not checkpointed."""
+        c = self._ctx
+        base = c.flat_param.data_ptr()
+        out = []
+        for name, var in c.vars.items():
+            off = (var.data_ptr() - base) // 4
+            if 0 <= off and off + var.numel() <= c.flat_param.numel() and var.data_ptr() >= base:
+                out.append((name, int(off), var))
+        return out
+
     def state_dict(self):
-        """Host copy of everything tf.train.Saver would write for this graph: the trainable variables
-        under their TF names, Adam's two slots per variable (`<name>/Adam`, `<name>/Adam_1`) and the
-        beta power accumulators."""
+        """Host copy of everything tf.train.Saver would write for this graph, under the reference's names: every
+        variable lives in the outer scope `dgcnn/` (trainval.py:29), slim stores a 1x1 convolution's weights as
+        [1, 1, Cin, Cout], Adam keeps two slots per trainable variable (`<name>/Adam`,
+        `<name>/Adam_1`) and two beta power accumulators, and every BatchNorm owns `moving_mean` / `moving_variance`,
+        which the reference never updates (their update ops sit in UPDATE_OPS and are never run, Appendix A.3): they
+        are written with their initial values (0 / 1) so that a reader keyed on the TF names finds them."""
         c = self._ctx
         out = {}
-        off = 0
         m, v = c.flat_m.cpu().numpy(), c.flat_v.cpu().numpy()
-        for name, var in c.vars.items():
+        as_tf = lambda a: a.reshape((1, 1) + a.shape) if a.ndim == 2 else a
+        for name, off, var in self._slots():
             n = var.numel()
-            out[name] = var.detach().cpu().numpy().copy()
-            out[name + "/Adam"] = m[off:off + n].reshape(tuple(var.shape)).copy()
-            out[name + "/Adam_1"] = v[off:off + n].reshape(tuple(var.shape)).copy()
-            off += n
+            key = TF_SCOPE + name
+            out[key] = as_tf(var.detach().cpu().numpy().copy())
+            out[key + "/Adam"] = as_tf(m[off:off + n].reshape(tuple(var.shape)).copy())
+            out[key + "/Adam_1"] = as_tf(v[off:off + n].reshape(tuple(var.shape)).copy())
+            if name.endswith("BatchNorm/beta"):
+                stem = key[:-len("beta")]
+                out[stem + "moving_mean"] = np.zeros(tuple(var.shape), np.float32)
+                out[stem + "moving_variance"] = np.ones(tuple(var.shape), np.float32)
         out["beta1_power"] = np.float32(0.9 ** (c.adam_t + 1))      # TF: beta^(t+1) after t updates
         out["beta2_power"] = np.float32(0.999 ** (c.adam_t + 1))
         out["adam_step"] = np.int64(c.adam_t)
@@ -202,26 +225,30 @@ class trainval(object):
         return out
 
     def load_state_dict(self, state, strict=True):
+        """Accepts the names / shapes state_dict writes and the round-1 form (no `dgcnn/` prefix, 2-D weights)."""
         c = self._ctx
-        missing = [n for n in c.vars if n not in state]
+        slots = self._slots()
+        find = lambda n: TF_SCOPE + n if TF_SCOPE + n in state else (n if n in state else None)
+        missing = [n for n, _, _ in slots if find(n) is None]
         if missing and strict:
             raise KeyError("checkpoint lacks variables: %s" % ", ".join(missing[:4]))
         m = np.zeros(c.flat_param.numel(), np.float32)
         v = np.zeros_like(m)
         p = c.flat_param.cpu().numpy().copy()
-        off = 0
-        for name, var in c.vars.items():
+        for name, off, var in slots:
             n = var.numel()
-            if name in state:
-                a = np.asarray(state[name], np.float32)
-                if a.shape != tuple(var.shape):
-                    raise ValueError("checkpoint variable %s has shape %s, graph wants %s"
-                                     % (name, a.shape, tuple(var.shape)))
-                p[off:off + n] = a.reshape(-1)
-                if name + "/Adam" in state:
-                    m[off:off + n] = np.asarray(state[name + "/Adam"], np.float32).reshape(-1)
-                    v[off:off + n] = np.asarray(state[name + "/Adam_1"], np.float32).reshape(-1)
-            off += n
+            key = find(name)
+            if key is None:
+                continue
+            a = np.asarray(state[key], np.float32)
+            if a.ndim == 4 and a.shape[:2] == (1, 1):
+                a = a[0, 0]
+            if a.shape != tuple(var.shape):
+                raise ValueError("checkpoint variable %s has shape %s, graph wants %s" % (key, a.shape, tuple(var.shape)))
+            p[off:off + n] = a.reshape(-1)
+            if key + "/Adam" in state:
+                m[off:off + n] = np.asarray(state[key + "/Adam"], np.float32).reshape(-1)
+                v[off:off + n] = np.asarray(state[key + "/Adam_1"], np.float32).reshape(-1)
         c.flat_param.copy_(torch.from_numpy(p))
         c.flat_m.copy_(torch.from_numpy(m))
         c.flat_v.copy_(torch.from_numpy(v))

@@ -40,7 +40,7 @@ def build_c(force: bool = False) -> str:
     if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
         os.makedirs(out_dir, exist_ok=True)
         subprocess.check_call(
-            ["gcc", "-O2", "-ffp-contract=off", "-fno-fast-math", "-shared", "-fPIC", "-o", so, src, "-lm"]
+            ["gcc", "-O2", "-fopenmp", "-ffp-contract=off", "-fno-fast-math", "-shared", "-fPIC", "-o", so, src, "-lm"]
         )
     return so
 
@@ -52,6 +52,12 @@ def _lib():
         _LIB.oracle_knn_f32.restype = ctypes.c_int
         _LIB.oracle_knn_f32.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                         ctypes.c_long, ctypes.c_int, ctypes.c_void_p]
+        _LIB.oracle_knn_rows_f32.restype = ctypes.c_int
+        _LIB.oracle_knn_rows_f32.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_long, ctypes.c_int,
+                                             ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+        _LIB.oracle_dist_pairs_f32.restype = None
+        _LIB.oracle_dist_pairs_f32.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_long, ctypes.c_void_p,
+                                               ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
         _LIB.oracle_dist_f32.restype = None
         _LIB.oracle_dist_f32.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_long,
                                          ctypes.c_void_p]
@@ -94,6 +100,31 @@ def k_nn(points: np.ndarray, k: int) -> np.ndarray:
     nn_dist = squared + np.transpose(squared, (0, 2, 1)) - 2 * inner    # ops.py:15-16
     order = np.argsort(nn_dist, axis=-1, kind="stable")                 # ops.py:18 (top_k of -D)
     return order[..., :k].astype(np.int32)
+
+
+def k_nn_rows(cloud: np.ndarray, k: int, rows: np.ndarray) -> np.ndarray:
+    """k_nn of ONE cloud (N,C) float32 restricted to the query rows `rows` -> (len(rows), k) int32.
+    Same C row routine as k_nn (bit-defined); for the N = 16384 / 65536 tests, where a seeded sample of
+    rows is checked instead of all 4.3e9 pairs of a cloud."""
+    x = np.ascontiguousarray(cloud, np.float32)
+    N, C = x.shape
+    rows = np.ascontiguousarray(rows, np.int32)
+    out = np.empty((len(rows), k), np.int32)
+    if _lib().oracle_knn_rows_f32(x.ctypes.data, N, C, C, k, rows.ctypes.data, len(rows), out.ctypes.data) != 0:
+        raise ValueError("k_nn: k=%d > N=%d (tf.nn.top_k raises InvalidArgument)" % (k, N))
+    return out
+
+
+def dist_pairs_f32(cloud: np.ndarray, rows: np.ndarray, cand: np.ndarray) -> np.ndarray:
+    """D[r][m] between query row rows[r] and candidate cand[r][m] of one cloud, normative arithmetic."""
+    x = np.ascontiguousarray(cloud, np.float32)
+    N, C = x.shape
+    rows = np.ascontiguousarray(rows, np.int32)
+    cand = np.ascontiguousarray(cand, np.int32)
+    D = np.empty(cand.shape, np.float32)
+    _lib().oracle_dist_pairs_f32(x.ctypes.data, N, C, C, rows.ctypes.data, len(rows), cand.ctypes.data, cand.shape[1],
+                                 D.ctypes.data)
+    return D
 
 
 # ----------------------------------------------------------------------------------------

@@ -113,8 +113,18 @@ def test_hip_two_replicas_adam_matches_golden():
         for n, ref in params_of(g, "accum:").items():
             got = tv.gradients[n].cpu().numpy()
             assert np.linalg.norm(got - ref) <= 1e-2 * max(np.linalg.norm(ref), 1e-6), n
+        old = params_of(g)
+        accum = params_of(g, "accum:")
         tv.apply_gradient(None)
         for n, ref in params_of(g, "new:").items():
-            np.testing.assert_allclose(tv.variables[n].cpu().numpy(), ref, rtol=0, atol=2.5e-3, err_msg=n)
+            # the first Adam step moves every weight by lr * g / (|g| + eps') ~= lr * sign(g): compare the UPDATE (not the
+            # parameter, which a missing update would also satisfy at any tolerance above lr) where the golden gradient
+            # is far enough from zero that its sign / magnitude ratio is stable: within 2 % of a step (lr = 1e-3)
+            d_got = tv.variables[n].cpu().numpy().astype(np.float64) - old[n]
+            d_ref = ref.astype(np.float64) - old[n]
+            solid = np.abs(accum[n]) > 5e-2 * np.abs(accum[n]).max()      # (gradient bar of this test: 1e-2 of the norm)
+            assert solid.mean() > 0.1, n
+            np.testing.assert_allclose(d_got[solid], d_ref[solid], rtol=0, atol=2e-5, err_msg=n)
+            assert np.abs(d_got[solid]).mean() > 0.9e-3 and np.abs(d_got).max() <= 1.001e-3, n
     finally:
         E.DROPOUT_KEEP = keep

@@ -1,0 +1,115 @@
+"""Data parallelism of the REAL trainer on the GPU box (BASELINE configs[3] logic).
+
+The box has one MI355X, so both replicas share cuda:0.  RCCL refuses two ranks on one device ("Duplicate GPU
+detected"), therefore:
+  * world_size 2: torch.distributed.run launches tests/dp_worker.py; backend "nccl" is tried first and, when RCCL
+    refuses the layout, "gloo" carries the same device tensors.  The post-all-reduce gradient must equal the
+    single-process two-tower result (mean over towers, sum over micro-steps: dgcnn/trainval.py:64-79) and the
+    replicas must end with identical parameters;
+  * world_size 1 with backend "nccl": the broadcast and the all-reduce of the flat bucket really go through RCCL.
+"""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+STEPS, GLOBAL_BATCH, N = 2, 4, 1024
+
+
+def launch(world, backend, out, data, port):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(HERE, "dp_worker.py"),
+           "--backend", backend, "--out", str(out), "--data", str(data)]
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    return p.returncode, p.stdout.decode(errors="replace")
+
+
+def reference_two_towers(data_file, towers):
+    """Single process: every micro-step feeds `towers` tower shards to ONE accum_gradient call (tower mean), the
+    accumulators sum over micro-steps, one Adam step."""
+    sys.path.insert(0, HERE)
+    import dp_worker
+    import dgcnn
+    from dgcnn import _engine as E
+    from dgcnn import parallel
+    z = np.load(data_file)
+    pts, lab = z["points"], z["labels"]
+    keep, E.DROPOUT_KEEP = E.DROPOUT_KEEP, 1.0
+    try:
+        tv = dgcnn.trainval(dp_worker.flags_for(dgcnn)).initialize()
+        init = dgcnn.ctx().flat_param.cpu().numpy().copy()
+        tv.zero_gradients(None)
+        for s in range(pts.shape[0]):
+            bounds = [parallel.shard_bounds(pts.shape[1], r, towers) for r in range(towers)]
+            tv.accum_gradient(None, [pts[s, lo:hi] for lo, hi in bounds], [lab[s, lo:hi] for lo, hi in bounds])
+        grad = dgcnn.ctx().flat_grad.cpu().numpy().copy()
+        tv.apply_gradient(None)
+        return init, grad, dgcnn.ctx().flat_param.cpu().numpy().copy()
+    finally:
+        E.DROPOUT_KEEP = keep
+        dgcnn.reset()
+
+
+@pytest.fixture(scope="module")
+def data_file(tmp_path_factory):
+    d = tmp_path_factory.mktemp("dp")
+    rng = np.random.default_rng(33)
+    np.savez(d / "batch.npz", points=rng.random((STEPS, GLOBAL_BATCH, N, 3), dtype=np.float32),
+             labels=rng.integers(0, 2, (STEPS, GLOBAL_BATCH, N)).astype(np.int32))
+    return d / "batch.npz"
+
+
+def close(a, b, rel):
+    return np.linalg.norm(a.astype(np.float64) - b) <= rel * max(np.linalg.norm(b), 1e-12)
+
+
+def test_two_replicas_on_one_gpu_match_two_towers(tmp_path, data_file):
+    out = tmp_path / "w2"
+    out.mkdir()
+    rc, log = launch(2, "nccl", out, data_file, 29611)
+    backend = "nccl"
+    if rc != 0:
+        assert "BACKEND_REFUSED" in log or "Duplicate GPU" in log, log[-3000:]
+        for f in out.glob("*.npz"):
+            f.unlink()
+        rc, log = launch(2, "gloo", out, data_file, 29612)
+        backend = "gloo"
+    assert rc == 0, log[-3000:]
+    r0, r1 = np.load(out / "rank0.npz"), np.load(out / "rank1.npz")
+    print("world_size 2 on one device ran over backend %s (%s)" % (backend, str(r0["backend"])))
+    # replicas: identical start (broadcast), identical all-reduced gradient, identical parameters after Adam
+    np.testing.assert_array_equal(r0["init"], r1["init"])
+    np.testing.assert_array_equal(r0["grad"], r1["grad"])
+    np.testing.assert_array_equal(r0["param"], r1["param"])
+    assert not np.array_equal(r0["local_grad"], r1["local_grad"])               # the shards really differ
+    np.testing.assert_allclose(r0["grad"], 0.5 * (r0["local_grad"].astype(np.float64) + r1["local_grad"]), rtol=0,
+                               atol=1e-6 * np.abs(r0["grad"]).max())           # all-reduce = mean of the local buckets
+    init, grad, param = reference_two_towers(data_file, towers=2)
+    np.testing.assert_array_equal(init, r0["init"])
+    # same math, different summation orders only through the fp64 atomics of the BN sums (run-to-run noise ~1e-5)
+    assert close(r0["grad"], grad, 2e-3), np.linalg.norm(r0["grad"] - grad) / np.linalg.norm(grad)
+    solid = np.abs(grad) > 5e-2 * np.abs(grad).max()
+    np.testing.assert_allclose((r0["param"] - init)[solid], (param - init)[solid], rtol=0, atol=2e-5)   # lr = 1e-3 steps
+    assert np.abs(r0["param"] - init).max() <= 1.001e-3 and np.abs(r0["param"] - init)[solid].mean() > 0.9e-3
+
+
+def test_rccl_world_size_one_runs_the_collectives(tmp_path, data_file):
+    """backend "nccl" (= RCCL) with a single rank: init, broadcast of the parameter bucket and the all-reduce of the
+    7 MB gradient bucket execute inside RCCL; the result equals the process-group-free run."""
+    out = tmp_path / "w1"
+    out.mkdir()
+    rc, log = launch(1, "nccl", out, data_file, 29613)
+    assert rc == 0, log[-3000:]
+    r0 = np.load(out / "rank0.npz")
+    assert str(r0["backend"]) == "nccl"
+    init, grad, param = reference_two_towers(data_file, towers=1)
+    np.testing.assert_array_equal(init, r0["init"])
+    assert close(r0["grad"], grad, 2e-3)
+    np.testing.assert_array_equal(r0["grad"], r0["local_grad"])                  # mean over one replica

@@ -56,7 +56,10 @@ def test_train_loop_logs_checkpoints_and_resumes(tmp_path, capsys):
     assert open(tmp_path / "w" / "checkpoint").read() == 'model_checkpoint_path: "snap-5"\n'
     assert M.latest_checkpoint(f.WEIGHT_PREFIX) == f.WEIGHT_PREFIX + "-5"
     z = np.load(tmp_path / "w" / "snap-5.npz")
-    assert z["EdgeConv0/conv0/weights"].shape == (6, 32) and "Final/BatchNorm/beta/Adam_1" in z.files
+    # TF names: outer scope dgcnn/ (trainval.py:29), slim's [1,1,Cin,Cout] weights, Adam slots, the (dead) moving statistics
+    assert z["dgcnn/EdgeConv0/conv0/weights"].shape == (1, 1, 6, 32) and "dgcnn/Final/BatchNorm/beta/Adam_1" in z.files
+    assert z["dgcnn/EdgeConv0/conv0/weights/Adam"].shape == (1, 1, 6, 32)
+    assert float(np.abs(z["dgcnn/FC0/BatchNorm/moving_mean"]).max()) == 0 and float(z["dgcnn/FC0/BatchNorm/moving_variance"].min()) == 1
     assert int(z["adam_step"]) == 6 and np.isclose(float(z["beta1_power"]), 0.9 ** 7)
     final = h.trainer._ctx.flat_param.clone()
 
@@ -97,6 +100,14 @@ def test_save_restore_roundtrip(tmp_path):
     tv.zero_gradients(None), tv.accum_gradient(None, [pts], [lab]), tv.apply_gradient(None)
     want = tv._ctx.flat_param.clone()
 
+    tv2 = dgcnn.trainval(_flags(tmp_path, LOG_DIR="", SEED=5)).initialize().restore(name)
+    c = tv2._ctx
+    # the round-1 checkpoint form (no dgcnn/ scope, 2-D weights) still loads to the same state
+    with np.load(name + ".npz") as z:
+        legacy = {(k[len("dgcnn/"):] if k.startswith("dgcnn/") else k): (z[k][0, 0] if z[k].ndim == 4 else z[k]) for k in z.files}
+    tv3 = dgcnn.trainval(_flags(tmp_path, LOG_DIR="", SEED=6)).initialize().load_state_dict(legacy)
+    assert torch.equal(tv3._ctx.flat_param, c.flat_param) and torch.equal(tv3._ctx.flat_v, c.flat_v)
+    # (initialize() resets the process-wide engine context: rebuild tv2 before using it again)
     tv2 = dgcnn.trainval(_flags(tmp_path, LOG_DIR="", SEED=5)).initialize().restore(name)
     c = tv2._ctx
     assert c.adam_t == 2 and float(c.flat_m.abs().sum()) > 0 and float(c.flat_v.abs().sum()) > 0
@@ -144,3 +155,43 @@ def test_inference_loop_logs_and_stores_softmax(tmp_path, capsys):
     assert float(r[0]["loss"]) == -1 and float(r[0]["accuracy"]) == -1
     with pytest.raises(NotImplementedError):
         h.trainer.accum_gradient(None, [data._data[:4]], [data._label[:4]])
+
+
+def test_train_and_inference_on_a_variable_n_source(tmp_path, capsys):
+    """N4: the production regime `-np -1 -mbs 1` (scripts/lsf/train_dgcnn.sh:28) -- every cloud has its own point count and
+    C = 4 channels (iotool.py:82), one cloud per micro-step, gradients summed over the BATCH_SIZE micro-steps
+    (main_funcs.py:139-166).  A ragged .npz with 5 distinct N (one cloud below the 256-point cut of iotool.py:81) goes
+    through train_loop, a checkpoint, and inference_loop, whose stored softmax rows must have each cloud's own length
+    and reproduce the trainer's inference on that cloud."""
+    rng = np.random.default_rng(4)
+    counts = [300, 1000, 120, 517, 2048, 300, 777]
+    off = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+    pts = rng.random((off[-1], 4), dtype=np.float32)
+    lab = (pts[:, 0] > 0.5).astype(np.int32)
+    np.savez(tmp_path / "ragged.npz", data=pts, label=lab, data_offsets=off)
+    common = dict(IO_TYPE="npz", INPUT_FILE=str(tmp_path / "ragged.npz"), NUM_POINT=-1, BATCH_SIZE=6, MINIBATCH_SIZE=1,
+                  SHUFFLE=0, KVALUE=8, NUM_CHANNEL=-1)
+    f = _flags(tmp_path, ITERATION=3, CHECKPOINT_STEP=3, SUMMARY_STEP=0, REPORT_STEP=0, **common)
+    h = M.train(f)
+    assert f.NUM_CHANNEL == 4 and h.data_io.num_entries() == 6           # the 120-point cloud is dropped
+    rows = _rows(tmp_path / "log" / "train_log-0000000.csv")
+    assert len(rows) == 3 and all(np.isfinite(float(r["loss"])) for r in rows)
+    assert os.path.exists(f.WEIGHT_PREFIX + "-2.npz")
+    g = _flags(tmp_path, ITERATION=1, MODEL_PATH=f.WEIGHT_PREFIX + "-2", OUTPUT_FILE=str(tmp_path / "out.npz"),
+               LOG_DIR=str(tmp_path / "ilog"), **common)
+    h2 = M.inference(g)
+    capsys.readouterr()
+    z = np.load(tmp_path / "out.npz")
+    kept = [c for c in counts if c >= 256]
+    assert z["idx"].tolist() == [0, 1, 2, 3, 4, 5] and np.diff(z["data_offsets"]).tolist() == kept
+    assert z["softmax"].shape == (sum(kept), 2) and np.allclose(z["softmax"].sum(1), 1.0, atol=1e-5)
+    # the stored rows of the third kept cloud (N = 517) == a direct inference call on that cloud
+    lo, hi = int(z["data_offsets"][2]), int(z["data_offsets"][3])
+    cloud = z["data"][lo:hi]
+    assert cloud.shape == (517, 4)
+    sm = h2.trainer.inference(None, [cloud[None]])[0].cpu().numpy()[0]
+    np.testing.assert_allclose(z["softmax"][lo:hi], sm, rtol=0, atol=2e-4)
+    # a micro-batch that mixes point counts is refused with the reason
+    bad = _flags(tmp_path, ITERATION=1, CHECKPOINT_STEP=0, LOG_DIR="", **dict(common, MINIBATCH_SIZE=2))
+    with pytest.raises(ValueError, match="minibatch_size 1"):
+        M.train(bad)

@@ -629,22 +629,22 @@ def test_model_logits_and_gradients(dg, cfg):
     p64 = {n: v.astype(np.float64) for n, v in params.items()}
     G, loss64, _, _ = O.train_step_grads(pts.astype(np.float64), labels, flags, p64, idx_list=idx_list)
     assert abs(float(res[2]) - float(loss64)) < 1e-3
+    # fp32 path vs the fp64 twin fed the same graphs.  Measured (profiles/r02/grad_error_3way.txt): 6e-5 .. 1.4e-4 relative
+    # Frobenius at (3,256), 1e-3 .. 2.2e-3 at (24,2048) -- an order of magnitude CLOSER to the twin than the fp32 numpy
+    # restatement is (3e-3 / 3e-2: its float32 BatchNorm reductions).  Isolated elements move more when a ReLU /
+    # max-over-k / global-max decision flips in fp32 (one point's whole contribution is rerouted): the elementwise
+    # bar is 2e-2 of the tensor's scale, the Frobenius bar 5e-3.  A wrong or missing term is O(1).
+    worst = (0.0, "")
     for n in params:
-        # fp32 path vs the fp64 twin through up to 3 dynamic-graph layers: a handful of ReLU / max-over-k
-        # decisions flip, so single elements move by ~1e-2 of the tensor's scale (the fp32 numpy oracle
-        # itself deviates from its fp64 twin by MORE than the HIP path does -- measured, DESIGN.md
-        # "Tolerances").  Bars: elementwise 2e-2 of max|ref| (99.9 % of the elements; 1e-1 for the rest), 2e-2 in relative Frobenius norm
-        # (observed 0.3e-2 .. 1.0e-2 run to run on the layer-0 weights, three dynamic graphs deep)
-        # (a wrong or missing term shows up as O(1)).
         g = host(tv.gradients[n]).astype(np.float64)
         ref = G[n]
         scale = max(float(np.abs(ref).max()), 1e-3)
         err = np.abs(g - ref)
-        # (summation orders are not run-to-run deterministic -- fp64 stat atomics, CSR fill order -- so WHICH
-        # decisions flip varies: allow 0.1 % of the elements up to 1e-1 of the scale, the rest 2e-2)
-        assert (err > 2e-2 * scale + 2e-2 * np.abs(ref)).sum() <= max(2, 1e-3 * err.size), n      # (2 elements of a small tensor)
-        assert err.max() <= 1e-1 * scale, n
-        assert np.linalg.norm(g - ref) <= 2e-2 * max(np.linalg.norm(ref), 1e-6), n
+        fro = np.linalg.norm(g - ref) / max(np.linalg.norm(ref), 1e-6)
+        worst = max(worst, (fro, n))
+        assert err.max() <= 2e-2 * scale, (n, err.max() / scale)
+        assert fro <= 5e-3, (n, fro)
+    print("%s: worst relative Frobenius gradient error vs the fp64 twin %.2e (%s)" % (cfg.get("MODEL_NAME"), worst[0], worst[1]))
 
 
 @pytest.mark.parametrize("ncls", [3, 4, 5, 8])

@@ -1,5 +1,7 @@
 """Host-side logic around the hot path that needs no GPU: batch sources (reference iotool.py),
 flags / CLI (flags.py) and the pure helpers of main_funcs.py."""
+import os
+
 import numpy as np
 import pytest
 
@@ -182,3 +184,83 @@ def test_prepare_rejects_indivisible_batch(capsys):
     with pytest.raises(SystemExit):
         M.prepare(_flags(BATCH_SIZE=5, MINIBATCH_SIZE=2))
     assert "must be a multiple" in capsys.readouterr().err
+
+
+CONDA_PY = "/opt/conda/bin/python3.9"      # the interpreter of this image that has h5py
+
+
+@pytest.mark.skipif(not os.path.exists(CONDA_PY), reason="no interpreter with h5py in this image")
+def test_real_hdf5_roundtrip_through_io_h5(tmp_path):
+    """N2: io_h5 against REAL HDF5 files (dense layout of iotool.py:212-231 and the ragged layout), written and re-read
+    with h5py by tests/h5_roundtrip.py under the interpreter that has h5py."""
+    import subprocess
+    here = os.path.dirname(os.path.abspath(__file__))
+    p = subprocess.run([CONDA_PY, os.path.join(here, "h5_roundtrip.py"), str(tmp_path)], stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, timeout=300, env={"PATH": os.environ.get("PATH", "")})
+    out = p.stdout.decode(errors="replace")
+    if p.returncode != 0 and "No module named 'h5py'" in out:
+        pytest.skip("h5py missing under %s" % CONDA_PY)
+    assert p.returncode == 0 and "H5_ROUNDTRIP_OK" in out, out[-2000:]
+
+
+def _ragged_file(path, counts, C=4, seed=0, weight=False):
+    rng = np.random.default_rng(seed)
+    off = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+    arrays = dict(data=rng.random((off[-1], C), dtype=np.float32), label=rng.integers(0, 2, off[-1]).astype(np.int32),
+                  data_offsets=off)
+    if weight:
+        arrays["w"] = rng.random(off[-1], dtype=np.float32)
+    np.savez(path, **arrays)
+    return arrays
+
+
+def test_ragged_npz_source(tmp_path):
+    """N4: clouds with different point counts (what io_larcv yields, iotool.py:76-98): lists out of next(), the
+    <256-point cut of iotool.py:81, sequential wrap-around, seeded contiguous shuffle window, CSR output."""
+    a = _ragged_file(tmp_path / "r.npz", [300, 255, 700, 256, 1000], weight=True)
+    off = a["data_offsets"]
+    f = _flags(IO_TYPE="npz", INPUT_FILE=str(tmp_path / "r.npz"), WEIGHT_KEY="w", BATCH_SIZE=3, OUTPUT_FILE=str(tmp_path / "o.npz"))
+    io = dgcnn.io_factory(f)
+    io.initialize()
+    assert io.num_entries() == 4 and io.num_channels() == 4           # 255 points: dropped
+    idx, data, label, weight = io.next()
+    assert idx.tolist() == [0, 1, 2] and [d.shape for d in data] == [(300, 4), (700, 4), (256, 4)]
+    assert np.array_equal(data[1], a["data"][off[2]:off[3]]) and np.array_equal(label[2], a["label"][off[3]:off[4]])
+    assert np.array_equal(weight[0], a["w"][:300])
+    assert io.next()[0].tolist() == [3, 0, 1]
+    io.store(1, np.ones((700, 2), np.float32))
+    io.finalize()
+    o = np.load(tmp_path / "o.npz")
+    assert o["data_offsets"].tolist() == [0, 700] and o["softmax"].shape == (700, 2) and o["label"].shape == (700,)
+    g = _flags(IO_TYPE="npz", INPUT_FILE=str(tmp_path / "r.npz"), BATCH_SIZE=2, SHUFFLE=1, MIN_POINTS=1)
+    io2 = dgcnn.io_factory(g)
+    io2.initialize()
+    assert io2.num_entries() == 5
+    for _ in range(6):
+        i2 = io2.next()[0]
+        assert i2[1] == i2[0] + 1 and 0 <= i2[0] <= 3                  # io_larcv.next: a contiguous window
+    # dense and ragged files do not mix; malformed offsets are refused
+    np.savez(tmp_path / "d.npz", data=np.zeros((2, 300, 4), np.float32), label=np.zeros((2, 300), np.int32))
+    with pytest.raises(ValueError):
+        dgcnn.io_factory(_flags(IO_TYPE="npz", INPUT_FILE="%s,%s" % (tmp_path / "r.npz", tmp_path / "d.npz"))).initialize()
+    np.savez(tmp_path / "bad.npz", data=np.zeros((10, 4), np.float32), label=np.zeros(10, np.int32), data_offsets=np.array([0, 4, 9]))
+    with pytest.raises(ValueError):
+        dgcnn.io_factory(_flags(IO_TYPE="npz", INPUT_FILE=str(tmp_path / "bad.npz"), MIN_POINTS=1)).initialize()
+
+
+def test_micro_batches_of_a_ragged_batch():
+    """main_funcs.py:139-155 with `-mbs 1`: every micro-step is ONE cloud as a (1, N_i, C) tower array; a micro-batch
+    that mixes point counts is refused with the reason."""
+    h = M.Handlers()
+    h.rank, h.world = 0, 1
+    rng = np.random.default_rng(0)
+    data = [rng.random((n, 4), dtype=np.float32) for n in (300, 512, 300, 700)]
+    label = [np.zeros(len(d), np.int32) for d in data]
+    f = _flags(BATCH_SIZE=4, MINIBATCH_SIZE=1)
+    steps = list(M._micro_batches(f, h, data, label, None))
+    assert [s[0][0].shape for s in steps] == [(1, 300, 4), (1, 512, 4), (1, 300, 4), (1, 700, 4)]
+    assert all(s[1][0].shape == (1, s[0][0].shape[1]) and s[2] is None for s in steps)
+    with pytest.raises(ValueError, match="minibatch_size 1"):
+        list(M._micro_batches(_flags(BATCH_SIZE=4, MINIBATCH_SIZE=2), h, data, label, None))
+    same = list(M._micro_batches(_flags(BATCH_SIZE=2, MINIBATCH_SIZE=2), h, [data[0], data[2]], [label[0], label[2]], None))
+    assert same[0][0][0].shape == (2, 300, 4)                            # equal N stacks
