@@ -69,6 +69,28 @@ __device__ __forceinline__ int sel_i(lmask_t m, int t, int f) {
   return r;
 }
 
+// smallest float greater than f (f finite or +inf; -0 counts as +0): d <= f  <=>  d < next_up(f)
+__device__ __forceinline__ float next_up(float f) {
+  const float g = f + 0.0f;
+  const unsigned u = __float_as_uint(g);
+  const unsigned v = (g >= 0.0f) ? u + 1u : u - 1u;
+  return (g == INFINITY) ? g : __uint_as_float(v);
+}
+
+#ifndef KNN_SHARE
+#define KNN_SHARE 1      // 0: every list filters with its own k-th distance only (A/B switch, profiles/r02)
+#endif
+#ifndef KNN_ABLATE
+#define KNN_ABLATE 0     // experiments only: 1 = no selection at all (distances + parking only; wrong results)
+#endif
+
+// Shared selection bound.  The candidates of a query row are split over FOUR sorted lists (KC entries each, KC % 4 == 0).
+// If every list holds at least KC/4 entries, the row has seen KC candidates with d <= tau := max_i list_i[KC/4 - 1], so a
+// candidate with d > tau has KC candidates strictly before it in (d, j) order and can never enter the row's top KC:
+// dropping it is exact.  Candidates with d == tau pass (the tie is decided by index in the final merge), hence the
+// filter  d < min(own k-th, next_up(tau)).  tau is about the row's GLOBAL k-th distance (the KC/4-th best of a quarter
+// of the candidates), where a list's own k-th is about the global 4k-th: ~2.5x fewer inserts.  The lists publish
+// list_i[KC/4 - 1] in LDS after every drain; a stale (older = larger) value only makes the filter looser.
 template <bool LEX>
 __device__ __forceinline__ lmask_t key_less(float d, int j, float dt, int jt) {
   return LEX ? (m_flt(d, dt) | (m_feq(d, dt) & m_ilt(j, jt))) : m_flt(d, dt);
@@ -106,10 +128,11 @@ __global__ __launch_bounds__(256, (knn_min_waves<CP, KC>())) void knn_kernel(con
   constexpr int DQ_F = PERW * 256;           // per-lane distance slots of the current 32 candidates
   constexpr int MERGE_F = ROWS * KC * 2;
   constexpr int SH = (TILE_F + DQ_F > MERGE_F ? TILE_F + DQ_F : MERGE_F);
-  __shared__ __attribute__((aligned(16))) float smem[SH + TJ];
+  __shared__ __attribute__((aligned(16))) float smem[SH + TJ + WAVES * ROWS];
   float* xs = smem;
   float* dq = smem + TILE_F;
   float* sjs = smem + SH;
+  volatile float* thrw = smem + SH + TJ;     // [4 lists = waves][64 rows]: list[KC/4 - 1] so far
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -133,6 +156,7 @@ __global__ __launch_bounds__(256, (knn_min_waves<CP, KC>())) void knn_kernel(con
     jl[t] = 0x7fffffff;
   }
 
+  thrw[tid] = INFINITY;
 #pragma unroll 1
   for (int j0 = 0; j0 < N; j0 += TJ) {
     __syncthreads();
@@ -166,7 +190,13 @@ __global__ __launch_bounds__(256, (knn_min_waves<CP, KC>())) void knn_kernel(con
     // the channel loop is fully unrolled so x_i stays in registers, fenced every 16 channels so
     // the scheduler cannot hoist every LDS read).  Each lane parks d in its LDS slot and keeps a
     // 32-bit mask of the candidates that beat its current k-th distance. ----
+#if KNN_SHARE
+    const float tau = fmaxf(fmaxf(dl[KC / 4 - 1], thrw[((w + 1) & 3) * ROWS + lane]),
+                            fmaxf(thrw[((w + 2) & 3) * ROWS + lane], thrw[((w + 3) & 3) * ROWS + lane]));
+    const float thr = fminf(dl[KC - 1], next_up(tau));
+#else
     const float thr = dl[KC - 1];
+#endif
     unsigned mask = 0u;
 #pragma unroll 1
     for (int g = 0; g < PERW; g += 2) {
@@ -191,6 +221,9 @@ __global__ __launch_bounds__(256, (knn_min_waves<CP, KC>())) void knn_kernel(con
       mask |= (unsigned)sel_i(m_flt(d0, thr), (int)(1u << g), 0);
       mask |= (unsigned)sel_i(m_flt(d1, thr), (int)(2u << g), 0);
     }
+#if KNN_ABLATE == 1
+    mask = 0u;
+#endif
     // ---- phase B: drain.  Every iteration each lane pops ITS lowest surviving candidate (ascending
     // j, which the tie rule needs) and all lanes run one insert: max-over-lanes(popcount) inserts
     // per 32 candidates instead of one per candidate with any taker. ----
@@ -201,6 +234,9 @@ __global__ __launch_bounds__(256, (knn_min_waves<CP, KC>())) void knn_kernel(con
       mask &= mask - 1u;
       list_insert<KC, false>(dl, jl, d, j0 + w * PERW + g);
     }
+#if KNN_SHARE
+    thrw[w * ROWS + lane] = dl[KC / 4 - 1];
+#endif
   }
 
   // ---- merge the 4 per-wave lists into wave 0 through LDS (lexicographic (d, j)) ----
@@ -259,13 +295,14 @@ __global__ __launch_bounds__(256, 2) void knn_mfma_kernel(const float* __restric
   constexpr int TILE_F = CP * ST;
   constexpr int DQ_F = 16 * 256;
   constexpr int MERGE_F = ROWS * KC * 2;
-  constexpr int WORK_F = 2 * TILE_F + DQ_F + 2 * TJM;
+  constexpr int WORK_F = 2 * TILE_F + DQ_F + 2 * TJM + 4 * ROWS;
   constexpr int SH = (WORK_F > MERGE_F ? WORK_F : MERGE_F);
   constexpr int NV = (TJM * (CP / 4)) / 256;  // float4 staged per thread per tile
   static_assert(NV >= 1, "tile too small");
   __shared__ __attribute__((aligned(16))) float smem[SH];
   float* dq = smem + 2 * TILE_F;
   float* sjs = smem + 2 * TILE_F + DQ_F;     // [2][TJM]
+  volatile float* thrw = smem + 2 * TILE_F + DQ_F + 2 * TJM;   // [4 lists][64 rows]: list[KC/4 - 1] so far
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -340,6 +377,9 @@ __global__ __launch_bounds__(256, 2) void knn_mfma_kernel(const float* __restric
   const int nt = (N + TJM - 1) / TJM;
   fetch(0);
   stash(0);
+  thrw[tid] = INFINITY;
+  const int lid = (w >> 1) * 2 + h;          // list id of this lane among the 4 lists of its row (= `me` below)
+  const int rslot = (w & 1) * 32 + l31;      // row within the block
   __syncthreads();
 
 #pragma unroll 1
@@ -383,7 +423,13 @@ __global__ __launch_bounds__(256, 2) void knn_mfma_kernel(const float* __restric
       }
 
       // ---- distances of this lane's 16 candidates; park them, flag the ones that beat the k-th ----
+#if KNN_SHARE
+      const float tau = fmaxf(fmaxf(dl[KC / 4 - 1], thrw[(lid ^ 1) * ROWS + rslot]),
+                              fmaxf(thrw[(lid ^ 2) * ROWS + rslot], thrw[(lid ^ 3) * ROWS + rslot]));
+      const float thr = fminf(dl[KC - 1], next_up(tau));
+#else
       const float thr = dl[KC - 1];
+#endif
       const float* sj = sjs + buf * TJM + cbase;
       unsigned mask = 0u;
 #pragma unroll
@@ -395,6 +441,9 @@ __global__ __launch_bounds__(256, 2) void knn_mfma_kernel(const float* __restric
         dq[r * 256 + tid] = d;
         mask |= (unsigned)sel_i(m_flt(d, thr), 1 << r, 0);
       }
+#if KNN_ABLATE == 1
+      mask = 0u;
+#endif
       // drain: the parked distance of the NEXT surviving candidate is fetched before the insert of
       // the current one (LDS round trip hidden behind ~90 VALU ops)
       int g = __builtin_ctz(mask | 0x80000000u) & 15;
@@ -410,6 +459,9 @@ __global__ __launch_bounds__(256, 2) void knn_mfma_kernel(const float* __restric
         list_insert<KC, false>(dl, jl, d, j0 + cbase + i);
         dcur = dnext;
       }
+#if KNN_SHARE
+      thrw[lid * ROWS + rslot] = dl[KC / 4 - 1];
+#endif
     }
     if (t + 1 < nt) stash(buf ^ 1);
     __syncthreads();
