@@ -24,30 +24,31 @@ constexpr int WAVES = 4;
 constexpr int TJ = 128;
 constexpr int PERW = TJ / WAVES;
 
-// s_i = sequential sum of fl(x^2) over c ascending (the oracle's order: no FMA, no reassociation), one thread
-// per row.  The rows of a block are staged through LDS in 32-column chunks so that the global reads are
-// coalesced (a thread walking its own 256-byte row touches 64 cache lines per wave-load: 21 us vs 5 at C = 64).
+// s_i = sequential sum of fl(x^2) over c ascending (the oracle's order: no FMA, no reassociation), one thread per row.
+// 64 rows per block (B*N/64 blocks: 768 at the headline shape -- the round-1 kernel ran 192 blocks of 256 rows, under one
+// block per CU, 24 us at C = 64): the block's rows are staged through LDS with coalesced loads (a thread walking its own
+// 256-byte row in global memory touches 64 cache lines per wave-load), then 64 threads walk one row each, stride C + 1.
+constexpr int SQ_ROWS = 64;
 __global__ __launch_bounds__(256) void sqnorm_kernel(const float* __restrict__ x, int64_t ldx, int64_t rows, int C,
                                                      float* __restrict__ sq) {
-  __shared__ float tile[256 * 33];
-  const int64_t r0 = (int64_t)blockIdx.x * 256;
+  extern __shared__ float sq_tile[];          // [64][C + 1]
+  const int64_t r0 = (int64_t)blockIdx.x * SQ_ROWS;
   const int t = threadIdx.x;
-  float s = 0.0f;
-  for (int c0 = 0; c0 < C; c0 += 32) {
-    const int w = (C - c0 < 32) ? (C - c0) : 32;
-    for (int e = t; e < 256 * 32; e += 256) {
-      const int rr = e >> 5, cc = e & 31;
-      if (cc < w && r0 + rr < rows) tile[rr * 33 + cc] = x[(r0 + rr) * ldx + c0 + cc];
-    }
-    __syncthreads();
-    for (int c = 0; c < w; ++c) {
-      const float v = tile[t * 33 + c];
+  const int S = C + 1;
+  for (int e = t; e < SQ_ROWS * C; e += 256) {
+    const int rr = e / C, cc = e - rr * C;
+    if (r0 + rr < rows) sq_tile[rr * S + cc] = x[(r0 + rr) * ldx + cc];
+  }
+  __syncthreads();
+  if (t < SQ_ROWS && r0 + t < rows) {
+    float s = 0.0f;
+    for (int c = 0; c < C; ++c) {
+      const float v = sq_tile[t * S + c];
       const float q = v * v;
       s = s + q;
     }
-    __syncthreads();
+    sq[r0 + t] = s;
   }
-  if (r0 + t < rows) sq[r0 + t] = s;
 }
 
 // ---- lane-mask helpers.  hipcc turns nested ?: on register arrays into exec-masked branches (20
@@ -78,7 +79,10 @@ __device__ __forceinline__ float next_up(float f) {
 }
 
 #ifndef KNN_SHARE
-#define KNN_SHARE 1      // 0: every list filters with its own k-th distance only (A/B switch, profiles/r02)
+#define KNN_SHARE 1      // MFMA kernel; 0: every list filters with its own k-th distance only (A/B switch, profiles/r02/knn_experiments.txt)
+#endif
+#ifndef KNN_SHARE_VALU
+#define KNN_SHARE_VALU 0 // the same bound in the VALU kernel (C <= 4): faster at N = 2048 (0.155 vs 0.163 ms), slower at N = 16384 (2.22 vs 2.05)
 #endif
 #ifndef KNN_ABLATE
 #define KNN_ABLATE 0     // experiments only: 1 = no selection at all (distances + parking only; wrong results)
@@ -91,6 +95,13 @@ __device__ __forceinline__ float next_up(float f) {
 // filter  d < min(own k-th, next_up(tau)).  tau is about the row's GLOBAL k-th distance (the KC/4-th best of a quarter
 // of the candidates), where a list's own k-th is about the global 4k-th: ~2.5x fewer inserts.  The lists publish
 // list_i[KC/4 - 1] in LDS after every drain; a stale (older = larger) value only makes the filter looser.
+// lane mask -> 0 / 1 with inline constants (sel_i would park its two constants in VGPRs)
+__device__ __forceinline__ unsigned sel_01(lmask_t m) {
+  unsigned r;
+  asm("v_cndmask_b32_e64 %0, 0, 1, %1" : "=v"(r) : "s"(m));
+  return r;
+}
+
 template <bool LEX>
 __device__ __forceinline__ lmask_t key_less(float d, int j, float dt, int jt) {
   return LEX ? (m_flt(d, dt) | (m_feq(d, dt) & m_ilt(j, jt))) : m_flt(d, dt);
@@ -190,7 +201,7 @@ __global__ __launch_bounds__(256, (knn_min_waves<CP, KC>())) void knn_kernel(con
     // the channel loop is fully unrolled so x_i stays in registers, fenced every 16 channels so
     // the scheduler cannot hoist every LDS read).  Each lane parks d in its LDS slot and keeps a
     // 32-bit mask of the candidates that beat its current k-th distance. ----
-#if KNN_SHARE
+#if KNN_SHARE_VALU
     const float tau = fmaxf(fmaxf(dl[KC / 4 - 1], thrw[((w + 1) & 3) * ROWS + lane]),
                             fmaxf(thrw[((w + 2) & 3) * ROWS + lane], thrw[((w + 3) & 3) * ROWS + lane]));
     const float thr = fminf(dl[KC - 1], next_up(tau));
@@ -234,7 +245,7 @@ __global__ __launch_bounds__(256, (knn_min_waves<CP, KC>())) void knn_kernel(con
       mask &= mask - 1u;
       list_insert<KC, false>(dl, jl, d, j0 + w * PERW + g);
     }
-#if KNN_SHARE
+#if KNN_SHARE_VALU
     thrw[w * ROWS + lane] = dl[KC / 4 - 1];
 #endif
   }
@@ -285,10 +296,10 @@ __global__ __launch_bounds__(256, (knn_min_waves<CP, KC>())) void knn_kernel(con
 //   two lanes per row, each with its own register-resident sorted list over its candidate subset.
 // Block = 64 query rows x 2 candidate halves (4 waves); 64-candidate LDS tiles, double buffered, next
 // tile prefetched into registers under the MFMAs; 4 lists per row merged through LDS.
-template <int CP, int KC>
-__global__ __launch_bounds__(256, 2) void knn_mfma_kernel(const float* __restrict__ x, const float* __restrict__ sq,
-                                                          int N, int C, int64_t ldx, int k, int vec_ok,
-                                                          int32_t* __restrict__ idx) {
+template <int CP, int KC, bool VEC>
+__global__ __launch_bounds__(256, (KC <= 20 ? 3 : 2)) void knn_mfma_kernel(const float* __restrict__ x, const float* __restrict__ sq,
+                                                                           int N, int C, int64_t ldx, int k,
+                                                                           int32_t* __restrict__ idx) {
   using f32x16 = __attribute__((ext_vector_type(16))) float;
   constexpr int TJM = 64;                    // candidates per LDS tile: 32 per candidate-half wave
   constexpr int ST = TJM + 2;                // k-major candidate tile [CP][ST]
@@ -334,6 +345,8 @@ __global__ __launch_bounds__(256, 2) void knn_mfma_kernel(const float* __restric
 
   // ---- candidate tiles: global -> registers one tile ahead, transposed ([c][cand]) into the other
   // LDS buffer after the current tile's MFMAs; one barrier per tile ----
+  // VEC (16-byte aligned rows, C % 4 == 0): one unconditional float4 load per piece from a clamped, always valid address;
+  // rows past N carry |x_j|^2 = +inf (their distance is +inf: never selected), channel quads past C are zeroed.
   float4 pre[NV];
   float pre_s = INFINITY;
   auto fetch = [&](int j0) {
@@ -344,16 +357,18 @@ __global__ __launch_bounds__(256, 2) void knn_mfma_kernel(const float* __restric
       const int c4 = (e % (CP / 4)) * 4;
       const int j = j0 + r;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (j < N) {
+      if (VEC) {
+        const int jc = j < N ? j : N - 1;
+        const int cc = c4 < C ? c4 : C - 4;
+        const float4 t4 = *reinterpret_cast<const float4*>(xb + (int64_t)jc * ldx + cc);
+        const bool ok = c4 < C;
+        v.x = ok ? t4.x : 0.f; v.y = ok ? t4.y : 0.f; v.z = ok ? t4.z : 0.f; v.w = ok ? t4.w : 0.f;
+      } else if (j < N) {
         const float* src = xb + (int64_t)j * ldx + c4;
-        if (vec_ok && c4 + 3 < C) {
-          v = *reinterpret_cast<const float4*>(src);
-        } else {
-          if (c4 + 0 < C) v.x = src[0];
-          if (c4 + 1 < C) v.y = src[1];
-          if (c4 + 2 < C) v.z = src[2];
-          if (c4 + 3 < C) v.w = src[3];
-        }
+        if (c4 + 0 < C) v.x = src[0];
+        if (c4 + 1 < C) v.y = src[1];
+        if (c4 + 2 < C) v.z = src[2];
+        if (c4 + 3 < C) v.w = src[3];
       }
       pre[i] = v;
     }
@@ -386,60 +401,59 @@ __global__ __launch_bounds__(256, 2) void knn_mfma_kernel(const float* __restric
   for (int t = 0; t < nt; ++t) {
     const int buf = t & 1;
     const int j0 = t * TJM;
+#if KNN_SHARE
+    thrw[lid * ROWS + rslot] = dl[KC / 4 - 1];       // publish this list's KC/4-th entry (as of the previous tile)
+#endif
     if (t + 1 < nt) fetch(j0 + TJM);
     const int cbase = cs * 32;
     if (j0 + cbase < N) {                    // wave-uniform
       const float* xsT = smem + buf * TILE_F;
+#if KNN_SHARE && !defined(KNN_SHARE_LATE)
+      // the other three lists' KC/4-th entries (shared selection bound): requested before the chain, needed after it
+      const float o1 = thrw[(lid ^ 1) * ROWS + rslot], o2 = thrw[(lid ^ 2) * ROWS + rslot], o3 = thrw[(lid ^ 3) * ROWS + rslot];
+#endif
       f32x16 acc;
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[r] = 0.f;
       const float* ap = xsT + h * ST + cbase + l31;
       {
-        // A operands are read in batches of BQ one batch ahead of the MFMAs that consume them
-        // (sched_barriers pin the order), so the LDS latency hides under the dependent MFMA chain.
+        // A operand ring, two MFMAs deep: the operand of step s + 2 is requested right behind MFMA s, whose 64 clocks in
+        // the pipe (the chain is dependent) cover the LDS round trip.  (Round 1 staged 8 + 8 operands: 12 registers more.)
         constexpr int NS = CP / 2;
-        constexpr int BQ = (NS >= 16) ? 8 : NS / 2;
-        float av0[BQ], av1[BQ];
+        float a0 = ap[0], a1 = ap[2 * ST];
 #pragma unroll
-        for (int q = 0; q < BQ; ++q) av0[q] = ap[2 * q * ST];
-#pragma unroll
-        for (int s2 = 0; s2 < NS; s2 += 2 * BQ) {
-#pragma unroll
-          for (int q = 0; q < BQ; ++q) av1[q] = ap[2 * (s2 + BQ + q) * ST];
-          __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int q = 0; q < BQ; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[q], bq[s2 + q], acc, 0, 0, 0);
-          __builtin_amdgcn_sched_barrier(0);
-          if (s2 + 2 * BQ < NS) {
-#pragma unroll
-            for (int q = 0; q < BQ; ++q) av0[q] = ap[2 * (s2 + 2 * BQ + q) * ST];
-          }
-          __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int q = 0; q < BQ; ++q)
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[q], bq[s2 + BQ + q], acc, 0, 0, 0);
-          __builtin_amdgcn_sched_barrier(0);
+        for (int s2 = 0; s2 < NS; s2 += 2) {
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bq[s2], acc, 0, 0, 0);
+          if (s2 + 2 < NS) a0 = ap[2 * (s2 + 2) * ST];
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bq[s2 + 1], acc, 0, 0, 0);
+          if (s2 + 3 < NS) a1 = ap[2 * (s2 + 3) * ST];
         }
       }
 
-      // ---- distances of this lane's 16 candidates; park them, flag the ones that beat the k-th ----
+      // ---- distances of this lane's 16 candidates; park them, flag the ones that can still enter the row's top KC ----
 #if KNN_SHARE
-      const float tau = fmaxf(fmaxf(dl[KC / 4 - 1], thrw[(lid ^ 1) * ROWS + rslot]),
-                              fmaxf(thrw[(lid ^ 2) * ROWS + rslot], thrw[(lid ^ 3) * ROWS + rslot]));
-      const float thr = fminf(dl[KC - 1], next_up(tau));
+#ifdef KNN_SHARE_LATE
+      const float o1 = thrw[(lid ^ 1) * ROWS + rslot], o2 = thrw[(lid ^ 2) * ROWS + rslot], o3 = thrw[(lid ^ 3) * ROWS + rslot];
+#endif
+      const float thr = fminf(dl[KC - 1], next_up(fmaxf(fmaxf(dl[KC / 4 - 1], o1), fmaxf(o2, o3))));
 #else
       const float thr = dl[KC - 1];
 #endif
-      const float* sj = sjs + buf * TJM + cbase;
+      const float* sj = sjs + buf * TJM + cbase + 4 * h;
       unsigned mask = 0u;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int i = (r & 3) + 8 * (r >> 2) + 4 * h;
-        const float tt = si + sj[i];
-        const float tp = 2.0f * acc[r];
-        const float d = tt - tp;
-        dq[r * 256 + tid] = d;
-        mask |= (unsigned)sel_i(m_flt(d, thr), 1 << r, 0);
+      for (int q = 0; q < 4; ++q) {
+        const float4 s4 = *reinterpret_cast<const float4*>(sj + 8 * q);     // candidates 8 q + 4 h + (0..3)
+        const float sv[4] = {s4.x, s4.y, s4.z, s4.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int r = 4 * q + e;
+          const float tt = si + sv[e];
+          const float tp = 2.0f * acc[r];
+          const float d = tt - tp;
+          dq[r * 256 + tid] = d;
+          mask |= sel_01(m_flt(d, thr)) << r;
+        }
       }
 #if KNN_ABLATE == 1
       mask = 0u;
@@ -459,9 +473,7 @@ __global__ __launch_bounds__(256, 2) void knn_mfma_kernel(const float* __restric
         list_insert<KC, false>(dl, jl, d, j0 + cbase + i);
         dcur = dnext;
       }
-#if KNN_SHARE
-      thrw[lid * ROWS + rslot] = dl[KC / 4 - 1];
-#endif
+
     }
     if (t + 1 < nt) stash(buf ^ 1);
     __syncthreads();
@@ -518,7 +530,8 @@ void launch_knn(const float* x, const float* sq, int B, int N, int C, int64_t ld
   dim3 grid((unsigned)dg::cdiv(N, ROWS), (unsigned)B);
   if constexpr (CP >= 16 && CP <= 64) {
     if (!knn_force_valu()) {
-      hipLaunchKernelGGL((knn_mfma_kernel<CP, KC>), grid, dim3(256), 0, st, x, sq, N, C, ldx, k, vec_ok, idx);
+      if (vec_ok && C % 4 == 0) hipLaunchKernelGGL((knn_mfma_kernel<CP, KC, true>), grid, dim3(256), 0, st, x, sq, N, C, ldx, k, idx);
+      else hipLaunchKernelGGL((knn_mfma_kernel<CP, KC, false>), grid, dim3(256), 0, st, x, sq, N, C, ldx, k, idx);
       return;
     }
   }
@@ -555,7 +568,8 @@ extern "C" int dgcnn_knn_f32(const float* x, int B, int N, int C, int64_t ldx, i
   DG_REQUIRE(C <= 128, DGCNN_EUNSUP, "dgcnn_knn_f32: C=%d > 128 unsupported", C);
   hipStream_t st = (hipStream_t)stream;
   const int64_t rows = (int64_t)B * N;
-  hipLaunchKernelGGL(sqnorm_kernel, dim3((unsigned)dg::cdiv(rows, 256)), dim3(256), 0, st, x, ldx, rows, C, sq_ws);
+  hipLaunchKernelGGL(sqnorm_kernel, dim3((unsigned)dg::cdiv(rows, SQ_ROWS)), dim3(256), sizeof(float) * SQ_ROWS * (C + 1), st, x,
+                     ldx, rows, C, sq_ws);
   const int vec_ok = (ldx % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
   if (C <= 4) return dispatch_k<4>(x, sq_ws, B, N, C, ldx, k, vec_ok, idx, st);
   if (C <= 16) return dispatch_k<16>(x, sq_ws, B, N, C, ldx, k, vec_ok, idx, st);
