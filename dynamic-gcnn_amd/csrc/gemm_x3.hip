@@ -8,6 +8,9 @@
 //             (as it does in the native kernel)                               -> 9/16 of the native MFMA time
 //     NP = 6  drops a2*b3, a3*b2, a3*b3 (<= 2^-23 |a*b| together, the size of ONE fp32 rounding of the
 //             product -- what an unfused multiply-add chain commits anyway)    -> 6/16 of the native MFMA time
+//     NP = 1  only a1*b1: plain bf16 OPERANDS (round to nearest even), fp32 accumulate -- the "bf16 edge-MLP" mode of
+//             BASELINE configs[2]; NOT fp32-class (2^-9 relative per operand), selected per GEMM by the host for the
+//             EdgeConv conv0 / conv1 products only (EDGE_MLP_DTYPE = bf16)      -> 1/16 of the native MFMA time
 // Inputs, outputs and accumulators stay fp32; tests/test_gpu_parity.py::test_gemm_split_accuracy measures
 // the error of both against an fp64 product next to the native fp32-MFMA kernel (profiles/r01_gemm_arith.txt).
 // Inf/NaN inputs produce NaN (Inf - Inf in the split); the path's activations are finite.
@@ -171,14 +174,17 @@ struct Stage {
     }
   }
 
+  template <int NPL = 3>      // planes written: 3, or only the leading bf16 term (single-product mode)
   __device__ __forceinline__ void write(const Packed (&P)[4], char* plane0) const {
     using I = Img<TILE>;
 #pragma unroll
     for (int j = 0; j < NC; ++j) {
       const unsigned off = (KIND == KCONTIG) ? I::at(r0 + 32 * j, c) : I::at(r0 + j, c);
       *reinterpret_cast<uint4*>(plane0 + off) = P[j].h;
-      *reinterpret_cast<uint4*>(plane0 + I::PB + off) = P[j].m;
-      *reinterpret_cast<uint4*>(plane0 + 2 * I::PB + off) = P[j].l;
+      if (NPL == 3) {
+        *reinterpret_cast<uint4*>(plane0 + I::PB + off) = P[j].m;
+        *reinterpret_cast<uint4*>(plane0 + 2 * I::PB + off) = P[j].l;
+      }
     }
   }
 };
@@ -294,8 +300,8 @@ __global__ __launch_bounds__(NT, 2) void gemm_x3_kernel(GemmP p) {
       else if (sb.on) sb.template split<MASK>(L, pm, P);
     };
     auto do_write = [&]() {
-      if (roleA) sa.write(P, As);
-      else if (sb.on) sb.write(P, Bs);
+      if (roleA) sa.template write<(NP == 1 ? 1 : 3)>(P, As);
+      else if (sb.on) sb.template write<(NP == 1 ? 1 : 3)>(P, Bs);
     };
     fetch(0);
     do_split();
@@ -432,7 +438,7 @@ struct Stage2 {
   static __device__ __forceinline__ float comp(const float2& v, int e) { return e == 0 ? v.x : v.y; }
 
   // split + write, one chunk at a time
-  template <bool MASK>
+  template <bool MASK, int NPL = 3>
   __device__ __forceinline__ void stage(const Vt (&L)[NL], unsigned pm, char* plane0) const {
     using I = Img<TILE>;
 #pragma unroll
@@ -454,8 +460,10 @@ struct Stage2 {
       }
       const Packed P = split8(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);
       *reinterpret_cast<uint4*>(plane0 + off) = P.h;
-      *reinterpret_cast<uint4*>(plane0 + I::PB + off) = P.m;
-      *reinterpret_cast<uint4*>(plane0 + 2 * I::PB + off) = P.l;
+      if (NPL == 3) {
+        *reinterpret_cast<uint4*>(plane0 + I::PB + off) = P.m;
+        *reinterpret_cast<uint4*>(plane0 + 2 * I::PB + off) = P.l;
+      }
     }
   }
 };
@@ -504,8 +512,8 @@ __global__ __launch_bounds__(768) void gemm_x3w2_kernel(GemmP p) {
       };
       auto stage = [&](int r, int buf) {
         char* base = smem_raw + buf * BUF;
-        sa.template stage<MASK>(LA[r], pa[r], base);
-        sb.template stage<MASK>(LB[r], pb[r], base + 3 * IA::PB);
+        sa.template stage<MASK, (NP == 1 ? 1 : 3)>(LA[r], pa[r], base);
+        sb.template stage<MASK, (NP == 1 ? 1 : 3)>(LB[r], pb[r], base + 3 * IA::PB);
       };
       fetch(0, 0);
       fetch(1, imin(1, nk - 1));
@@ -597,14 +605,17 @@ template <int AKIND, int BKIND>
 void launch_kind(GemmP& p, hipStream_t st, int bn, int np, dim3 grid) {
   if (p.bm == 256) {
     if (np == 9) hipLaunchKernelGGL((gemm_x3w2_kernel<AKIND, BKIND, 9>), grid, dim3(768), 0, st, p);
+    else if (np == 1) hipLaunchKernelGGL((gemm_x3w2_kernel<AKIND, BKIND, 1>), grid, dim3(768), 0, st, p);
     else hipLaunchKernelGGL((gemm_x3w2_kernel<AKIND, BKIND, 6>), grid, dim3(768), 0, st, p);
     return;
   }
   if (bn == 64) {
     if (np == 9) hipLaunchKernelGGL((gemm_x3_kernel<AKIND, BKIND, 64, 9>), grid, dim3(NT), 0, st, p);
+    else if (np == 1) hipLaunchKernelGGL((gemm_x3_kernel<AKIND, BKIND, 64, 1>), grid, dim3(NT), 0, st, p);
     else hipLaunchKernelGGL((gemm_x3_kernel<AKIND, BKIND, 64, 6>), grid, dim3(NT), 0, st, p);
   } else {
     if (np == 9) hipLaunchKernelGGL((gemm_x3_kernel<AKIND, BKIND, 128, 9>), grid, dim3(NT), 0, st, p);
+    else if (np == 1) hipLaunchKernelGGL((gemm_x3_kernel<AKIND, BKIND, 128, 1>), grid, dim3(NT), 0, st, p);
     else hipLaunchKernelGGL((gemm_x3_kernel<AKIND, BKIND, 128, 6>), grid, dim3(NT), 0, st, p);
   }
 }
@@ -617,7 +628,7 @@ int gemm_arith() {
   if (g_arith < 0) {
     const char* e = getenv("DGCNN_GEMM_ARITH");      // f32 | bf16x6 | bf16x9
     int v = DGCNN_GEMM_ARITH_DEFAULT;
-    if (e) v = (e[0] == 'f' || e[0] == '0') ? 0 : ((e[0] == '9' || (e[0] == 'b' && e[5] == '9')) ? 9 : 6);
+    if (e) v = (e[0] == 'f' || e[0] == '0') ? 0 : ((e[0] == '9' || (e[0] == 'b' && e[5] == '9')) ? 9 : ((e[0] == '1' || (e[0] == 'b' && e[5] == '1')) ? 1 : 6));
     g_arith = v;
   }
   return g_arith;
@@ -647,7 +658,7 @@ void launch_gemm_x3(int asrc, int bsrc, void* pv, hipStream_t st, int bn, int np
 }  // namespace dg
 
 extern "C" int dgcnn_gemm_set_arith(int mode) {
-  DG_REQUIRE(mode == 0 || mode == 6 || mode == 9, DGCNN_EINVAL, "dgcnn_gemm_set_arith: mode must be 0, 6 or 9 (got %d)", mode);
+  DG_REQUIRE(mode == 0 || mode == 1 || mode == 6 || mode == 9, DGCNN_EINVAL, "dgcnn_gemm_set_arith: mode must be 0, 1, 6 or 9 (got %d)", mode);
   dg::set_gemm_arith(mode);
   return DGCNN_OK;
 }

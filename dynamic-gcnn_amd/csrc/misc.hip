@@ -363,6 +363,17 @@ __global__ void dropout_kernel(const float* x, float* y, int64_t n, float keep, 
   }
 }
 
+// the same with the seed read from device memory: a captured HIP graph replays with a new mask every step
+__global__ void dropout_dev_kernel(const float* x, float* y, int64_t n, float keep, const uint64_t* __restrict__ seed_dev) {
+  const float scale = 1.0f / keep;
+  const uint32_t thr = (keep >= 1.f) ? 0xffffffffu : (uint32_t)((double)keep * 4294967296.0);
+  const uint64_t seed = *seed_dev;
+  GRID_STRIDE(i, n) {
+    const uint32_t r = mix32(seed * 0xD1342543DE82EF95ull + (uint64_t)i);
+    y[i] = (r < thr) ? x[i] * scale : 0.f;
+  }
+}
+
 __global__ void add_relu_kernel(const float* __restrict__ a, int64_t lda, const float* __restrict__ b, int64_t ldb,
                                 int64_t R, int F, float* __restrict__ out, int64_t ldo) {
   GRID_STRIDE(i, R * F) {
@@ -564,6 +575,13 @@ extern "C" int dgcnn_dropout_f32(const float* x, float* y, int64_t n, float keep
   DG_REQUIRE(x && y && n > 0 && keep > 0.f && keep <= 1.f, DGCNN_EINVAL, "dgcnn_dropout_f32: bad args");
   hipLaunchKernelGGL(dropout_kernel, dim3(grid1d(n)), dim3(256), 0, ST, x, y, n, keep, seed);
   return dg::check_launch("dgcnn_dropout_f32");
+}
+
+extern "C" int dgcnn_dropout_dev_f32(const float* x, float* y, int64_t n, float keep, const uint64_t* seed_dev,
+                                     void* stream) {
+  DG_REQUIRE(x && y && seed_dev && n > 0 && keep > 0.f && keep <= 1.f, DGCNN_EINVAL, "dgcnn_dropout_dev_f32: bad args");
+  hipLaunchKernelGGL(dropout_dev_kernel, dim3(grid1d(n)), dim3(256), 0, ST, x, y, n, keep, seed_dev);
+  return dg::check_launch("dgcnn_dropout_dev_f32");
 }
 
 extern "C" int dgcnn_add_relu_f32(const float* a, int64_t lda, const float* b, int64_t ldb, int64_t R, int F,

@@ -60,6 +60,9 @@ class Context(object):
         self.stat_arena = None
         self.stat_off = 0
         self.step_seed = 0
+        self.seed_dev = None             # device uint64: the dropout seed of the running step (read by the kernels)
+        self.capturing = False           # inside a HIP-graph capture: no host-side per-step state may be baked in
+        self.edge_mlp_arith = None       # 1: bf16 operands for the EdgeConv conv0 / conv1 products (EDGE_MLP_DTYPE = 'bf16')
         self.debug = False
 
     # ---- device / scratch -------------------------------------------------------------
@@ -116,13 +119,26 @@ class Context(object):
         return s
 
     def begin_step(self):
-        """Drop the previous tape / gradient roots and re-zero the statistics arena."""
+        """Drop the previous tape / gradient roots, re-zero the statistics arena and advance the dropout stream."""
         self.tape = []
         self.roots = []
-        if self.stat_arena is not None and self.stat_off > 0:
-            self.stat_arena[:self.stat_off].zero_()
+        if self.stat_arena is not None:
+            if self.capturing:
+                self.stat_arena.zero_()          # a captured step cannot know what ran before it: whole arena (8 MB memset)
+            elif self.stat_off > 0:
+                self.stat_arena[:self.stat_off].zero_()
         self.stat_off = 0
+        if not self.capturing:                   # (a replayed graph gets its seed from advance_seed(), called by the replayer)
+            self.advance_seed()
+
+    def advance_seed(self):
+        """Next position of the dropout mask stream.  The seed lives in DEVICE memory (dgcnn_dropout_dev_f32 reads it at
+        execution time), written here by a fill kernel that carries the value as a launch argument -- stream ordered, so
+        several towers / micro-steps in flight each see their own value, and a captured graph sees a fresh one per replay."""
         self.step_seed += 1
+        if self.seed_dev is None or self.seed_dev.device != self.device:
+            self.seed_dev = torch.zeros(1, dtype=torch.int64, device=self.device)
+        self.seed_dev.fill_((self.seed * 1000003 + self.step_seed) & 0xFFFFFFFFFFFF)
 
     # ---- variables (tf.variable_scope / slim variables) ---------------------------------
     def full_name(self, leaf):
@@ -294,8 +310,16 @@ def _tile_m(M, N):
     return 128
 
 
-def gemm(A, Bm, C, transA=False, transB=False, beta=0.0, gbias=None, rpg=0, stats=None):
-    """C (+)= op(A) op(B); shapes are those of the stored matrices."""
+def gemm(A, Bm, C, transA=False, transB=False, beta=0.0, gbias=None, rpg=0, stats=None, arith=None):
+    """C (+)= op(A) op(B); shapes are those of the stored matrices.  arith: arithmetic of THIS product (None = the
+    process-wide setting; 1 = bf16 operands, the EDGE_MLP_DTYPE='bf16' mode of the EdgeConv conv0 / conv1 products)."""
+    if arith is not None and arith != H.gemm_arith():
+        prev = H.gemm_arith()
+        H.set_gemm_arith(arith)
+        try:
+            return gemm(A, Bm, C, transA, transB, beta, gbias, rpg, stats)
+        finally:
+            H.set_gemm_arith(prev)
     M = A.shape[1] if transA else A.shape[0]
     K = A.shape[0] if transA else A.shape[1]
     N = Bm.shape[0] if transB else Bm.shape[1]
@@ -334,7 +358,7 @@ def bn_finalize(stats, F, count):
 # slim.conv2d(1x1, no bias) + slim.batch_norm + activation on per-point tensors (k = 1)
 # dgcnn/ops.py:62-70,125-133,153-160 ; dgcnn/model.py:46-53,65-72,94-101
 # ----------------------------------------------------------------------------------------------
-def conv_bn_act(x, leaf_scope, num_outputs, relu=True, out=None, out2=None, gbias=None, rpg=0, w_rows=None):
+def conv_bn_act(x, leaf_scope, num_outputs, relu=True, out=None, out2=None, gbias=None, rpg=0, w_rows=None, arith=None):
     """x: (R,Cin) view.  Variables `<scope>/weights` [Cin(+extra), Cout], `<scope>/BatchNorm/beta`.
     w_rows: (lo, hi) row range of the weight that multiplies x (FC0 with the folded global feature).
     Returns the (R,Cout) output (a fresh tracked buffer unless `out` is given)."""
@@ -351,7 +375,7 @@ def conv_bn_act(x, leaf_scope, num_outputs, relu=True, out=None, out2=None, gbia
     F = num_outputs
     T = torch.empty((R, F), dtype=torch.float32, device=x.device)
     st = c.stats(F)
-    gemm(x, Wx, T, gbias=gbias, rpg=rpg, stats=st)
+    gemm(x, Wx, T, gbias=gbias, rpg=rpg, stats=st, arith=arith)
     mean, rstd = bn_finalize(st, F, R)
     if out is None:
         out = c.new_buffer(R, F)
@@ -378,10 +402,10 @@ def conv_bn_act(x, leaf_scope, num_outputs, relu=True, out=None, out2=None, gbia
             dT = T
             dWx = c.var_grads[wname] if w_rows is None else c.var_grads[wname][w_rows[0]:w_rows[1]]
             with c.off_critical_path(rows=R):
-                gemm(x, dT, dWx, transA=True, beta=1.0)                # dW += x^T dT
+                gemm(x, dT, dWx, transA=True, beta=1.0, arith=arith)   # dW += x^T dT
             dx, bx = c.grad_w(x)
             if dx is not None:
-                gemm(dT, Wx, dx, transB=True, beta=bx)                 # dx (+)= dT W^T
+                gemm(dT, Wx, dx, transB=True, beta=bx, arith=arith)    # dx (+)= dT W^T
             if gbias is not None:
                 dgb = c.grad(gbias)
                 if dgb is not None:                                     # tf.tile^T: sum over the cloud
@@ -434,7 +458,7 @@ def edge_conv_block(x, B, N, k, num_filters, relu1=True, outs=None, net2=None):
             wcat = torch.empty((C, 2 * F), dtype=torch.float32, device=x.device)
         H.call("dgcnn_edge_weight_split_f32", W0.data_ptr(), C, F, wcat.data_ptr())
         UV = torch.empty((R, 2 * F), dtype=torch.float32, device=x.device)
-        gemm(xg, wcat, UV)
+        gemm(xg, wcat, UV, arith=c.edge_mlp_arith)
         H.call("dgcnn_edge_gather_add_f32", UV[:, F:].data_ptr(), 2 * F, UV.data_ptr(), 2 * F, idx.data_ptr(),
                B, N, k, F, H._p(Y), st.data_ptr(),
                tag="edge_gather_add_kernel", work=4.0 * ((0 if virtual else R * k * F) + 2 * R * F) + 4.0 * R * k)   # ops.py:21-52
@@ -548,10 +572,10 @@ def edge_conv_block(x, B, N, k, num_filters, relu1=True, outs=None, net2=None):
                 # dUV / dwcat are locals of this closure allocated on the main stream: record them on the side stream,
                 # or the caching allocator may hand dUV's block to the next main-stream allocation while the side GEMM reads it
                 with c.off_critical_path(dwcat, dUV, rows=R):
-                    gemm(xg, dUV, dwcat, transA=True)
+                    gemm(xg, dUV, dwcat, transA=True, arith=c.edge_mlp_arith)
                     H.call("dgcnn_edge_wgrad_combine_f32", dwcat.data_ptr(), C, F, dW0.data_ptr())
                 if dx is not None:
-                    gemm(dUV, wcat[:C], dx, transB=True, beta=1.0)
+                    gemm(dUV, wcat[:C], dx, transB=True, beta=1.0, arith=c.edge_mlp_arith)
                 return
             if literal:
                 H.call("dgcnn_edge_mlp_wgrad_f32", x.data_ptr(), H.ld2(x), idx.data_ptr(), dY.data_ptr(), B, N, C, k, F,
@@ -588,7 +612,7 @@ def edge_conv_block(x, B, N, k, num_filters, relu1=True, outs=None, net2=None):
                     gemm(S, W0[C:], dx, transB=True, beta=1.0)
         c.tape.append(bwd)
 
-    net = conv_bn_act(mm, "conv1", 64, relu=relu1, out=net_out, out2=net2)   # ops.py:62-70 (64 hard-coded)
+    net = conv_bn_act(mm, "conv1", 64, relu=relu1, out=net_out, out2=net2, arith=c.edge_mlp_arith)   # ops.py:62-70 (64 hard-coded)
     return mm, net, idx
 
 
@@ -623,8 +647,10 @@ def dropout(x, keep=DROPOUT_KEEP):
     R, F = x.shape
     assert x.is_contiguous()
     out = c.new_buffer(R, F)
-    seed = (c.seed * 1000003 + c.step_seed) & 0xFFFFFFFFFFFF
-    H.call("dgcnn_dropout_f32", x.data_ptr(), out.data_ptr(), R * F, float(keep), seed)
+    if c.seed_dev is None:
+        c.advance_seed()
+    seed = c.seed_dev                       # device-resident: the backward regenerates the mask from the same value
+    H.call("dgcnn_dropout_dev_f32", x.data_ptr(), out.data_ptr(), R * F, float(keep), seed.data_ptr())
     if c.recording:
         def bwd():
             dout = c.grad(out)
@@ -634,10 +660,10 @@ def dropout(x, keep=DROPOUT_KEEP):
             if dx is None:
                 return
             if bx == 0.0:                                   # first touch of d(x): write the masked gradient in place
-                H.call("dgcnn_dropout_f32", dout.data_ptr(), dx.data_ptr(), R * F, float(keep), seed)
+                H.call("dgcnn_dropout_dev_f32", dout.data_ptr(), dx.data_ptr(), R * F, float(keep), seed.data_ptr())
                 return
             tmp = torch.empty_like(dout)
-            H.call("dgcnn_dropout_f32", dout.data_ptr(), tmp.data_ptr(), R * F, float(keep), seed)
+            H.call("dgcnn_dropout_dev_f32", dout.data_ptr(), tmp.data_ptr(), R * F, float(keep), seed.data_ptr())
             H.call("dgcnn_copy2d_f32", tmp.data_ptr(), F, dx.data_ptr(), H.ld2(dx), R, F, 1)
         c.tape.append(bwd)
     return out

@@ -64,6 +64,7 @@ PROTOTYPES = {
     "dgcnn_global_max_bwd_f32": [c_vp, c_vp, c_int, c_int, c_int, c_vp, c_i64, c_vp],
     "dgcnn_group_colsum_f32": [c_vp, c_i64, c_int, c_int, c_int, c_vp, c_vp],
     "dgcnn_dropout_f32": [c_vp, c_vp, c_i64, c_f32, c_u64, c_vp],
+    "dgcnn_dropout_dev_f32": [c_vp, c_vp, c_i64, c_f32, c_vp, c_vp],
     "dgcnn_add_relu_f32": [c_vp, c_i64, c_vp, c_i64, c_i64, c_int, c_vp, c_i64, c_vp],
     "dgcnn_relu_bwd_f32": [c_vp, c_i64, c_vp, c_i64, c_i64, c_int, c_vp, c_i64, c_vp],
     "dgcnn_copy2d_f32": [c_vp, c_i64, c_vp, c_i64, c_i64, c_int, c_int, c_vp],
@@ -96,7 +97,7 @@ def load():
 
 
 def set_gemm_arith(mode):
-    """0 = native fp32 MFMA, 6 / 9 = partial products of the exact 3-way bf16 split (include/dgcnn_hip.h)."""
+    """0 = native fp32 MFMA, 6 / 9 = partial products of the exact 3-way bf16 split, 1 = bf16 operands (include/dgcnn_hip.h)."""
     lib = load()
     if lib.dgcnn_gemm_set_arith(int(mode)) != 0:
         raise ValueError(lib.dgcnn_last_error().decode())

@@ -49,6 +49,8 @@ _OPTIONS = [
     ("CHECKPOINT_NUM", "-chkn", int, 10, "t", "number of latest checkpoints to keep"),
     ("CHECKPOINT_HOUR", "-chkh", float, 0.4, "t", "accepted for compatibility; unused"),
     ("WEIGHT_KEY", "-wkey", str, "", "tf", "keyword to fetch weight from file"),
+    ("USE_GRAPH", "-ug", str, "auto", "ti", "replay the tower as a captured HIP graph: 0 | 1 | auto (launch-bound shapes only)"),
+    ("EDGE_MLP_DTYPE", "-emd", str, "f32", "ti", "operand type of the EdgeConv conv0 / conv1 products: f32 | bf16"),
 ]
 
 
@@ -61,6 +63,7 @@ class DGCNN_FLAGS(object):
         for name, _, _, default, _, _ in _OPTIONS:
             setattr(self, name, default)
         self.SEED = 1         # library default; the CLI default stays -1 (= time based) as in flags.py:20
+        self.USE_GRAPH = "0"  # library default: eager launches (the CLI default is "auto")
         self.NUM_CHANNEL = 3
         self.update(kw)
 

@@ -13,6 +13,7 @@ from __future__ import annotations
 
 import math
 import os
+import sys
 
 import numpy as np
 import torch
@@ -70,6 +71,15 @@ class trainval(object):
         self._lr = float(f.LEARNING_RATE)
         self._dist, self._rank, self._world = parallel.dist_state()
         parallel.broadcast_(self._ctx.flat_param, self._dist, src=0)
+        emd = str(getattr(f, "EDGE_MLP_DTYPE", "f32")).lower()
+        if emd not in ("f32", "fp32", "float32", "bf16", "bfloat16"):
+            raise ValueError("EDGE_MLP_DTYPE must be 'f32' or 'bf16', got %r" % (emd,))
+        # BASELINE configs[2] "bf16 edge-MLP": the conv0 / conv1 products of every EdgeConv layer (forward, dgrad, wgrad) take
+        # bf16 OPERANDS with fp32 accumulation (one bf16 MFMA product instead of six); everything else stays fp32-class
+        self._ctx.edge_mlp_arith = 1 if emd.startswith("b") else None
+        self._graphs, self._graph_seen = {}, set()
+        ug = str(getattr(f, "USE_GRAPH", "0")).lower()
+        self._use_graph = "auto" if ug == "auto" else ug in ("1", "true", "yes", "on")
         return self
 
     @property
@@ -101,12 +111,22 @@ class trainval(object):
 
     def _tower(self, data, label, weight, train):
         """forward (+ backward when train) of one tower; returns (softmax (MBS,N,ncls), scal[loss, acc])."""
-        c = self._ctx
         pts = self._to_dev(data, torch.float32)
         lab = self._to_dev(label, torch.int32)
         wgt = self._to_dev(weight, torch.float32)
         if pts.dim() != 3:
             raise ValueError("points must be (MINIBATCH_SIZE, N, NUM_CHANNEL), got %s" % (tuple(pts.shape),))
+        use = self._use_graph
+        if use == "auto":                 # graphs pay where the step is launch bound (profiles/r02/config_sweep.txt)
+            use = pts.shape[0] * pts.shape[1] < E.SIDE_STREAM_MIN_ROWS
+        if use and H.TIMER is None:
+            out = self._tower_graph(pts, lab, wgt, train)
+            if out is not None:
+                return out
+        return self._tower_eager(pts, lab, wgt, train)
+
+    def _tower_body(self, pts, lab, wgt, train):
+        c = self._ctx
         c.begin_step()
         c.recording = bool(train)
         logits = model.build(pts, self._flags)                       # trainval.py:38
@@ -117,6 +137,61 @@ class trainval(object):
             c.backward()                                             # compute_gradients, trainval.py:54
         c.recording = False
         return sm.view(B, N, ncls), scal
+
+    def _tower_eager(self, pts, lab, wgt, train):
+        return self._tower_body(pts, lab, wgt, train)
+
+    # ---- HIP-graph replay of a tower (the reference replays a static TF graph with sess.run: trainval.py:103-119) ----
+    def use_graph(self, on=True):
+        """Capture forward + loss + backward of a tower into a HIP graph the second time a (shape, mode) is seen and replay it
+        afterwards: one graph launch instead of ~150 kernel launches per micro-step (host enqueue 2.3 ms -> ~0.1 ms at
+        configs[1]; configs[0] is entirely launch bound).  Off by default for the library (tests hook into the eager path);
+        bench.py and the run loops switch it on.  Shapes seen once (variable-N sources) run eagerly."""
+        self._use_graph = "auto" if on == "auto" else bool(on)
+        return self
+
+    def _tower_graph(self, pts, lab, wgt, train):
+        c = self._ctx
+        key = (tuple(pts.shape), bool(train), lab is not None, wgt is not None, float(E.DROPOUT_KEEP), H.gemm_arith(),
+               E.WGRAD_SIDE_STREAM, c.edge_mlp_arith)
+        ent = self._graphs.get(key)
+        if ent is None:
+            if key not in self._graph_seen:          # first sight: a normal eager step (also allocates workspaces / arenas)
+                self._graph_seen.add(key)
+                return None
+            ent = self._capture(key, pts, lab, wgt, train)
+            if ent is None:
+                return None
+        for dst, src in ((ent["pts"], pts), (ent["lab"], lab), (ent["wgt"], wgt)):
+            if dst is not None and dst.data_ptr() != src.data_ptr():
+                dst.copy_(src, non_blocking=True)
+        c.advance_seed()
+        ent["graph"].replay()
+        return ent["sm"], ent["scal"]
+
+    def _capture(self, key, pts, lab, wgt, train):
+        c = self._ctx
+        ent = {"pts": pts.clone(), "lab": None if lab is None else lab.clone(), "wgt": None if wgt is None else wgt.clone()}
+        try:
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            c.capturing = True
+            with torch.cuda.graph(g):
+                ent["sm"], ent["scal"] = self._tower_body(ent["pts"], ent["lab"], ent["wgt"], train)
+            ent["graph"] = g
+        except Exception as e:                        # capture is an optimisation: fall back to eager launches, loudly
+            sys.stderr.write("dgcnn: HIP graph capture failed (%s: %s); running eagerly\n" % (type(e).__name__, e))
+            self._use_graph = False
+            ent = None
+        finally:
+            c.capturing = False
+            c.recording = False
+            c.tape = []
+            c.roots = []
+            c.side_busy = False
+        if ent is not None:
+            self._graphs[key] = ent
+        return ent
 
     def make_summary(self, sess, data, label, weight):
         if not self._flags.TRAIN:

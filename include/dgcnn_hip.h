@@ -150,7 +150,9 @@ int dgcnn_edge_bn_bwd_apply_f32(const float* V, int64_t ldv, const float* U, int
  * and contiguous extents multiples of 4):  0 = v_mfma_f32_32x32x2_f32 (an fmaf chain, 157 TFLOP/s peak);
  * 6 / 9 = every fp32 operand is split EXACTLY into three bf16 terms and 6 (terms below 2^-23 |a b| dropped)
  * or all 9 partial products run on the bf16 matrix pipe with fp32 accumulation (fp32-class results, see
- * gemm_x3.hip).  Default 6, or $DGCNN_GEMM_ARITH = f32 | bf16x6 | bf16x9.  Process-wide.               */
+ * gemm_x3.hip).  1 = only the leading bf16 term of each operand: plain bf16 operands with fp32 accumulation (NOT fp32
+ * class: the bf16 edge-MLP mode of BASELINE configs[2]; the host selects it around the EdgeConv conv0 / conv1 products).
+ * Default 6, or $DGCNN_GEMM_ARITH = f32 | bf16x6 | bf16x9 | bf16x1.  Process-wide.                     */
 int dgcnn_gemm_set_arith(int mode);
 int dgcnn_gemm_get_arith(void);
 int dgcnn_gemm_f32(int transA, int transB, int M, int N, int K,
@@ -201,6 +203,9 @@ int dgcnn_group_colsum_f32(const float* x, int64_t ldx, int G, int rows_per_grou
 /* tf.nn.dropout(net, keep) (model.py:91): counter-based RNG keyed by (seed, element index) so the
  * backward regenerates the same mask.  y may alias x. */
 int dgcnn_dropout_f32(const float* x, float* y, int64_t n, float keep, uint64_t seed, void* stream);
+/* the same mask function with the seed read from DEVICE memory at execution time: the host advances *seed_dev between
+ * replays of a captured HIP graph (a by-value seed would be frozen into the graph). */
+int dgcnn_dropout_dev_f32(const float* x, float* y, int64_t n, float keep, const uint64_t* seed_dev, void* stream);
 /* out = relu(a + b) (ops.py:134); bwd: d = dout * [out > 0] */
 int dgcnn_add_relu_f32(const float* a, int64_t lda, const float* b, int64_t ldb, int64_t R, int F,
                        float* out, int64_t ldo, void* stream);
