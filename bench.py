@@ -39,11 +39,21 @@ def make_flags(dgcnn, train=True):
                              LEARNING_RATE=1e-3, TRAIN=train, DEBUG=False, SEED=1)
 
 
-def cpu_baseline(clouds=8, iters=2):
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown CPU"
+
+
+def cpu_baseline(clouds=8, iters=5):
     """The reference graph restated op-for-op on torch-CPU (oracle/torch_twin.py), fwd+bwd, timed on
-    this host's cores on a bounded sample of the same workload.  torch's intra-op pool collapses
-    when oversubscribed (256 threads: 0.14 clouds/s, 16 threads: 2.9 clouds/s on the 2x EPYC 9575F
-    GPU-box host, profiles/r01_cpu_threads.txt), so a short sweep picks the thread count first and
+    this host's cores on a bounded sample of the same workload (8 of the 24 clouds, MEDIAN of 5 iterations, ~15 s).
+    torch's intra-op pool collapses when oversubscribed (256 threads: 0.14 clouds/s, 16 threads: 2.9 clouds/s on the
+    2x EPYC 9575F GPU-box host, profiles/r01_cpu_threads.txt), so a short sweep picks the thread count first and
     `cores` reports the count actually used."""
     from oracle import dgcnn_oracle as O
     from oracle import torch_twin as T
@@ -68,11 +78,11 @@ def cpu_baseline(clouds=8, iters=2):
         t0 = time.perf_counter()
         T.train_step(pts, lab, flags, P)
         ts.append(time.perf_counter() - t0)
-    best = min(ts)
-    return {"value": round(clouds / best, 3), "unit": "clouds/s", "cores": best_nt, "kind": "port",
-            "sample": "%d of the 24 clouds (N=2048,k=20,C=3, same model) fwd+bwd, best of %d, %.1f s/iter, %d torch "
-                      "threads (best of a {8,16,32} sweep) on a %d-CPU host; torch-CPU op-for-op restatement of the "
-                      "TF1 graph (TF1 itself cannot run, BASELINE.md 2)" % (clouds, iters, best, best_nt, ncpu)}
+    med = float(np.median(ts))
+    return {"value": round(clouds / med, 3), "unit": "clouds/s", "cores": best_nt, "kind": "port", "cpu_model": cpu_model(),
+            "sample": "%d of the 24 clouds (N=2048,k=20,C=3, same model) fwd+bwd, median of %d iterations (%.1f s each), %d torch "
+                      "threads (best of a {8,16,32} sweep) on a %d-CPU host (%s); torch-CPU op-for-op restatement of the "
+                      "TF1 graph (TF1 itself cannot run, BASELINE.md 2)" % (clouds, iters, med, best_nt, ncpu, cpu_model())}
 
 
 def main():

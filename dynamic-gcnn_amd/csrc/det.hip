@@ -1,0 +1,153 @@
+// det.hip -- fixed-order (run-to-run reproducible) versions of the three steps of the path whose default kernels
+// accumulate with atomics: BatchNorm column statistics, the two sums of the BatchNorm backward, and the fill order of the
+// transposed adjacency.  Selected by the host in deterministic mode (dgcnn._engine.DETERMINISTIC / DGCNN_DETERMINISTIC=1);
+// slower than the fused epilogues (one extra pass over the tensor, G blocks x sequential rows), same math:
+//   stage 1  block g owns the contiguous row range g: every thread walks its columns down the rows in order, fp64 sums;
+//   stage 2  one thread per column adds the G partials in g order -> slot 0 of the caller's (zeroed) stats buffer,
+//            the layout dgcnn_bn_finalize_f32 / dgcnn_bn_bwd_apply_f32 read.
+#include "common.h"
+#include <math.h>
+
+namespace {
+
+constexpr int DET_G = 256;     // row ranges (workgroups) of stage 1
+constexpr int DET_C = 4;       // columns per thread (F <= 1024 with 256 threads)
+
+__global__ __launch_bounds__(256) void colstats_det_kernel(const float* __restrict__ Y, int64_t rows, int F, int64_t ld,
+                                                           double* __restrict__ part) {
+  const int64_t chunk = (rows + DET_G - 1) / DET_G;
+  const int64_t r0 = (int64_t)blockIdx.x * chunk;
+  const int64_t r1 = (r0 + chunk < rows) ? r0 + chunk : rows;
+  double s[DET_C], q[DET_C];
+#pragma unroll
+  for (int c = 0; c < DET_C; ++c) { s[c] = 0.0; q[c] = 0.0; }
+  for (int64_t r = r0; r < r1; ++r) {
+#pragma unroll
+    for (int c = 0; c < DET_C; ++c) {
+      const int f = threadIdx.x + 256 * c;
+      if (f < F) {
+        const double v = (double)Y[r * ld + f];
+        s[c] += v;
+        q[c] += v * v;
+      }
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < DET_C; ++c) {
+    const int f = threadIdx.x + 256 * c;
+    if (f < F) {
+      part[((int64_t)blockIdx.x * 2 + 0) * F + f] = s[c];
+      part[((int64_t)blockIdx.x * 2 + 1) * F + f] = q[c];
+    }
+  }
+}
+
+__global__ void det_stage2_kernel(const double* __restrict__ part, int F, double* __restrict__ out) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;     // e in [0, 2F): which * F + f
+  if (e >= 2 * F) return;
+  const int which = e / F, f = e % F;
+  double t = 0.0;
+  for (int g = 0; g < DET_G; ++g) t += part[((int64_t)g * 2 + which) * F + f];
+  out[(int64_t)which * F + f] = t;                         // slot 0
+}
+
+// sum dZ and sum dZ * xhat over all R*k rows (dgcnn_bn_bwd_reduce_f32's quantities, same formulas as bn.hip) from the
+// materialised Y.  dmean == NULL: the k = 1 form (dZ = relu'(z) dout).
+__global__ __launch_bounds__(256) void bn_bwd_reduce_det_kernel(
+    const float* __restrict__ Y, int64_t R, int k, int F, const float* __restrict__ mean, const float* __restrict__ rstd,
+    const float* __restrict__ beta, int relu, const float* __restrict__ dmax, int64_t lddmax,
+    const float* __restrict__ dmean, int64_t lddmean, const float* __restrict__ mx_in, int64_t ldmx,
+    const float* __restrict__ cnt_in, double* __restrict__ part) {
+  const int64_t chunk = (R + DET_G - 1) / DET_G;
+  const int64_t r0 = (int64_t)blockIdx.x * chunk;
+  const int64_t r1 = (r0 + chunk < R) ? r0 + chunk : R;
+  const float invk = 1.0f / (float)k;
+  double s[DET_C], q[DET_C];
+  float mu[DET_C], rs[DET_C], be[DET_C];
+#pragma unroll
+  for (int c = 0; c < DET_C; ++c) {
+    s[c] = 0.0; q[c] = 0.0;
+    const int f = threadIdx.x + 256 * c;
+    mu[c] = (f < F) ? mean[f] : 0.f; rs[c] = (f < F) ? rstd[f] : 0.f; be[c] = (f < F) ? beta[f] : 0.f;
+  }
+  for (int64_t r = r0; r < r1; ++r) {
+#pragma unroll
+    for (int c = 0; c < DET_C; ++c) {
+      const int f = threadIdx.x + 256 * c;
+      if (f >= F) continue;
+      const float dmx = dmax[r * lddmax + f];
+      float dmn = 0.f, mx = 0.f, cnt = 1.f;
+      if (dmean) { dmn = dmean[r * lddmean + f]; mx = mx_in[r * ldmx + f]; cnt = cnt_in[r * F + f]; }
+      for (int m = 0; m < k; ++m) {
+        const float y = Y[(r * k + m) * F + f];
+        const float xh = (y - mu[c]) * rs[c];
+        float z = xh + be[c];
+        if (relu) z = fmaxf(z, 0.f);
+        float dz;
+        if (dmean) dz = ((z == mx) ? dmx / cnt : 0.f) + dmn * invk;
+        else dz = dmx;
+        if (relu && !(z > 0.f)) dz = 0.f;
+        s[c] += (double)dz;
+        q[c] += (double)(dz * xh);
+      }
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < DET_C; ++c) {
+    const int f = threadIdx.x + 256 * c;
+    if (f < F) {
+      part[((int64_t)blockIdx.x * 2 + 0) * F + f] = s[c];
+      part[((int64_t)blockIdx.x * 2 + 1) * F + f] = q[c];
+    }
+  }
+}
+
+// every bucket of the transposed adjacency in ascending edge order (the build fills buckets through LDS cursors: any order)
+__global__ void csr_sort_kernel(const int32_t* __restrict__ off, int32_t* __restrict__ rev, int64_t R) {
+  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= R) return;
+  const int b = off[j], e = off[j + 1];
+  for (int i = b + 1; i < e; ++i) {                        // insertion sort: buckets hold ~k entries
+    const int32_t v = rev[i];
+    int p = i - 1;
+    while (p >= b && rev[p] > v) { rev[p + 1] = rev[p]; --p; }
+    rev[p + 1] = v;
+  }
+}
+
+}  // namespace
+
+#define ST ((hipStream_t)stream)
+
+extern "C" int dgcnn_det_workspace_bytes(int F) { return (int)(sizeof(double) * DET_G * 2 * (size_t)F); }
+
+extern "C" int dgcnn_colstats_det_f32(const float* Y, int64_t rows, int F, int64_t ld, double* stats, void* ws,
+                                      size_t ws_bytes, void* stream) {
+  DG_REQUIRE(Y && stats && ws && rows > 0 && F > 0 && F <= 256 * DET_C, DGCNN_EINVAL, "dgcnn_colstats_det_f32: bad args (F <= %d)", 256 * DET_C);
+  DG_REQUIRE(ws_bytes >= sizeof(double) * DET_G * 2 * (size_t)F, DGCNN_ENOSPC, "dgcnn_colstats_det_f32: workspace too small");
+  double* part = reinterpret_cast<double*>(ws);
+  hipLaunchKernelGGL(colstats_det_kernel, dim3(DET_G), dim3(256), 0, ST, Y, rows, F, ld, part);
+  hipLaunchKernelGGL(det_stage2_kernel, dim3((unsigned)dg::cdiv(2 * F, 256)), dim3(256), 0, ST, part, F, stats);
+  return dg::check_launch("dgcnn_colstats_det_f32");
+}
+
+extern "C" int dgcnn_bn_bwd_reduce_det_f32(const float* Y, int64_t R, int k, int F, const float* mean, const float* rstd,
+                                           const float* beta, int relu, const float* dmax, int64_t lddmax,
+                                           const float* dmean, int64_t lddmean, const float* mx_in, int64_t ldmx,
+                                           const float* cnt_in, double* red, void* ws, size_t ws_bytes, void* stream) {
+  DG_REQUIRE(Y && mean && rstd && beta && dmax && red && ws && R > 0 && k > 0 && F > 0 && F <= 256 * DET_C, DGCNN_EINVAL,
+             "dgcnn_bn_bwd_reduce_det_f32: bad args");
+  DG_REQUIRE(!dmean || (mx_in && cnt_in), DGCNN_EINVAL, "dgcnn_bn_bwd_reduce_det_f32: the k > 1 form needs the forward's max / tie counts");
+  DG_REQUIRE(ws_bytes >= sizeof(double) * DET_G * 2 * (size_t)F, DGCNN_ENOSPC, "dgcnn_bn_bwd_reduce_det_f32: workspace too small");
+  double* part = reinterpret_cast<double*>(ws);
+  hipLaunchKernelGGL(bn_bwd_reduce_det_kernel, dim3(DET_G), dim3(256), 0, ST, Y, R, k, F, mean, rstd, beta, relu, dmax, lddmax,
+                     dmean, lddmean, mx_in, ldmx, cnt_in, part);
+  hipLaunchKernelGGL(det_stage2_kernel, dim3((unsigned)dg::cdiv(2 * F, 256)), dim3(256), 0, ST, part, F, red);
+  return dg::check_launch("dgcnn_bn_bwd_reduce_det_f32");
+}
+
+extern "C" int dgcnn_edge_csr_sort(const int32_t* off, int32_t* rev, int64_t R, void* stream) {
+  DG_REQUIRE(off && rev && R > 0, DGCNN_EINVAL, "dgcnn_edge_csr_sort: bad args");
+  hipLaunchKernelGGL(csr_sort_kernel, dim3((unsigned)dg::cdiv(R, 256)), dim3(256), 0, ST, off, rev, R);
+  return dg::check_launch("dgcnn_edge_csr_sort");
+}

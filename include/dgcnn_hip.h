@@ -190,6 +190,23 @@ int dgcnn_bn_bwd_apply_f32(const float* Y, int64_t R, int k, int F,
                            double* red, float* dY, float* dYsum, int64_t lddysum, float* dbeta,
                            float dbeta_beta, void* stream);
 
+/* ---- deterministic mode: fixed-order replacements of the three atomically accumulated steps -------------------------
+ * (the fused epilogues sum the BatchNorm statistics with LDS / fp64 atomics and the transposed adjacency is filled through
+ * LDS cursors: results are reproducible to ~1e-7 only, and a dynamic graph amplifies that into different neighbour lists).
+ * Two-stage sums: DGCNN_DET blocks own contiguous row ranges and walk them in order, then one thread per column adds the
+ * partials in block order into SLOT 0 of `stats` / `red` (caller-zeroed, same layout as above).  ws: dgcnn_det_workspace_bytes(F). */
+int dgcnn_det_workspace_bytes(int F);
+/* column sum / sum of squares of a materialised (rows, F) tensor (leading dimension ld): slim.batch_norm's statistics */
+int dgcnn_colstats_det_f32(const float* Y, int64_t rows, int F, int64_t ld, double* stats, void* ws, size_t ws_bytes,
+                           void* stream);
+/* dgcnn_bn_bwd_reduce_f32 on a materialised Y (dmean == NULL: the k = 1 form) */
+int dgcnn_bn_bwd_reduce_det_f32(const float* Y, int64_t R, int k, int F, const float* mean, const float* rstd,
+                                const float* beta, int relu, const float* dmax, int64_t lddmax,
+                                const float* dmean, int64_t lddmean, const float* mx_in, int64_t ldmx,
+                                const float* cnt_in, double* red, void* ws, size_t ws_bytes, void* stream);
+/* sort every bucket of the transposed adjacency (dgcnn_edge_csr_build) by edge number */
+int dgcnn_edge_csr_sort(const int32_t* off, int32_t* rev, int64_t R, void* stream);
+
 /* ---- head helpers (model.py:76-91) and residual add (ops.py:134) -------------------------- */
 /* max_pool_v2 over the N points of each cloud: out[b][f] = max_i x[b][i][f], arg[b][f] = first i */
 int dgcnn_global_max_f32(const float* x, int64_t ldx, int B, int N, int F, float* out, int32_t* arg,

@@ -36,7 +36,7 @@ def tag_of(name):
     if m:
         kinds = {0: "KCONTIG", 1: "KSTRIDED"}
         return "gemm_x3_kernel<%s,%s,%s,bf16x%s>" % (kinds[int(m.group(1))], kinds[int(m.group(2))], m.group(3), m.group(4))
-    m = re.match(r"knn_(mfma_)?kernel<(\d+), (\d+)>", n)
+    m = re.match(r"knn_(mfma_)?kernel<(\d+), (\d+)(, \w+)?>", n)
     if m:
         return "knn_kernel<C%s,k%s>" % (m.group(2), m.group(3))
     return re.sub(r"<.*", "", n)
