@@ -10,36 +10,75 @@
 
 namespace {
 
-constexpr int DET_G = 256;     // row ranges (workgroups) of stage 1
+constexpr int DET_G = 1024;    // row ranges (workgroups) of stage 1
 constexpr int DET_C = 4;       // columns per thread (F <= 1024 with 256 threads)
+
+// thread -> (column f, row lane): narrow tensors (F < 256) split a block's row range over 256 / F lanes, whose partials are
+// added in lane order through LDS; wide ones give every thread up to DET_C columns.
+struct DetMap {
+  int lanes, lane, f0, nf;       // this thread's columns: f0 + 256 * c, c < nf  (lanes == 1)  or the single column f0
+  bool on;
+  __device__ __forceinline__ DetMap(int F) {
+    lanes = (F < 256) ? 256 / F : 1;
+    if (lanes > 1) { lane = threadIdx.x / F; f0 = threadIdx.x % F; nf = 1; on = lane < lanes; }
+    else { lane = 0; f0 = threadIdx.x; nf = (F - threadIdx.x + 255) / 256; on = f0 < F; }
+  }
+};
+
+__device__ __forceinline__ void det_store(const DetMap& m, int F, const double (&s)[DET_C], const double (&q)[DET_C],
+                                          double* __restrict__ part, double* lds) {
+  if (m.lanes > 1) {                                  // lds[lane][2][F]
+    if (m.on) { lds[(m.lane * 2 + 0) * F + m.f0] = s[0]; lds[(m.lane * 2 + 1) * F + m.f0] = q[0]; }
+    __syncthreads();
+    if (m.on && m.lane == 0) {
+      double ts = 0.0, tq = 0.0;
+      for (int l = 0; l < m.lanes; ++l) { ts += lds[(l * 2 + 0) * F + m.f0]; tq += lds[(l * 2 + 1) * F + m.f0]; }
+      part[((int64_t)blockIdx.x * 2 + 0) * F + m.f0] = ts;
+      part[((int64_t)blockIdx.x * 2 + 1) * F + m.f0] = tq;
+    }
+  } else if (m.on) {
+#pragma unroll
+    for (int c = 0; c < DET_C; ++c)
+      if (c < m.nf) {
+        part[((int64_t)blockIdx.x * 2 + 0) * F + m.f0 + 256 * c] = s[c];
+        part[((int64_t)blockIdx.x * 2 + 1) * F + m.f0 + 256 * c] = q[c];
+      }
+  }
+}
+
+// rows [r0, r1) of the block, then the sub-range of this thread's lane
+__device__ __forceinline__ void det_range(const DetMap& m, int64_t rows, int64_t& r0, int64_t& r1) {
+  const int64_t chunk = (rows + DET_G - 1) / DET_G;
+  int64_t b0 = (int64_t)blockIdx.x * chunk;
+  int64_t b1 = (b0 + chunk < rows) ? b0 + chunk : rows;
+  if (b0 > rows) b0 = rows;
+  const int64_t sub = (b1 - b0 + m.lanes - 1) / m.lanes;
+  r0 = b0 + sub * m.lane;
+  r1 = (r0 + sub < b1) ? r0 + sub : b1;
+  if (r0 > b1) r0 = b1;
+}
 
 __global__ __launch_bounds__(256) void colstats_det_kernel(const float* __restrict__ Y, int64_t rows, int F, int64_t ld,
                                                            double* __restrict__ part) {
-  const int64_t chunk = (rows + DET_G - 1) / DET_G;
-  const int64_t r0 = (int64_t)blockIdx.x * chunk;
-  const int64_t r1 = (r0 + chunk < rows) ? r0 + chunk : rows;
+  __shared__ double lds[2 * 256];
+  const DetMap m(F);
+  int64_t r0, r1;
+  det_range(m, rows, r0, r1);
   double s[DET_C], q[DET_C];
 #pragma unroll
   for (int c = 0; c < DET_C; ++c) { s[c] = 0.0; q[c] = 0.0; }
-  for (int64_t r = r0; r < r1; ++r) {
+  if (m.on) {
+    for (int64_t r = r0; r < r1; ++r) {
 #pragma unroll
-    for (int c = 0; c < DET_C; ++c) {
-      const int f = threadIdx.x + 256 * c;
-      if (f < F) {
-        const double v = (double)Y[r * ld + f];
-        s[c] += v;
-        q[c] += v * v;
-      }
+      for (int c = 0; c < DET_C; ++c)
+        if (c < m.nf) {
+          const double v = (double)Y[r * ld + m.f0 + 256 * c];
+          s[c] += v;
+          q[c] += v * v;
+        }
     }
   }
-#pragma unroll
-  for (int c = 0; c < DET_C; ++c) {
-    const int f = threadIdx.x + 256 * c;
-    if (f < F) {
-      part[((int64_t)blockIdx.x * 2 + 0) * F + f] = s[c];
-      part[((int64_t)blockIdx.x * 2 + 1) * F + f] = q[c];
-    }
-  }
+  det_store(m, F, s, q, part, lds);
 }
 
 __global__ void det_stage2_kernel(const double* __restrict__ part, int F, double* __restrict__ out) {
@@ -58,48 +97,45 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_det_kernel(
     const float* __restrict__ beta, int relu, const float* __restrict__ dmax, int64_t lddmax,
     const float* __restrict__ dmean, int64_t lddmean, const float* __restrict__ mx_in, int64_t ldmx,
     const float* __restrict__ cnt_in, double* __restrict__ part) {
-  const int64_t chunk = (R + DET_G - 1) / DET_G;
-  const int64_t r0 = (int64_t)blockIdx.x * chunk;
-  const int64_t r1 = (r0 + chunk < R) ? r0 + chunk : R;
+  __shared__ double lds[2 * 256];
+  const DetMap m(F);
+  int64_t r0, r1;
+  det_range(m, R, r0, r1);
   const float invk = 1.0f / (float)k;
   double s[DET_C], q[DET_C];
   float mu[DET_C], rs[DET_C], be[DET_C];
 #pragma unroll
   for (int c = 0; c < DET_C; ++c) {
     s[c] = 0.0; q[c] = 0.0;
-    const int f = threadIdx.x + 256 * c;
-    mu[c] = (f < F) ? mean[f] : 0.f; rs[c] = (f < F) ? rstd[f] : 0.f; be[c] = (f < F) ? beta[f] : 0.f;
+    const int f = m.f0 + 256 * c;
+    const bool ok = m.on && c < m.nf;
+    mu[c] = ok ? mean[f] : 0.f; rs[c] = ok ? rstd[f] : 0.f; be[c] = ok ? beta[f] : 0.f;
   }
-  for (int64_t r = r0; r < r1; ++r) {
+  if (m.on) {
+    for (int64_t r = r0; r < r1; ++r) {
 #pragma unroll
-    for (int c = 0; c < DET_C; ++c) {
-      const int f = threadIdx.x + 256 * c;
-      if (f >= F) continue;
-      const float dmx = dmax[r * lddmax + f];
-      float dmn = 0.f, mx = 0.f, cnt = 1.f;
-      if (dmean) { dmn = dmean[r * lddmean + f]; mx = mx_in[r * ldmx + f]; cnt = cnt_in[r * F + f]; }
-      for (int m = 0; m < k; ++m) {
-        const float y = Y[(r * k + m) * F + f];
-        const float xh = (y - mu[c]) * rs[c];
-        float z = xh + be[c];
-        if (relu) z = fmaxf(z, 0.f);
-        float dz;
-        if (dmean) dz = ((z == mx) ? dmx / cnt : 0.f) + dmn * invk;
-        else dz = dmx;
-        if (relu && !(z > 0.f)) dz = 0.f;
-        s[c] += (double)dz;
-        q[c] += (double)(dz * xh);
+      for (int c = 0; c < DET_C; ++c) {
+        if (c >= m.nf) continue;
+        const int f = m.f0 + 256 * c;
+        const float dmx = dmax[r * lddmax + f];
+        float dmn = 0.f, mx = 0.f, cnt = 1.f;
+        if (dmean) { dmn = dmean[r * lddmean + f]; mx = mx_in[r * ldmx + f]; cnt = cnt_in[r * F + f]; }
+        for (int mm = 0; mm < k; ++mm) {
+          const float y = Y[(r * k + mm) * F + f];
+          const float xh = (y - mu[c]) * rs[c];
+          float z = xh + be[c];
+          if (relu) z = fmaxf(z, 0.f);
+          float dz;
+          if (dmean) dz = ((z == mx) ? dmx / cnt : 0.f) + dmn * invk;
+          else dz = dmx;
+          if (relu && !(z > 0.f)) dz = 0.f;
+          s[c] += (double)dz;
+          q[c] += (double)(dz * xh);
+        }
       }
     }
   }
-#pragma unroll
-  for (int c = 0; c < DET_C; ++c) {
-    const int f = threadIdx.x + 256 * c;
-    if (f < F) {
-      part[((int64_t)blockIdx.x * 2 + 0) * F + f] = s[c];
-      part[((int64_t)blockIdx.x * 2 + 1) * F + f] = q[c];
-    }
-  }
+  det_store(m, F, s, q, part, lds);
 }
 
 // every bucket of the transposed adjacency in ascending edge order (the build fills buckets through LDS cursors: any order)

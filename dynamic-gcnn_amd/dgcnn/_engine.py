@@ -40,6 +40,13 @@ EDGE_BWD_REDUCE_POINTS = True   # BN backward sums of conv0 from per-point data 
 SIDE_STREAM_MIN_ROWS = 16384   # below this many points the side stream is not used
 EDGE_MLP_NBR_GEMM = False  # True: factored conv0 with an edge-level neighbour GEMM instead of point-level GEMM + gather-add
 SCATTER_ATOMICS = False  # True: dx_j += dY W^T by fp32 atomics in the GEMM epilogue (A/B switch)
+# Deterministic mode: run-to-run bit-reproducible results.  The default kernels sum the BatchNorm statistics (forward and the
+# two backward sums) with LDS / fp64 atomics and fill the transposed adjacency through LDS cursors -- reproducible to ~1e-7
+# only, which the dynamic graphs amplify into a few different neighbour lists per step.  With this switch the statistics come
+# from fixed-order two-stage sums over MATERIALISED tensors (csrc/det.hip: conv0's output is written out for it) and the
+# adjacency buckets are sorted: slower (~2x at configs[1]), same math.  The reported loss / accuracy scalars are still summed
+# with atomics (they feed nothing back).
+DETERMINISTIC = os.environ.get("DGCNN_DETERMINISTIC", "0") not in ("0", "")
 
 
 class Context(object):
@@ -347,6 +354,25 @@ def gemm(A, Bm, C, transA=False, transB=False, beta=0.0, gbias=None, rpg=0, stat
            H._p(stats), ws.data_ptr(), ws.numel(), tag=tag, work=2.0 * M * N * K)
 
 
+def colstats_det(T, st):
+    """Fixed-order BatchNorm column sums of the materialised (R,F) tensor T into slot 0 of `st` (deterministic mode)."""
+    ws = ctx().workspace()
+    H.call("dgcnn_colstats_det_f32", T.data_ptr(), T.shape[0], T.shape[1], H.ld2(T), st.data_ptr(), ws.data_ptr(), ws.numel())
+
+
+def bn_bwd_reduce(Y, R, k, F, mean, rstd, beta, relu, dmx, dmn, mx, cnt, red, tag, work):
+    """sum dZ / sum dZ*xhat of a materialised Y: the atomically accumulated kernel, or its fixed-order twin."""
+    if DETERMINISTIC:
+        ws = ctx().workspace()
+        H.call("dgcnn_bn_bwd_reduce_det_f32", Y.data_ptr(), R, k, F, mean.data_ptr(), rstd.data_ptr(), beta.data_ptr(), int(relu),
+               dmx.data_ptr(), H.ld2(dmx), H._p(dmn), 0 if dmn is None else H.ld2(dmn), H._p(mx), 0 if mx is None else H.ld2(mx),
+               H._p(cnt), red.data_ptr(), ws.data_ptr(), ws.numel())
+    else:
+        H.call("dgcnn_bn_bwd_reduce_f32", Y.data_ptr(), R, k, F, mean.data_ptr(), rstd.data_ptr(), beta.data_ptr(), int(relu),
+               dmx.data_ptr(), H.ld2(dmx), H._p(dmn), 0 if dmn is None else H.ld2(dmn), H._p(mx), 0 if mx is None else H.ld2(mx),
+               H._p(cnt), red.data_ptr(), tag=tag, work=work)
+
+
 def bn_finalize(stats, F, count):
     dev = stats.device
     mr = torch.empty((2, F), dtype=torch.float32, device=dev)
@@ -375,7 +401,9 @@ def conv_bn_act(x, leaf_scope, num_outputs, relu=True, out=None, out2=None, gbia
     F = num_outputs
     T = torch.empty((R, F), dtype=torch.float32, device=x.device)
     st = c.stats(F)
-    gemm(x, Wx, T, gbias=gbias, rpg=rpg, stats=st, arith=arith)
+    gemm(x, Wx, T, gbias=gbias, rpg=rpg, stats=None if DETERMINISTIC else st, arith=arith)
+    if DETERMINISTIC:
+        colstats_det(T, st)
     mean, rstd = bn_finalize(st, F, R)
     if out is None:
         out = c.new_buffer(R, F)
@@ -393,9 +421,8 @@ def conv_bn_act(x, leaf_scope, num_outputs, relu=True, out=None, out2=None, gbia
                 if d2 is not None:      # the second copy's gradient joins the first
                     H.call("dgcnn_copy2d_f32", d2.data_ptr(), H.ld2(d2), dout.data_ptr(), H.ld2(dout), R, F, 1)
             red = c.stats(F)
-            H.call("dgcnn_bn_bwd_reduce_f32", T.data_ptr(), R, 1, F, mean.data_ptr(), rstd.data_ptr(), beta.data_ptr(),
-                   int(relu), dout.data_ptr(), H.ld2(dout), 0, 0, 0, 0, 0, red.data_ptr(),
-                   tag="bn_bwd_reduce_kernel<k=1>", work=4.0 * R * F * 2)
+            bn_bwd_reduce(T, R, 1, F, mean, rstd, beta, relu, dout, None, None, None, red,
+                          tag="bn_bwd_reduce_kernel<k=1>", work=4.0 * R * F * 2)
             H.call("dgcnn_bn_bwd_apply_f32", T.data_ptr(), R, 1, F, mean.data_ptr(), rstd.data_ptr(), beta.data_ptr(),
                    int(relu), dout.data_ptr(), H.ld2(dout), 0, 0, 0, 0, 0, red.data_ptr(), T.data_ptr(), 0, 0,
                    c.var_grads[bname].data_ptr(), 1.0, tag="bn_bwd_apply_kernel<k=1>", work=4.0 * R * F * 3)
@@ -434,14 +461,17 @@ def edge_conv_block(x, B, N, k, num_filters, relu1=True, outs=None, net2=None):
     st = c.stats(F)
     literal = EDGE_MLP_LITERAL
     gather = (not literal) and (not EDGE_MLP_NBR_GEMM) and F % 4 == 0 and F <= 1024
-    virtual = gather and not EDGE_MATERIALIZE_Y and k < 256   # conv0 output never written: recomputed from (V, U, idx)
+    virtual = gather and not EDGE_MATERIALIZE_Y and not DETERMINISTIC and k < 256   # conv0 output never written: recomputed from (V, U, idx)
     #                                                           (the edge BN passes pack tie / positive counts: k < 256)
     Y = None if virtual else torch.empty((R * k, F), dtype=torch.float32, device=x.device)
     wd = wcat = UV = None
     if literal:
         H.call("dgcnn_edge_mlp_f32", x.data_ptr(), H.ld2(x), idx.data_ptr(), W0.data_ptr(), B, N, C, k, F,
-               Y.data_ptr(), st.data_ptr(), tag="gemm_kernel<A_EDGE,B_ROW,STORE,%d,%d>" % (_tile_m(R * k, F), 64 if F <= 64 else 128),
+               Y.data_ptr(), 0 if DETERMINISTIC else st.data_ptr(),
+               tag="gemm_kernel<A_EDGE,B_ROW,STORE,%d,%d>" % (_tile_m(R * k, F), 64 if F <= 64 else 128),
                work=2.0 * R * k * 2 * C * F)                            # ops.py:21-52 (gather fused)
+        if DETERMINISTIC:
+            colstats_det(Y, st)
     elif gather:
         # conv0 is linear: E W0 = x_i (Wa-Wb) + x_j Wb = U[i] + V[j] with [U | V] = X [Wa-Wb | Wb] -- ONE
         # point-level GEMM (k times fewer MACs than the edge tensor product), then a per-edge gather-add
@@ -460,8 +490,10 @@ def edge_conv_block(x, B, N, k, num_filters, relu1=True, outs=None, net2=None):
         UV = torch.empty((R, 2 * F), dtype=torch.float32, device=x.device)
         gemm(xg, wcat, UV, arith=c.edge_mlp_arith)
         H.call("dgcnn_edge_gather_add_f32", UV[:, F:].data_ptr(), 2 * F, UV.data_ptr(), 2 * F, idx.data_ptr(),
-               B, N, k, F, H._p(Y), st.data_ptr(),
+               B, N, k, F, H._p(Y), 0 if DETERMINISTIC else st.data_ptr(),
                tag="edge_gather_add_kernel", work=4.0 * ((0 if virtual else R * k * F) + 2 * R * F) + 4.0 * R * k)   # ops.py:21-52
+        if DETERMINISTIC:
+            colstats_det(Y, st)
         if not virtual:
             UV = None
     else:
@@ -473,9 +505,11 @@ def edge_conv_block(x, B, N, k, num_filters, relu1=True, outs=None, net2=None):
         U = torch.empty((R, F), dtype=torch.float32, device=x.device)
         gemm(x, wd, U)
         H.call("dgcnn_edge_nbr_gemm_f32", x.data_ptr(), H.ld2(x), idx.data_ptr(), W0[C:].data_ptr(), U.data_ptr(), F,
-               B, N, C, k, F, Y.data_ptr(), st.data_ptr(),
+               B, N, C, k, F, Y.data_ptr(), 0 if DETERMINISTIC else st.data_ptr(),
                tag="gemm_kernel<A_EDGE,B_ROW,STORE,%d,%d>" % (_tile_m(R * k, F), 64 if F <= 64 else 128),
                work=2.0 * R * k * C * F)                                # ops.py:21-52 (gather fused)
+        if DETERMINISTIC:
+            colstats_det(Y, st)
     mean, rstd = bn_finalize(st, F, R * k)                              # ops.py:53
     if outs is None:
         mm = c.new_buffer(R, 2 * F)
@@ -502,6 +536,8 @@ def edge_conv_block(x, B, N, k, num_filters, relu1=True, outs=None, net2=None):
         rev_t = torch.empty(R * k, dtype=torch.int32, device=x.device)
         with c.off_critical_path(cws, off_t, rev_t, rows=R):
             H.call("dgcnn_edge_csr_build", idx.data_ptr(), B, N, k, cws.data_ptr(), off_t.data_ptr(), rev_t.data_ptr())
+            if DETERMINISTIC:
+                H.call("dgcnn_edge_csr_sort", off_t.data_ptr(), rev_t.data_ptr(), R)
         csr = (off_t, rev_t)
 
     if c.recording:
@@ -523,10 +559,8 @@ def edge_conv_block(x, B, N, k, num_filters, relu1=True, outs=None, net2=None):
                        mx.data_ptr(), H.ld2(mx), cnt.data_ptr(), red.data_ptr(),
                        tag="bn_bwd_reduce_kernel<edge>", work=4.0 * (6 * R * F) + 4.0 * R * k)
             else:
-                H.call("dgcnn_bn_bwd_reduce_f32", Y.data_ptr(), R, k, F, mean.data_ptr(), rstd.data_ptr(),
-                       beta0.data_ptr(), 1, dmx.data_ptr(), H.ld2(dmx), dmn.data_ptr(), H.ld2(dmn),
-                       mx.data_ptr(), H.ld2(mx), cnt.data_ptr(), red.data_ptr(),
-                       tag="bn_bwd_reduce_kernel", work=4.0 * (R * k * F + 2 * R * F))
+                bn_bwd_reduce(Y, R, k, F, mean, rstd, beta0, 1, dmx, dmn, mx, cnt, red,
+                              tag="bn_bwd_reduce_kernel", work=4.0 * (R * k * F + 2 * R * F))
             dx = c.grad(x)
             need_sum = (dx is not None) or not literal
             dUV = dysum = None
@@ -562,6 +596,8 @@ def edge_conv_block(x, B, N, k, num_filters, relu1=True, outs=None, net2=None):
                     off = torch.empty(R + 1, dtype=torch.int32, device=x.device)
                     rev = torch.empty(R * k, dtype=torch.int32, device=x.device)
                     H.call("dgcnn_edge_csr_build", idx.data_ptr(), B, N, k, cws.data_ptr(), off.data_ptr(), rev.data_ptr())
+                    if DETERMINISTIC:
+                        H.call("dgcnn_edge_csr_sort", off.data_ptr(), rev.data_ptr(), R)
                 H.call("dgcnn_edge_gather_sum_f32", dY.data_ptr(), off.data_ptr(), rev.data_ptr(), R, F, S.data_ptr(),
                        H.ld2(S), tag="csr_gather_sum_kernel", work=4.0 * (R * k * F + R * F))
 

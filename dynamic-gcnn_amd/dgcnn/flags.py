@@ -51,6 +51,7 @@ _OPTIONS = [
     ("WEIGHT_KEY", "-wkey", str, "", "tf", "keyword to fetch weight from file"),
     ("USE_GRAPH", "-ug", str, "auto", "ti", "replay the tower as a captured HIP graph: 0 | 1 | auto (launch-bound shapes only)"),
     ("EDGE_MLP_DTYPE", "-emd", str, "f32", "ti", "operand type of the EdgeConv conv0 / conv1 products: f32 | bf16"),
+    ("DETERMINISTIC", "-det", _BOOL, None, "ti", "fixed-order BatchNorm sums / sorted adjacency: bit-reproducible runs (slower)"),
 ]
 
 

@@ -71,6 +71,8 @@ class trainval(object):
         self._lr = float(f.LEARNING_RATE)
         self._dist, self._rank, self._world = parallel.dist_state()
         parallel.broadcast_(self._ctx.flat_param, self._dist, src=0)
+        if getattr(f, "DETERMINISTIC", None) is not None:
+            E.DETERMINISTIC = bool(f.DETERMINISTIC)                  # process-wide, like the GEMM arithmetic
         emd = str(getattr(f, "EDGE_MLP_DTYPE", "f32")).lower()
         if emd not in ("f32", "fp32", "float32", "bf16", "bfloat16"):
             raise ValueError("EDGE_MLP_DTYPE must be 'f32' or 'bf16', got %r" % (emd,))
@@ -153,7 +155,7 @@ class trainval(object):
     def _tower_graph(self, pts, lab, wgt, train):
         c = self._ctx
         key = (tuple(pts.shape), bool(train), lab is not None, wgt is not None, float(E.DROPOUT_KEEP), H.gemm_arith(),
-               E.WGRAD_SIDE_STREAM, c.edge_mlp_arith)
+               E.WGRAD_SIDE_STREAM, c.edge_mlp_arith, E.DETERMINISTIC)
         ent = self._graphs.get(key)
         if ent is None:
             if key not in self._graph_seen:          # first sight: a normal eager step (also allocates workspaces / arenas)

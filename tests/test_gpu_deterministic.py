@@ -1,0 +1,105 @@
+"""Deterministic mode (dgcnn._engine.DETERMINISTIC / DGCNN_FLAGS(DETERMINISTIC=True) / DGCNN_DETERMINISTIC=1): the BatchNorm
+statistics and backward sums come from fixed-order two-stage reductions and the transposed adjacency is sorted, so two runs of
+the same schedule are BIT-identical -- logits, dynamic graphs, gradients and parameters after several optimizer steps -- where
+the default (atomically accumulated) kernels agree to ~1e-7 only."""
+import numpy as np
+import pytest
+import torch
+
+import dgcnn
+from dgcnn import _engine as E, _hip as H
+from gpu_helpers import dev, host, capture_layers
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture()
+def det():
+    old = E.DETERMINISTIC
+    E.DETERMINISTIC = True
+    yield
+    E.DETERMINISTIC = old
+    dgcnn.reset()
+
+
+def _flags(**kw):
+    base = dict(MODEL_NAME="residual-dgcnn", EDGE_CONV_LAYERS=3, EDGE_CONV_FILTERS=64, KVALUE=16, FC_LAYERS=2, FC_FILTERS=[128, 64],
+                NUM_CLASS=3, NUM_CHANNEL=3, TRAIN=True, SEED=5, LEARNING_RATE=1e-3)
+    base.update(kw)
+    return dgcnn.DGCNN_FLAGS(**base)
+
+
+def _run(steps, pts, lab, graphs=False):
+    tv = dgcnn.trainval(_flags()).initialize().use_graph(graphs)
+    c = dgcnn.ctx()
+    grads, idxs = [], []
+    for s in range(steps):
+        tv.zero_gradients(None)
+        with capture_layers(keep_inputs=False) as cap:
+            tv.accum_gradient(None, [pts[s]], [lab[s]])
+        idxs.append([cap.layers["EdgeConv%d" % i][1] for i in range(3)])
+        grads.append(c.flat_grad.clone())
+        tv.apply_gradient(None)
+    return c.flat_param.clone(), grads, idxs
+
+
+def test_two_runs_are_bit_identical(det):
+    rng = np.random.default_rng(0)
+    pts = torch.from_numpy(rng.random((4, 6, 1024, 3), dtype=np.float32)).cuda()       # 4 steps of 6 clouds x 1024 points
+    lab = torch.from_numpy(rng.integers(0, 3, (4, 6, 1024)).astype(np.int32)).cuda()
+    p1, g1, i1 = _run(4, pts, lab)
+    p2, g2, i2 = _run(4, pts, lab)
+    for a, b in zip(g1, g2):
+        assert torch.equal(a, b)
+    for sa, sb in zip(i1, i2):
+        for a, b in zip(sa, sb):
+            np.testing.assert_array_equal(a, b)                   # the dynamic graphs themselves are reproduced
+    assert torch.equal(p1, p2)
+    assert float((p1 - dgcnn.trainval(_flags()).initialize()._ctx.flat_param).abs().max()) > 1e-3
+
+
+def test_deterministic_mode_agrees_with_default_kernels():
+    """Same math: one step in both modes agrees to the default mode's own run-to-run noise (forward bitwise-close, gradients
+    to ~1e-5 of their scale)."""
+    rng = np.random.default_rng(1)
+    pts = torch.from_numpy(rng.random((1, 4, 512, 3), dtype=np.float32)).cuda()
+    lab = torch.from_numpy(rng.integers(0, 3, (1, 4, 512)).astype(np.int32)).cuda()
+    keep, E.DROPOUT_KEEP = E.DROPOUT_KEEP, 1.0
+    old = E.DETERMINISTIC
+    try:
+        E.DETERMINISTIC = False
+        _, g0, i0 = _run(1, pts, lab)
+        E.DETERMINISTIC = True
+        _, g1, i1 = _run(1, pts, lab)
+    finally:
+        E.DETERMINISTIC, E.DROPOUT_KEEP = old, keep
+        dgcnn.reset()
+    np.testing.assert_array_equal(i0[0][0], i1[0][0])             # layer 0: identical inputs
+    a, b = g0[0].cpu().numpy(), g1[0].cpu().numpy()
+    assert np.linalg.norm(a - b) <= 2e-3 * np.linalg.norm(a), np.linalg.norm(a - b) / np.linalg.norm(a)
+
+
+def test_det_kernels_against_numpy(det):
+    rng = np.random.default_rng(2)
+    R, F = 5000, 70
+    wide = rng.normal(size=(R, 100)).astype(np.float32)
+    T = dev(wide)[:, 10:10 + F]
+    st = torch.zeros(H.STAT_SLOTS * 2 * F, dtype=torch.float64, device="cuda")
+    E.colstats_det(T, st)
+    s = host(st).reshape(H.STAT_SLOTS, 2, F)
+    assert np.abs(s[1:]).max() == 0
+    np.testing.assert_allclose(s[0, 0], wide[:, 10:10 + F].astype(np.float64).sum(0), rtol=1e-12, atol=1e-9)
+    np.testing.assert_allclose(s[0, 1], (wide[:, 10:10 + F].astype(np.float64) ** 2).sum(0), rtol=1e-12, atol=1e-9)
+    # sorted adjacency
+    B, N, k = 3, 200, 7
+    idx = dev(rng.integers(0, N, (B, N, k)).astype(np.int32))
+    Rn = B * N
+    cws = torch.zeros(2 * Rn, dtype=torch.int32, device="cuda")
+    off = torch.empty(Rn + 1, dtype=torch.int32, device="cuda")
+    rev = torch.empty(Rn * k, dtype=torch.int32, device="cuda")
+    H.call("dgcnn_edge_csr_build", idx.data_ptr(), B, N, k, cws.data_ptr(), off.data_ptr(), rev.data_ptr())
+    H.call("dgcnn_edge_csr_sort", off.data_ptr(), rev.data_ptr(), Rn)
+    o, r = host(off), host(rev)
+    for j in range(Rn):
+        seg = r[o[j]:o[j + 1]]
+        assert (np.diff(seg) > 0).all()
