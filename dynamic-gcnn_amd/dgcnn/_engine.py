@@ -446,6 +446,35 @@ def conv_bn_act(x, leaf_scope, num_outputs, relu=True, out=None, out2=None, gbia
 # ----------------------------------------------------------------------------------------------
 # dgcnn/ops.py:42-73 edge_conv as one block
 # ----------------------------------------------------------------------------------------------
+UV_UNDER_KNN = os.environ.get("DGCNN_UV_UNDER_KNN", "0") != "0"     # A/B switch, off: measured SLOWER (5.34-5.87 vs 5.05 ms/step at
+#                                                                    configs[1]: the GEMM's 157 KB workgroups displace k-NN blocks)
+
+
+def _point_gemm(c, x, W0, R, C, F, side):
+    """Wcat = [Wa - Wb | Wb] and [U | V] = X Wcat (conv0 folded to the points).  C = 3 (raw coordinates): the reduction
+    dimension is padded to 4 with a zero column / zero weight row so that the GEMM takes the float4 path."""
+    Cp = (C + 3) // 4 * 4
+    xg = x
+    if Cp != C:
+        xg = torch.zeros((R, Cp), dtype=torch.float32, device=x.device)
+        wcat = torch.zeros((Cp, 2 * F), dtype=torch.float32, device=x.device)
+    else:
+        wcat = torch.empty((C, 2 * F), dtype=torch.float32, device=x.device)
+    UV = torch.empty((R, 2 * F), dtype=torch.float32, device=x.device)
+
+    def issue():
+        if Cp != C:
+            H.call("dgcnn_copy2d_f32", x.data_ptr(), H.ld2(x), xg.data_ptr(), Cp, R, C, 0)
+        H.call("dgcnn_edge_weight_split_f32", W0.data_ptr(), C, F, wcat.data_ptr())
+        gemm(xg, wcat, UV, arith=c.edge_mlp_arith)
+    if side:
+        with c.off_critical_path(xg, wcat, UV, rows=R):
+            issue()
+    else:
+        issue()
+    return Cp, xg, wcat, UV
+
+
 def edge_conv_block(x, B, N, k, num_filters, relu1=True, outs=None, net2=None):
     """x: (B*N, C) view.  Returns (mm, net, idx): mm = (R,2F) [max | mean], net = (R,64).
     outs = (mm_view, net_view) destination slices (model path) or None (fresh buffers)."""
@@ -457,10 +486,15 @@ def edge_conv_block(x, B, N, k, num_filters, relu1=True, outs=None, net2=None):
     with variable_scope("conv0"):
         w0name, W0 = c.get_variable("weights", (2 * C, F))
         b0name, beta0 = c.get_variable("BatchNorm/beta", (F,))
-    idx = knn(x, B, N, k)                                               # ops.py:8-19
     st = c.stats(F)
     literal = EDGE_MLP_LITERAL
     gather = (not literal) and (not EDGE_MLP_NBR_GEMM) and F % 4 == 0 and F <= 1024
+    # the point-level GEMM [U|V] = X Wcat needs only x: it CAN be issued on the side stream under the k-NN kernel (switch)
+    uv_early = gather and UV_UNDER_KNN and WGRAD_SIDE_STREAM and R >= SIDE_STREAM_MIN_ROWS
+    pre = _point_gemm(c, x, W0, R, C, F, side=True) if uv_early else None
+    idx = knn(x, B, N, k)                                               # ops.py:8-19
+    if uv_early:
+        c.join_side()
     virtual = gather and not EDGE_MATERIALIZE_Y and not DETERMINISTIC and k < 256   # conv0 output never written: recomputed from (V, U, idx)
     #                                                           (the edge BN passes pack tie / positive counts: k < 256)
     Y = None if virtual else torch.empty((R * k, F), dtype=torch.float32, device=x.device)
@@ -478,17 +512,7 @@ def edge_conv_block(x, B, N, k, num_filters, relu1=True, outs=None, net2=None):
         # bound by the HBM write of Y, which also takes the BatchNorm column sums.
         # C = 3 (raw coordinates): pad the reduction dimension to 4 with a zero column / zero weight row so that
         # the point-level GEMMs take the float4 path (the generic scalar kernel costs ~10x more on them)
-        Cp = (C + 3) // 4 * 4
-        xg = x
-        if Cp != C:
-            xg = torch.zeros((R, Cp), dtype=torch.float32, device=x.device)
-            H.call("dgcnn_copy2d_f32", x.data_ptr(), H.ld2(x), xg.data_ptr(), Cp, R, C, 0)
-            wcat = torch.zeros((Cp, 2 * F), dtype=torch.float32, device=x.device)
-        else:
-            wcat = torch.empty((C, 2 * F), dtype=torch.float32, device=x.device)
-        H.call("dgcnn_edge_weight_split_f32", W0.data_ptr(), C, F, wcat.data_ptr())
-        UV = torch.empty((R, 2 * F), dtype=torch.float32, device=x.device)
-        gemm(xg, wcat, UV, arith=c.edge_mlp_arith)
+        Cp, xg, wcat, UV = pre if pre is not None else _point_gemm(c, x, W0, R, C, F, side=False)
         H.call("dgcnn_edge_gather_add_f32", UV[:, F:].data_ptr(), 2 * F, UV.data_ptr(), 2 * F, idx.data_ptr(),
                B, N, k, F, H._p(Y), 0 if DETERMINISTIC else st.data_ptr(),
                tag="edge_gather_add_kernel", work=4.0 * ((0 if virtual else R * k * F) + 2 * R * F) + 4.0 * R * k)   # ops.py:21-52

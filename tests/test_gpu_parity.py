@@ -582,6 +582,9 @@ CONFIGS = [
     dict(MODEL_NAME="dgcnn", EDGE_CONV_LAYERS=2, EDGE_CONV_FILTERS=[6, 10], KVALUE=3, B=1, N=50, C=3),
     # filter counts that are multiples of 4 but not powers of two (gather path with 12 / 20 float4 lanes per row), C = 4
     dict(MODEL_NAME="dgcnn", EDGE_CONV_LAYERS=2, EDGE_CONV_FILTERS=[48, 80], KVALUE=5, B=2, N=77, C=4),
+    # residual stack whose filter count changes to 64: the `shortcut` 1x1 conv + BN (no activation) of ops.py:124-133 EXISTS
+    # and runs (conv1 always emits 64 channels, so 64 is the only changed width whose add at ops.py:134 has matching shapes)
+    dict(MODEL_NAME="residual-dgcnn", EDGE_CONV_LAYERS=3, EDGE_CONV_FILTERS=[32, 64, 64], KVALUE=9, B=2, N=160, C=3),
 ]
 
 
@@ -749,6 +752,22 @@ def test_errors_match_reference(dg):
                  lambda: tv.accum_gradient(None, [None], [None])):
         with pytest.raises(NotImplementedError):                                              # trainval.py:111-128
             call()
+
+
+def test_residual_shortcut_shape_mismatch_is_reproduced(dg):
+    """ops.py:124-134: when num_filters[i] != num_filters[i-1] the shortcut is convolved to num_filters[i] channels while conv1
+    always emits 64 (ops.py:62-63), so any changed width other than 64 fails at the add -- TF raises a shape error at
+    graph-build time; here ValueError at the same call."""
+    x = torch.rand(1, 64, 3, device="cuda")
+    with pytest.raises(ValueError, match="shortcut"):
+        dg.ops.repeat_residual_edge_conv(x, 2, 5, [64, 128], True)
+    dg.reset()
+    out = dg.ops.repeat_residual_edge_conv(x, 2, 5, [32, 64], True)       # changed width 64: the shortcut conv runs
+    assert "EdgeConv1/shortcut/weights" in dg.ctx().vars and tuple(dg.ctx().vars["EdgeConv1/shortcut/weights"].shape) == (64, 64)
+    assert tuple(out[-1].shape) == (1, 64, 1, 64) and float(out[-1].min()) >= 0.0      # relu(shortcut + net)
+    dg.reset()
+    dg.ops.repeat_residual_edge_conv(x, 2, 5, 64, True)
+    assert not any("shortcut" in n for n in dg.ctx().vars)               # equal widths: no shortcut variables (production, train_dgcnn.sh:9)
 
 
 def test_dropout_and_misc_kernels(dg):
