@@ -515,6 +515,282 @@ __global__ __launch_bounds__(256, (KC <= 20 ? 3 : 2)) void knn_mfma_kernel(const
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Large-N kernel (C = 64 feature graphs, N >= 8192): distances on the BF16 matrix pipe, exact fp32 only for the survivors.
+//
+// At N = 65536 the fp32 MFMA chain is ~80 % of the kernel above (almost nothing survives the filter), and on gfx950
+// v_mfma_f32_32x32x2_f32 runs at the vector rate and blocks the vector pipe.  Here every 32 x 32 tile of inner products is
+// computed APPROXIMATELY from the two leading bf16 terms of each operand (x = x1 + x2 + x3 exactly; products x1y1 + x1y2 +
+// x2y1 on v_mfma_f32_32x32x16_bf16: 12 instructions of 32 clocks per tile instead of 32 of 64), with a rigorous bound:
+//     |p' - P| <= 3.25 * 2^-16 * sum|x_c y_c|   (dropped terms x2y2, x3 y, (x1+x2) y3 and the fp32 accumulation)
+//     |p  - P| <= C * 2^-24 * sum|x_c y_c|      (the oracle's fmaf chain p; P = exact inner product)
+//  => |d' - d| <= 2 |p' - p| + 2^-22 t  <  2^-14 t,   t = fl(s_i + s_j)   (sum|xy| <= (S_i + S_j)/2; d, d' share t)
+// A candidate can enter the list only if d < thr, hence only if d' < thr + eps with eps = 2^-13 t (2x margin).  For those
+// (and only those) the NORMATIVE distance is recomputed on the VALU -- fmaf chain over c ascending from +0, x_i and x_j from
+// fp32 LDS copies of the block's query rows and of the current candidate tile (a first version read x_j from global memory:
+// 60 ms at (8,65536,64,20) against 9.8 ms without any re-check -- the re-check is latency, not work) -- and goes through the
+// exact filter and the same insert as everywhere else.  Indices are therefore bit-identical to the oracle's; the tests that pin knn_mfma_kernel
+// pin this kernel too (N = 16384 / 65536 compares, and every small-N case with the kernel forced on).
+// No parking area: a survivor is identified by its mask bit, its distance is recomputed anyway.
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+
+__device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {
+  unsigned r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+  return r;
+}
+// (x0, x1) -> packed bf16 pairs of the two leading split terms
+__device__ __forceinline__ void split2_pair(float x0, float x1, unsigned& h, unsigned& m) {
+  h = cvt_pk_bf16(x0, x1);
+  const float r0 = x0 - __uint_as_float(h << 16);
+  const float r1 = x1 - __uint_as_float(h & 0xffff0000u);
+  m = cvt_pk_bf16(r0, r1);
+}
+
+template <int KC, bool UNUSED = true>
+struct Bf16fCfg {
+  static constexpr int OCC = (KC <= 20) ? 3 : 2;
+};
+
+template <int KC>
+__global__ __launch_bounds__(256, (Bf16fCfg<KC>::OCC)) void knn_bf16f_kernel(const float* __restrict__ x, const float* __restrict__ sq,
+                                                                            int N, int C, int64_t ldx, int k,
+                                                                            int32_t* __restrict__ idx) {
+  using f32x16 = __attribute__((ext_vector_type(16))) float;
+  constexpr int CP = 64;
+  constexpr int TJM = 64;
+  constexpr unsigned CS = TJM * 16 + 16;     // bytes per 8-channel chunk of one bf16 plane: [cand][8 bf16], padded (bank shift of 4)
+  constexpr unsigned PB = 8 * CS;            // bytes per plane (8 chunks = 64 channels)
+  constexpr unsigned TILE_B = 2 * PB;        // two planes (single buffer: the MFMA phase of a tile is short, other blocks of the CU fill the refill)
+  constexpr int RS = CP + 4;                 // fp32 row stride of the two re-check tiles: 16-byte aligned rows, bank = 4 row + c
+  constexpr unsigned WORK_B = TILE_B + 4 * (2 * ROWS * RS + TJM + 4 * ROWS);
+  constexpr unsigned MERGE_B = 4u * ROWS * KC * 2;
+  constexpr unsigned SH_B = WORK_B > MERGE_B ? WORK_B : MERGE_B;
+  __shared__ __attribute__((aligned(16))) char smem_raw[SH_B];
+  float* xq = reinterpret_cast<float*>(smem_raw + TILE_B);         // [64 query rows][RS]    fp32, resident
+  float* xc = xq + ROWS * RS;                                      // [64 candidates][RS]    fp32 copy of the current tile
+  float* sjs = xc + TJM * RS;                                      // [TJM]
+  volatile float* thrw = sjs + TJM;                                // [4 lists][64 rows]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int w = tid >> 6;
+  const int l31 = lane & 31, h = lane >> 5;
+  const int qg = w & 1;
+  const int cs = w >> 1;
+  const int b = blockIdx.y;
+  const int row0 = blockIdx.x * ROWS;
+  const int row = row0 + qg * 32 + l31;
+  const float* xb = x + (int64_t)b * N * ldx;
+  const float* sqb = sq + (int64_t)b * N;
+  const int rowc = row < N ? row : N - 1;
+  const int cbase = cs * 32;
+  const int lid = cs * 2 + h;
+  const int rslot = qg * 32 + l31;
+  const float si = sqb[rowc];
+  const float* xi_row = xb + (int64_t)rowc * ldx;
+
+  // B operand: this lane's query row, channels 16 s + 8 h + (0..7), two bf16 planes
+  bf16x8 q1[4], q2[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int c = 16 * s + 8 * h + 4 * e;
+      float4 t4 = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (c < C) t4 = *reinterpret_cast<const float4*>(xi_row + c);
+      v[4 * e] = t4.x; v[4 * e + 1] = t4.y; v[4 * e + 2] = t4.z; v[4 * e + 3] = t4.w;
+    }
+    unsigned hh[4], mm[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) split2_pair(v[2 * e], v[2 * e + 1], hh[e], mm[e]);
+    const uint4 H4 = make_uint4(hh[0], hh[1], hh[2], hh[3]), M4 = make_uint4(mm[0], mm[1], mm[2], mm[3]);
+    q1[s] = *reinterpret_cast<const bf16x8*>(&H4);
+    q2[s] = *reinterpret_cast<const bf16x8*>(&M4);
+  }
+  // fp32 copy of the block's query rows for the exact re-check
+  for (int e = tid; e < ROWS * (CP / 4); e += 256) {
+    const int r = e / (CP / 4), c4 = (e % (CP / 4)) * 4;
+    const int rr = (row0 + r < N) ? row0 + r : N - 1;
+    float4 t4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c4 < C) t4 = *reinterpret_cast<const float4*>(xb + (int64_t)rr * ldx + c4);
+    *reinterpret_cast<float4*>(xq + r * RS + c4) = t4;
+  }
+
+  float dl[KC];
+  int jl[KC];
+#pragma unroll
+  for (int t = 0; t < KC; ++t) {
+    dl[t] = INFINITY;
+    jl[t] = 0x7fffffff;
+  }
+
+  // candidate tile: 64 rows x 64 channels -> registers (float4 pieces) -> two bf16 planes in LDS
+  constexpr int NV = (TJM * (CP / 4)) / 256;   // 4
+  float4 pre[NV];
+  float pre_s = INFINITY;
+  auto fetch = [&](int j0) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int e = tid + 256 * i;
+      const int r = e / (CP / 4);
+      const int c4 = (e % (CP / 4)) * 4;
+      const int j = j0 + r;
+      const int jc = j < N ? j : N - 1;
+      const int cc = c4 < C ? c4 : C - 4;
+      const float4 t4 = *reinterpret_cast<const float4*>(xb + (int64_t)jc * ldx + cc);
+      const bool ok = c4 < C;
+      pre[i] = make_float4(ok ? t4.x : 0.f, ok ? t4.y : 0.f, ok ? t4.z : 0.f, ok ? t4.w : 0.f);
+    }
+    if (tid < TJM) pre_s = (j0 + tid < N) ? sqb[j0 + tid] : INFINITY;
+  };
+  auto stash = [&]() {
+    char* base = smem_raw;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int e = tid + 256 * i;
+      const int r = e / (CP / 4);
+      const int c4 = (e % (CP / 4)) * 4;
+      unsigned h0, m0, h1, m1;
+      split2_pair(pre[i].x, pre[i].y, h0, m0);
+      split2_pair(pre[i].z, pre[i].w, h1, m1);
+      const unsigned off = (unsigned)(c4 >> 3) * CS + (unsigned)r * 16u + (unsigned)(c4 & 4) * 2u;
+      *reinterpret_cast<uint2*>(base + off) = make_uint2(h0, h1);
+      *reinterpret_cast<uint2*>(base + PB + off) = make_uint2(m0, m1);
+      *reinterpret_cast<float4*>(xc + r * RS + c4) = pre[i];
+    }
+    if (tid < TJM) sjs[tid] = pre_s;
+  };
+
+  const int nt = (N + TJM - 1) / TJM;
+  fetch(0);
+  thrw[tid] = INFINITY;
+  const unsigned a_off = (unsigned)h * CS + (unsigned)(cbase + l31) * 16u;     // chunk 2 s + h of candidate cbase + l31
+  const float kappa = 1.0f / 8192.0f;                                          // eps = 2^-13 (s_i + s_j)
+
+#pragma unroll 1
+  for (int t = 0; t < nt; ++t) {
+    const int j0 = t * TJM;
+    if (t > 0) __syncthreads();              // every wave is done with tile t-1 (planes, fp32 copy)
+    stash();                                 // tile t: registers -> LDS
+#if KNN_SHARE
+    thrw[lid * ROWS + rslot] = dl[KC / 4 - 1];
+#endif
+    if (t + 1 < nt) fetch(j0 + TJM);         // tile t+1: global -> registers, in flight during this step
+    __syncthreads();
+    if (j0 + cbase < N) {                    // wave-uniform
+#if KNN_SHARE
+      const float o1 = thrw[(lid ^ 1) * ROWS + rslot], o2 = thrw[(lid ^ 2) * ROWS + rslot], o3 = thrw[(lid ^ 3) * ROWS + rslot];
+#endif
+      const char* base = smem_raw + a_off;
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(base + 2 * s * CS);
+        const bf16x8 a2 = *reinterpret_cast<const bf16x8*>(base + PB + 2 * s * CS);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, q1[s], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, q2[s], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, q1[s], acc, 0, 0, 0);
+      }
+      // ---- conservative filter on the approximate distances
+#if KNN_SHARE
+      const float thr = fminf(dl[KC - 1], next_up(fmaxf(fmaxf(dl[KC / 4 - 1], o1), fmaxf(o2, o3))));
+#else
+      const float thr = dl[KC - 1];
+#endif
+      const float* sj = sjs + cbase + 4 * h;
+      unsigned mask = 0u;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 s4 = *reinterpret_cast<const float4*>(sj + 8 * q);
+        const float sv[4] = {s4.x, s4.y, s4.z, s4.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int r = 4 * q + e;
+          const float tt = si + sv[e];
+          const float tp = 2.0f * acc[r];
+          const float da = tt - tp;
+          const float lim = fmaf(tt, kappa, thr);            // thr + eps(i, j); +inf while the list is not full
+          mask |= sel_01(m_flt(da, lim)) << r;
+        }
+      }
+#if KNN_ABLATE == 2
+      mask = 0u;                             // experiment: no re-check, no insert (wrong results): the filter's floor
+#endif
+      // ---- survivors: the normative distance on the VALU, the exact filter, the insert
+      while (__any(mask != 0u)) {
+        const lmask_t live = m_ine((int)mask, 0);
+        const int g = __builtin_ctz(mask | 0x80000000u) & 15;
+        mask &= mask - 1u;
+        const int i = (g & 3) + 8 * (g >> 2) + 4 * h;
+        const int j = j0 + cbase + i;
+        const float* xj = xc + (cbase + i) * RS;             // fp32 copy of the candidate row (rows past N: zeros, s_j = +inf)
+        const float* xi = xq + rslot * RS;
+        float p = 0.f;
+#pragma unroll 2
+        for (int c0 = 0; c0 < C; c0 += 4) {                  // C % 4 == 0: the oracle's chain, c ascending from +0
+          const float4 a = *reinterpret_cast<const float4*>(xi + c0);
+          const float4 v = *reinterpret_cast<const float4*>(xj + c0);
+          p = fmaf(a.x, v.x, p);
+          p = fmaf(a.y, v.y, p);
+          p = fmaf(a.z, v.z, p);
+          p = fmaf(a.w, v.w, p);
+        }
+        const float tt = si + sjs[cbase + i];
+        const float tp = 2.0f * p;
+        const float d = tt - tp;
+        const lmask_t pass = live & m_flt(d, thr);           // exact filter (thr as of the start of the tile: conservative)
+        list_insert<KC, false>(dl, jl, sel_f(pass, d, INFINITY), j);
+      }
+    }
+  }
+
+  // ---- merge: 4 lists per query row -> lanes 0..31 of waves 0,1 ----
+  __syncthreads();
+  float* md = reinterpret_cast<float*>(smem_raw);
+  int* mj = reinterpret_cast<int*>(smem_raw) + ROWS * KC;
+#pragma unroll 1
+  for (int src = 1; src < 4; ++src) {
+    if (src > 1) __syncthreads();
+    if (lid == src) {
+#pragma unroll
+      for (int t = 0; t < KC; ++t) {
+        md[t * ROWS + rslot] = dl[t];
+        mj[t * ROWS + rslot] = jl[t];
+      }
+    }
+    __syncthreads();
+    if (cs == 0) {
+#pragma unroll 1
+      for (int t = 0; t < KC; ++t) {
+        const float d = (h == 0) ? md[t * ROWS + rslot] : INFINITY;
+        const int j = (h == 0) ? mj[t * ROWS + rslot] : 0x7fffffff;
+        const lmask_t need = key_less<true>(d, j, dl[KC - 1], jl[KC - 1]);
+        if (need == 0) break;
+        list_insert<KC, true>(dl, jl, d, j);
+      }
+    }
+  }
+  if (lid == 0 && row < N) {
+    int32_t* out = idx + ((int64_t)b * N + row) * k;
+#pragma unroll
+    for (int t = 0; t < KC; ++t)
+      if (t < k) out[t] = jl[t];
+  }
+}
+
+int g_knn_bf16f = -1;      // -1: not resolved; 0 never; 1 always (where applicable); 2 auto (N >= 8192)
+int knn_bf16f_mode() {
+  if (g_knn_bf16f < 0) {
+    const char* e = getenv("DGCNN_KNN_BF16F");   // A/B switch: 0 | 1 | auto
+    g_knn_bf16f = e ? ((e[0] == 'a') ? 2 : atoi(e)) : 2;
+  }
+  return g_knn_bf16f;
+}
+
 int g_knn_valu = -1;
 bool knn_force_valu() {
   if (g_knn_valu < 0) {
@@ -528,6 +804,13 @@ template <int CP, int KC>
 void launch_knn(const float* x, const float* sq, int B, int N, int C, int64_t ldx, int k, int vec_ok,
                 int32_t* idx, hipStream_t st) {
   dim3 grid((unsigned)dg::cdiv(N, ROWS), (unsigned)B);
+  if constexpr (CP == 64) {                      // large feature-space graphs: bf16 matrix pipe + exact re-check of the survivors
+    const int m = knn_bf16f_mode();
+    if (!knn_force_valu() && vec_ok && C % 4 == 0 && C > 16 && (m == 1 || (m == 2 && N >= 8192))) {
+      hipLaunchKernelGGL((knn_bf16f_kernel<KC>), grid, dim3(256), 0, st, x, sq, N, C, ldx, k, idx);
+      return;
+    }
+  }
   if constexpr (CP >= 16 && CP <= 64) {
     if (!knn_force_valu()) {
       if (vec_ok && C % 4 == 0) hipLaunchKernelGGL((knn_mfma_kernel<CP, KC, true>), grid, dim3(256), 0, st, x, sq, N, C, ldx, k, idx);
@@ -553,6 +836,12 @@ int dispatch_k(const float* x, const float* sq, int B, int N, int C, int64_t ldx
 extern "C" int dgcnn_knn_force_valu(int on) {   // A/B switch (tests): 1 = VALU fmaf distances for every C, 0 = MFMA for C > 4
   const int prev = knn_force_valu() ? 1 : 0;
   g_knn_valu = on ? 1 : 0;
+  return prev;
+}
+
+extern "C" int dgcnn_knn_bf16_filter(int mode) {   // A/B switch (tests): 0 never, 1 whenever applicable, 2 auto (N >= 8192); returns the previous mode
+  const int prev = knn_bf16f_mode();
+  g_knn_bf16f = mode;
   return prev;
 }
 

@@ -48,6 +48,11 @@ int dgcnn_knn_workspace_bytes(int B, int N);
  * v_mfma_f32_32x32x2_f32 for C > 4 (bit-identical on gfx950; the tests compare both).  Returns the
  * previous setting. */
 int dgcnn_knn_force_valu(int on);
+/* Large feature-space graphs (16 < C <= 64, C % 4 == 0, 16-byte aligned rows): approximate distances from the two leading bf16
+ * terms of every operand on the bf16 matrix pipe with a rigorous error bound as a conservative filter, the normative fp32 fmaf
+ * chain only for the survivors -- the same indices, bit for bit.  mode 0 = never, 1 = whenever applicable, 2 (default) = for
+ * N >= 8192 ($DGCNN_KNN_BF16F = 0 | 1 | auto).  Returns the previous mode. */
+int dgcnn_knn_bf16_filter(int mode);
 int dgcnn_knn_f32(const float* x, int B, int N, int C, int64_t ldx, int k, int32_t* idx,
                   float* sq_ws, void* stream);
 

@@ -107,6 +107,39 @@ def test_knn_mfma_equals_valu_at_large_n(dg):
     np.testing.assert_array_equal(host(dg.ops.k_nn(dev(pts), 40)), O.k_nn(pts, 40))
 
 
+@pytest.mark.parametrize("B,N,C,k,kind", [
+    (2, 256, 64, 20, "relu"), (1, 300, 64, 40, "relu"), (2, 2048, 64, 20, "relu"), (1, 1000, 48, 8, "uniform"),
+    (2, 200, 20, 33, "uniform"), (1, 130, 64, 64, "integer"), (1, 4096, 32, 20, "zeros"), (3, 700, 64, 20, "dupes"),
+])
+def test_knn_bf16_filter_kernel_bit_exact(dg, B, N, C, k, kind):
+    """The large-N kernel (approximate distances from two bf16 terms on the bf16 matrix pipe as a conservative filter, the
+    normative fp32 fmaf chain for the survivors), forced on at small N: the same indices as the C oracle, including exact
+    ties / duplicate points (integer data), all-zero rows, C < 64 and C % 4 == 0 paddings, ragged N, every list size."""
+    from dgcnn import _hip as H
+    rng = np.random.default_rng(B * 977 + N + C + k)
+    if kind == "uniform":
+        pts = rng.random((B, N, C), dtype=np.float32)
+    elif kind == "integer":
+        pts = rng.integers(0, 4, (B, N, C)).astype(np.float32)
+    elif kind == "zeros":
+        pts = np.maximum(rng.normal(0, 1, (B, N, C)), 0).astype(np.float32)
+        pts[:, ::7] = 0.0                                              # many identical all-zero rows
+    elif kind == "dupes":
+        pts = np.maximum(rng.normal(0, 1, (B, N, C)), 0).astype(np.float32)
+        pts[:, 100:200] = pts[:, 0:100]                                # exact duplicates: ties at d = 0 decided by index
+    else:
+        pts = np.maximum(rng.normal(0, 1, (B, N, C)), 0).astype(np.float32)
+    pts = (pts * np.exp(rng.normal(0, 2, (B, N, 1)))).astype(np.float32) if kind == "relu" else pts     # wide range of norms
+    ref = O.k_nn(pts, k)
+    prev = H.load().dgcnn_knn_bf16_filter(1)
+    try:
+        idx = dg.ops.k_nn(dev(pts), k)
+    finally:
+        H.load().dgcnn_knn_bf16_filter(prev)
+    _assert_idx_equal(idx, ref, "k_nn bf16-filter kernel %s" % ((B, N, C, k, kind),))
+    assert torch.equal(idx, dg.ops.k_nn(dev(pts), k))                   # == the default kernel at this size
+
+
 def test_knn_headline_shape_properties(dg):
     """(24,2048,3) k=20: full bit-exact compare + size-independent properties."""
     rng = np.random.default_rng(0)
