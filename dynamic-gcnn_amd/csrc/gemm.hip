@@ -15,7 +15,7 @@
 //   epilogue  E_STORE  C = acc (+ beta C) (+ per-cloud bias) (+ BN column statistics) or
 //                      split-K partial;  E_SCATTER  dx[neighbour(row)][n] += acc (fp32 atomics)
 //
-// Tiling (wave64, 256 threads = 2x2 waves): block tile BM x BN x 16, BM in {128,256}, BN in {64,128};
+// Tiling (wave64, 256 threads = 2x2 waves): block tile 128 x BN x 16, BN in {64,128};
 // each wave owns (BM/2 x BN/2) as TM x TN tiles of 32x32 MFMA accumulators (16 VGPR each).  Both LDS tiles
 // are k-major ([k][m] / [k][n]) so an MFMA operand read is one conflict-free ds_read_b32 of 32
 // consecutive floats per half-wave; row-major sources are transposed on the LDS write with a +2
@@ -378,225 +378,6 @@ __global__ __launch_bounds__(NT) void gemm_kernel(GemmP p) {
   gemm_epilogue<EPI, BM, BN, VEC, TM, TN>(p, acc, smem, m0, n0, mt, z, t, wr, wc, l31, lh);
 }
 
-// ------------------------------------------------------------------------------------------------
-// LDS-DMA variant (plain A_ROW/A_COL x B_ROW/B_COL, K % 16 == 0, float4-aligned operands).
-// EXPERIMENT, off by default (DGCNN_GEMM_DMA=1): BOTH tiles are filled by LDS-DMA, one tile ahead, into
-// a double buffer; one vmcnt(0) + barrier per k-step.  Measured equal to the register-staged kernel
-// (104 vs 102-104 TFLOP/s on FC0): what looked like a 20 % staging cost in the ablations
-// (profiles/r01_gemm_ablation.txt) was data-dependent clocking -- a pure-MFMA loop sustains 155 TFLOP/s
-// on static operands but 138 on changing random ones (profiles/ubench/mfma_peak.hip), so both
-// kernels sit at ~75-80 % of the realistic matrix-pipe rate.
-//   k-major sources ([k][m] / [k][n]): the LDS image is the k-major tile itself (lane-linear rows),
-//     operands are read with conflict-free ds_read_b32 as before.
-//   row-major sources (k contiguous): DMA cannot transpose, so the LDS image is [row][4 chunks of
-//     16 B] with the chunk index XOR-swizzled by (row>>2)&3 (done on the SOURCE address, the image
-//     stays lane-linear); a lane reads one chunk with ds_read_b128 -- the 16 lanes of every
-//     b128 service group then hit 16 distinct 16-B slots (conflict-free) -- and picks its k = 2s+h
-//     element with one v_cndmask per MFMA operand.  Lanes 4r..4r+3 still fetch one contiguous 64-B
-//     row segment, so global coalescing is unchanged.
-// Out-of-range rows / columns are fetched from clamped (valid) addresses: they only feed output
-// rows / columns that the epilogue never stores.
-// One LDS-DMA piece: 64 lanes x 16 B from per-lane global addresses to LDS [m0, m0 + 1 KiB).
-// Inline asm on purpose: with the builtin hipcc counts the DMA as a pending LDS write and drains
-// vmcnt(0) before the next ds_read of the OTHER buffer (no overlap at all); the asm form is invisible
-// to its waitcnt pass and is waited for by hand (vmcnt(0) right before the k-step barrier).
-__device__ __forceinline__ void dma16(const float* gsrc, unsigned lds_byte) {
-  unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep)
-               : "v"(gsrc), "s"(lds_byte)
-               : "memory");
-}
-
-template <int ASRC, int BSRC, int EPI, int BN>
-__global__ __launch_bounds__(NT) void gemm_dma_kernel(GemmP p) {
-  constexpr int BM = 128;
-  constexpr bool A_T = (ASRC == A_ROW);
-  constexpr bool B_T = (BSRC == B_COL);
-  constexpr int TM = 2;
-  constexpr int TN = BN / 64;
-  constexpr int AF = BM * BK;               // floats per A tile
-  constexpr int BF = BN * BK;
-  constexpr int BUF = AF + BF;
-  constexpr int SMEM_F = (2 * BUF > 64 * BN) ? 2 * BUF : 64 * BN;
-  __shared__ __attribute__((aligned(16))) float smem[SMEM_F];
-
-  const int t = threadIdx.x;
-  const int lane = t & 63;
-  const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
-  const int wr = wv >> 1, wc = wv & 1;
-  const int l31 = lane & 31, lh = lane >> 5;
-
-  const int id = blockIdx.x;
-  int mt, nt;
-  if (p.xcd_group) {
-    mt = ((id >> 3) / p.ntiles) * 8 + (id & 7);
-    nt = (id >> 3) % p.ntiles;
-  } else {
-    mt = id / p.ntiles;
-    nt = id % p.ntiles;
-  }
-  if (mt >= p.mtiles) return;
-  const int m0 = mt * BM;
-  const int n0 = nt * BN;
-  const int z = blockIdx.z;
-  const int kbeg = z * p.kchunk;
-  const int kend = (kbeg + p.kchunk < p.K) ? (kbeg + p.kchunk) : p.K;
-  const int nk = (kend - kbeg) / BK;
-
-  // ---- per-lane DMA sources (k offset added per tile) ----
-  // row-major tile of R rows: instr j covers rows 16j..16j+15; lane -> (row 16j + lane/4, slot lane%4)
-  // k-major tile of width W: instr j covers floats [256j, 256j+256) of the [16][W] image
-  constexpr int NIA = AF / 256 / 4;          // DMA instructions per wave for A (8 instr / 4 waves)
-  constexpr int NIB = BF / 256 / 4;          // BN=128: 2, BN=64: 1
-  const float* asrc[NIA];
-  int64_t astep;                             // source advance per k-tile (floats)
-#pragma unroll
-  for (int q = 0; q < NIA; ++q) {
-    const int j = wv + 4 * q;
-    if (A_T) {
-      const int r = 16 * j + (lane >> 2);
-      const int c = (lane & 3) ^ ((r >> 2) & 3);
-      asrc[q] = p.A + (int64_t)imin(m0 + r, p.M - 1) * p.lda + kbeg + 4 * c;
-    } else {
-      const int flat = 256 * j + 4 * lane;
-      const int kk = flat / BM, mm = flat % BM;
-      asrc[q] = p.A + (int64_t)(kbeg + kk) * p.lda + imin(m0 + mm, p.M - 4);
-    }
-  }
-  astep = A_T ? (int64_t)BK : (int64_t)BK * p.lda;
-  const float* bsrc[NIB];
-  int64_t bstep;
-#pragma unroll
-  for (int q = 0; q < NIB; ++q) {
-    const int j = wv + 4 * q;
-    if (B_T) {
-      const int r = 16 * j + (lane >> 2);
-      const int c = (lane & 3) ^ ((r >> 2) & 3);
-      bsrc[q] = p.B + (int64_t)imin(n0 + r, p.N - 1) * p.ldb + kbeg + 4 * c;
-    } else {
-      const int flat = 256 * j + 4 * lane;
-      const int kk = flat / BN, nn = flat % BN;
-      bsrc[q] = p.B + (int64_t)(kbeg + kk) * p.ldb + imin(n0 + nn, p.N - 4);
-    }
-  }
-  bstep = B_T ? (int64_t)BK : (int64_t)BK * p.ldb;
-
-  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)smem;   // LDS byte offset of smem
-  auto dma_tile = [&](int kt, int buf) {     // kt clamped by the caller: always a valid tile
-    const unsigned ab = lds0 + 4u * (unsigned)(buf * BUF);
-    const unsigned bb = ab + 4u * AF;
-#pragma unroll
-    for (int q = 0; q < NIA; ++q)
-      dma16(asrc[q] + (int64_t)kt * astep, __builtin_amdgcn_readfirstlane(ab + 1024u * (unsigned)(wv + 4 * q)));
-#pragma unroll
-    for (int q = 0; q < NIB; ++q)
-      dma16(bsrc[q] + (int64_t)kt * bstep, __builtin_amdgcn_readfirstlane(bb + 1024u * (unsigned)(wv + 4 * q)));
-  };
-
-  f32x16 acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  // ---- operand read offsets (floats, relative to the tile base) ----
-  int a_row[TM], a_swz[TM], b_row[TN], b_swz[TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i) {
-    const int r = wr * 64 + i * 32 + l31;
-    a_row[i] = A_T ? r * 16 : r;
-    a_swz[i] = (r >> 2) & 3;
-  }
-#pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int r = wc * (BN / 2) + j * 32 + l31;
-    b_row[j] = B_T ? r * 16 : r;
-    b_swz[j] = (r >> 2) & 3;
-  }
-
-  if (nk > 0) dma_tile(0, 0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-
-  // operands of k-chunk c (k = 4c..4c+3  ->  MFMA steps s = 2c, 2c+1)
-  // raw LDS reads of k-chunk c (k = 4c..4c+3 -> MFMA steps s = 2c, 2c+1) ...
-  auto load_chunk = [&](const float* ab, const float* bb, int c, float4 (&va)[TM], float4 (&vb)[TN]) {
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-      if (A_T) va[i] = *reinterpret_cast<const float4*>(ab + a_row[i] + ((c ^ a_swz[i]) << 2));
-      else va[i] = make_float4(ab[(4 * c + lh) * BM + a_row[i]], 0.f, ab[(4 * c + 2 + lh) * BM + a_row[i]], 0.f);
-    }
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      if (B_T) vb[j] = *reinterpret_cast<const float4*>(bb + b_row[j] + ((c ^ b_swz[j]) << 2));
-      else vb[j] = make_float4(bb[(4 * c + lh) * BN + b_row[j]], 0.f, bb[(4 * c + 2 + lh) * BN + b_row[j]], 0.f);
-    }
-  };
-  // ... the k = 2s + h pick (one v_cndmask per operand for row-major images) ...
-  auto select_chunk = [&](const float4 (&va)[TM], const float4 (&vb)[TN], float (&av)[TM][2], float (&bv)[TN][2]) {
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-      av[i][0] = (A_T && lh) ? va[i].y : va[i].x;
-      av[i][1] = (A_T && lh) ? va[i].w : va[i].z;
-    }
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      bv[j][0] = (B_T && lh) ? vb[j].y : vb[j].x;
-      bv[j][1] = (B_T && lh) ? vb[j].w : vb[j].z;
-    }
-  };
-  // ... and its 2 x TM x TN MFMAs
-  auto mma_chunk = [&](float (&av)[TM][2], float (&bv)[TN][2]) {
-#pragma unroll
-    for (int u = 0; u < 2; ++u)
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][u], bv[j][u], acc[i][j], 0, 0, 0);
-  };
-
-#pragma unroll 1
-  for (int kt = 0; kt < nk; ++kt) {
-    const int buf = kt & 1;
-    dma_tile((kt + 1 < nk) ? kt + 1 : kt, buf ^ 1);      // unconditional: no branch in the loop body
-    const float* ab = smem + buf * BUF;
-    const float* bb = ab + AF;
-    // software pipeline (pinned with sched_barriers): the raw reads of chunk c+2 and the selects of
-    // chunk c+1 are issued behind the MFMAs of chunk c, so neither LDS latency nor the v_cndmasks
-    // sit in front of an MFMA group
-    float4 ra0[TM], rb0[TN], ra1[TM], rb1[TN];
-    float av0[TM][2], bv0[TN][2], av1[TM][2], bv1[TN][2];
-    load_chunk(ab, bb, 0, ra0, rb0);
-    load_chunk(ab, bb, 1, ra1, rb1);
-    select_chunk(ra0, rb0, av0, bv0);
-    __builtin_amdgcn_sched_barrier(0);
-    mma_chunk(av0, bv0);                      // chunk 0
-    __builtin_amdgcn_sched_barrier(0);
-    load_chunk(ab, bb, 2, ra0, rb0);
-    select_chunk(ra1, rb1, av1, bv1);
-    __builtin_amdgcn_sched_barrier(0);
-    mma_chunk(av1, bv1);                      // chunk 1
-    __builtin_amdgcn_sched_barrier(0);
-    load_chunk(ab, bb, 3, ra1, rb1);
-    select_chunk(ra0, rb0, av0, bv0);
-    __builtin_amdgcn_sched_barrier(0);
-    mma_chunk(av0, bv0);                      // chunk 2
-    __builtin_amdgcn_sched_barrier(0);
-    select_chunk(ra1, rb1, av1, bv1);
-    __builtin_amdgcn_sched_barrier(0);
-    mma_chunk(av1, bv1);                      // chunk 3
-    __builtin_amdgcn_sched_barrier(0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-  }
-
-  gemm_epilogue<EPI, BM, BN, true, TM, TN>(p, acc, smem, m0, n0, mt, z, t, wr, wc, l31, lh);
-}
-
 // C (+)= sum over splits of the partial tiles.  64 consecutive elements x 16 split-lanes per block
 // (1024 threads): coalesced 256-B rows, 16-way split parallelism, 4 independent loads in flight per
 // lane, fixed summation order (deterministic).
@@ -876,25 +657,12 @@ void launch_bm(GemmP& p, hipStream_t st, bool vec, int bn) {
   }
 }
 
-inline int tile_m_env() {
-  static int v = -2;
-  if (v == -2) { const char* e = getenv("DGCNN_GEMM_BM"); v = e ? atoi(e) : -1; }   // experiments only
-  return v;
-}
-
 inline int tile_m(int M, int N, int splits) {
-  // Measured on MI355X (profiles/r01_gemm_tile_height.txt): 128-row tiles (4 workgroups = 16 waves
-  // per CU) match or beat 192 / 256 rows on every shape of the model -- the kernel is MFMA-issue
-  // bound (~105 TFLOP/s), not L2-bound -- so the taller variants are kept for experiments only.
-  if (tile_m_env() > 0) return tile_m_env();
+  // Measured on MI355X in round 1 (profiles/r01_gemm_tile_height.txt): 128-row tiles (4 workgroups = 16 waves per CU) match
+  // or beat 192 / 256 rows on every shape of the model for the native fp32-MFMA kernel; the taller instantiations and the
+  // LDS-DMA staged variant (measured equal, profiles/r01_gemm_ablation.txt) were removed in round 2.
   (void)M; (void)N; (void)splits;
   return 128;
-}
-
-inline int gemm_dma_env() {
-  static int v = -2;
-  if (v == -2) { const char* e = getenv("DGCNN_GEMM_DMA"); v = e ? atoi(e) : 0; }   // 1 = LDS-DMA staged kernel (A/B switch; measured equal)
-  return v;
 }
 
 template <int ASRC, int BSRC, int EPI>
@@ -908,26 +676,17 @@ int launch(GemmP& p, hipStream_t st, const char* what) {
     if (p.splits > 1) p.cvec = (p.N % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.partial) & 15) == 0);
     else p.cvec = (p.ldc % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.C) & 15) == 0);
   }
-  constexpr bool dma_kind = (ASRC == A_ROW || ASRC == A_COL) && EPI == E_STORE;
-  if (dma_kind && vec && dg::gemm_arith() != 0) {          // bf16-split kernel (gemm_x3.hip)
+  constexpr bool plain = (ASRC == A_ROW || ASRC == A_COL) && EPI == E_STORE;
+  if (plain && vec && dg::gemm_arith() != 0) {          // bf16-split kernel (gemm_x3.hip)
     p.bm = dg::x3_tile_m(p.M, p.N);
     p.mtiles = (int)dg::cdiv(p.M, p.bm);
     p.ntiles = (int)dg::cdiv(p.N, bn);
     p.xcd_group = (p.ntiles > 1 && p.mtiles >= 16 && p.splits == 1) ? 1 : 0;
     dg::launch_gemm_x3(ASRC, BSRC, &p, st, bn, dg::gemm_arith());
-  } else if (dma_kind && vec && p.K % BK == 0 && p.kchunk % BK == 0 && p.bm == 128 && gemm_dma_env()) {
-    p.mtiles = (int)dg::cdiv(p.M, 128);
-    p.ntiles = (int)dg::cdiv(p.N, bn);
-    p.xcd_group = (p.ntiles > 1 && p.mtiles >= 16 && p.splits == 1) ? 1 : 0;
-    const unsigned gx = p.xcd_group ? (unsigned)(dg::cdiv(p.mtiles, 8) * 8 * p.ntiles) : (unsigned)(p.mtiles * p.ntiles);
-    dim3 grid(gx, 1, (unsigned)p.splits);
-    if constexpr (dma_kind) {
-      if (bn == 64) hipLaunchKernelGGL((gemm_dma_kernel<ASRC, BSRC, EPI, 64>), grid, dim3(NT), 0, st, p);
-      else hipLaunchKernelGGL((gemm_dma_kernel<ASRC, BSRC, EPI, 128>), grid, dim3(NT), 0, st, p);
-    }
-  } else if (p.bm == 256) launch_bm<ASRC, BSRC, EPI, 256>(p, st, vec, bn);
-  else if (p.bm == 192 && (ASRC == A_ROW || ASRC == A_EDGE)) launch_bm<ASRC, BSRC, EPI, (ASRC == A_ROW || ASRC == A_EDGE) ? 192 : 128>(p, st, vec, bn);
-  else { p.bm = 128; launch_bm<ASRC, BSRC, EPI, 128>(p, st, vec, bn); }
+  } else {
+    p.bm = 128;
+    launch_bm<ASRC, BSRC, EPI, 128>(p, st, vec, bn);
+  }
   int rc = dg::check_launch(what);
   if (rc) return rc;
   if (p.splits > 1) {

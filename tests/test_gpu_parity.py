@@ -273,34 +273,6 @@ def test_gemm_split_accuracy(dg):
         H.set_gemm_arith(old)
 
 
-def test_gemm_dma_kernel_matches_register_kernel(dg):
-    """The opt-in LDS-DMA staged kernel (DGCNN_GEMM_DMA=1) accumulates in the same k order as the default
-    register-staged kernel: results must be bit-identical.  Run in a subprocess (the switch is read once)."""
-    import subprocess, sys, os, textwrap
-    code = textwrap.dedent("""
-        import sys, numpy as np, torch
-        sys.path.insert(0, %r)
-        from dgcnn import _engine as E
-        rng = np.random.default_rng(0)
-        out = []
-        for (M, N, K, ta, tb) in [(1024, 512, 192, 0, 0), (640, 128, 256, 0, 1), (256, 128, 4096, 1, 0), (300, 64, 64, 0, 0)]:
-            A = torch.from_numpy(rng.normal(size=(K, M) if ta else (M, K)).astype(np.float32)).cuda()
-            B = torch.from_numpy(rng.normal(size=(N, K) if tb else (K, N)).astype(np.float32)).cuda()
-            C = torch.zeros((M, N), device="cuda")
-            E.gemm(A, B, C, transA=bool(ta), transB=bool(tb))
-            out.append(C.cpu().numpy())
-        np.savez(sys.argv[1], *out)
-    """ % os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "dynamic-gcnn_amd"))
-    import tempfile
-    res = []
-    for dma in ("0", "1"):
-        f = tempfile.mktemp(suffix=".npz")
-        subprocess.check_call([sys.executable, "-c", code, f], env=dict(os.environ, DGCNN_GEMM_DMA=dma, DGCNN_GEMM_ARITH="f32"))
-        res.append(dict(np.load(f)))
-    for k in res[0]:
-        np.testing.assert_array_equal(res[0][k], res[1][k])
-
-
 def test_gemm_strided_stats_and_group_bias(dg, arith):
     from dgcnn import _engine as E
     rng = np.random.default_rng(7)
