@@ -730,14 +730,29 @@ __global__ __launch_bounds__(256, (Bf16fCfg<KC>::OCC)) void knn_bf16f_kernel(con
         const float* xj = xc + (cbase + i) * RS;             // fp32 copy of the candidate row (rows past N: zeros, s_j = +inf)
         const float* xi = xq + rslot * RS;
         float p = 0.f;
+        // the oracle's chain, c ascending from +0 (C % 4 == 0).  C = 64 (every feature-space graph of the model): fully
+        // unrolled with the row quads of step q + 2 requested before the four fmas of step q -- the chain is latency bound
+        // (16 dependent LDS round trips otherwise; 0.68 -> 0.31 ms at (24,2048,64,20) with the kernel forced on).
+        if (C == 64) {
+          float4 a[3], v[3];
+          a[0] = *reinterpret_cast<const float4*>(xi); v[0] = *reinterpret_cast<const float4*>(xj);
+          a[1] = *reinterpret_cast<const float4*>(xi + 4); v[1] = *reinterpret_cast<const float4*>(xj + 4);
+#pragma unroll
+          for (int q = 0; q < 16; ++q) {
+            if (q + 2 < 16) {
+              a[(q + 2) % 3] = *reinterpret_cast<const float4*>(xi + 4 * (q + 2));
+              v[(q + 2) % 3] = *reinterpret_cast<const float4*>(xj + 4 * (q + 2));
+            }
+            const float4 aa = a[q % 3], vv = v[q % 3];
+            p = fmaf(aa.x, vv.x, p); p = fmaf(aa.y, vv.y, p); p = fmaf(aa.z, vv.z, p); p = fmaf(aa.w, vv.w, p);
+          }
+        } else {
 #pragma unroll 2
-        for (int c0 = 0; c0 < C; c0 += 4) {                  // C % 4 == 0: the oracle's chain, c ascending from +0
-          const float4 a = *reinterpret_cast<const float4*>(xi + c0);
-          const float4 v = *reinterpret_cast<const float4*>(xj + c0);
-          p = fmaf(a.x, v.x, p);
-          p = fmaf(a.y, v.y, p);
-          p = fmaf(a.z, v.z, p);
-          p = fmaf(a.w, v.w, p);
+          for (int c0 = 0; c0 < C; c0 += 4) {
+            const float4 aa = *reinterpret_cast<const float4*>(xi + c0);
+            const float4 vv = *reinterpret_cast<const float4*>(xj + c0);
+            p = fmaf(aa.x, vv.x, p); p = fmaf(aa.y, vv.y, p); p = fmaf(aa.z, vv.z, p); p = fmaf(aa.w, vv.w, p);
+          }
         }
         const float tt = si + sjs[cbase + i];
         const float tp = 2.0f * p;
@@ -782,6 +797,9 @@ __global__ __launch_bounds__(256, (Bf16fCfg<KC>::OCC)) void knn_bf16f_kernel(con
   }
 }
 
+// Dispatch threshold: with the pipelined re-check the kernel also wins in isolation at (24,2048,64,20) (0.253 vs 0.272 ms), but
+// inside the training step it LOSES there (5.19 vs 5.05 ms/step with the side stream on, 5.06 vs 5.11 with it off): its 54 KB x 3
+// workgroups leave no LDS for the transposed-adjacency build that runs on the side stream.  So: N >= 8192 only.
 int g_knn_bf16f = -1;      // -1: not resolved; 0 never; 1 always (where applicable); 2 auto (N >= 8192)
 int knn_bf16f_mode() {
   if (g_knn_bf16f < 0) {
