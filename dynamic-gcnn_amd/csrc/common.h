@@ -33,7 +33,7 @@ static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 // three-way bf16 split on the bf16 matrix pipe) and its launcher (pv = GemmP*, tiles already planned)
 int gemm_arith();
 void set_gemm_arith(int v);
-int x3_tile_m(int M, int N);
+int x3_tile_m(int M, int N, int K);
 void launch_gemm_x3(int asrc, int bsrc, void* pv, hipStream_t st, int bn, int np);
 
 }  // namespace dg

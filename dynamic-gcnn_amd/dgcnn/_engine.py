@@ -339,10 +339,12 @@ def gemm(A, Bm, C, transA=False, transB=False, beta=0.0, gbias=None, rpg=0, stat
         vec = (lda % 4 == 0 and ldb % 4 == 0 and A.data_ptr() % 16 == 0 and Bm.data_ptr() % 16 == 0 and
                ((M if transA else K) % 4 == 0) and ((K if transB else N) % 4 == 0))
         arith = H.gemm_arith()
-        bn = 64 if N <= 64 else 128
+        cd = lambda a, b: -(-a // b)
+        small = cd(M, 128) * cd(N, 128) * cd(K, 256) < 256       # gemm.hip:tile_n
+        bn = 64 if (N <= 64 or small) else 128
         if vec and arith:
             kinds = ("KSTRIDED" if transA else "KCONTIG", "KCONTIG" if transB else "KSTRIDED")
-            if M > 128 and N > 64:           # dg::x3_tile_m: 256 x 128 wave-specialised kernel
+            if M > 128 and N > 64 and cd(M, 256) * cd(N, 128) * cd(K, 256) >= 256:   # dg::x3_tile_m: 256 x 128 wave-specialised kernel
                 tag = "gemm_x3w2_kernel<%s,%s,bf16x%d>" % (kinds + (arith,))
             else:
                 tag = "gemm_x3_kernel<%s,%s,%d,bf16x%d>" % (kinds + (bn, arith))
