@@ -25,7 +25,8 @@ import torch.distributed as dist
 def flags_for(dgcnn):
     return dgcnn.DGCNN_FLAGS(MODEL_NAME="dgcnn", EDGE_CONV_LAYERS=3, EDGE_CONV_FILTERS=[64, 64, 128], FC_LAYERS=2,
                              FC_FILTERS=[512, 256], NUM_CLASS=2, KVALUE=20, NUM_CHANNEL=3, TRAIN=True, SEED=7,
-                             LEARNING_RATE=1e-3)
+                             LEARNING_RATE=1e-3, DETERMINISTIC=True)   # bit-reproducible kernels: the comparison between
+    #                          separate processes must not depend on which near-tie neighbour an atomically summed BN picked
 
 
 def main():

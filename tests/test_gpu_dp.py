@@ -5,7 +5,9 @@ detected"), therefore:
   * world_size 2: torch.distributed.run launches tests/dp_worker.py; backend "nccl" is tried first and, when RCCL
     refuses the layout, "gloo" carries the same device tensors.  The post-all-reduce gradient must equal the
     single-process two-tower result (mean over towers, sum over micro-steps: dgcnn/trainval.py:64-79) and the
-    replicas must end with identical parameters;
+    replicas must end with identical parameters.  Both sides run the DETERMINISTIC kernels (dp_worker.flags_for): with the
+    default atomically summed BatchNorm statistics two processes differ by ~3e-3 whenever a layer >= 1 graph picks another
+    near-tie neighbour, which has nothing to do with data parallelism;
   * world_size 1 with backend "nccl": the broadcast and the all-reduce of the flat bucket really go through RCCL.
 """
 import os
@@ -42,6 +44,7 @@ def reference_two_towers(data_file, towers):
     z = np.load(data_file)
     pts, lab = z["points"], z["labels"]
     keep, E.DROPOUT_KEEP = E.DROPOUT_KEEP, 1.0
+    det = E.DETERMINISTIC                       # flags_for() switches the deterministic kernels on (process-wide): restore
     try:
         tv = dgcnn.trainval(dp_worker.flags_for(dgcnn)).initialize()
         init = dgcnn.ctx().flat_param.cpu().numpy().copy()
@@ -54,6 +57,7 @@ def reference_two_towers(data_file, towers):
         return init, grad, dgcnn.ctx().flat_param.cpu().numpy().copy()
     finally:
         E.DROPOUT_KEEP = keep
+        E.DETERMINISTIC = det
         dgcnn.reset()
 
 
@@ -93,8 +97,8 @@ def test_two_replicas_on_one_gpu_match_two_towers(tmp_path, data_file):
                                atol=1e-6 * np.abs(r0["grad"]).max())           # all-reduce = mean of the local buckets
     init, grad, param = reference_two_towers(data_file, towers=2)
     np.testing.assert_array_equal(init, r0["init"])
-    # same math, different summation orders only through the fp64 atomics of the BN sums (run-to-run noise ~1e-5)
-    assert close(r0["grad"], grad, 2e-3), np.linalg.norm(r0["grad"] - grad) / np.linalg.norm(grad)
+    # same math in deterministic mode (fixed-order reductions in both processes); what remains is the order of the tower mean
+    assert close(r0["grad"], grad, 1e-5), np.linalg.norm(r0["grad"] - grad) / np.linalg.norm(grad)
     solid = np.abs(grad) > 5e-2 * np.abs(grad).max()
     np.testing.assert_allclose((r0["param"] - init)[solid], (param - init)[solid], rtol=0, atol=2e-5)   # lr = 1e-3 steps
     assert np.abs(r0["param"] - init).max() <= 1.001e-3 and np.abs(r0["param"] - init)[solid].mean() > 0.9e-3
@@ -111,5 +115,5 @@ def test_rccl_world_size_one_runs_the_collectives(tmp_path, data_file):
     assert str(r0["backend"]) == "nccl"
     init, grad, param = reference_two_towers(data_file, towers=1)
     np.testing.assert_array_equal(init, r0["init"])
-    assert close(r0["grad"], grad, 2e-3)
+    assert close(r0["grad"], grad, 1e-6), np.linalg.norm(r0["grad"] - grad) / np.linalg.norm(grad)   # deterministic kernels both sides
     np.testing.assert_array_equal(r0["grad"], r0["local_grad"])                  # mean over one replica

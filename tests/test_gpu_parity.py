@@ -798,3 +798,100 @@ def test_dropout_and_misc_kernels(dg):
     cs = torch.empty((3, 70), device="cuda")
     H.call("dgcnn_group_colsum_f32", dev(a).data_ptr(), 70, 3, 500, 70, cs.data_ptr())
     np.testing.assert_allclose(host(cs), a.astype(np.float64).sum(1), rtol=1e-5, atol=1e-4)
+
+
+# ------------------------------------------------------------------------------------------
+# per-block gradients of the head: MergedEdgeConv -> global max -> FC0 with the FOLDED global feature
+# (model.py:65-88; the tiled 1024 channels are never materialised, see dgcnn/model.py) -> FC1 -> Final, against torch fp64
+# autograd of the literal graph (tile + concat).  Block-level bars like test_edge_conv_forward_backward: 1e-3.
+# ------------------------------------------------------------------------------------------
+def _bn_act64(t, beta, relu=True):
+    mu = t.mean(0, keepdim=True)
+    var = t.var(0, unbiased=False, keepdim=True)
+    z = (t - mu) / torch.sqrt(var + 1e-3) + beta
+    return torch.relu(z) if relu else z
+
+
+@pytest.mark.parametrize("B,N,widths,fcf,ncls", [(2, 96, [64, 64, 128], [512, 256], 2), (3, 50, [8, 12], [64, 32], 3)])
+def test_head_block_gradients(dg, B, N, widths, fcf, ncls):
+    from dgcnn import _engine as E
+    rng = np.random.default_rng(B * N)
+    R, L = B * N, len(widths)
+    local_w = sum(2 * f + 64 for f in widths)
+    ctot = local_w + 1024
+    local = rng.normal(size=(R, local_w)).astype(np.float32)
+    min_ = np.abs(rng.normal(size=(R, 64 * L))).astype(np.float32)
+    P = {"MergedEdgeConv/weights": rng.normal(0, 0.1, (64 * L, 1024)), "MergedEdgeConv/BatchNorm/beta": rng.normal(0, 0.2, 1024),
+         "FC0/weights": rng.normal(0, 0.05, (1024 + ctot, fcf[0])), "FC0/BatchNorm/beta": rng.normal(0, 0.2, fcf[0]),
+         "FC1/weights": rng.normal(0, 0.1, (fcf[0], fcf[1])), "FC1/BatchNorm/beta": rng.normal(0, 0.2, fcf[1]),
+         "Final/weights": rng.normal(0, 0.2, (fcf[1], ncls)), "Final/BatchNorm/beta": rng.normal(0, 0.2, ncls)}
+    P = {n: v.astype(np.float32) for n, v in P.items()}
+    dfin = rng.normal(size=(R, ncls)).astype(np.float32)
+
+    # ---- HIP path: the statements of dgcnn/model.py:build for the head ----
+    c = dg.ctx()
+    c.begin_step()
+    c.recording = True
+    for n, v in P.items():
+        c.get_variable(n, v.shape)
+    _set_vars(dg, P)
+    big = c.new_buffer(R, ctot)
+    big[:, :local_w].copy_(dev(local))
+    merged_in = c.new_buffer(R, 64 * L)
+    merged_in.copy_(dev(min_))
+    merged = E.conv_bn_act(merged_in, "MergedEdgeConv", 1024, relu=True, out=big[:, ctot - 1024:])
+    g = E.global_max(merged, B, N)
+    with E.variable_scope("FC0"):
+        wleaf = c.get_variable("weights", (1024 + ctot, fcf[0]))
+    gb = E.plain_gemm(g, wleaf, (0, 1024), fcf[0])
+    net = E.conv_bn_act(big, "FC0", fcf[0], relu=True, gbias=gb, rpg=N, w_rows=(1024, 1024 + ctot, 1024 + ctot))
+    net = E.conv_bn_act(net, "FC1", fcf[1], relu=True)
+    fin = E.conv_bn_act(net, "Final", ncls, relu=True)
+    c.grad(fin).copy_(dev(dfin))
+    c.backward()
+    torch.cuda.synchronize()
+
+    # ---- torch fp64 autograd of the literal graph (global feature tiled and concatenated in front: model.py:80-85) ----
+    t = {n: torch.tensor(v.astype(np.float64), requires_grad=True) for n, v in P.items()}
+    tl = torch.tensor(local.astype(np.float64), requires_grad=True)
+    tm = torch.tensor(min_.astype(np.float64), requires_grad=True)
+    m64 = _bn_act64(tm @ t["MergedEdgeConv/weights"], t["MergedEdgeConv/BatchNorm/beta"])
+    g64 = m64.view(B, N, 1024).max(1).values
+    x64 = torch.cat([g64[:, None, :].expand(B, N, 1024).reshape(R, 1024), tl, m64], 1)
+    h = _bn_act64(x64 @ t["FC0/weights"], t["FC0/BatchNorm/beta"])
+    h = _bn_act64(h @ t["FC1/weights"], t["FC1/BatchNorm/beta"])
+    f64 = _bn_act64(h @ t["Final/weights"], t["Final/BatchNorm/beta"])
+    (f64 * torch.tensor(dfin.astype(np.float64))).sum().backward()
+
+    np.testing.assert_allclose(host(fin), f64.detach().numpy(), rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(host(g), g64.detach().numpy(), rtol=1e-4, atol=1e-4)
+    scale = lambda r: 1e-3 * max(1.0, float(np.abs(r).max()))
+    chk = [("d merged_in", host(c.grad(merged_in)), tm.grad.numpy()), ("d local", host(c.grad(big))[:, :local_w], tl.grad.numpy())]
+    chk += [(n, host(c.var_grads[n]), t[n].grad.numpy()) for n in P]
+    for name, got, ref in chk:
+        np.testing.assert_allclose(got, ref, rtol=1e-3, atol=scale(ref), err_msg=name)
+        fro = np.linalg.norm(got - ref) / max(np.linalg.norm(ref), 1e-12)
+        assert fro <= 1e-3, (name, fro)
+
+
+@pytest.mark.parametrize("R,F,ld", [(300, 64, 64), (77, 12, 20), (1000, 128, 192)])
+def test_residual_add_relu_gradients_exact(dg, R, F, ld):
+    """ops.py:134 `relu(net + shortcut)`: forward and both input gradients are exact (elementwise, no reduction)."""
+    from dgcnn import _engine as E
+    rng = np.random.default_rng(R + F)
+    a, b = rng.normal(size=(R, F)).astype(np.float32), rng.normal(size=(R, F)).astype(np.float32)
+    d = rng.normal(size=(R, F)).astype(np.float32)
+    c = dg.ctx()
+    c.begin_step()
+    c.recording = True
+    ta, tb_full = c.new_buffer(R, F), c.new_buffer(R, ld)
+    tb = tb_full[:, :F]                                           # a strided view, as the concat buffer hands out
+    ta.copy_(dev(a)); tb.copy_(dev(b))
+    out = E.add_relu(ta, tb)
+    c.grad(out).copy_(dev(d))
+    c.backward()
+    ref = np.maximum(a + b, 0)
+    np.testing.assert_array_equal(host(out), ref)
+    gd = d * (ref > 0)
+    np.testing.assert_array_equal(host(c.grad(ta)), gd)
+    np.testing.assert_array_equal(host(c.grad(tb_full))[:, :F], gd)
