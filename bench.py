@@ -85,6 +85,36 @@ def cpu_baseline(clouds=8, iters=5):
                       "TF1 graph (TF1 itself cannot run, BASELINE.md 2)" % (clouds, iters, med, best_nt, ncpu, cpu_model())}
 
 
+def edgeconv_stack_rate(dgcnn, pts, iters=10, warm=3):
+    """the EdgeConv stack ALONE (3 layers: k-NN, conv0, BN+ReLU, max/mean over k, conv1 and all their backward
+    passes; no head, no loss, no optimizer), forward + backward on the same resident batch.  Runs after the timed region in a
+    fresh engine context (its own variables); the nine outputs [max, mean, net] x 3 get a constant upstream gradient."""
+    from dgcnn import _engine as E, ops
+    dgcnn.reset()
+    c = dgcnn.ctx()
+
+    def once():
+        c.begin_step()
+        c.recording = True
+        tensors = ops.repeat_edge_conv(pts, repeat=3, k=K_NN, num_filters=[64, 64, 128], trainable=True)
+        for t in tensors:
+            v, _, _ = E.as2d(t)
+            c.grad(v).fill_(1e-3)
+        c.backward()
+
+    for _ in range(warm):
+        once()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        once()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / iters
+    return {"value": round(B / dt, 1), "unit": "clouds/s", "ms_per_pass": round(dt * 1e3, 3),
+            "what": "3 EdgeConv layers (64,64,128) forward+backward alone on the same 24 clouds: k-NN, conv0 (folded), BN+ReLU, "
+                    "max/mean over k, conv1 and their backward; no head / loss / optimizer"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -247,6 +277,8 @@ def main():
                        "final_loss": round(loss, 5), "host_enqueue_ms_per_step": round(t_issue / args.steps * 1e3, 3)},
             "roofline": roof,
         }
+        if world == 1:
+            out["edgeconv_stack"] = edgeconv_stack_rate(dgcnn, pts)     # after the timed region; resets the engine context
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))
