@@ -70,10 +70,18 @@ def main():
     for k in sorted(set(fetch) | set(write)):
         traffic[k] = int(fetch.get(k, 0.0) * 1024 * 2 + write.get(k, 0.0) * 1024)
     json.dump(traffic, open(os.path.join(HERE, "pmc_traffic.json"), "w"), indent=1, sort_keys=True)
+    # mean duration per tag from the (counter-free) kernel-trace pass -> achieved HBM GB/s and its fraction of 8 TB/s
+    dur = collections.defaultdict(list)
+    for r in csv.DictReader(open(one("trace/*/*kernel_trace.csv"))):
+        dur[tag_of(r["Kernel_Name"])].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
     with open(os.path.join(HERE, "%s_pmc_hbm_bytes.txt" % tag), "w") as f:
-        f.write("# HBM bytes per launch (mean over launches of the tag): FETCH_SIZE*1024*2 + WRITE_SIZE*1024, separate --pmc passes\n")
+        f.write("# HBM bytes per launch (mean over launches of the tag): FETCH_SIZE*1024*2 + WRITE_SIZE*1024, separate --pmc passes;\n"
+                "# avg_us from the kernel-trace pass (no counters; kernels of the two streams overlap there) -> GB/s, fraction of the 8 TB/s HBM3E peak\n")
         for k, v in sorted(traffic.items(), key=lambda kv: -kv[1]):
-            f.write("%-48s fetch_KB %12.0f  write_KB %12.0f  hbm_MB %10.1f\n" % (k, fetch.get(k, 0), write.get(k, 0), v / 1e6))
+            us = sum(dur[k]) / len(dur[k]) if dur.get(k) else 0.0
+            gbs = v / 1e3 / us if us > 0 else 0.0
+            f.write("%-48s fetch_KB %12.0f  write_KB %12.0f  hbm_MB %10.1f  avg_us %8.1f  GB/s %7.0f  of_peak %5.3f\n"
+                    % (k, fetch.get(k, 0), write.get(k, 0), v / 1e6, us, gbs, gbs / 8000.0))
     json.dump(json.load(open(os.path.join(src, "bench.json"))), open(os.path.join(HERE, "%s_bench.json" % tag), "w"), indent=1)
 
 
