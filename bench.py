@@ -11,6 +11,8 @@
 Launch:  python bench.py [--gpus N --steps K --warmup W]
    N>1 : python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
             --master-port P bench.py --gpus N --steps K --warmup W      (one rank per GPU, RCCL)
+         or plain `python bench.py --gpus N ...` from a bare shell: with no WORLD_SIZE in the environment the script
+         re-launches itself as N ranks through torch.distributed.run (self_launch below) and relays rank 0's JSON line.
 Prints ONE JSON line on rank 0 (roofline + cpu_baseline objects: see DESIGN.md "Measurement").
 """
 import argparse
@@ -115,6 +117,23 @@ def edgeconv_stack_rate(dgcnn, pts, iters=10, warm=3):
                     "max/mean over k, conv1 and their backward; no head / loss / optimizer"}
 
 
+def self_launch(ngpus):
+    """`python bench.py --gpus N` from a bare shell (no torchrun environment): start the N ranks ourselves -- the same
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py <argv>`
+    command the driver uses -- and hand its exit code back.  Rank 0's JSON line goes to our stdout unchanged."""
+    import socket
+    import subprocess
+    with socket.socket() as s:                      # a free rendezvous port on the loopback interface
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL across processes needs it on this driver
+    env["DGCNN_BENCH_SELF_LAUNCHED"] = "1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ngpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -131,9 +150,13 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus != world and world == 1 and args.gpus > 1:
-        raise SystemExit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d bench.py ...`"
-                         % (args.gpus, args.gpus))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        if os.environ.get("DGCNN_BENCH_SELF_LAUNCHED"):
+            raise SystemExit("bench.py: launched as a rank but WORLD_SIZE is not set")
+        raise SystemExit(self_launch(args.gpus))
+    if args.gpus != world:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: start one rank per GPU (`python bench.py --gpus N` does it itself)"
+                         % (args.gpus, world))
     if args.same_device:
         local_rank = 0
     torch.cuda.set_device(local_rank)
@@ -217,6 +240,9 @@ def main():
         if not torch.equal(lo, hi):
             raise SystemExit("replicas diverged: parameter checksums differ across ranks")
 
+    # the group the gradient all-reduce ran in: backend "nccl" IS RCCL on ROCm (gloo only in the one-device sanity run)
+    coll_backend = dist.get_backend() if dist is not None else None
+    rccl_ranks = dist.get_world_size() if (dist is not None and coll_backend == "nccl") else (1 if dist is None else 0)
     arith_name = {0: "native fp32 MFMA", 6: "exact 3-way bf16 split, 6 partial products on the bf16 MFMA pipe",
                   9: "exact 3-way bf16 split, 9 partial products on the bf16 MFMA pipe"}[H.gemm_arith()]
     if rank == 0:
@@ -274,6 +300,7 @@ def main():
                                    "FC (512,256) + Final, fp32 in/out/accumulate (GEMM arithmetic: %s), dropout on; step = zero-grad + fwd + loss + bwd + "
                                    "(RCCL all-reduce) + Adam" % arith_name,
                        "global_batch": world * B, "points_per_cloud": N, "parallelism": "dp%d" % world,
+                       "collective_backend": coll_backend, "rccl_ranks": rccl_ranks,
                        "final_loss": round(loss, 5), "host_enqueue_ms_per_step": round(t_issue / args.steps * 1e3, 3)},
             "roofline": roof,
         }

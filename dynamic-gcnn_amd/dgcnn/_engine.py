@@ -46,7 +46,8 @@ SCATTER_ATOMICS = False  # True: dx_j += dY W^T by fp32 atomics in the GEMM epil
 # from fixed-order two-stage sums over MATERIALISED tensors (csrc/det.hip: conv0's output is written out for it) and the
 # adjacency buckets are sorted: slower (~2x at configs[1]), same math.  The reported loss / accuracy scalars are still summed
 # with atomics (they feed nothing back).
-DETERMINISTIC = os.environ.get("DGCNN_DETERMINISTIC", "0") not in ("0", "")
+DETERMINISTIC_ENV_DEFAULT = os.environ.get("DGCNN_DETERMINISTIC", "0") not in ("0", "")
+DETERMINISTIC = DETERMINISTIC_ENV_DEFAULT      # trainval.initialize() sets it per instance (flag, else this default)
 
 
 class Context(object):

@@ -195,6 +195,35 @@ def _replica_mean(h, values):
     return float(t)
 
 
+def _gather_rows(h, softmax, idx):
+    """Softmax rows of the whole batch on rank 0, in batch order.  Every replica holds the towers of its own shard
+    [lo, hi) (main_funcs.py:264-268 stores from the one process the reference has).  The entry indices `idx` must be the
+    same on every rank (each rank draws them from an identically seeded source): checked against rank 0's.  Equal-shaped
+    rows travel as ONE device all_gather (RCCL); ragged batches (-np -1 -mbs 1) go through a host object gather."""
+    if h.world == 1:
+        return [row for tower in softmax for row in tower.cpu().numpy()]
+    dist = parallel.dist_state()[0]
+    dev = softmax[0].device
+    mine = torch.as_tensor(np.asarray(idx, dtype=np.int64), device=dev)
+    ref = mine.clone()
+    dist.broadcast(ref, src=0)
+    if not torch.equal(ref, mine):
+        raise RuntimeError("inference_loop: rank %d drew different entry indices than rank 0 (data sources must be seeded "
+                           "identically on every replica)" % h.rank)
+    shapes = {tuple(t.shape[1:]) for t in softmax}
+    same = torch.tensor([1 if len(shapes) == 1 else 0], device=dev)
+    dist.all_reduce(same, op=dist.ReduceOp.MIN)
+    if int(same.item()):
+        local = torch.cat([t.reshape((-1,) + t.shape[1:]) for t in softmax]).contiguous()
+        box = [torch.empty_like(local) for _ in range(h.world)]
+        dist.all_gather(box, local)
+        return [row for part in box for row in part.cpu().numpy()] if h.rank == 0 else []
+    rows = [row for tower in softmax for row in tower.cpu().numpy()]
+    box = [None] * h.world if h.rank == 0 else None
+    dist.gather_object(rows, box, dst=0)
+    return [r for part in box for r in part] if h.rank == 0 else []
+
+
 def train_loop(flags, h):
     if h.csv_logger:
         h.csv_logger.write(TRAIN_COLUMNS + "\n")
@@ -296,12 +325,7 @@ def inference_loop(flags, h):
         if getattr(flags, "OUTPUT_FILE", ""):
             # every replica holds the softmax of its own shard [lo, hi) of the batch: gather the shards to rank 0,
             # which owns the output file (main_funcs.py:264-268 stores from the one process the reference has)
-            rows = [row for tower in softmax for row in tower.cpu().numpy()]
-            if h.world > 1:
-                dist = parallel.dist_state()[0]
-                box = [None] * h.world if h.rank == 0 else None
-                dist.gather_object(rows, box, dst=0)
-                rows = [r for part in box for r in part] if h.rank == 0 else []
+            rows = _gather_rows(h, softmax, idx)
             if h.rank == 0:
                 for at, row in enumerate(rows):
                     h.data_io.store(idx[at], row)

@@ -14,6 +14,7 @@ from __future__ import annotations
 import math
 import os
 import sys
+from collections import OrderedDict
 
 import numpy as np
 import torch
@@ -25,6 +26,10 @@ from . import parallel
 
 
 TF_SCOPE = "dgcnn/"       # tf.variable_scope('dgcnn', reuse=tf.AUTO_REUSE): trainval.py:29
+GRAPH_CACHE_MAX = 8       # captured towers kept per trainval (each pins a private pool with that shape's activations)
+GRAPH_CAPTURE_AFTER = 1   # eager sightings of a (shape, mode) before it is captured; "auto" mode uses GRAPH_CAPTURE_AFTER_AUTO
+GRAPH_CAPTURE_AFTER_AUTO = 3
+GRAPH_SEEN_MAX = 4096     # distinct keys remembered for the sighting count (variable-N sources produce thousands)
 
 
 def param_specs(flags, num_channel):
@@ -71,15 +76,24 @@ class trainval(object):
         self._lr = float(f.LEARNING_RATE)
         self._dist, self._rank, self._world = parallel.dist_state()
         parallel.broadcast_(self._ctx.flat_param, self._dist, src=0)
-        if getattr(f, "DETERMINISTIC", None) is not None:
-            E.DETERMINISTIC = bool(f.DETERMINISTIC)                  # process-wide, like the GEMM arithmetic
+        # resolved on EVERY initialize (flag, else the DGCNN_DETERMINISTIC environment default): an instance never inherits
+        # the mode of an earlier one.  The switch itself is process-wide, like the GEMM arithmetic.
+        det = getattr(f, "DETERMINISTIC", None)
+        E.DETERMINISTIC = E.DETERMINISTIC_ENV_DEFAULT if det is None else bool(det)
+        if E.DETERMINISTIC:
+            # csrc/det.hip walks at most 1024 columns per launch and reads its (R*k, F) input densely (ld == F): say so
+            # here, not as an EINVAL from the middle of a step
+            wide = [n for n, shp in param_specs(f, int(f.NUM_CHANNEL)) if n.endswith("weights") and shp[1] > 1024]
+            if wide:
+                raise ValueError("DETERMINISTIC mode supports at most 1024 filters per layer (csrc/det.hip); too wide: %s"
+                                 % ", ".join(wide))
         emd = str(getattr(f, "EDGE_MLP_DTYPE", "f32")).lower()
         if emd not in ("f32", "fp32", "float32", "bf16", "bfloat16"):
             raise ValueError("EDGE_MLP_DTYPE must be 'f32' or 'bf16', got %r" % (emd,))
         # BASELINE configs[2] "bf16 edge-MLP": the conv0 / conv1 products of every EdgeConv layer (forward, dgrad, wgrad) take
         # bf16 OPERANDS with fp32 accumulation (one bf16 MFMA product instead of six); everything else stays fp32-class
         self._ctx.edge_mlp_arith = 1 if emd.startswith("b") else None
-        self._graphs, self._graph_seen = {}, set()
+        self._graphs, self._graph_seen = OrderedDict(), {}     # captured towers (LRU order) / sightings per key
         ug = str(getattr(f, "USE_GRAPH", "0")).lower()
         self._use_graph = "auto" if ug == "auto" else ug in ("1", "true", "yes", "on")
         return self
@@ -158,18 +172,29 @@ class trainval(object):
                E.WGRAD_SIDE_STREAM, c.edge_mlp_arith, E.DETERMINISTIC)
         ent = self._graphs.get(key)
         if ent is None:
-            if key not in self._graph_seen:          # first sight: a normal eager step (also allocates workspaces / arenas)
-                self._graph_seen.add(key)
+            # first sightings run eagerly (the very first also allocates workspaces / arenas).  A variable-N source
+            # (-np -1 -mbs 1) shows thousands of distinct point counts: under "auto" a shape must come back a few times
+            # before it is worth a capture (a capture costs a device synchronisation and pins that shape's activations)
+            need = GRAPH_CAPTURE_AFTER_AUTO if self._use_graph == "auto" else GRAPH_CAPTURE_AFTER
+            n = self._graph_seen.get(key, 0)
+            if n < need:
+                if len(self._graph_seen) >= GRAPH_SEEN_MAX and key not in self._graph_seen:
+                    self._graph_seen.clear()
+                self._graph_seen[key] = n + 1
                 return None
             ent = self._capture(key, pts, lab, wgt, train)
             if ent is None:
                 return None
+        else:
+            self._graphs.move_to_end(key)
         for dst, src in ((ent["pts"], pts), (ent["lab"], lab), (ent["wgt"], wgt)):
             if dst is not None and dst.data_ptr() != src.data_ptr():
                 dst.copy_(src, non_blocking=True)
         c.advance_seed()
         ent["graph"].replay()
-        return ent["sm"], ent["scal"]
+        # the graph's output buffers are overwritten by the next replay of this key: hand out copies (stream ordered),
+        # so that several towers / micro-steps of one shape each keep their own softmax and [loss, accuracy]
+        return ent["sm"].clone(), ent["scal"].clone()
 
     def _capture(self, key, pts, lab, wgt, train):
         c = self._ctx
@@ -193,6 +218,11 @@ class trainval(object):
             c.side_busy = False
         if ent is not None:
             self._graphs[key] = ent
+            while len(self._graphs) > GRAPH_CACHE_MAX:           # least recently replayed first; frees its private pool
+                _, old = self._graphs.popitem(last=False)
+                torch.cuda.current_stream().synchronize()        # (a replay of it may still be in flight)
+                old["graph"].reset()
+                old.clear()
         return ent
 
     def make_summary(self, sess, data, label, weight):

@@ -34,3 +34,23 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     assert r["traffic"] is None or r["traffic"] > 0
     s = d["edgeconv_stack"]                                           # the EdgeConv stack alone
     assert s["unit"] == "clouds/s" and s["value"] > d["value"]       # the stack alone is faster than the whole model
+
+
+def test_bench_gpus_2_from_a_bare_shell_launches_two_ranks_itself():
+    """`python bench.py --gpus 2 ...` with no torchrun environment re-launches itself as 2 ranks (bench.self_launch); on the
+    one-GPU box both ranks share cuda:0 and the collective runs over gloo (RCCL refuses two ranks on one device).  Checks the
+    contract of the N > 1 line and that the replica-checksum guard ran (the run would exit non-zero on diverged replicas)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--same-device", "--backend", "gloo",
+                        "--steps", "3", "--warmup", "2", "--no-cpu-baseline"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900, cwd=ROOT, env=env)
+    assert p.returncode == 0, p.stderr.decode(errors="replace")[-3000:]
+    lines = [l for l in p.stdout.decode().splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == "weak"
+    c = d["config"]
+    assert c["parallelism"] == "dp2" and c["global_batch"] == 48
+    assert c["collective_backend"] == "gloo" and c["rccl_ranks"] == 0
+    assert abs(d["value"] - 48 * 1e3 / d["ms_per_step"]) / d["value"] < 1e-3       # whole-job clouds/s over BOTH ranks
+    assert "roofline" in d and "cpu_baseline" not in d and "edgeconv_stack" not in d

@@ -24,7 +24,8 @@ def det():
 
 def _flags(**kw):
     base = dict(MODEL_NAME="residual-dgcnn", EDGE_CONV_LAYERS=3, EDGE_CONV_FILTERS=64, KVALUE=16, FC_LAYERS=2, FC_FILTERS=[128, 64],
-                NUM_CLASS=3, NUM_CHANNEL=3, TRAIN=True, SEED=5, LEARNING_RATE=1e-3)
+                NUM_CLASS=3, NUM_CHANNEL=3, TRAIN=True, SEED=5, LEARNING_RATE=1e-3,
+                DETERMINISTIC=bool(E.DETERMINISTIC))      # initialize() resolves the mode from the flag on every instance
     base.update(kw)
     return dgcnn.DGCNN_FLAGS(**base)
 
@@ -103,3 +104,16 @@ def test_det_kernels_against_numpy(det):
     for j in range(Rn):
         seg = r[o[j]:o[j + 1]]
         assert (np.diff(seg) > 0).all()
+
+
+def test_every_trainval_resolves_the_mode_for_itself():
+    """An instance created with the default flag (None) must not inherit deterministic mode from an earlier instance."""
+    old = E.DETERMINISTIC
+    try:
+        dgcnn.trainval(_flags(DETERMINISTIC=True)).initialize()
+        assert E.DETERMINISTIC is True
+        dgcnn.trainval(_flags(DETERMINISTIC=None)).initialize()
+        assert E.DETERMINISTIC == E.DETERMINISTIC_ENV_DEFAULT
+    finally:
+        E.DETERMINISTIC = old
+        dgcnn.reset()

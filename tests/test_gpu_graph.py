@@ -99,3 +99,65 @@ def test_graph_replay_inference_and_new_shapes():
     other = torch.rand(2, 300, 3, device="cuda")                 # a shape seen once runs eagerly, no graph is kept for it
     tv.inference(None, [other])
     assert len(tv._graphs) == 1
+
+
+def test_graph_outputs_of_several_towers_and_micro_steps_do_not_alias():
+    """Every replay of one (shape, mode) key writes the same static buffers: the softmax / [loss, accuracy] handed to the
+    caller must be copies, or every tower of a multi-tower call (and every gathered micro-step) shows the LAST replay."""
+    pts, lab = _data(steps=4, B=2, N=384, seed=3)
+    towers_p, towers_l = [pts[0], pts[1]], [lab[0], lab[1]]
+    f = _flags(TRAIN=False)
+    tv = dgcnn.trainval(f).initialize().use_graph(False)
+    want = tv.inference(None, towers_p, towers_l)
+    tv.use_graph(True)
+    got = None
+    for _ in range(3):                                            # eager sighting, capture + replay, replay
+        got = tv.inference(None, towers_p, towers_l)
+    assert len(tv._graphs) == 1
+    assert float((got[0] - got[1]).abs().max()) > 1e-3           # two different towers
+    for t in range(2):
+        np.testing.assert_allclose(got[t].cpu().numpy(), want[t].cpu().numpy(), rtol=0, atol=2e-4)
+    assert abs(float(got[-1]) - float(want[-1])) < 2e-4 and abs(float(got[-2]) - float(want[-2])) < 1e-6   # tower MEAN loss / accuracy
+
+    keep, E.DROPOUT_KEEP = E.DROPOUT_KEEP, 1.0
+    try:
+        def micro_losses(graph):
+            tv = dgcnn.trainval(_flags()).initialize().use_graph(graph)
+            tv.zero_gradients(None)
+            tv.accum_gradient(None, [pts[0]], [lab[0]])           # (graph mode: the eager sighting)
+            tv.zero_gradients(None)
+            res = [tv.accum_gradient(None, [pts[s]], [lab[s]]) for s in range(4)]      # results read AFTER all micro-steps
+            tv.apply_gradient(None)
+            return [float(r[2]) for r in res], tv
+        le, _ = micro_losses(False)
+        lg, tvg = micro_losses(True)
+        assert len(tvg._graphs) == 1
+        assert len({round(x, 6) for x in lg}) == 4, lg           # four different micro-batches, four different losses
+        np.testing.assert_allclose(lg, le, rtol=0, atol=2e-5)
+    finally:
+        E.DROPOUT_KEEP = keep
+
+
+def test_graph_cache_is_bounded():
+    """Variable-N sources: every distinct point count would otherwise pin a captured graph and its activations for ever."""
+    from dgcnn import trainval as TV
+    tv = dgcnn.trainval(_flags(TRAIN=False)).initialize().use_graph(True)
+    old = TV.GRAPH_CACHE_MAX
+    TV.GRAPH_CACHE_MAX = 3
+    try:
+        for n in (256, 288, 320, 352, 384):
+            x = torch.rand(1, n, 3, device="cuda")
+            for _ in range(3):
+                out = tv.inference(None, [x])
+            assert out[0].shape == (1, n, 2)
+        assert len(tv._graphs) == 3
+        assert [k[0][1] for k in tv._graphs] == [320, 352, 384]   # least recently used shapes were dropped
+        tv.use_graph("auto")                                      # "auto": a shape must come back a few times first
+        x = torch.rand(1, 416, 3, device="cuda")
+        for i in range(TV.GRAPH_CAPTURE_AFTER_AUTO):
+            tv.inference(None, [x])
+            assert all(k[0][1] != 416 for k in tv._graphs)
+        tv.inference(None, [x])
+        assert any(k[0][1] == 416 for k in tv._graphs)
+    finally:
+        TV.GRAPH_CACHE_MAX = old
