@@ -756,6 +756,13 @@ int plan_splits(GemmP& p, void* ws, size_t ws_bytes, const char* what) {
 
 }  // namespace
 
+namespace dg {
+void launch_reduce_partials(const float* part, int splits, int M, int N, float* C, int64_t ldc, float beta, hipStream_t st) {
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)dg::cdiv((int64_t)M * N, 64)), dim3(64 * RL), 0, st, part, splits, M, N,
+                     C, ldc, beta);
+}
+}  // namespace dg
+
 extern "C" int dgcnn_gemm_f32(int transA, int transB, int M, int N, int K,
                               const float* A, int64_t lda, const float* B, int64_t ldb,
                               float* C, int64_t ldc, float beta,

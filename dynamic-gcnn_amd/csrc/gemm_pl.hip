@@ -1,0 +1,469 @@
+// gemm_pl.hip -- fp32 GEMM on the 16-bit matrix pipe from PRE-SPLIT operand planes (gfx950).
+//
+// gemm_x3.hip splits every fp32 operand element into three bf16 terms inside the GEMM: every column tile of an
+// output row panel repeats the split of the same A rows in VALU (4x for FC0, 8x for MergedEdgeConv), and that
+// staging work next to the MFMAs is what the kernel pays for under the package power cap
+// (profiles/r01_gemm_x3_ablation.txt).  Here the operands arrive already split -- "planes" written ONCE by the
+// kernel that produced the tensor (or by dgcnn_split_planes_f32) -- and the GEMM does no VALU work on them at
+// all: loader waves DMA the planes straight into LDS (global_load_lds_dwordx4), consumer waves read MFMA
+// operands and issue MFMAs.
+//
+// Plane layout ("chunk-major"), one set per tensor X (rows x cols), NPL planes of 16-bit elements:
+//     element (row, c) of plane p:  base + p * plane_stride + ((c / 8) * rows_alloc + row) * 16 + (c % 8) * 2   [bytes]
+//   i.e. [plane][cols/8][rows_alloc][8]: the 8 channels of one row form one 16-byte slot, consecutive rows of the
+//   same channel octet are consecutive slots.  rows_alloc = rows rounded up to 64; the pad rows hold zeros.
+//   ONE layout serves both uses of a tensor:
+//     PL_KC  the reduction runs over the channels (forward X W, dgrad dY W^T): an MFMA operand of lane (row, k-octet)
+//            is exactly one slot; a DMA instruction moves 64 consecutive rows of one octet (1 KiB contiguous);
+//     PL_TR  the reduction runs over the rows (wgrad X^T dY): the LDS tile keeps the [octet][row][8] slots and the
+//            consumer reads it with ds_read_b64_tr_b16 (hardware 4x4 transpose), so no second copy of the tensor.
+//   Weights are tiny: dgcnn_split_planes_f32 writes them in whichever orientation the product needs.
+//
+// Formats:  DGCNN_PLANES_BF16X3  a = a1 + a2 + a3 exactly (3 x bf16); 6 partial products (all but a2b3, a3b2, a3b3),
+//                                same arithmetic as gemm_x3.hip NP = 6.
+//           DGCNN_PLANES_F16X2   a * 2^e = h1 + h2 (2 x fp16, |a - (h1+h2) 2^-e| <= 2^-22 |a| while h2 is a normal
+//                                fp16 number); 3 partial products (h1h1, h1h2, h2h1) -- see split_f16x2 below.
+//
+// Kernel: 256 x 128 output tile, 32-k slabs, 768 threads: waves 0-7 consumers (4 x 2, 64 x 64 each as 2 x 2
+// 32x32x16 MFMA tiles), waves 8-11 loaders.  Two LDS stages; per slab one barrier.
+#include "gemm_common.h"
+
+namespace {
+
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
+using s16x4 = __attribute__((ext_vector_type(4))) short;
+using s16x8 = __attribute__((ext_vector_type(8))) short;
+
+enum { PL_KC = 0, PL_TR = 1 };
+
+template <int FMT> struct Fmt;
+template <> struct Fmt<DGCNN_PLANES_BF16X3> {
+  static constexpr int NPL = 3, NP = 6;
+  static __device__ __forceinline__ f32x16 mfma(s16x8 a, s16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+  }
+};
+template <> struct Fmt<DGCNN_PLANES_F16X2> {
+  static constexpr int NPL = 2, NP = 3;
+  static __device__ __forceinline__ f32x16 mfma(s16x8 a, s16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  }
+};
+
+struct PlP {
+  GemmP g;                       // shapes, C / partial, epilogue options, tile mapping (A / B pointers unused)
+  const char* Ap; int64_t a_ps; int64_t a_rows;      // plane 0 of the operand (at its first octet), plane stride [B], rows_alloc
+  const char* Bp; int64_t b_ps; int64_t b_rows;
+  float out_scale;               // 2^-(ea+eb) for the scaled fp16 format, 1 otherwise
+};
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+template <int FORM, int FMT>
+__global__ __launch_bounds__(768) void gemm_pl_kernel(PlP q) {
+  using F = Fmt<FMT>;
+  constexpr int BM = 256, BN = 128, TM = 2, TN = 2, NPL = F::NPL;
+  constexpr unsigned PA = BM * 64, PB = BN * 64;               // bytes per plane per 32-k slab (tile rows x 4 octets x 16 B)
+  constexpr unsigned STAGE = NPL * (PA + PB);
+  constexpr unsigned EPI_BYTES = 128 * BN * 4;
+  constexpr unsigned LDS_BYTES = 2 * STAGE > EPI_BYTES ? 2 * STAGE : EPI_BYTES;
+  static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+  __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
+  const GemmP& p = q.g;
+
+  const int t = threadIdx.x;
+  const int lane = t & 63;
+  const int wv = t >> 6;
+
+  int mt, nt, z;
+  if (!block_tile(p, mt, nt, z)) return;
+  const int m0 = mt * BM;
+  const int n0 = nt * BN;
+  const int kbeg = z * p.kchunk;
+  const int kend = (kbeg + p.kchunk < p.K) ? (kbeg + p.kchunk) : p.K;
+  const int nk = (kend - kbeg + 31) >> 5;                      // PL_TR: the last slab may run into the zero pad rows
+
+  if (wv >= 8) {
+    // ------------------------------------------------------------------ loaders: 4 waves x NI/4 DMA instructions per slab
+    constexpr int NIA = NPL * 16, NIB = NPL * 8, NI = NIA + NIB, PER = NI / 4;
+    const int lw = __builtin_amdgcn_readfirstlane(wv - 8);
+    const char* src[PER];
+    unsigned dst[PER];
+    unsigned ok = 0;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int e = lw + 4 * i;                                // wave-uniform
+      const bool isA = e < NIA;
+      const int ee = isA ? e : e - NIA;
+      const int per_plane = isA ? 16 : 8;
+      const int pl = ee / per_plane, r = ee % per_plane;
+      const char* base = (isA ? q.Ap + pl * q.a_ps : q.Bp + pl * q.b_ps);
+      const int64_t rows = isA ? q.a_rows : q.b_rows;
+      const int row0 = isA ? m0 : n0;
+      const unsigned pbase = isA ? pl * PA : NPL * PA + pl * PB;
+      if (FORM == PL_KC) {
+        // 64 consecutive tile rows of one k-octet: image [octet c][tile row] slots
+        const int nrb = isA ? 4 : 2;
+        const int c = r / nrb, rb = r % nrb;
+        const int64_t row = row0 + rb * 64;
+        if (row < rows) ok |= 1u << i;
+        const int64_t rowc = row < rows ? row : 0;
+        src[i] = base + (((int64_t)(kbeg >> 3) + c) * rows + rowc + lane) * 16;
+        dst[i] = pbase + (unsigned)((c * (isA ? BM : BN) + rb * 64) * 16);
+      } else {
+        // two channel octets x 32 reduction rows; slot (octet cidx, row r) at cidx * 32 + (r ^ 4 (cidx & 3)): the XOR
+        // spreads the four octets a transpose-read touches over the four 64-byte quarters of a bank row
+        const int cidx = 2 * r + (lane >> 5);                  // tile-local octet
+        const int rr = (lane & 31) ^ (4 * (cidx & 3));
+        const int64_t oct = (row0 >> 3) + cidx;
+        const int64_t noct = ((isA ? p.M : p.N) + 7) >> 3;
+        if ((int64_t)(row0 >> 3) + 2 * r < noct) ok |= 1u << i;        // (M, N multiples of 16: an instruction's two octets are both in or both out)
+        const int64_t octc = oct < noct ? oct : 0;
+        src[i] = base + (octc * rows + kbeg + rr) * 16;
+        dst[i] = pbase + (unsigned)(r * 64 * 16);
+      }
+    }
+    const int64_t stepA = (FORM == PL_KC) ? q.a_rows * 64 : 512;       // bytes per slab
+    const int64_t stepB = (FORM == PL_KC) ? q.b_rows * 64 : 512;
+    auto issue = [&](int buf, int slab) {
+#pragma unroll
+      for (int i = 0; i < PER; ++i) {
+        const bool isA = (lw + 4 * i) < NIA;
+        if ((ok >> i) & 1u) {
+          const char* s = src[i] + (int64_t)slab * (isA ? stepA : stepB);
+          char* d = smem + buf * STAGE + dst[i];
+          __builtin_amdgcn_global_load_lds((gptr_t)s, (lptr_t)d, 16, 0, 0);
+        }
+      }
+    };
+    issue(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+#pragma unroll 1
+    for (int kt = 0; kt < nk; ++kt) {
+      if (kt + 1 < nk) issue((kt + 1) & 1, kt + 1);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
+    return;
+  }
+
+  // -------------------------------------------------------------------- consumers (512 threads, 4 x 2 waves)
+  const int wr = wv >> 1, wc = wv & 1;
+  const int l31 = lane & 31, lh = lane >> 5;
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // per-lane LDS offsets of the operand reads
+  unsigned a_off[TM][2], b_off[TN][2];
+  if (FORM == PL_KC) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i) a_off[i][0] = a_off[i][1] = (unsigned)((lh * BM + wr * 64 + i * 32 + l31) * 16);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) b_off[j][0] = b_off[j][1] = NPL * PA + (unsigned)((lh * BN + wc * 64 + j * 32 + l31) * 16);
+  } else {
+    // ds_read_b64_tr_b16: within a 16-lane group lane 4 jj + qq supplies the 8-byte piece (row jj, channels 4 qq .. 4 qq + 3)
+    // and lane c receives channel c of rows 0..3.  Groups: g & 1 -> channels 16..31 of the 32-row MFMA tile, g >> 1 -> k half.
+    const int g = lane >> 4, jj = (lane >> 2) & 3, qq = lane & 3;
+    const int cb3 = 2 * (g & 1) + (qq >> 1);                   // (tile-local octet) & 3: the tile bases are multiples of 4 octets
+    const int kh = g >> 1;
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) {
+      const int x = ((2 * kh + tt) ^ cb3);                     // swizzled (k row >> 2) & 3
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+        a_off[i][tt] = (unsigned)(((wr * 8 + i * 4 + cb3) * 32 + x * 4 + jj) * 16 + (qq & 1) * 8);
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        b_off[j][tt] = NPL * PA + (unsigned)(((wc * 8 + j * 4 + cb3) * 32 + x * 4 + jj) * 16 + (qq & 1) * 8);
+    }
+  }
+
+  __syncthreads();                                 // stage 0 landed
+#pragma unroll 1
+  for (int kt = 0; kt < nk; ++kt) {
+    const char* base = smem + (kt & 1) * STAGE;
+    s16x8 a[2][TM][NPL], b[2][TN][NPL];
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int pl = 0; pl < NPL; ++pl) {
+        if (FORM == PL_KC) {
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+            a[s][i][pl] = *reinterpret_cast<const s16x8*>(base + pl * PA + a_off[i][0] + s * 2 * BM * 16);
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            b[s][j][pl] = *reinterpret_cast<const s16x8*>(base + pl * PB + b_off[j][0] + s * 2 * BN * 16);
+        } else {
+#pragma unroll
+          for (int i = 0; i < TM; ++i) {
+            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + pl * PA + a_off[i][0] + s * 256));
+            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + pl * PA + a_off[i][1] + s * 256));
+            a[s][i][pl] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+          }
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + pl * PB + b_off[j][0] + s * 256));
+            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + pl * PB + b_off[j][1] + s * 256));
+            b[s][j][pl] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+          }
+        }
+      }
+    // partial products, largest first: (1,1) (1,2) (2,1) (2,2) (1,3) (3,1)
+    constexpr int PRA[6] = {0, 0, 1, 1, 0, 2};
+    constexpr int PRB[6] = {0, 1, 0, 1, 2, 0};
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int pr = 0; pr < F::NP; ++pr)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = F::mfma(a[s][i][PRA[pr]], b[s][j][PRB[pr]], acc[i][j]);
+    __syncthreads();
+  }
+
+  if (q.out_scale != 1.f) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] *= q.out_scale;
+  }
+  gemm_epilogue<E_STORE, BM, BN, true, TM, TN, 4, 512>(p, acc, reinterpret_cast<float*>(smem), m0, n0, mt, z, t, wr, wc, l31, lh);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// fp32 -> planes
+// ------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {
+  unsigned r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+  return r;
+}
+
+// (x0, x1) -> packed pairs of the split terms (x0 in the low half)
+__device__ __forceinline__ void split_bf16x3(float x0, float x1, unsigned (&o)[3]) {
+  o[0] = cvt_pk_bf16(x0, x1);
+  const float r0 = x0 - __uint_as_float(o[0] << 16);
+  const float r1 = x1 - __uint_as_float(o[0] & 0xffff0000u);
+  o[1] = cvt_pk_bf16(r0, r1);
+  const float s0 = r0 - __uint_as_float(o[1] << 16);
+  const float s1 = r1 - __uint_as_float(o[1] & 0xffff0000u);
+  o[2] = cvt_pk_bf16(s0, s1);
+}
+
+// fp16 pair: h1 = rn16(x), h2 = rn16(x - h1) (x already scaled by the tensor's power of two; |x| <= 65504 or it saturates)
+__device__ __forceinline__ void split_f16x2(float x0, float x1, unsigned (&o)[3]) {
+  const float lim = 65504.f;
+  x0 = fminf(fmaxf(x0, -lim), lim);
+  x1 = fminf(fmaxf(x1, -lim), lim);
+  const _Float16 h0 = (_Float16)x0, h1 = (_Float16)x1;
+  const _Float16 l0 = (_Float16)(x0 - (float)h0), l1 = (_Float16)(x1 - (float)h1);
+  o[0] = (unsigned)__builtin_bit_cast(unsigned short, h0) | ((unsigned)__builtin_bit_cast(unsigned short, h1) << 16);
+  o[1] = (unsigned)__builtin_bit_cast(unsigned short, l0) | ((unsigned)__builtin_bit_cast(unsigned short, l1) << 16);
+  o[2] = 0;
+}
+
+template <int FMT>
+__device__ __forceinline__ void split8(const float (&v)[8], float scale, uint4 (&o)[3]) {
+  unsigned w[4][3];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    if (FMT == DGCNN_PLANES_BF16X3) split_bf16x3(v[2 * e], v[2 * e + 1], w[e]);
+    else split_f16x2(v[2 * e] * scale, v[2 * e + 1] * scale, w[e]);
+  }
+#pragma unroll
+  for (int pl = 0; pl < 3; ++pl) o[pl] = make_uint4(w[0][pl], w[1][pl], w[2][pl], w[3][pl]);
+}
+
+// Activations: src (rows x cols) row-major, ld % 4 == 0, cols % 8 == 0.  Block = 64 rows x 16 octets; the split slots go
+// through LDS so that every wave store is 64 consecutive rows of one octet (1 KiB contiguous).  Pad rows [rows, rows_alloc)
+// are written as zeros.
+template <int FMT>
+__global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict__ src, int64_t ld, int64_t rows, int cols,
+                                                         char* __restrict__ dst, int64_t plane_stride, int64_t rows_alloc,
+                                                         const float* __restrict__ scale_dev) {
+  constexpr int NPL = Fmt<FMT>::NPL;
+  constexpr int CS = 65;                                     // slots per octet in LDS (+1: conflict-free ds_write_b128)
+  __shared__ __attribute__((aligned(16))) uint4 sh[NPL][16 * CS];
+  const int t = threadIdx.x;
+  const int64_t r0 = (int64_t)blockIdx.x * 64;
+  const int o0 = blockIdx.y * 16;
+  const int noct = cols >> 3;
+  const float scale = (FMT == DGCNN_PLANES_F16X2 && scale_dev) ? *scale_dev : 1.f;
+  {
+    const int rl = t >> 2;                                   // 4 threads per row: 128 contiguous bytes per load instruction
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int ol = (t & 3) + 4 * u;
+      const int64_t row = r0 + rl;
+      float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      if (row < rows && o0 + ol < noct) {
+        const float4 a = *reinterpret_cast<const float4*>(src + row * ld + (int64_t)(o0 + ol) * 8);
+        const float4 b = *reinterpret_cast<const float4*>(src + row * ld + (int64_t)(o0 + ol) * 8 + 4);
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+      }
+      uint4 o[3];
+      split8<FMT>(v, scale, o);
+#pragma unroll
+      for (int pl = 0; pl < NPL; ++pl) sh[pl][ol * CS + rl] = o[pl];
+    }
+  }
+  __syncthreads();
+  const int lane = t & 63, wv = t >> 6;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int ol = wv * 4 + u;
+    const int64_t row = r0 + lane;
+    if (o0 + ol < noct && row < rows_alloc) {
+#pragma unroll
+      for (int pl = 0; pl < NPL; ++pl)
+        *reinterpret_cast<uint4*>(dst + pl * plane_stride + ((int64_t)(o0 + ol) * rows_alloc + row) * 16) = sh[pl][ol * CS + lane];
+    }
+  }
+}
+
+// Generic (small tensors: weights).  Plane element (row, c) = src[row * rs + c * cs]; rows / cols of the PLANE SET.
+template <int FMT>
+__global__ __launch_bounds__(256) void split_strided_kernel(const float* __restrict__ src, int64_t rs, int64_t cs, int64_t rows,
+                                                            int cols, char* __restrict__ dst, int64_t plane_stride,
+                                                            int64_t rows_alloc, const float* __restrict__ scale_dev) {
+  constexpr int NPL = Fmt<FMT>::NPL;
+  const int noct = (cols + 7) >> 3;
+  const int64_t item = (int64_t)blockIdx.x * 256 + threadIdx.x;        // (octet, row) with the row fastest
+  if (item >= (int64_t)noct * rows_alloc) return;
+  const int64_t row = item % rows_alloc;
+  const int oc = (int)(item / rows_alloc);
+  const float scale = (FMT == DGCNN_PLANES_F16X2 && scale_dev) ? *scale_dev : 1.f;
+  float v[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int c = oc * 8 + e;
+    v[e] = (row < rows && c < cols) ? src[row * rs + (int64_t)c * cs] : 0.f;
+  }
+  uint4 o[3];
+  split8<FMT>(v, scale, o);
+#pragma unroll
+  for (int pl = 0; pl < NPL; ++pl) *reinterpret_cast<uint4*>(dst + pl * plane_stride + item * 16) = o[pl];
+}
+
+inline bool aligned16p(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
+
+}  // namespace
+
+namespace dg {
+void launch_reduce_partials(const float* part, int splits, int M, int N, float* C, int64_t ldc, float beta, hipStream_t st);
+}
+
+#define ST ((hipStream_t)stream)
+
+extern "C" int dgcnn_split_planes_f32(const float* src, int64_t row_stride, int64_t col_stride, int64_t rows, int cols, int fmt,
+                                      const float* scale_dev, void* dst, int64_t plane_stride, int64_t rows_alloc, void* stream) {
+  DG_REQUIRE(src && dst && rows > 0 && cols > 0, DGCNN_EINVAL, "dgcnn_split_planes_f32: bad args");
+  DG_REQUIRE(fmt == DGCNN_PLANES_BF16X3 || fmt == DGCNN_PLANES_F16X2, DGCNN_EINVAL, "dgcnn_split_planes_f32: unknown format %d", fmt);
+  DG_REQUIRE(rows_alloc >= rows && rows_alloc % 64 == 0 && plane_stride % 16 == 0 && aligned16p(dst), DGCNN_EINVAL,
+             "dgcnn_split_planes_f32: rows_alloc must be a multiple of 64 >= rows, planes 16-byte aligned");
+  const int noct = (cols + 7) / 8;
+  DG_REQUIRE(plane_stride >= (int64_t)noct * rows_alloc * 16, DGCNN_EINVAL, "dgcnn_split_planes_f32: plane stride too small");
+  const bool fast = col_stride == 1 && cols % 8 == 0 && row_stride % 4 == 0 && aligned16p(src);
+  if (fast) {
+    dim3 grid((unsigned)(rows_alloc / 64), (unsigned)dg::cdiv(noct, 16));
+    if (fmt == DGCNN_PLANES_BF16X3)
+      hipLaunchKernelGGL((split_rows_kernel<DGCNN_PLANES_BF16X3>), grid, dim3(256), 0, ST, src, row_stride, rows, cols, (char*)dst, plane_stride, rows_alloc, scale_dev);
+    else
+      hipLaunchKernelGGL((split_rows_kernel<DGCNN_PLANES_F16X2>), grid, dim3(256), 0, ST, src, row_stride, rows, cols, (char*)dst, plane_stride, rows_alloc, scale_dev);
+  } else {
+    const unsigned g = (unsigned)dg::cdiv((int64_t)noct * rows_alloc, 256);
+    if (fmt == DGCNN_PLANES_BF16X3)
+      hipLaunchKernelGGL((split_strided_kernel<DGCNN_PLANES_BF16X3>), dim3(g), dim3(256), 0, ST, src, row_stride, col_stride, rows, cols, (char*)dst, plane_stride, rows_alloc, scale_dev);
+    else
+      hipLaunchKernelGGL((split_strided_kernel<DGCNN_PLANES_F16X2>), dim3(g), dim3(256), 0, ST, src, row_stride, col_stride, rows, cols, (char*)dst, plane_stride, rows_alloc, scale_dev);
+  }
+  return dg::check_launch("dgcnn_split_planes_f32");
+}
+
+// C (M x N, fp32) (+)= A B^T-style product of two plane sets.
+//   form = DGCNN_PL_KC: A rows = M, B rows = N, both reduce over their K channels (K % 32 == 0; plane pointers at the first octet)
+//   form = DGCNN_PL_TR: A channels = M, B channels = N (both % 16 == 0), both reduce over their K rows (pad rows are zero)
+extern "C" int dgcnn_gemm_planes_f32(int form, int fmt, int M, int N, int K,
+                                     const void* A, int64_t a_plane_stride, int64_t a_rows_alloc,
+                                     const void* B, int64_t b_plane_stride, int64_t b_rows_alloc,
+                                     float* C, int64_t ldc, float beta, float out_scale,
+                                     const float* gbias, int64_t ldgbias, int rows_per_group,
+                                     double* stats, void* ws, size_t ws_bytes, void* stream) {
+  DG_REQUIRE(A && B && C && M > 0 && N > 0 && K > 0, DGCNN_EINVAL, "dgcnn_gemm_planes_f32: bad args");
+  DG_REQUIRE(form == DGCNN_PL_KC || form == DGCNN_PL_TR, DGCNN_EINVAL, "dgcnn_gemm_planes_f32: unknown form %d", form);
+  DG_REQUIRE(fmt == DGCNN_PLANES_BF16X3 || fmt == DGCNN_PLANES_F16X2, DGCNN_EINVAL, "dgcnn_gemm_planes_f32: unknown format %d", fmt);
+  DG_REQUIRE(aligned16p(A) && aligned16p(B) && a_plane_stride % 16 == 0 && b_plane_stride % 16 == 0 && a_rows_alloc % 64 == 0 &&
+                 b_rows_alloc % 64 == 0, DGCNN_EINVAL, "dgcnn_gemm_planes_f32: planes must be 16-byte aligned, rows_alloc a multiple of 64");
+  DG_REQUIRE(!gbias || rows_per_group > 0, DGCNN_EINVAL, "dgcnn_gemm_planes_f32: rows_per_group");
+  PlP q = {};
+  GemmP& p = q.g;
+  p.C = C; p.ldc = ldc; p.M = M; p.N = N; p.K = K; p.beta = beta;
+  p.gbias = gbias; p.ldgbias = ldgbias; p.rpg = rows_per_group > 0 ? rows_per_group : 1;
+  p.gbvec = gbias && (ldgbias % 4 == 0) && aligned16p(gbias);
+  p.stats = stats;
+  p.splits = 1; p.kchunk = K; p.bm = 256;
+  q.Ap = (const char*)A; q.a_ps = a_plane_stride; q.a_rows = a_rows_alloc;
+  q.Bp = (const char*)B; q.b_ps = b_plane_stride; q.b_rows = b_rows_alloc;
+  q.out_scale = out_scale;
+  p.mtiles = (int)dg::cdiv(M, 256);
+  p.ntiles = (int)dg::cdiv(N, 128);
+  if (form == DGCNN_PL_KC) {
+    DG_REQUIRE(K % 32 == 0, DGCNN_EUNSUP, "dgcnn_gemm_planes_f32(KC): K %% 32 != 0 (%d)", K);
+    DG_REQUIRE(M <= a_rows_alloc && N <= b_rows_alloc, DGCNN_EINVAL, "dgcnn_gemm_planes_f32(KC): rows_alloc smaller than the operand");
+  } else {
+    DG_REQUIRE(M % 16 == 0 && N % 16 == 0, DGCNN_EUNSUP, "dgcnn_gemm_planes_f32(TR): M, N must be multiples of 16 (%d, %d)", M, N);
+    DG_REQUIRE(a_rows_alloc == b_rows_alloc && K <= a_rows_alloc, DGCNN_EINVAL, "dgcnn_gemm_planes_f32(TR): both operands must share rows_alloc >= K");
+    DG_REQUIRE(!gbias && !stats, DGCNN_EUNSUP, "dgcnn_gemm_planes_f32(TR): bias / statistics unsupported");
+    // split the reduction over the rows: every k-chunk pinned to one XCD (gemm_common.h:block_tile), whole rounds of 32 workgroups
+    const int64_t tiles = (int64_t)p.mtiles * p.ntiles;
+    const int64_t maxs = K / 256 > 0 ? K / 256 : 1;
+    if (maxs >= 8 && ws) {
+      double best_eff = 0.0;
+      int64_t best = 0;
+      for (int64_t R = 1; R <= 3; ++R) {
+        int64_t per = (32 * R) / tiles;
+        if (per < 1) per = 1;
+        if (8 * per > maxs) per = maxs / 8;
+        const double eff = (double)(tiles * per) / (double)(32 * dg::cdiv(tiles * per, 32));
+        if (eff > best_eff + 0.03) { best_eff = eff; best = 8 * per; }
+      }
+      if (best >= 8) {
+        int64_t chunk = dg::cdiv(dg::cdiv(K, best), 32) * 32;
+        const int64_t s = dg::cdiv(K, chunk);
+        if (s > 1 && ws_bytes >= (size_t)s * M * N * sizeof(float)) {
+          p.splits = (int)s; p.kchunk = (int)chunk; p.zmajor = 1; p.partial = reinterpret_cast<float*>(ws);
+        }
+      }
+    }
+  }
+  if (p.splits > 1) p.cvec = (N % 4 == 0) && aligned16p(p.partial);
+  else p.cvec = (ldc % 4 == 0) && aligned16p(C);
+  p.xcd_group = (p.ntiles > 1 && p.mtiles >= 16 && p.splits == 1) ? 1 : 0;
+  const unsigned gx = p.xcd_group ? (unsigned)(dg::cdiv(p.mtiles, 8) * 8 * p.ntiles) : (unsigned)(p.mtiles * p.ntiles);
+  dim3 grid(gx, 1, 1);
+  if (p.zmajor) grid = dim3((unsigned)(dg::cdiv(p.splits, 8) * 8 * p.mtiles * p.ntiles), 1, 1);
+#define DG_PL(FORM, FMT) hipLaunchKernelGGL((gemm_pl_kernel<FORM, FMT>), grid, dim3(768), 0, ST, q)
+  if (form == DGCNN_PL_KC) { if (fmt == DGCNN_PLANES_BF16X3) DG_PL(PL_KC, DGCNN_PLANES_BF16X3); else DG_PL(PL_KC, DGCNN_PLANES_F16X2); }
+  else { if (fmt == DGCNN_PLANES_BF16X3) DG_PL(PL_TR, DGCNN_PLANES_BF16X3); else DG_PL(PL_TR, DGCNN_PLANES_F16X2); }
+#undef DG_PL
+  int rc = dg::check_launch("dgcnn_gemm_planes_f32");
+  if (rc) return rc;
+  if (p.splits > 1) {
+    dg::launch_reduce_partials(p.partial, p.splits, M, N, C, ldc, beta, ST);
+    rc = dg::check_launch("dgcnn_gemm_planes_f32(reduce)");
+  }
+  return rc;
+}

@@ -166,6 +166,34 @@ int dgcnn_gemm_f32(int transA, int transB, int M, int N, int K,
                    const float* gbias, int64_t ldgbias, int rows_per_group,
                    double* stats, void* ws, size_t ws_bytes, void* stream);
 
+/* ---- GEMM from PRE-SPLIT operand planes (gemm_pl.hip) -------------------------------------------
+ * The same 1x1 convolutions and their dgrad / wgrad (ops.py:62-70,153-160; model.py:65-72) when the
+ * operands were split into 16-bit planes ONCE by their producer instead of inside every GEMM tile.
+ * Plane set of a tensor X (rows x cols):  element (row, c) of plane p at
+ *     base + p * plane_stride + ((c / 8) * rows_alloc + row) * 16 + (c % 8) * 2        [bytes]
+ * rows_alloc = rows rounded up to 64, pad rows are zero.
+ *   DGCNN_PLANES_BF16X3: x = x1 + x2 + x3 exactly (3 bf16 planes), 6 partial products (== dgcnn_gemm_f32 arithmetic 6)
+ *   DGCNN_PLANES_F16X2 : x * scale = h1 + h2 (2 fp16 planes; scale = a power of two read from scale_dev), 3 partial
+ *                        products; the caller passes out_scale = 1 / (scale_A * scale_B).
+ * dgcnn_split_planes_f32: plane element (row, c) = src[row * row_stride + c * col_stride]  (col_stride 1 = an activation
+ *   view; row_stride 1 = the transpose of a row-major matrix, for weights).
+ * dgcnn_gemm_planes_f32:  C[M][N] (+= beta C) = sum_k A(m,k) B(n,k)
+ *   DGCNN_PL_KC: A has M rows, B has N rows, the reduction runs over the K channels of both (K % 32 == 0); A / B point at the
+ *                first octet of the channel range;   DGCNN_PL_TR: A has M channels, B has N channels (M, N % 16 == 0), the
+ *                reduction runs over the K rows of both (X^T dY; split over K into ws).  gbias / stats as dgcnn_gemm_f32 (KC only). */
+#define DGCNN_PLANES_BF16X3 0
+#define DGCNN_PLANES_F16X2 1
+#define DGCNN_PL_KC 0
+#define DGCNN_PL_TR 1
+int dgcnn_split_planes_f32(const float* src, int64_t row_stride, int64_t col_stride, int64_t rows, int cols, int fmt,
+                           const float* scale_dev, void* dst, int64_t plane_stride, int64_t rows_alloc, void* stream);
+int dgcnn_gemm_planes_f32(int form, int fmt, int M, int N, int K,
+                          const void* A, int64_t a_plane_stride, int64_t a_rows_alloc,
+                          const void* B, int64_t b_plane_stride, int64_t b_rows_alloc,
+                          float* C, int64_t ldc, float beta, float out_scale,
+                          const float* gbias, int64_t ldgbias, int rows_per_group,
+                          double* stats, void* ws, size_t ws_bytes, void* stream);
+
 /* ---- K4/K5: slim.batch_norm (ops.py:53,68 ...) + activation + reduce_max/mean (ops.py:56-57)
  * mean/rstd from the stats slots: mean = S/count, var = Q/count - mean^2 (double), rstd=1/sqrt(var+eps) */
 int dgcnn_bn_finalize_f32(const double* stats, int F, double count, float eps,

@@ -156,14 +156,40 @@ def edges_bwd(dE: np.ndarray, idx: np.ndarray, B: int, N: int, C: int) -> np.nda
 # ----------------------------------------------------------------------------------------
 # slim.conv2d(kernel 1, no bias) + slim.batch_norm(defaults) + activation   [TF1-lib A.2/A.3]
 # ----------------------------------------------------------------------------------------
+def tree_colsum(a):
+    """Column sums of a (..., F) array over all leading axes IN THE ARRAY'S OWN DTYPE, by fold-in-half pairwise
+    summation -- the oracle's normative order for every reduction over the BatchNorm axes (SURVEY Appendix A gives TF1
+    no order; Eigen's reductions are tree-shaped / vectorised, not a running row-by-row sum):
+
+        rows r_0 .. r_{n-1};  while n > 1:  h = n // 2;  r_i <- r_i + r_{n-h+i} for i < h;  n <- n - h;   result r_0
+
+    (with n odd the middle row waits for the next round).  Every addition is one rounding in dtype; the error grows with
+    log2(n) instead of n: at the 983 040 rows of configs[1]'s conv0 a running float32 sum (what numpy's `mean(axis=0)`
+    does over a non-contiguous axis) is 1.9e-3 off in the logits and 2-4e-2 in the gradients, this order ~1e-5 (measured
+    against the float64 evaluation, profiles/r03/oracle_reduction.txt)."""
+    F = a.shape[-1]
+    r = np.array(a, copy=True).reshape(-1, F)
+    n = r.shape[0]
+    while n > 1:
+        h = n // 2
+        r[:h] += r[n - h:n]
+        n -= h
+    return r[0].copy()
+
+
+def tree_colmean(a):
+    n = a.size // a.shape[-1]
+    return tree_colsum(a) / a.dtype.type(n)
+
+
 def conv_bn_act(x, W, beta, relu=True, eps=BN_EPS):
     """x (..., Cin) @ W (Cin,Cout); BN over all axes but the last with batch statistics
-    (biased variance), +beta, no gamma; optional ReLU.  Returns (out, cache)."""
+    (biased variance), +beta, no gamma; optional ReLU.  Returns (out, cache).
+    Reductions over the BatchNorm axes: tree_colsum (fold-in-half pairwise, in the working dtype)."""
     dt = x.dtype
     y = np.matmul(x, W)
-    axes = tuple(range(y.ndim - 1))
-    mu = y.mean(axis=axes, dtype=dt)
-    var = np.mean(np.square(y - mu), axis=axes, dtype=dt)
+    mu = tree_colmean(y)
+    var = tree_colmean(np.square(y - mu))
     rstd = (1.0 / np.sqrt(var + dt.type(eps))).astype(dt)
     xhat = (y - mu) * rstd
     z = xhat + beta
@@ -175,10 +201,9 @@ def conv_bn_act_bwd(dout, cache):
     """-> (dx, dW, dbeta).  BN-train backward of SURVEY A.5; ReLU grad = [out>0]."""
     x, W, xhat, rstd = cache["x"], cache["W"], cache["xhat"], cache["rstd"]
     dz = dout * (cache["out"] > 0) if cache["relu"] else dout
-    axes = tuple(range(dz.ndim - 1))
-    dbeta = dz.sum(axis=axes)
-    m1 = dz.mean(axis=axes)
-    m2 = (dz * xhat).mean(axis=axes)
+    dbeta = tree_colsum(dz)
+    m1 = dbeta / dz.dtype.type(dz.size // dz.shape[-1])
+    m2 = tree_colmean(dz * xhat)
     dy = rstd * (dz - m1 - xhat * m2)
     Cin, Cout = W.shape
     dW = np.matmul(x.reshape(-1, Cin).T, dy.reshape(-1, Cout))
