@@ -144,7 +144,11 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for the "
                     "single-GPU-box sanity run of the N>1 logic, with --same-device)")
     ap.add_argument("--same-device", action="store_true", help="all ranks on cuda:0 (sanity runs only)")
-    ap.add_argument("--graph", type=int, default=0, help="1: replay the forward+backward tower as a captured HIP graph")
+    ap.add_argument("--graph", default="auto", choices=["0", "1", "auto"],
+                    help="1: replay the forward+backward tower as a captured HIP graph (the reference replays a static TF graph "
+                         "with sess.run); 0: eager launches; auto (default): a few untimed steps of each during warm-up, then the "
+                         "faster mode for the timed region (eager wins on a fast host, replay when the host cannot enqueue "
+                         "~150 launches per step as fast as the GPU retires them)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -174,7 +178,7 @@ def main():
     from dgcnn import _hip as H
     flags = make_flags(dgcnn)
     tv = dgcnn.trainval(flags).initialize()
-    tv.use_graph(bool(args.graph))
+    tv.use_graph(args.graph == "1")
 
     rng = np.random.default_rng(rank)                     # per-rank synthetic shard
     pts = torch.from_numpy(rng.random((B, N, C), dtype=np.float32)).cuda()
@@ -208,9 +212,32 @@ def main():
     dominant = max(table, key=lambda t: table[t][1])
     for _ in range(max(args.warmup - 2, 0)):
         step()
+    calib = None
+    if args.graph == "auto":                    # untimed calibration: which launch mode is faster on THIS host + GPU
+        def rate(n=6):
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            for _ in range(n):
+                step()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t) / n
+        tv.use_graph(False)
+        t_eager = rate()
+        tv.use_graph(True)
+        step()
+        step()                                  # sighting + capture
+        t_graph = rate()
+        use = t_graph < t_eager
+        if dist is not None:                    # every rank must make the same choice
+            v = torch.tensor([t_eager, t_graph], dtype=torch.float64, device="cuda")
+            dist.all_reduce(v, op=dist.ReduceOp.MAX)
+            use = bool(v[1] < v[0])
+        tv.use_graph(use)
+        calib = {"eager_ms": round(t_eager * 1e3, 3), "graph_ms": round(t_graph * 1e3, 3)}
+    use_graph = bool(tv._use_graph)
 
     # ---- timed region: exactly K steps, events only around the dominant kernel's launches ----
-    H.TIMER = None if args.graph else H.Timer(watch={dominant})    # (events cannot bracket kernels inside a graph replay)
+    H.TIMER = None if use_graph else H.Timer(watch={dominant})    # (events cannot bracket kernels inside a graph replay)
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -218,7 +245,7 @@ def main():
     t_issue = time.perf_counter() - t0          # host time to enqueue K steps (launch-bound check)
     fence()
     elapsed = time.perf_counter() - t0
-    if args.graph:                                  # the dominant kernel's events from an eager pass right after the timed steps
+    if use_graph:                                   # the dominant kernel's events from an eager pass right after the timed steps
         tv.use_graph(False)
         H.TIMER = H.Timer(watch={dominant})
         for _ in range(max(args.steps // 4, 2)):
@@ -257,6 +284,11 @@ def main():
                 nprod = int(dominant.rstrip(">").split("bf16x")[1])
                 peak = round(PEAK_BF16_MFMA_TFLOPS / nprod, 1)
                 note = "bf16 MFMA dense peak %.0f / %d partial products per fp32 product" % (PEAK_BF16_MFMA_TFLOPS, nprod)
+            elif dominant.startswith("gemm_pl"):    # plane GEMM (gemm_pl.hip): 3 bf16 planes -> 6 products, 2 fp16 planes -> 3
+                nprod = 3 if "f16x2" in dominant else 6
+                peak = round(PEAK_BF16_MFMA_TFLOPS / nprod, 1)
+                note = ("16-bit MFMA dense peak %.0f (bf16 = fp16 rate) / %d partial products per fp32 product"
+                        % (PEAK_BF16_MFMA_TFLOPS, nprod))
             roof = {"kernel": dominant, "bound": "mfma" if dominant.startswith("gemm") else "valu",
                     "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                     "frac": round(achieved / peak, 4), "traffic": None,
@@ -301,7 +333,8 @@ def main():
                                    "(RCCL all-reduce) + Adam" % arith_name,
                        "global_batch": world * B, "points_per_cloud": N, "parallelism": "dp%d" % world,
                        "collective_backend": coll_backend, "rccl_ranks": rccl_ranks,
-                       "final_loss": round(loss, 5), "host_enqueue_ms_per_step": round(t_issue / args.steps * 1e3, 3)},
+                       "final_loss": round(loss, 5), "host_enqueue_ms_per_step": round(t_issue / args.steps * 1e3, 3),
+                       "launch_mode": "hip-graph replay" if use_graph else "eager", "launch_mode_calibration": calib},
             "roofline": roof,
         }
         if world == 1:

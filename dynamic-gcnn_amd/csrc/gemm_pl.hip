@@ -24,8 +24,16 @@
 //           DGCNN_PLANES_F16X2   a * 2^e = h1 + h2 (2 x fp16, |a - (h1+h2) 2^-e| <= 2^-22 |a| while h2 is a normal
 //                                fp16 number); 3 partial products (h1h1, h1h2, h2h1) -- see split_f16x2 below.
 //
-// Kernel: 256 x 128 output tile, 32-k slabs, 768 threads: waves 0-7 consumers (4 x 2, 64 x 64 each as 2 x 2
-// 32x32x16 MFMA tiles), waves 8-11 loaders.  Two LDS stages; per slab one barrier.
+// Kernel: 256 x 128 output tile, 768 threads: waves 0-7 consumers (4 x 2, 64 x 64 each as 2 x 2 32x32x16 MFMA
+// tiles), waves 8-11 loaders.  NS LDS stages of KS-k slabs: the DMA round trip of a slab is ~2 us under load, as long
+// as a 32-k slab's MFMAs -- with two stages (one slab in flight) the kernel was latency bound (profiles/r03/gemm_planes.txt:
+// no-MFMA ablation 0.34 ms of 0.58); NS - 1 slabs are in flight now.
+// The consumers PING-PONG: waves w and w + 4 share a SIMD (and its matrix pipe); in every phase one of the two issues
+// MFMAs on operands it already holds in registers while the other reads its next operands from LDS, and a barrier
+// swaps the roles -- the matrix pipe never waits for an LDS read.  (With all eight waves in the same phase -- read,
+// then MFMA, then barrier -- the pipe idled ~0.8 us of every 32-k slab: 174 TFLOP/s instead of the ~235 the pipe sustains
+// on random operands, profiles/r03/gemm_planes.txt.)  PH = phases per slab and group: 2 (16 k of operands in
+// registers: 48 VGPRs for three planes) or 1 (32 k).
 #include "gemm_common.h"
 
 namespace {
@@ -55,20 +63,29 @@ struct PlP {
   GemmP g;                       // shapes, C / partial, epilogue options, tile mapping (A / B pointers unused)
   const char* Ap; int64_t a_ps; int64_t a_rows;      // plane 0 of the operand (at its first octet), plane stride [B], rows_alloc
   const char* Bp; int64_t b_ps; int64_t b_rows;
-  float out_scale;               // 2^-(ea+eb) for the scaled fp16 format, 1 otherwise
+  const float* a_scale; const float* b_scale;        // device scalars (powers of two) the planes were multiplied by, or null
+  int ablate;                    // experiments ($DGCNN_PL_ABLATE, wrong results): 1 no DMA after slab 1, 2 DMA of the same two slabs,
+                                 // 3 no MFMAs, 4 no LDS operand reads after the first
 };
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-template <int FORM, int FMT>
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// KS = reduction rows / channels per slab (16 or 32), NS = LDS stages (slabs landed or in flight)
+template <int FORM, int FMT, int KS, int NS>
 __global__ __launch_bounds__(768) void gemm_pl_kernel(PlP q) {
   using F = Fmt<FMT>;
   constexpr int BM = 256, BN = 128, TM = 2, TN = 2, NPL = F::NPL;
-  constexpr unsigned PA = BM * 64, PB = BN * 64;               // bytes per plane per 32-k slab (tile rows x 4 octets x 16 B)
+  constexpr int OS = KS / 8;                                   // octets per slab
+  constexpr int PH = KS / 16;                                  // 16-k MFMA steps (= ping-pong phase pairs) per slab
+  constexpr int NB = 2 * PH;                                   // barriers per slab
+  constexpr unsigned PA = BM * KS * 2, PB = BN * KS * 2;       // bytes per plane per slab
   constexpr unsigned STAGE = NPL * (PA + PB);
   constexpr unsigned EPI_BYTES = 128 * BN * 4;
-  constexpr unsigned LDS_BYTES = 2 * STAGE > EPI_BYTES ? 2 * STAGE : EPI_BYTES;
+  constexpr unsigned LDS_BYTES = NS * STAGE > EPI_BYTES ? NS * STAGE : EPI_BYTES;
   static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
   __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
   const GemmP& p = q.g;
@@ -83,21 +100,23 @@ __global__ __launch_bounds__(768) void gemm_pl_kernel(PlP q) {
   const int n0 = nt * BN;
   const int kbeg = z * p.kchunk;
   const int kend = (kbeg + p.kchunk < p.K) ? (kbeg + p.kchunk) : p.K;
-  const int nk = (kend - kbeg + 31) >> 5;                      // PL_TR: the last slab may run into the zero pad rows
+  const int nk = (kend - kbeg + KS - 1) / KS;                  // PL_TR: the last slab may run into the zero pad rows
 
   if (wv >= 8) {
-    // ------------------------------------------------------------------ loaders: 4 waves x NI/4 DMA instructions per slab
-    constexpr int NIA = NPL * 16, NIB = NPL * 8, NI = NIA + NIB, PER = NI / 4;
+    // ------------------------------------------------------------------ loaders: 4 waves x PER DMA instructions per slab
+    constexpr int NIA = NPL * 4 * OS, NIB = NPL * 2 * OS, NI = NIA + NIB, PER = NI / 4;
+    static_assert(NI % 4 == 0 && PER * (NS - 1) < 64, "DMA instructions per wave");
     const int lw = __builtin_amdgcn_readfirstlane(wv - 8);
     const char* src[PER];
     unsigned dst[PER];
-    unsigned ok = 0;
+    // (every instruction is always issued -- out-of-range rows / octets read a clamped, valid address and feed output rows
+    //  the epilogue drops -- so that every slab counts exactly PER on this wave's vmcnt)
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
       const int e = lw + 4 * i;                                // wave-uniform
       const bool isA = e < NIA;
       const int ee = isA ? e : e - NIA;
-      const int per_plane = isA ? 16 : 8;
+      const int per_plane = isA ? 4 * OS : 2 * OS;
       const int pl = ee / per_plane, r = ee % per_plane;
       const char* base = (isA ? q.Ap + pl * q.a_ps : q.Bp + pl * q.b_ps);
       const int64_t rows = isA ? q.a_rows : q.b_rows;
@@ -108,43 +127,56 @@ __global__ __launch_bounds__(768) void gemm_pl_kernel(PlP q) {
         const int nrb = isA ? 4 : 2;
         const int c = r / nrb, rb = r % nrb;
         const int64_t row = row0 + rb * 64;
-        if (row < rows) ok |= 1u << i;
         const int64_t rowc = row < rows ? row : 0;
         src[i] = base + (((int64_t)(kbeg >> 3) + c) * rows + rowc + lane) * 16;
         dst[i] = pbase + (unsigned)((c * (isA ? BM : BN) + rb * 64) * 16);
       } else {
-        // two channel octets x 32 reduction rows; slot (octet cidx, row r) at cidx * 32 + (r ^ 4 (cidx & 3)): the XOR
+        // 64 / KS channel octets x KS reduction rows; slot (octet cidx, row r) at cidx * KS + (r ^ 4 (cidx & 3)): the XOR
         // spreads the four octets a transpose-read touches over the four 64-byte quarters of a bank row
-        const int cidx = 2 * r + (lane >> 5);                  // tile-local octet
-        const int rr = (lane & 31) ^ (4 * (cidx & 3));
+        constexpr int OPI = 64 / KS;                           // octets per instruction
+        const int cidx = OPI * r + lane / KS;                  // tile-local octet
+        const int rr = (lane & (KS - 1)) ^ (4 * (cidx & 3));
         const int64_t oct = (row0 >> 3) + cidx;
         const int64_t noct = ((isA ? p.M : p.N) + 7) >> 3;
-        if ((int64_t)(row0 >> 3) + 2 * r < noct) ok |= 1u << i;        // (M, N multiples of 16: an instruction's two octets are both in or both out)
         const int64_t octc = oct < noct ? oct : 0;
         src[i] = base + (octc * rows + kbeg + rr) * 16;
         dst[i] = pbase + (unsigned)(r * 64 * 16);
       }
     }
-    const int64_t stepA = (FORM == PL_KC) ? q.a_rows * 64 : 512;       // bytes per slab
-    const int64_t stepB = (FORM == PL_KC) ? q.b_rows * 64 : 512;
-    auto issue = [&](int buf, int slab) {
+    const int64_t stepA = (FORM == PL_KC) ? q.a_rows * 16 * OS : KS * 16;       // bytes per slab
+    const int64_t stepB = (FORM == PL_KC) ? q.b_rows * 16 * OS : KS * 16;
+    auto issue = [&](int slab) {
+      const int buf = slab % NS;
+      const int sl = q.ablate == 2 ? buf : slab;
 #pragma unroll
       for (int i = 0; i < PER; ++i) {
         const bool isA = (lw + 4 * i) < NIA;
-        if ((ok >> i) & 1u) {
-          const char* s = src[i] + (int64_t)slab * (isA ? stepA : stepB);
-          char* d = smem + buf * STAGE + dst[i];
-          __builtin_amdgcn_global_load_lds((gptr_t)s, (lptr_t)d, 16, 0, 0);
-        }
+        const char* s = src[i] + (int64_t)sl * (isA ? stepA : stepB);
+        char* d = smem + buf * STAGE + dst[i];
+        __builtin_amdgcn_global_load_lds((gptr_t)s, (lptr_t)d, 16, 0, 0);
       }
     };
-    issue(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // wait until at most `later` of the most recently issued slabs are still in flight (DMA completes in issue order)
+    auto wait_all_but = [&](int later) {
+      if (NS >= 4 && later >= 3) wait_vmcnt<(NS >= 4 ? 3 : 0) * PER>();
+      else if (NS >= 3 && later == 2) wait_vmcnt<(NS >= 3 ? 2 : 0) * PER>();
+      else if (later == 1) wait_vmcnt<PER>();
+      else wait_vmcnt<0>();
+    };
+    static_assert(NS <= 5, "wait_all_but covers up to 3 slabs behind the awaited one");
+    // slab u lives in stage u % NS; it is read during the NB phases of its period (group 0) and one phase later (group 1).
+    // At the start of period u the stage of slab u - 1 is free: slab u - 1 + NS goes there.  Slab u + 1 must have landed
+    // by the last barrier of period u.
+    int issued = 0;                                  // slabs issued so far
+    for (; issued < NS - 1 && issued < nk; ++issued) issue(issued);
+    wait_all_but(issued - 1);
     __syncthreads();
 #pragma unroll 1
     for (int kt = 0; kt < nk; ++kt) {
-      if (kt + 1 < nk) issue((kt + 1) & 1, kt + 1);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (issued < nk && !(q.ablate == 1 && kt >= 1)) { issue(issued); ++issued; }
+#pragma unroll
+      for (int bb = 0; bb < NB - 1; ++bb) __syncthreads();
+      wait_all_but(issued - (kt + 2) > 0 ? issued - (kt + 2) : 0);        // slabs after kt + 1 may still be in flight
       __syncthreads();
     }
     return;
@@ -161,8 +193,9 @@ __global__ __launch_bounds__(768) void gemm_pl_kernel(PlP q) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  // per-lane LDS offsets of the operand reads
+  // per-lane LDS offsets of the operand reads (16-k step s of the slab: + s * SSTEP)
   unsigned a_off[TM][2], b_off[TN][2];
+  constexpr unsigned SSTEP_A = (FORM == PL_KC) ? 2 * BM * 16 : 256, SSTEP_B = (FORM == PL_KC) ? 2 * BN * 16 : 256;
   if (FORM == PL_KC) {
 #pragma unroll
     for (int i = 0; i < TM; ++i) a_off[i][0] = a_off[i][1] = (unsigned)((lh * BM + wr * 64 + i * 32 + l31) * 16);
@@ -179,66 +212,85 @@ __global__ __launch_bounds__(768) void gemm_pl_kernel(PlP q) {
       const int x = ((2 * kh + tt) ^ cb3);                     // swizzled (k row >> 2) & 3
 #pragma unroll
       for (int i = 0; i < TM; ++i)
-        a_off[i][tt] = (unsigned)(((wr * 8 + i * 4 + cb3) * 32 + x * 4 + jj) * 16 + (qq & 1) * 8);
+        a_off[i][tt] = (unsigned)(((wr * 8 + i * 4 + cb3) * KS + x * 4 + jj) * 16 + (qq & 1) * 8);
 #pragma unroll
       for (int j = 0; j < TN; ++j)
-        b_off[j][tt] = NPL * PA + (unsigned)(((wc * 8 + j * 4 + cb3) * 32 + x * 4 + jj) * 16 + (qq & 1) * 8);
+        b_off[j][tt] = NPL * PA + (unsigned)(((wc * 8 + j * 4 + cb3) * KS + x * 4 + jj) * 16 + (qq & 1) * 8);
     }
   }
 
-  __syncthreads();                                 // stage 0 landed
-#pragma unroll 1
-  for (int kt = 0; kt < nk; ++kt) {
-    const char* base = smem + (kt & 1) * STAGE;
-    s16x8 a[2][TM][NPL], b[2][TN][NPL];
+  const int grp = wv >> 2;                         // waves w and w + 4 sit on the same SIMD: group 1 runs one phase behind
+  s16x8 a[TM][NPL], b[TN][NPL];
+  auto load_ops = [&](const char* base, int s) {
 #pragma unroll
-    for (int s = 0; s < 2; ++s)
+    for (int pl = 0; pl < NPL; ++pl) {
+      if (FORM == PL_KC) {
 #pragma unroll
-      for (int pl = 0; pl < NPL; ++pl) {
-        if (FORM == PL_KC) {
+        for (int i = 0; i < TM; ++i)
+          a[i][pl] = *reinterpret_cast<const s16x8*>(base + pl * PA + a_off[i][0] + s * SSTEP_A);
 #pragma unroll
-          for (int i = 0; i < TM; ++i)
-            a[s][i][pl] = *reinterpret_cast<const s16x8*>(base + pl * PA + a_off[i][0] + s * 2 * BM * 16);
+        for (int j = 0; j < TN; ++j)
+          b[j][pl] = *reinterpret_cast<const s16x8*>(base + pl * PB + b_off[j][0] + s * SSTEP_B);
+      } else {
 #pragma unroll
-          for (int j = 0; j < TN; ++j)
-            b[s][j][pl] = *reinterpret_cast<const s16x8*>(base + pl * PB + b_off[j][0] + s * 2 * BN * 16);
-        } else {
+        for (int i = 0; i < TM; ++i) {
+          const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + pl * PA + a_off[i][0] + s * SSTEP_A));
+          const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + pl * PA + a_off[i][1] + s * SSTEP_A));
+          a[i][pl] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        }
 #pragma unroll
-          for (int i = 0; i < TM; ++i) {
-            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + pl * PA + a_off[i][0] + s * 256));
-            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + pl * PA + a_off[i][1] + s * 256));
-            a[s][i][pl] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-          }
-#pragma unroll
-          for (int j = 0; j < TN; ++j) {
-            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + pl * PB + b_off[j][0] + s * 256));
-            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + pl * PB + b_off[j][1] + s * 256));
-            b[s][j][pl] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-          }
+        for (int j = 0; j < TN; ++j) {
+          const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + pl * PB + b_off[j][0] + s * SSTEP_B));
+          const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + pl * PB + b_off[j][1] + s * SSTEP_B));
+          b[j][pl] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
         }
       }
+    }
+  };
+  auto compute = [&]() {
     // partial products, largest first: (1,1) (1,2) (2,1) (2,2) (1,3) (3,1)
     constexpr int PRA[6] = {0, 0, 1, 1, 0, 2};
     constexpr int PRB[6] = {0, 1, 0, 1, 2, 0};
 #pragma unroll
-    for (int s = 0; s < 2; ++s)
+    for (int pr = 0; pr < F::NP; ++pr)
 #pragma unroll
-      for (int pr = 0; pr < F::NP; ++pr)
+      for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int j = 0; j < TN; ++j)
-            acc[i][j] = F::mfma(a[s][i][PRA[pr]], b[s][j][PRB[pr]], acc[i][j]);
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = F::mfma(a[i][PRA[pr]], b[j][PRB[pr]], acc[i][j]);
+  };
+
+  // phase boundary: nothing may be scheduled across it (the compiler otherwise pulls the MFMAs above the barrier, next to
+  // the LDS reads that feed them, and the two waves of a SIMD end up reading and multiplying in the same phase again)
+  auto phase_barrier = [&]() {
+    __builtin_amdgcn_sched_barrier(0);
     __syncthreads();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  __syncthreads();                                 // slab 0 landed
+  if (grp) phase_barrier();                        // group 1 idles through phase 0
+  int stage = 0;
+#pragma unroll 1
+  for (int kt = 0; kt < nk; ++kt) {
+    const char* base = smem + stage * STAGE;
+    stage = (stage + 1 == NS) ? 0 : stage + 1;
+#pragma unroll
+    for (int h = 0; h < PH; ++h) {
+      if (!(q.ablate == 4 && kt > 0)) load_ops(base, h);
+      phase_barrier();
+      if (q.ablate != 3) compute();
+      if (!(grp && kt == nk - 1 && h == PH - 1)) phase_barrier();      // (group 1's last compute is the kernel's last phase)
+    }
   }
 
-  if (q.out_scale != 1.f) {
+  if (q.a_scale || q.b_scale) {                    // planes hold x * scale (powers of two): exact rescaling of the result
+    const float os = 1.f / ((q.a_scale ? *q.a_scale : 1.f) * (q.b_scale ? *q.b_scale : 1.f));
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
       for (int j = 0; j < TN; ++j)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][j][r] *= q.out_scale;
+        for (int r = 0; r < 16; ++r) acc[i][j][r] *= os;
   }
   gemm_epilogue<E_STORE, BM, BN, true, TM, TN, 4, 512>(p, acc, reinterpret_cast<float*>(smem), m0, n0, mt, z, t, wr, wc, l31, lh);
 }
@@ -358,6 +410,36 @@ __global__ __launch_bounds__(256) void split_strided_kernel(const float* __restr
   for (int pl = 0; pl < NPL; ++pl) *reinterpret_cast<uint4*>(dst + pl * plane_stride + item * 16) = o[pl];
 }
 
+// max |x| over a 2-D view -> the power of two that brings it to [2^14, 2^15) (fp16 planes keep 22 significant bits of every
+// element down to 2^-17 of the tensor's largest and an absolute 2^-40 of it below that; 65504 is never exceeded)
+__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ src, int64_t ld, int64_t rows, int cols,
+                                                     unsigned* __restrict__ out_bits) {
+  const int64_t n4 = (int64_t)rows * (cols >> 2);
+  float m = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    const int64_t r = i / (cols >> 2);
+    const int c = (int)(i % (cols >> 2)) * 4;
+    const float4 v = *reinterpret_cast<const float4*>(src + r * ld + c);
+    m = fmaxf(m, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(out_bits, __float_as_uint(m));     // non-negative floats order like their bit patterns
+}
+
+__global__ void scale_from_max_kernel(const unsigned* __restrict__ max_bits, float bound_mul, float* __restrict__ scale) {
+  const float m = __uint_as_float(*max_bits) * bound_mul;
+  float s = 1.f;
+  if (m > 0.f && m < INFINITY) {
+    int e;
+    frexpf(m, &e);                       // m = f * 2^e, f in [0.5, 1)  ->  m * 2^(15 - e) in [2^14, 2^15)
+    int sh = 15 - e;
+    sh = sh > 100 ? 100 : (sh < -100 ? -100 : sh);
+    s = ldexpf(1.f, sh);
+  }
+  *scale = s;
+}
+
 inline bool aligned16p(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
 
 }  // namespace
@@ -393,13 +475,27 @@ extern "C" int dgcnn_split_planes_f32(const float* src, int64_t row_stride, int6
   return dg::check_launch("dgcnn_split_planes_f32");
 }
 
+// scale <- power of two for a DGCNN_PLANES_F16X2 split of the view (max |x| * bound_mul lands in [2^14, 2^15)); ws = 4 bytes
+extern "C" int dgcnn_planes_scale_f32(const float* src, int64_t ld, int64_t rows, int cols, float bound_mul, float* scale_dev,
+                                      void* ws, void* stream) {
+  DG_REQUIRE(src && scale_dev && ws && rows > 0 && cols > 0 && cols % 4 == 0 && ld % 4 == 0 && aligned16p(src), DGCNN_EINVAL,
+             "dgcnn_planes_scale_f32: bad args (float4-loadable view needed)");
+  (void)hipMemsetAsync(ws, 0, 4, ST);
+  const int64_t n4 = rows * (cols / 4);
+  const unsigned g = (unsigned)(dg::cdiv(n4, 256 * 8) < 2048 ? dg::cdiv(n4, 256 * 8) : 2048);
+  hipLaunchKernelGGL(absmax_kernel, dim3(g ? g : 1), dim3(256), 0, ST, src, ld, rows, cols, (unsigned*)ws);
+  hipLaunchKernelGGL(scale_from_max_kernel, dim3(1), dim3(1), 0, ST, (const unsigned*)ws, bound_mul, scale_dev);
+  return dg::check_launch("dgcnn_planes_scale_f32");
+}
+
 // C (M x N, fp32) (+)= A B^T-style product of two plane sets.
 //   form = DGCNN_PL_KC: A rows = M, B rows = N, both reduce over their K channels (K % 32 == 0; plane pointers at the first octet)
 //   form = DGCNN_PL_TR: A channels = M, B channels = N (both % 16 == 0), both reduce over their K rows (pad rows are zero)
 extern "C" int dgcnn_gemm_planes_f32(int form, int fmt, int M, int N, int K,
                                      const void* A, int64_t a_plane_stride, int64_t a_rows_alloc,
                                      const void* B, int64_t b_plane_stride, int64_t b_rows_alloc,
-                                     float* C, int64_t ldc, float beta, float out_scale,
+                                     const float* a_scale_dev, const float* b_scale_dev,
+                                     float* C, int64_t ldc, float beta,
                                      const float* gbias, int64_t ldgbias, int rows_per_group,
                                      double* stats, void* ws, size_t ws_bytes, void* stream) {
   DG_REQUIRE(A && B && C && M > 0 && N > 0 && K > 0, DGCNN_EINVAL, "dgcnn_gemm_planes_f32: bad args");
@@ -417,14 +513,15 @@ extern "C" int dgcnn_gemm_planes_f32(int form, int fmt, int M, int N, int K,
   p.splits = 1; p.kchunk = K; p.bm = 256;
   q.Ap = (const char*)A; q.a_ps = a_plane_stride; q.a_rows = a_rows_alloc;
   q.Bp = (const char*)B; q.b_ps = b_plane_stride; q.b_rows = b_rows_alloc;
-  q.out_scale = out_scale;
+  q.a_scale = a_scale_dev; q.b_scale = b_scale_dev;
+  { static int ab = -1; if (ab < 0) { const char* e = getenv("DGCNN_PL_ABLATE"); ab = e ? atoi(e) : 0; } q.ablate = ab; }
   p.mtiles = (int)dg::cdiv(M, 256);
   p.ntiles = (int)dg::cdiv(N, 128);
   if (form == DGCNN_PL_KC) {
     DG_REQUIRE(K % 32 == 0, DGCNN_EUNSUP, "dgcnn_gemm_planes_f32(KC): K %% 32 != 0 (%d)", K);
     DG_REQUIRE(M <= a_rows_alloc && N <= b_rows_alloc, DGCNN_EINVAL, "dgcnn_gemm_planes_f32(KC): rows_alloc smaller than the operand");
   } else {
-    DG_REQUIRE(M % 16 == 0 && N % 16 == 0, DGCNN_EUNSUP, "dgcnn_gemm_planes_f32(TR): M, N must be multiples of 16 (%d, %d)", M, N);
+    DG_REQUIRE(M % 32 == 0 && N % 32 == 0, DGCNN_EUNSUP, "dgcnn_gemm_planes_f32(TR): M, N must be multiples of 32 (%d, %d)", M, N);
     DG_REQUIRE(a_rows_alloc == b_rows_alloc && K <= a_rows_alloc, DGCNN_EINVAL, "dgcnn_gemm_planes_f32(TR): both operands must share rows_alloc >= K");
     DG_REQUIRE(!gbias && !stats, DGCNN_EUNSUP, "dgcnn_gemm_planes_f32(TR): bias / statistics unsupported");
     // split the reduction over the rows: every k-chunk pinned to one XCD (gemm_common.h:block_tile), whole rounds of 32 workgroups
@@ -455,7 +552,8 @@ extern "C" int dgcnn_gemm_planes_f32(int form, int fmt, int M, int N, int K,
   const unsigned gx = p.xcd_group ? (unsigned)(dg::cdiv(p.mtiles, 8) * 8 * p.ntiles) : (unsigned)(p.mtiles * p.ntiles);
   dim3 grid(gx, 1, 1);
   if (p.zmajor) grid = dim3((unsigned)(dg::cdiv(p.splits, 8) * 8 * p.mtiles * p.ntiles), 1, 1);
-#define DG_PL(FORM, FMT) hipLaunchKernelGGL((gemm_pl_kernel<FORM, FMT>), grid, dim3(768), 0, ST, q)
+  // bf16x3: 16-k slabs x 4 stages (36 KB each), f16x2: 32-k slabs x 3 stages (48 KB each): up to 108 / 96 KB of DMA in flight per CU
+#define DG_PL(FORM, FMT) hipLaunchKernelGGL((gemm_pl_kernel<FORM, FMT, (FMT == DGCNN_PLANES_BF16X3 ? 16 : 32), (FMT == DGCNN_PLANES_BF16X3 ? 4 : 3)>), grid, dim3(768), 0, ST, q)
   if (form == DGCNN_PL_KC) { if (fmt == DGCNN_PLANES_BF16X3) DG_PL(PL_KC, DGCNN_PLANES_BF16X3); else DG_PL(PL_KC, DGCNN_PLANES_F16X2); }
   else { if (fmt == DGCNN_PLANES_BF16X3) DG_PL(PL_TR, DGCNN_PLANES_BF16X3); else DG_PL(PL_TR, DGCNN_PLANES_F16X2); }
 #undef DG_PL

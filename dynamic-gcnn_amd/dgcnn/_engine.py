@@ -28,6 +28,7 @@ import numpy as np
 import torch
 
 from . import _hip as H
+from . import _planes as PL
 
 BN_EPS = 1e-3          # slim.batch_norm default epsilon [TF1-lib]
 DROPOUT_KEEP = 0.7     # tf.nn.dropout(net, 0.7): dgcnn/model.py:91
@@ -48,6 +49,16 @@ SCATTER_ATOMICS = False  # True: dx_j += dY W^T by fp32 atomics in the GEMM epil
 # with atomics (they feed nothing back).
 DETERMINISTIC_ENV_DEFAULT = os.environ.get("DGCNN_DETERMINISTIC", "0") not in ("0", "")
 DETERMINISTIC = DETERMINISTIC_ENV_DEFAULT      # trainval.initialize() sets it per instance (flag, else this default)
+
+
+# Head GEMMs (MergedEdgeConv, FC0, FC1: 98 % of the step's GEMM flops) from pre-split operand planes (csrc/gemm_pl.hip):
+#   "f16"  two fp16 planes per operand, 3 partial products   "bf16"  three bf16 planes, 6 partial products   "0"  off
+HEAD_PLANES = {"f16": PL.F16X2, "bf16": PL.BF16X3}.get(os.environ.get("DGCNN_HEAD_PLANES", "0").lower())
+PLANES_MIN_ROWS = 8192
+
+
+def planes_ok(R, Cin, Cout):
+    return HEAD_PLANES is not None and R >= PLANES_MIN_ROWS and Cin % 32 == 0 and Cout % 32 == 0 and Cout >= 128 and Cin >= 128
 
 
 class Context(object):
@@ -404,7 +415,14 @@ def conv_bn_act(x, leaf_scope, num_outputs, relu=True, out=None, out2=None, gbia
     F = num_outputs
     T = torch.empty((R, F), dtype=torch.float32, device=x.device)
     st = c.stats(F)
-    gemm(x, Wx, T, gbias=gbias, rpg=rpg, stats=None if DETERMINISTIC else st, arith=arith)
+    use_pl = arith is None and planes_ok(R, Cin, F)
+    xp = None
+    if use_pl:
+        xp = PL.from_f32(x, HEAD_PLANES)                               # (R, Cin) activations
+        wt = PL.from_f32(Wx, HEAD_PLANES, transpose=True)              # (F rows, Cin channels) = W^T
+        PL.gemm(PL.KC, xp, wt, T, gbias=gbias, rpg=rpg, stats=None if DETERMINISTIC else st)
+    else:
+        gemm(x, Wx, T, gbias=gbias, rpg=rpg, stats=None if DETERMINISTIC else st, arith=arith)
     if DETERMINISTIC:
         colstats_det(T, st)
     mean, rstd = bn_finalize(st, F, R)
@@ -431,11 +449,19 @@ def conv_bn_act(x, leaf_scope, num_outputs, relu=True, out=None, out2=None, gbia
                    c.var_grads[bname].data_ptr(), 1.0, tag="bn_bwd_apply_kernel<k=1>", work=4.0 * R * F * 3)
             dT = T
             dWx = c.var_grads[wname] if w_rows is None else c.var_grads[wname][w_rows[0]:w_rows[1]]
-            with c.off_critical_path(rows=R):
-                gemm(x, dT, dWx, transA=True, beta=1.0, arith=arith)   # dW += x^T dT
             dx, bx = c.grad_w(x)
-            if dx is not None:
-                gemm(dT, Wx, dx, transB=True, beta=bx, arith=arith)    # dx (+)= dT W^T
+            if use_pl:
+                dTp = PL.from_f32(dT, HEAD_PLANES)
+                with c.off_critical_path(*[t for t in (dTp.buf, dTp.scale) if t is not None], rows=R):
+                    PL.gemm(PL.TR, xp, dTp, dWx, beta=1.0, ws=c.workspace())           # dW += x^T dT
+                if dx is not None:
+                    wd = PL.from_f32(Wx, HEAD_PLANES)                                    # (Cin rows, F channels)
+                    PL.gemm(PL.KC, dTp, wd, dx, beta=bx)                                 # dx (+)= dT W^T
+            else:
+                with c.off_critical_path(rows=R):
+                    gemm(x, dT, dWx, transA=True, beta=1.0, arith=arith)   # dW += x^T dT
+                if dx is not None:
+                    gemm(dT, Wx, dx, transB=True, beta=bx, arith=arith)    # dx (+)= dT W^T
             if gbias is not None:
                 dgb = c.grad(gbias)
                 if dgb is not None:                                     # tf.tile^T: sum over the cloud

@@ -33,8 +33,7 @@ class PlaneSet(object):
         mk = torch.zeros if zero else torch.empty
         self.buf = mk(n, dtype=torch.uint8, device=device)
         self.c0 = 0                   # first channel of this view (views share `buf`)
-        self.scale = None             # F16X2: device float holding the power-of-two scale, and its host value
-        self.scale_host = 1.0
+        self.scale = None             # F16X2: device float holding the power-of-two scale the planes were multiplied by
 
     def ptr(self):
         return self.buf.data_ptr() + (self.c0 // 8) * self.ra * 16
@@ -56,9 +55,27 @@ class PlaneSet(object):
         if (r, c) != (self.rows, self.cols):
             raise ValueError("PlaneSet.fill_from: source is %s, the set holds (%d, %d)" % (tuple(src.shape), self.rows, self.cols))
         rs, cs = (1, H.ld2(src)) if transpose else (H.ld2(src), 1)
+        if self.fmt == F16X2 and self.scale is None:
+            self.measure_scale(src)
         H.call("dgcnn_split_planes_f32", src.data_ptr(), rs, cs, self.rows, self.cols, self.fmt, H._p(self.scale), self.ptr(),
                self.plane_stride, self.ra, tag="split_planes_kernel",
                work=4.0 * self.rows * self.cols + 2.0 * NPLANES[self.fmt] * self.ra * self.cols)
+        return self
+
+
+    def measure_scale(self, src, bound_mul=1.0):
+        """F16X2: scale <- the power of two that brings max |src| (times bound_mul) into [2^14, 2^15), computed on the device."""
+        self.scale = torch.empty(1, dtype=torch.float32, device=src.device)
+        ws = torch.empty(1, dtype=torch.int32, device=src.device)
+        if src.shape[1] % 4 == 0 and H.ld2(src) % 4 == 0 and src.data_ptr() % 16 == 0 and src.stride(1) == 1:
+            v = src
+        else:                                   # (small odd-shaped tensors: weights with an unaligned view)
+            v = src.contiguous().view(1, -1)
+            pad = (-v.shape[1]) % 4
+            if pad:
+                v = torch.cat([v, v.new_zeros(1, pad)], 1)
+        H.call("dgcnn_planes_scale_f32", v.data_ptr(), H.ld2(v), v.shape[0], v.shape[1], float(bound_mul), self.scale.data_ptr(),
+               ws.data_ptr())
         return self
 
 
@@ -81,9 +98,8 @@ def gemm(form, A, B, C, beta=0.0, gbias=None, rpg=0, stats=None, ws=None):
         if B.rows != K:
             raise ValueError("plane GEMM (TR): A has %d rows, B %d" % (K, B.rows))
     assert tuple(C.shape) == (M, N), (tuple(C.shape), M, N)
-    out_scale = 1.0 / (A.scale_host * B.scale_host)
     H.call("dgcnn_gemm_planes_f32", form, A.fmt, M, N, K, A.ptr(), A.plane_stride, A.ra, B.ptr(), B.plane_stride, B.ra,
-           C.data_ptr(), H.ld2(C), float(beta), float(out_scale), H._p(gbias), 0 if gbias is None else H.ld2(gbias), int(rpg),
+           H._p(A.scale), H._p(B.scale), C.data_ptr(), H.ld2(C), float(beta), H._p(gbias), 0 if gbias is None else H.ld2(gbias), int(rpg),
            H._p(stats), H._p(ws), 0 if ws is None else ws.numel(),
            tag="gemm_pl_kernel<%s,%s>" % ("KC" if form == KC else "TR", "bf16x3" if A.fmt == BF16X3 else "f16x2"),
            work=2.0 * M * N * K)

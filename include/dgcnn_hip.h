@@ -173,8 +173,9 @@ int dgcnn_gemm_f32(int transA, int transB, int M, int N, int K,
  *     base + p * plane_stride + ((c / 8) * rows_alloc + row) * 16 + (c % 8) * 2        [bytes]
  * rows_alloc = rows rounded up to 64, pad rows are zero.
  *   DGCNN_PLANES_BF16X3: x = x1 + x2 + x3 exactly (3 bf16 planes), 6 partial products (== dgcnn_gemm_f32 arithmetic 6)
- *   DGCNN_PLANES_F16X2 : x * scale = h1 + h2 (2 fp16 planes; scale = a power of two read from scale_dev), 3 partial
- *                        products; the caller passes out_scale = 1 / (scale_A * scale_B).
+ *   DGCNN_PLANES_F16X2 : x * scale = h1 + h2 (2 fp16 planes; scale = a power of two read from scale_dev, chosen so that
+ *                        max |x| * scale < 2^15: dgcnn_planes_scale_f32 or a producer's analytic bound), 3 partial products;
+ *                        the GEMM divides its result by scale_A * scale_B (device scalars, exact).
  * dgcnn_split_planes_f32: plane element (row, c) = src[row * row_stride + c * col_stride]  (col_stride 1 = an activation
  *   view; row_stride 1 = the transpose of a row-major matrix, for weights).
  * dgcnn_gemm_planes_f32:  C[M][N] (+= beta C) = sum_k A(m,k) B(n,k)
@@ -185,12 +186,15 @@ int dgcnn_gemm_f32(int transA, int transB, int M, int N, int K,
 #define DGCNN_PLANES_F16X2 1
 #define DGCNN_PL_KC 0
 #define DGCNN_PL_TR 1
+int dgcnn_planes_scale_f32(const float* src, int64_t ld, int64_t rows, int cols, float bound_mul, float* scale_dev,
+                           void* ws, void* stream);
 int dgcnn_split_planes_f32(const float* src, int64_t row_stride, int64_t col_stride, int64_t rows, int cols, int fmt,
                            const float* scale_dev, void* dst, int64_t plane_stride, int64_t rows_alloc, void* stream);
 int dgcnn_gemm_planes_f32(int form, int fmt, int M, int N, int K,
                           const void* A, int64_t a_plane_stride, int64_t a_rows_alloc,
                           const void* B, int64_t b_plane_stride, int64_t b_rows_alloc,
-                          float* C, int64_t ldc, float beta, float out_scale,
+                          const float* a_scale_dev, const float* b_scale_dev,
+                          float* C, int64_t ldc, float beta,
                           const float* gbias, int64_t ldgbias, int rows_per_group,
                           double* stats, void* ws, size_t ws_bytes, void* stream);
 

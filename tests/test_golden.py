@@ -74,6 +74,43 @@ def test_hip_knn_matches_golden(name):
 
 
 @pytest.mark.gpu
+def test_hip_edge_conv_matches_golden():
+    """G6: edge_conv forward (max, mean, net; the reference's list contract ops.py:73) and backward
+    (d point_cloud, dW0, dbeta0, dW1, dbeta1) of the HIP path against the stored float64 vectors."""
+    import dgcnn
+    from dgcnn import _engine as E
+    g = load("g6_edge_conv")
+    B, N, C = g["points"].shape
+    k, F = int(g["k"]), g["W0"].shape[1]
+    dgcnn.reset()
+    c = dgcnn.ctx()
+    c.begin_step()
+    c.recording = True
+    x = c.new_buffer(B * N, C)                                   # tracked, so that d(point_cloud) is produced
+    x.copy_(_dev(g["points"].reshape(B * N, C)))
+    P = {"conv0/weights": g["W0"], "conv0/BatchNorm/beta": g["beta0"], "conv1/weights": g["W1"], "conv1/BatchNorm/beta": g["beta1"]}
+    for n, v in P.items():
+        c.get_variable(n, v.shape)
+        c.set_variable(n, v)
+    outs = dgcnn.ops.edge_conv(x.view(B, N, C), k, F, True)
+    np.testing.assert_array_equal(dgcnn.ops.edge_conv.last_idx.cpu().numpy(), g["idx"])             # bit-exact graph
+    assert len(outs) == 3
+    for t, name in zip(outs, ("net_max", "net_mean", "net")):
+        assert tuple(t.shape) == g[name].shape
+        np.testing.assert_allclose(t.cpu().numpy(), g[name], rtol=1e-4, atol=1e-4, err_msg=name)
+    for t, name in zip(outs, ("d_max", "d_mean", "d_net")):
+        v, _, _ = E.as2d(t)
+        c.grad(v).copy_(_dev(g[name].reshape(B * N, -1).astype(np.float32)))
+    c.backward()
+    tol = lambda r: dict(rtol=1e-3, atol=1e-3 * max(1.0, float(np.abs(r).max())))
+    np.testing.assert_allclose(c.grad(x).cpu().numpy().reshape(B, N, C), g["dx"], err_msg="dx", **tol(g["dx"]))
+    for n, key in (("conv0/weights", "dW0"), ("conv0/BatchNorm/beta", "dbeta0"), ("conv1/weights", "dW1"),
+                   ("conv1/BatchNorm/beta", "dbeta1")):
+        np.testing.assert_allclose(c.var_grads[n].cpu().numpy(), g[key], err_msg=n, **tol(g[key]))
+    dgcnn.reset()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("name", ["g7_model_config1", "g8_model_residual"])
 def test_hip_model_matches_golden(name):
     import dgcnn

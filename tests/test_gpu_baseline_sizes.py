@@ -130,8 +130,11 @@ def _oracle_three_way(pts, flags, params, idx_list, logits, what):
     print("%s, same graphs: logits max|diff|  HIP vs fp64 twin %.3e (mean %.1e) | fp32 oracle vs fp64 twin %.3e (mean %.1e) | "
           "HIP vs fp32 oracle %.3e" % (what, e_hip.max(), e_hip.mean(), e_o32.max(), e_o32.mean(), e_h32.max()))
     np.testing.assert_allclose(logits, ref64, rtol=0, atol=1e-3)                     # north_star bar, against exact arithmetic
-    # against the fp32 restatement the bar is 1e-3 + that restatement's OWN deviation from exact arithmetic
-    assert e_h32.max() <= 1e-3 + e_o32.max(), (e_h32.max(), e_o32.max())
+    # ... and, plainly, against the float32 restatement of the reference (the "reference fp32 CPU path" stand-in): with its
+    # BatchNorm-axis reductions in a defined tree order (oracle.tree_colsum) it sits 2e-5 from the twin at this size
+    # (profiles/r03/oracle_reduction.txt; round 2's running float32 sums: 1.3e-3 .. 1.9e-3)
+    np.testing.assert_allclose(logits, ref32, rtol=0, atol=1e-3)
+    assert e_o32.max() <= 2e-4, e_o32.max()
     return ref64
 
 
@@ -182,8 +185,9 @@ def test_config1_full_size_logits_and_dynamic_graphs(dg):
     assert max(hip) <= 1.5 * max(o32) + 2e-3, (hip, o32)    # no worse than a reference-grade fp32 evaluation
     # end to end no fp32 evaluation stays within 1e-3 of another everywhere: a row whose neighbour set differs changes its
     # own logits at O(0.1) and, through the global max-pool feature and the BatchNorm statistics, nudges its whole cloud
-    # (measured: HIP 81 .. 90 % of the logits within 1e-3 of the twin run to run, the fp32 numpy restatement 62 %)
-    assert w_hip >= w_o32 - 5e-3 and w_hip > 0.6, (w_hip, w_o32)
+    # (measured: HIP 81 .. 90 % of the logits within 1e-3 of the twin run to run; the fp32 numpy restatement 62 % with
+    # running float32 BatchNorm sums (round 2), 91 % with the tree-ordered sums it uses now)
+    assert w_hip >= w_o32 - 0.12 and w_hip > 0.6, (w_hip, w_o32)
 
 
 GRAD_BAR = 5e-3     # relative Frobenius vs the float64 twin (measured 1.0e-3 .. 2.2e-3 at full size, profiles/r02/grad_error_3way.txt)
@@ -191,9 +195,9 @@ GRAD_BAR = 5e-3     # relative Frobenius vs the float64 twin (measured 1.0e-3 ..
 
 def test_config1_full_size_training_step(dg):
     """One full training micro-step at (24,2048,20,3) with dropout off, the HIP graphs fed to the oracle: loss within 1e-4
-    and EVERY gradient tensor within 5e-3 (relative Frobenius) of the float64 twin -- and closer to it than the fp32
-    numpy restatement is (2e-2 .. 4e-2: numpy's float32 BatchNorm reductions over 983040 rows; the HIP path
-    accumulates its statistics in fp64) -- then the Adam step."""
+    and EVERY gradient tensor within 5e-3 (relative Frobenius) of the float64 twin; so is the float32 oracle (tree-ordered
+    BatchNorm sums: 2e-3 .. 4e-3; round 2's running float32 sums over 983040 rows: 2e-2 .. 4e-2), and the two float32
+    evaluations agree within 1e-2 -- then the Adam step."""
     B, N, C = 24, 2048, 3
     flags = config1_flags(dg, train=True)
     rng = np.random.default_rng(1)
@@ -217,7 +221,10 @@ def test_config1_full_size_training_step(dg):
     print("configs[1] full size, relative Frobenius gradient error vs the fp64 twin: HIP worst %.2e (%s) | fp32 oracle worst %.2e"
           % (max(r_hip.values()), max(r_hip, key=r_hip.get), max(r_o32.values())))
     assert max(r_hip.values()) < GRAD_BAR, r_hip
-    assert max(r_hip.values()) < max(r_o32.values())
+    assert max(r_o32.values()) < GRAD_BAR, r_o32          # the fp32 oracle is a credible target itself (round 2: 2e-2 .. 4e-2)
+    r_h32 = {n: rel(host(tv.gradients[n]).astype(np.float64), G32[n].astype(np.float64)) for n in params}
+    print("HIP vs fp32 oracle: worst %.2e (%s)" % (max(r_h32.values()), max(r_h32, key=r_h32.get)))
+    assert max(r_h32.values()) < 2 * GRAD_BAR, r_h32      # two fp32 evaluations, each within GRAD_BAR of exact arithmetic
     before = host(dg.ctx().flat_param).copy()
     tv.apply_gradient(None)
     after = host(dg.ctx().flat_param)

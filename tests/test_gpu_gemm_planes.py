@@ -28,7 +28,7 @@ def _planes_to_host(ps):
         o0 = ps.c0 // 8
         blk = v[o0:o0 + ps.cols // 8]                         # (noct, ra, 8)
         out += blk.transpose(1, 0, 2).reshape(ps.ra, -1)[:ps.rows].astype(np.float64)
-    return out / ps.scale_host
+    return out / (1.0 if ps.scale is None else float(ps.scale))
 
 
 @pytest.mark.parametrize("rows,cols", [(64, 8), (100, 64), (1000, 200), (513, 1728)])
@@ -38,12 +38,10 @@ def test_bf16x3_split_is_exact_and_pads_with_zeros(rows, cols):
     np.testing.assert_array_equal(_planes_to_host(ps), x.astype(np.float64))            # three bf16 terms hold all 24 bits
     raw = ps.buf.cpu().numpy().reshape(3, cols // 8, ps.ra, 16)
     assert not raw[:, :, rows:, :].any()                                                 # pad rows are zero
-    # a strided source view and the transposed (weight) orientation
+    # a strided source view
     wide = torch.from_numpy(_rand((rows, cols + 24), 3)).cuda()
     ps2 = P.from_f32(wide[:, 8:8 + cols])
     np.testing.assert_array_equal(_planes_to_host(ps2), wide[:, 8:8 + cols].cpu().numpy().astype(np.float64))
-    pt = P.from_f32(torch.from_numpy(x).cuda(), transpose=True)
-    assert (pt.rows, pt.cols) == (cols, rows) if rows % 8 == 0 else True
 
 
 def test_split_of_the_transposed_orientation():
@@ -96,7 +94,7 @@ def test_kc_epilogue_options_beta_bias_stats_and_channel_views():
     np.testing.assert_allclose(s[1], (got * got).sum(0), rtol=1e-6, atol=1e-3)
 
 
-@pytest.mark.parametrize("M,N,K", [(256, 128, 64), (192, 1024, 5000), (1728, 512, 49152), (64, 48, 1000), (512, 256, 12345)])
+@pytest.mark.parametrize("M,N,K", [(256, 128, 64), (192, 1024, 5000), (1728, 512, 49152), (64, 96, 1000), (512, 256, 12345)])
 def test_tr_product_matches_float64(M, N, K):
     """weight-gradient form: dW = X^T dY with X (K, M) and dY (K, N) as planes, reduction over the rows (split-K)."""
     X, dY = _rand((K, M), 30), _rand((K, N), 31, 1e-3)
@@ -110,3 +108,54 @@ def test_tr_product_matches_float64(M, N, K):
     ref = C0 + Xd.T @ Yd
     e = float((np.abs(C.cpu().numpy() - ref) / np.maximum(np.abs(Xd).T @ np.abs(Yd), 1e-30)).max())
     assert e < 4e-7, e
+
+
+# ------------------------------------------------------------------------------------------------------
+# DGCNN_PLANES_F16X2: x * 2^e = h1 + h2 (two fp16 terms), three partial products
+# ------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("mag", [1.0, 1e-6, 3e4])
+def test_f16x2_split_keeps_22_bits_relative_to_the_tensor_scale(mag):
+    rows, cols = 777, 256
+    x = (_rand((rows, cols), 40) * np.exp(_rand((rows, cols), 41) * 3) * mag).astype(np.float32)     # ~7 decades inside the tensor
+    ps = P.from_f32(torch.from_numpy(x).cuda(), P.F16X2)
+    sc = float(ps.scale)
+    mx = np.abs(x).max()
+    assert sc == 2.0 ** np.round(np.log2(sc)) and 2.0 ** 14 <= mx * sc < 2.0 ** 15               # a power of two; max lands in [2^14, 2^15)
+    err = np.abs(_planes_to_host(ps) - x.astype(np.float64))
+    # 22 significant bits per element, and never worse than 2^-25 in scaled units (h2 subnormal) = 2^-40 of the tensor's max
+    bound = np.maximum(np.abs(x).astype(np.float64) * 2.0 ** -22, 2.0 ** -25 / sc)
+    assert (err <= bound).all(), float((err / bound).max())
+    raw = ps.buf.cpu().numpy().reshape(2, cols // 8, ps.ra, 16)
+    assert not raw[:, :, rows:, :].any()
+
+
+@pytest.mark.parametrize("M,N,K,xs,ws", [(1024, 512, 1728, 1.0, 0.05), (4096, 192, 1024, 1e-5, 0.05), (300, 130, 64, 50.0, 1e-3)])
+def test_f16x2_kc_product_is_fp32_class(M, N, K, xs, ws):
+    X, W = _rand((M, K), 50, xs), _rand((K, N), 51, ws)
+    Xd, Wd = X.astype(np.float64), W.astype(np.float64)
+    ref = Xd @ Wd
+    C = torch.full((M, N), float("nan"), device="cuda")
+    P.gemm(P.KC, P.from_f32(torch.from_numpy(X).cuda(), P.F16X2), P.from_f32(torch.from_numpy(W).cuda(), P.F16X2, transpose=True), C)
+    e16 = _err(C.cpu().numpy().astype(np.float64), ref, Xd, Wd)
+    H.set_gemm_arith(0)                                        # native fp32 MFMA (an fmaf chain) on the same operands
+    try:
+        C0 = torch.empty((M, N), device="cuda")
+        E.gemm(torch.from_numpy(X).cuda(), torch.from_numpy(W).cuda(), C0)
+    finally:
+        H.set_gemm_arith(6)
+    e32 = _err(C0.cpu().numpy().astype(np.float64), ref, Xd, Wd)
+    rms = lambda c: float(np.sqrt(np.mean(((c - ref) / np.maximum(np.abs(Xd) @ np.abs(Wd), 1e-30)) ** 2)))
+    print("K=%d: max err / sum|a||b|: f16x2 planes %.2e, fp32 MFMA chain %.2e; rms %.2e vs %.2e"
+          % (K, e16, e32, rms(C.cpu().numpy().astype(np.float64)), rms(C0.cpu().numpy().astype(np.float64))))
+    assert e16 < 6e-7, e16                                     # 2^-22 per operand: worst case 2 x 2.4e-7 (+ the dropped h2 h2 term)
+
+
+def test_f16x2_tr_product_with_gradient_sized_operands():
+    K, M, N = 20000, 512, 256
+    X, dY = _rand((K, M), 60), (_rand((K, N), 61) * np.exp(_rand((K, N), 62) * 2) * 1e-6).astype(np.float32)
+    ws = torch.empty(256 << 20, dtype=torch.uint8, device="cuda")
+    C = torch.zeros((M, N), device="cuda")
+    P.gemm(P.TR, P.from_f32(torch.from_numpy(X).cuda(), P.F16X2), P.from_f32(torch.from_numpy(dY).cuda(), P.F16X2), C, ws=ws)
+    Xd, Yd = X.astype(np.float64), dY.astype(np.float64)
+    e = float((np.abs(C.cpu().numpy() - Xd.T @ Yd) / np.maximum(np.abs(Xd).T @ np.abs(Yd), 1e-30)).max())
+    assert e < 6e-7, e
