@@ -35,6 +35,7 @@
 // on random operands, profiles/r03/gemm_planes.txt.)  PH = phases per slab and group: 2 (16 k of operands in
 // registers: 48 VGPRs for three planes) or 1 (32 k).
 #include "gemm_common.h"
+#include "planes_common.h"
 
 namespace {
 
@@ -298,47 +299,6 @@ __global__ __launch_bounds__(768) void gemm_pl_kernel(PlP q) {
 // ------------------------------------------------------------------------------------------------------
 // fp32 -> planes
 // ------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {
-  unsigned r;
-  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
-  return r;
-}
-
-// (x0, x1) -> packed pairs of the split terms (x0 in the low half)
-__device__ __forceinline__ void split_bf16x3(float x0, float x1, unsigned (&o)[3]) {
-  o[0] = cvt_pk_bf16(x0, x1);
-  const float r0 = x0 - __uint_as_float(o[0] << 16);
-  const float r1 = x1 - __uint_as_float(o[0] & 0xffff0000u);
-  o[1] = cvt_pk_bf16(r0, r1);
-  const float s0 = r0 - __uint_as_float(o[1] << 16);
-  const float s1 = r1 - __uint_as_float(o[1] & 0xffff0000u);
-  o[2] = cvt_pk_bf16(s0, s1);
-}
-
-// fp16 pair: h1 = rn16(x), h2 = rn16(x - h1) (x already scaled by the tensor's power of two; |x| <= 65504 or it saturates)
-__device__ __forceinline__ void split_f16x2(float x0, float x1, unsigned (&o)[3]) {
-  const float lim = 65504.f;
-  x0 = fminf(fmaxf(x0, -lim), lim);
-  x1 = fminf(fmaxf(x1, -lim), lim);
-  const _Float16 h0 = (_Float16)x0, h1 = (_Float16)x1;
-  const _Float16 l0 = (_Float16)(x0 - (float)h0), l1 = (_Float16)(x1 - (float)h1);
-  o[0] = (unsigned)__builtin_bit_cast(unsigned short, h0) | ((unsigned)__builtin_bit_cast(unsigned short, h1) << 16);
-  o[1] = (unsigned)__builtin_bit_cast(unsigned short, l0) | ((unsigned)__builtin_bit_cast(unsigned short, l1) << 16);
-  o[2] = 0;
-}
-
-template <int FMT>
-__device__ __forceinline__ void split8(const float (&v)[8], float scale, uint4 (&o)[3]) {
-  unsigned w[4][3];
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    if (FMT == DGCNN_PLANES_BF16X3) split_bf16x3(v[2 * e], v[2 * e + 1], w[e]);
-    else split_f16x2(v[2 * e] * scale, v[2 * e + 1] * scale, w[e]);
-  }
-#pragma unroll
-  for (int pl = 0; pl < 3; ++pl) o[pl] = make_uint4(w[0][pl], w[1][pl], w[2][pl], w[3][pl]);
-}
-
 // Activations: src (rows x cols) row-major, ld % 4 == 0, cols % 8 == 0.  Block = 64 rows x 16 octets; the split slots go
 // through LDS so that every wave store is 64 consecutive rows of one octet (1 KiB contiguous).  Pad rows [rows, rows_alloc)
 // are written as zeros.
@@ -346,42 +306,33 @@ template <int FMT>
 __global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict__ src, int64_t ld, int64_t rows, int cols,
                                                          char* __restrict__ dst, int64_t plane_stride, int64_t rows_alloc,
                                                          const float* __restrict__ scale_dev) {
-  constexpr int NPL = Fmt<FMT>::NPL;
-  constexpr int CS = 65;                                     // slots per octet in LDS (+1: conflict-free ds_write_b128)
-  __shared__ __attribute__((aligned(16))) uint4 sh[NPL][16 * CS];
-  const int t = threadIdx.x;
-  const int64_t r0 = (int64_t)blockIdx.x * 64;
-  const int o0 = blockIdx.y * 16;
+  // thread = one row x 4 adjacent channel octets (a full 128-byte line of the source row), lane = row: every wave store is
+  // 64 consecutive slots of one octet (1 KiB per plane)
+  const int lane = threadIdx.x & 63;
+  const int oc0 = (blockIdx.y * 4 + (threadIdx.x >> 6)) * 4;
   const int noct = cols >> 3;
+  if (oc0 >= noct) return;
   const float scale = (FMT == DGCNN_PLANES_F16X2 && scale_dev) ? *scale_dev : 1.f;
-  {
-    const int rl = t >> 2;                                   // 4 threads per row: 128 contiguous bytes per load instruction
+  const int64_t step = (int64_t)gridDim.x * 64;
+  for (int64_t r = (int64_t)blockIdx.x * 64 + lane; r < rows_alloc; r += step) {
+    float4 a[4], b[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      const int ol = (t & 3) + 4 * u;
-      const int64_t row = r0 + rl;
-      float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      if (row < rows && o0 + ol < noct) {
-        const float4 a = *reinterpret_cast<const float4*>(src + row * ld + (int64_t)(o0 + ol) * 8);
-        const float4 b = *reinterpret_cast<const float4*>(src + row * ld + (int64_t)(o0 + ol) * 8 + 4);
-        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+      a[u] = b[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (r < rows && oc0 + u < noct) {
+        a[u] = *reinterpret_cast<const float4*>(src + r * ld + (int64_t)(oc0 + u) * 8);
+        b[u] = *reinterpret_cast<const float4*>(src + r * ld + (int64_t)(oc0 + u) * 8 + 4);
       }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (oc0 + u >= noct) break;
+      const float v[8] = {a[u].x, a[u].y, a[u].z, a[u].w, b[u].x, b[u].y, b[u].z, b[u].w};
       uint4 o[3];
       split8<FMT>(v, scale, o);
 #pragma unroll
-      for (int pl = 0; pl < NPL; ++pl) sh[pl][ol * CS + rl] = o[pl];
-    }
-  }
-  __syncthreads();
-  const int lane = t & 63, wv = t >> 6;
-#pragma unroll
-  for (int u = 0; u < 4; ++u) {
-    const int ol = wv * 4 + u;
-    const int64_t row = r0 + lane;
-    if (o0 + ol < noct && row < rows_alloc) {
-#pragma unroll
-      for (int pl = 0; pl < NPL; ++pl)
-        *reinterpret_cast<uint4*>(dst + pl * plane_stride + ((int64_t)(o0 + ol) * rows_alloc + row) * 16) = sh[pl][ol * CS + lane];
+      for (int pl = 0; pl < PlaneFmt<FMT>::NPL; ++pl)
+        *reinterpret_cast<uint4*>(dst + pl * plane_stride + ((int64_t)(oc0 + u) * rows_alloc + r) * 16) = o[pl];
     }
   }
 }
@@ -391,7 +342,7 @@ template <int FMT>
 __global__ __launch_bounds__(256) void split_strided_kernel(const float* __restrict__ src, int64_t rs, int64_t cs, int64_t rows,
                                                             int cols, char* __restrict__ dst, int64_t plane_stride,
                                                             int64_t rows_alloc, const float* __restrict__ scale_dev) {
-  constexpr int NPL = Fmt<FMT>::NPL;
+  constexpr int NPL = PlaneFmt<FMT>::NPL;
   const int noct = (cols + 7) >> 3;
   const int64_t item = (int64_t)blockIdx.x * 256 + threadIdx.x;        // (octet, row) with the row fastest
   if (item >= (int64_t)noct * rows_alloc) return;
@@ -428,16 +379,7 @@ __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ s
 }
 
 __global__ void scale_from_max_kernel(const unsigned* __restrict__ max_bits, float bound_mul, float* __restrict__ scale) {
-  const float m = __uint_as_float(*max_bits) * bound_mul;
-  float s = 1.f;
-  if (m > 0.f && m < INFINITY) {
-    int e;
-    frexpf(m, &e);                       // m = f * 2^e, f in [0.5, 1)  ->  m * 2^(15 - e) in [2^14, 2^15)
-    int sh = 15 - e;
-    sh = sh > 100 ? 100 : (sh < -100 ? -100 : sh);
-    s = ldexpf(1.f, sh);
-  }
-  *scale = s;
+  *scale = pow2_scale_for(__uint_as_float(*max_bits) * bound_mul);
 }
 
 inline bool aligned16p(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
@@ -460,7 +402,10 @@ extern "C" int dgcnn_split_planes_f32(const float* src, int64_t row_stride, int6
   DG_REQUIRE(plane_stride >= (int64_t)noct * rows_alloc * 16, DGCNN_EINVAL, "dgcnn_split_planes_f32: plane stride too small");
   const bool fast = col_stride == 1 && cols % 8 == 0 && row_stride % 4 == 0 && aligned16p(src);
   if (fast) {
-    dim3 grid((unsigned)(rows_alloc / 64), (unsigned)dg::cdiv(noct, 16));
+    const int64_t gy = dg::cdiv(noct, 16);
+    int64_t gx = rows_alloc / 64;
+    if (gx * gy > 8192) gx = dg::cdiv(8192, gy);
+    dim3 grid((unsigned)gx, (unsigned)gy);
     if (fmt == DGCNN_PLANES_BF16X3)
       hipLaunchKernelGGL((split_rows_kernel<DGCNN_PLANES_BF16X3>), grid, dim3(256), 0, ST, src, row_stride, rows, cols, (char*)dst, plane_stride, rows_alloc, scale_dev);
     else

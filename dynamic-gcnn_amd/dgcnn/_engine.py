@@ -58,7 +58,10 @@ PLANES_MIN_ROWS = 8192
 
 
 def planes_ok(R, Cin, Cout):
-    return HEAD_PLANES is not None and R >= PLANES_MIN_ROWS and Cin % 32 == 0 and Cout % 32 == 0 and Cout >= 128 and Cin >= 128
+    """The plane GEMM takes this layer: head-sized problems with tile-friendly widths, variables in the flat bucket (the
+    step's scales come from it), default (atomically summed) BatchNorm statistics."""
+    return (HEAD_PLANES is not None and not DETERMINISTIC and ctx().flat_param is not None and R >= PLANES_MIN_ROWS and
+            Cin % 32 == 0 and Cout % 32 == 0 and Cout >= 128 and Cin >= 128 and Cout <= 1024)
 
 
 class Context(object):
@@ -83,6 +86,10 @@ class Context(object):
         self.capturing = False           # inside a HIP-graph capture: no host-side per-step state may be baked in
         self.edge_mlp_arith = None       # 1: bf16 operands for the EdgeConv conv0 / conv1 products (EDGE_MLP_DTYPE = 'bf16')
         self.debug = False
+        self.planes = {}                 # (data_ptr, rows, cols) of an fp32 2-D view -> PlaneSet holding it as GEMM operand planes (this step)
+        self.pl_scales = None            # device float[2]: power-of-two scales of the step's activation / weight plane sets (fp16 planes)
+        self.pl_scales_ready = False
+        self.pl_ws = None
 
     # ---- device / scratch -------------------------------------------------------------
     @property
@@ -137,10 +144,59 @@ class Context(object):
         self.stat_off += n
         return s
 
+    # ---- operand planes of the head GEMMs (csrc/gemm_pl.hip, planes_bn.hip) ------------------------------
+    @staticmethod
+    def plane_key(v):
+        return (v.data_ptr(), int(v.shape[0]), int(v.shape[1]))
+
+    def ensure_plane_scales(self, rows_max):
+        """One pass over the parameter bucket per step: the power-of-two scales of every activation plane set
+        (|z| <= 2 (sqrt(rows_max) + max |parameter|) bounds any batch-normalised tensor of the model and the residual sums
+        of two of them) and of the weight plane sets.  Only the fp16 plane format is scaled."""
+        if HEAD_PLANES != PL.F16X2 or self.pl_scales_ready:
+            return
+        if self.pl_scales is None or self.pl_scales.device != self.device:
+            self.pl_scales = torch.ones(2, dtype=torch.float32, device=self.device)
+            self.pl_ws = torch.zeros(1, dtype=torch.int32, device=self.device)
+        H.call("dgcnn_param_scales_f32", self.flat_param.data_ptr(), self.flat_param.numel(), float(rows_max), 2.0,
+               self.pl_scales.data_ptr(), self.pl_ws.data_ptr())
+        self.pl_scales_ready = True
+
+    def new_planes(self, rows, cols, kind):
+        """An empty plane set in the head format; kind 'act' / 'w' picks the step's preset scale, 'own' leaves it to the producer."""
+        ps = PL.PlaneSet(rows, cols, HEAD_PLANES, device=self.device)
+        if HEAD_PLANES == PL.F16X2:
+            if kind == "own":
+                ps.scale = torch.empty(1, dtype=torch.float32, device=self.device)
+            else:
+                ps.scale = self.pl_scales[0:1] if kind == "act" else self.pl_scales[1:2]
+        return ps
+
+    def planes_of(self, x):
+        """The operand planes of the fp32 view x: registered by its producer, or split here (one extra pass)."""
+        ps = self.planes.get(self.plane_key(x))
+        if ps is None:
+            ps = self.new_planes(x.shape[0], x.shape[1], "act").fill_from(x)
+            self.planes[self.plane_key(x)] = ps
+        return ps
+
+    def stats_raw(self, n):
+        """n zeroed doubles from the per-step arena."""
+        if self.stat_arena is None or self.stat_arena.device != self.device:
+            self.stats(1)
+            self.stat_off = 0
+        if self.stat_off + n > self.stat_arena.numel():
+            return torch.zeros(n, dtype=torch.float64, device=self.device)
+        s = self.stat_arena[self.stat_off:self.stat_off + n]
+        self.stat_off += n
+        return s
+
     def begin_step(self):
         """Drop the previous tape / gradient roots, re-zero the statistics arena and advance the dropout stream."""
         self.tape = []
         self.roots = []
+        self.planes = {}
+        self.pl_scales_ready = False
         if self.stat_arena is not None:
             if self.capturing:
                 self.stat_arena.zero_()          # a captured step cannot know what ran before it: whole arena (8 MB memset)
@@ -398,10 +454,15 @@ def bn_finalize(stats, F, count):
 # slim.conv2d(1x1, no bias) + slim.batch_norm + activation on per-point tensors (k = 1)
 # dgcnn/ops.py:62-70,125-133,153-160 ; dgcnn/model.py:46-53,65-72,94-101
 # ----------------------------------------------------------------------------------------------
-def conv_bn_act(x, leaf_scope, num_outputs, relu=True, out=None, out2=None, gbias=None, rpg=0, w_rows=None, arith=None):
+def conv_bn_act(x, leaf_scope, num_outputs, relu=True, out=None, out2=None, gbias=None, rpg=0, w_rows=None, arith=None,
+                plane_out=None, f32_out=True, gmax=None):
     """x: (R,Cin) view.  Variables `<scope>/weights` [Cin(+extra), Cout], `<scope>/BatchNorm/beta`.
     w_rows: (lo, hi) row range of the weight that multiplies x (FC0 with the folded global feature).
-    Returns the (R,Cout) output (a fresh tracked buffer unless `out` is given)."""
+    Returns the (R,Cout) output (a fresh tracked buffer unless `out` is given).
+    Plane mode (HEAD_PLANES, planes_ok): the products run on the plane GEMM; plane_out = PlaneSet view that receives the
+    activated output as operand planes of the NEXT product (f32_out = False: the fp32 `out` is then never written -- it only
+    names the tensor and carries its gradient); gmax = (B, N): also return the per-cloud max over the points of the output
+    (model.py:76-77), taken on the GEMM output and normalised afterwards (BN + ReLU are monotone)."""
     c = ctx()
     R, Cin = x.shape
     with variable_scope(leaf_scope):
@@ -418,19 +479,28 @@ def conv_bn_act(x, leaf_scope, num_outputs, relu=True, out=None, out2=None, gbia
     use_pl = arith is None and planes_ok(R, Cin, F)
     xp = None
     if use_pl:
-        xp = PL.from_f32(x, HEAD_PLANES)                               # (R, Cin) activations
-        wt = PL.from_f32(Wx, HEAD_PLANES, transpose=True)              # (F rows, Cin channels) = W^T
-        PL.gemm(PL.KC, xp, wt, T, gbias=gbias, rpg=rpg, stats=None if DETERMINISTIC else st)
+        c.ensure_plane_scales(R)
+        xp = c.planes_of(x)                                                # (R, Cin) activations
+        wt = c.new_planes(F, Cin, "w").fill_from(Wx, transpose=True)       # (F rows, Cin channels) = W^T
+        PL.gemm(PL.KC, xp, wt, T, gbias=gbias, rpg=rpg, stats=st)
     else:
+        plane_out, f32_out = None, True
         gemm(x, Wx, T, gbias=gbias, rpg=rpg, stats=None if DETERMINISTIC else st, arith=arith)
     if DETERMINISTIC:
         colstats_det(T, st)
     mean, rstd = bn_finalize(st, F, R)
     if out is None:
         out = c.new_buffer(R, F)
-    H.call("dgcnn_bn_act_kreduce_f32", T.data_ptr(), R, 1, F, mean.data_ptr(), rstd.data_ptr(), beta.data_ptr(),
-           int(relu), out.data_ptr(), H.ld2(out), 0, 0, H._p(out2), 0 if out2 is None else H.ld2(out2), 0,
-           tag="bn_act_kreduce_kernel<k=1>", work=4.0 * R * F * (2 if out2 is None else 3))
+    if plane_out is not None:
+        H.call("dgcnn_bn_act_planes_f32", T.data_ptr(), F, R, F, mean.data_ptr(), rstd.data_ptr(), beta.data_ptr(), int(relu),
+               plane_out.fmt, H._p(plane_out.scale), plane_out.ptr(), plane_out.plane_stride, plane_out.ra,
+               out.data_ptr() if f32_out else 0, H.ld2(out), H._p(out2) if f32_out else 0, 0 if out2 is None else H.ld2(out2),
+               tag="bn_act_planes_kernel", work=4.0 * R * F * (2 + (1 if f32_out else 0)))
+        c.planes[c.plane_key(out)] = plane_out
+    else:
+        H.call("dgcnn_bn_act_kreduce_f32", T.data_ptr(), R, 1, F, mean.data_ptr(), rstd.data_ptr(), beta.data_ptr(),
+               int(relu), out.data_ptr(), H.ld2(out), 0, 0, H._p(out2), 0 if out2 is None else H.ld2(out2), 0,
+               tag="bn_act_kreduce_kernel<k=1>", work=4.0 * R * F * (2 if out2 is None else 3))
 
     if c.recording:
         def bwd():
@@ -442,34 +512,72 @@ def conv_bn_act(x, leaf_scope, num_outputs, relu=True, out=None, out2=None, gbia
                 if d2 is not None:      # the second copy's gradient joins the first
                     H.call("dgcnn_copy2d_f32", d2.data_ptr(), H.ld2(d2), dout.data_ptr(), H.ld2(dout), R, F, 1)
             red = c.stats(F)
+            dWx = c.var_grads[wname] if w_rows is None else c.var_grads[wname][w_rows[0]:w_rows[1]]
+            dgb = c.grad(gbias) if gbias is not None else None
+            if use_pl:
+                # sums + column maxima -> bound on |dT| -> the dT plane set's scale -> dT written as planes (never as fp32)
+                maxbits = c.stats_raw(F + 1)                              # uint32[2 F + 1]: column maxima + the tensor-wide bound
+                H.call("dgcnn_bn1_bwd_reduce_max_f32", T.data_ptr(), R, F, mean.data_ptr(), rstd.data_ptr(), beta.data_ptr(),
+                       int(relu), dout.data_ptr(), H.ld2(dout), red.data_ptr(), maxbits.data_ptr(),
+                       tag="bn1_bwd_reduce_max_kernel", work=4.0 * R * F * 2)
+                dTp = PL.PlaneSet(R, F, HEAD_PLANES, device=x.device)
+                sc = torch.empty(1, dtype=torch.float32, device=x.device)
+                if HEAD_PLANES == PL.F16X2:
+                    dTp.scale = sc
+                fused_gsum = dgb is not None and rpg % 64 == 0
+                tmp = torch.zeros_like(gbias) if fused_gsum else None
+                dT32 = T if (dgb is not None and not fused_gsum) else None        # (in place: every element is read before it is written)
+                H.call("dgcnn_bn1_bwd_apply_planes_f32", T.data_ptr(), R, F, mean.data_ptr(), rstd.data_ptr(), beta.data_ptr(),
+                       int(relu), dout.data_ptr(), H.ld2(dout), red.data_ptr(), maxbits.data_ptr(), HEAD_PLANES, sc.data_ptr(),
+                       dTp.ptr(), dTp.plane_stride, dTp.ra, H._p(dT32), H._p(tmp), F, int(rpg), c.var_grads[bname].data_ptr(), 1.0,
+                       tag="bn1_bwd_apply_planes_kernel", work=4.0 * R * F * 3)
+                with c.off_critical_path(dTp.buf, sc, rows=R):
+                    PL.gemm(PL.TR, xp, dTp, dWx, beta=1.0, ws=c.workspace())           # dW += x^T dT
+                dx, bx = c.grad_w(x)
+                if dx is not None:
+                    wd = c.new_planes(Wx.shape[0], F, "w").fill_from(Wx)                # (Cin rows, F channels)
+                    PL.gemm(PL.KC, dTp, wd, dx, beta=bx)                                 # dx (+)= dT W^T
+                if dgb is not None:                                                     # tf.tile^T: sum over the cloud
+                    if not fused_gsum:
+                        tmp = torch.empty_like(gbias)
+                        H.call("dgcnn_group_colsum_f32", dT32.data_ptr(), F, gbias.shape[0], rpg, F, tmp.data_ptr())
+                    H.call("dgcnn_axpby_f32", tmp.data_ptr(), 1.0, dgb.data_ptr(), 1.0, tmp.numel())
+                return
             bn_bwd_reduce(T, R, 1, F, mean, rstd, beta, relu, dout, None, None, None, red,
                           tag="bn_bwd_reduce_kernel<k=1>", work=4.0 * R * F * 2)
             H.call("dgcnn_bn_bwd_apply_f32", T.data_ptr(), R, 1, F, mean.data_ptr(), rstd.data_ptr(), beta.data_ptr(),
                    int(relu), dout.data_ptr(), H.ld2(dout), 0, 0, 0, 0, 0, red.data_ptr(), T.data_ptr(), 0, 0,
                    c.var_grads[bname].data_ptr(), 1.0, tag="bn_bwd_apply_kernel<k=1>", work=4.0 * R * F * 3)
             dT = T
-            dWx = c.var_grads[wname] if w_rows is None else c.var_grads[wname][w_rows[0]:w_rows[1]]
+            with c.off_critical_path(rows=R):
+                gemm(x, dT, dWx, transA=True, beta=1.0, arith=arith)   # dW += x^T dT
             dx, bx = c.grad_w(x)
-            if use_pl:
-                dTp = PL.from_f32(dT, HEAD_PLANES)
-                with c.off_critical_path(*[t for t in (dTp.buf, dTp.scale) if t is not None], rows=R):
-                    PL.gemm(PL.TR, xp, dTp, dWx, beta=1.0, ws=c.workspace())           # dW += x^T dT
-                if dx is not None:
-                    wd = PL.from_f32(Wx, HEAD_PLANES)                                    # (Cin rows, F channels)
-                    PL.gemm(PL.KC, dTp, wd, dx, beta=bx)                                 # dx (+)= dT W^T
-            else:
-                with c.off_critical_path(rows=R):
-                    gemm(x, dT, dWx, transA=True, beta=1.0, arith=arith)   # dW += x^T dT
-                if dx is not None:
-                    gemm(dT, Wx, dx, transB=True, beta=bx, arith=arith)    # dx (+)= dT W^T
-            if gbias is not None:
-                dgb = c.grad(gbias)
-                if dgb is not None:                                     # tf.tile^T: sum over the cloud
-                    tmp = torch.empty_like(gbias)
-                    H.call("dgcnn_group_colsum_f32", dT.data_ptr(), H.ld2(dT), gbias.shape[0], rpg, F, tmp.data_ptr())
-                    H.call("dgcnn_axpby_f32", tmp.data_ptr(), 1.0, dgb.data_ptr(), 1.0, tmp.numel())
+            if dx is not None:
+                gemm(dT, Wx, dx, transB=True, beta=bx, arith=arith)    # dx (+)= dT W^T
+            if dgb is not None:                                         # tf.tile^T: sum over the cloud
+                tmp = torch.empty_like(gbias)
+                H.call("dgcnn_group_colsum_f32", dT.data_ptr(), H.ld2(dT), gbias.shape[0], rpg, F, tmp.data_ptr())
+                H.call("dgcnn_axpby_f32", tmp.data_ptr(), 1.0, dgb.data_ptr(), 1.0, tmp.numel())
         c.tape.append(bwd)
-    return out
+    if gmax is None:
+        return out
+    # model.py:76-77 max_pool over the points of each cloud, on the GEMM output: z = relu((t - mean) rstd + beta) is
+    # non-decreasing in t, so max_n z[n] = z(max_n t[n]) and the first arg-max of t is an arg-max of z
+    Bc, Nc = gmax
+    graw = torch.empty((Bc, F), dtype=torch.float32, device=x.device)
+    arg = torch.empty((Bc, F), dtype=torch.int32, device=x.device)
+    H.call("dgcnn_global_max_f32", T.data_ptr(), F, Bc, Nc, F, graw.data_ptr(), arg.data_ptr())
+    g = c.new_buffer(Bc, F)
+    H.call("dgcnn_bn_act_kreduce_f32", graw.data_ptr(), Bc, 1, F, mean.data_ptr(), rstd.data_ptr(), beta.data_ptr(),
+           int(relu), g.data_ptr(), F, 0, 0, 0, 0, 0)
+    if c.recording:
+        def bwd_g():
+            dg_, dout = c.grad(g), c.grad(out)
+            if dg_ is None or dout is None:
+                return
+            H.call("dgcnn_global_max_bwd_f32", dg_.data_ptr(), arg.data_ptr(), Bc, Nc, F, dout.data_ptr(), H.ld2(dout))
+        c.tape.append(bwd_g)
+    return out, g
 
 
 # ----------------------------------------------------------------------------------------------

@@ -58,6 +58,12 @@ PROTOTYPES = {
     "dgcnn_planes_scale_f32": [c_vp, c_i64, c_i64, c_int, c_f32, c_vp, c_vp, c_vp],
     "dgcnn_gemm_planes_f32": [c_int, c_int, c_int, c_int, c_int, c_vp, c_i64, c_i64, c_vp, c_i64, c_i64, c_vp, c_vp, c_vp, c_i64, c_f32,
                               c_vp, c_i64, c_int, c_vp, c_vp, c_sz, c_vp],
+    "dgcnn_param_scales_f32": [c_vp, c_i64, c_f64, c_f32, c_vp, c_vp, c_vp],
+    "dgcnn_bn_act_planes_f32": [c_vp, c_i64, c_i64, c_int, c_vp, c_vp, c_vp, c_int, c_int, c_vp, c_vp, c_i64, c_i64, c_vp, c_i64,
+                                c_vp, c_i64, c_vp],
+    "dgcnn_bn1_bwd_reduce_max_f32": [c_vp, c_i64, c_int, c_vp, c_vp, c_vp, c_int, c_vp, c_i64, c_vp, c_vp, c_vp],
+    "dgcnn_bn1_bwd_apply_planes_f32": [c_vp, c_i64, c_int, c_vp, c_vp, c_vp, c_int, c_vp, c_i64, c_vp, c_vp, c_int, c_vp, c_vp,
+                                       c_i64, c_i64, c_vp, c_vp, c_i64, c_int, c_vp, c_f32, c_vp],
     "dgcnn_bn_finalize_f32": [c_vp, c_int, c_f64, c_f32, c_vp, c_vp, c_vp],
     "dgcnn_bn_act_kreduce_f32": [c_vp, c_i64, c_int, c_int, c_vp, c_vp, c_vp, c_int, c_vp, c_i64, c_vp, c_i64,
                                  c_vp, c_i64, c_vp, c_vp],

@@ -68,18 +68,38 @@ def build(point_cloud, flags):
         fin = E.conv_bn_act(last, "Final", num_class, relu=True)
         return fin.view(B, N, num_class)
 
-    merged = E.conv_bn_act(merged_in, "MergedEdgeConv", 1024, relu=True, out=big[:, ctot - 1024:])  # model.py:65-72
-    tensors.append(E.rank4(merged, B, N))                          # model.py:74
-    g = E.global_max(merged, B, N)                                 # model.py:76-77 (B,1024)
-
-    # model.py:80-88: concat([tile(g)] + tensors) -> fc.  FC0 is split as described in the docstring.
     fcf = ops._listify(num_fc_filters, num_fc, "num_filters")
     if num_fc < 1:
         raise NotImplementedError("FC_LAYERS=0 is not supported by the HIP path (reference default is 2)")
+    # Plane mode (E.HEAD_PLANES): MergedEdgeConv, FC0 and FC1 -- 98 % of the GEMM flops -- read their operands as 16-bit planes
+    # written once by the producing pass (csrc/gemm_pl.hip, planes_bn.hip).  The EdgeConv outputs (first ctot - 1024 channels
+    # of `big`, and the conv1 copies) are split by one pass each; MergedEdgeConv's BatchNorm pass writes its 1024 channels
+    # straight into big's plane set (the fp32 slice of `big` is never written: nothing else reads it -- the global max-pool
+    # is taken on the GEMM output) and FC0's writes the planes FC1 reads.
+    pl_head = (E.planes_ok(R, 64 * num_edge_conv, 1024) and E.planes_ok(R, ctot, fcf[0]) and ctot % 32 == 0 and
+               (num_fc < 2 or E.planes_ok(R, fcf[0], fcf[1])))
+    if pl_head:
+        kmax = max(ops._listify(k, num_edge_conv, "k"))
+        c.ensure_plane_scales(R * kmax)
+        bigP = c.new_planes(R, ctot, "act")
+        bigP.cols_view(0, ctot - 1024).fill_from(big[:, :ctot - 1024])
+        merged, g = E.conv_bn_act(merged_in, "MergedEdgeConv", 1024, relu=True, out=big[:, ctot - 1024:],
+                                  plane_out=bigP.cols_view(ctot - 1024, ctot), f32_out=False, gmax=(B, N))   # model.py:65-77
+        c.planes[c.plane_key(big)] = bigP
+    else:
+        merged = E.conv_bn_act(merged_in, "MergedEdgeConv", 1024, relu=True, out=big[:, ctot - 1024:])  # model.py:65-72
+        g = E.global_max(merged, B, N)                             # model.py:76-77 (B,1024)
+    tensors.append(E.rank4(merged, B, N))                          # model.py:74
+
+    # model.py:80-88: concat([tile(g)] + tensors) -> fc.  FC0 is split as described in the docstring.
     with E.variable_scope("FC0"):
         wleaf = c.get_variable("weights", (1024 + ctot, fcf[0]))
     gb = E.plain_gemm(g, wleaf, (0, 1024), fcf[0])                 # per-cloud term (B, fcf0)
-    net = E.conv_bn_act(big, "FC0", fcf[0], relu=True, gbias=gb, rpg=N, w_rows=(1024, 1024 + ctot, 1024 + ctot))
+    if pl_head and num_fc >= 2:
+        net = E.conv_bn_act(big, "FC0", fcf[0], relu=True, gbias=gb, rpg=N, w_rows=(1024, 1024 + ctot, 1024 + ctot),
+                            plane_out=c.new_planes(R, fcf[0], "act"), f32_out=False)
+    else:
+        net = E.conv_bn_act(big, "FC0", fcf[0], relu=True, gbias=gb, rpg=N, w_rows=(1024, 1024 + ctot, 1024 + ctot))
     for i in range(1, num_fc):                                     # ops.py:151-160
         net = E.conv_bn_act(net, "FC%d" % i, fcf[i], relu=True)
     if is_training:

@@ -198,6 +198,32 @@ int dgcnn_gemm_planes_f32(int form, int fmt, int M, int N, int K,
                           const float* gbias, int64_t ldgbias, int rows_per_group,
                           double* stats, void* ws, size_t ws_bytes, void* stream);
 
+/* ---- BatchNorm passes that WRITE operand planes (planes_bn.hip) ------------------------------------
+ * The per-point conv + BN + ReLU layers of the head (model.py:65-72, ops.py:153-160): the pass that normalises a GEMM
+ * output writes the planes the next plane GEMM reads; the backward-apply pass writes dT as planes.
+ * dgcnn_param_scales_f32: scales[0] = power-of-two scale of every activation plane set of the step, from the bound
+ *   |z| <= act_mul (sqrt(rows_max) + max |parameter|) that holds for any batch-normalised tensor; scales[1] = scale of the
+ *   weight plane sets (max |parameter|).  ws = 4 bytes.
+ * dgcnn_bn_act_planes_f32: z = relu?((T - mean) rstd + beta) -> planes (pad rows zero) and, optionally, fp32 copies.
+ * dgcnn_bn1_bwd_reduce_max_f32: red[slot][0/1][F] += column sums of dz, dz xhat; maxbits[0/1][F] = max |dz|, max |xhat| (uint bits;
+ *   maxbits has 2 F + 1 zeroed words, the last one receives the tensor-wide bound in the apply call).
+ * dgcnn_bn1_bwd_apply_planes_f32: finalises red (slot 0 <- sums; dbeta; maxbits is overwritten by the two column means), bounds |dT| per column from the maxima, writes the
+ *   plane set's power-of-two scale to scale_dev and dT = rstd (dz - c1 - xhat c2) as planes (+ optional fp32 dT, + optional
+ *   per-group column sums gsum[row / rows_per_group][F], rows_per_group % 64 == 0). */
+int dgcnn_param_scales_f32(const float* params, int64_t n, double rows_max, float act_mul, float* scales, void* ws, void* stream);
+int dgcnn_bn_act_planes_f32(const float* T, int64_t ldt, int64_t R, int F, const float* mean, const float* rstd,
+                            const float* beta, int relu, int fmt, const float* scale_dev, void* planes,
+                            int64_t plane_stride, int64_t rows_alloc, float* out, int64_t ldo, float* out2, int64_t ldo2,
+                            void* stream);
+int dgcnn_bn1_bwd_reduce_max_f32(const float* T, int64_t R, int F, const float* mean, const float* rstd,
+                                 const float* beta, int relu, const float* dout, int64_t lddo, double* red,
+                                 void* maxbits, void* stream);
+int dgcnn_bn1_bwd_apply_planes_f32(const float* T, int64_t R, int F, const float* mean, const float* rstd,
+                                   const float* beta, int relu, const float* dout, int64_t lddo, double* red,
+                                   void* maxbits, int fmt, float* scale_dev, void* planes, int64_t plane_stride,
+                                   int64_t rows_alloc, float* dT, float* gsum, int64_t ldgsum, int rows_per_group,
+                                   float* dbeta, float dbeta_beta, void* stream);
+
 /* ---- K4/K5: slim.batch_norm (ops.py:53,68 ...) + activation + reduce_max/mean (ops.py:56-57)
  * mean/rstd from the stats slots: mean = S/count, var = Q/count - mean^2 (double), rstd=1/sqrt(var+eps) */
 int dgcnn_bn_finalize_f32(const double* stats, int F, double count, float eps,

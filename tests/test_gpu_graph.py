@@ -36,21 +36,23 @@ def _train(graph, steps, pts, lab, **kw):
 
 
 def test_graph_replay_matches_eager_training():
+    """Same dropout stream (the seed advances per tower call in both modes), same arithmetic.  The default kernels are not
+    bit-reproducible run to run (atomically accumulated BatchNorm sums -> last-bit feature differences -> a few different
+    layer-1 neighbour lists -> Adam amplifies; two EAGER runs differ by the same amount, which made a noise-relative bar
+    flaky): the comparison runs the deterministic kernels, where graph replay must retrace the eager run exactly."""
     pts, lab = _data()
-    tv_e, loss_e, p_e = _train(False, 4, pts, lab)
-    tv_e2, loss_e2, p_e2 = _train(False, 4, pts, lab)              # a second eager run: the run-to-run noise floor
-    tv_g, loss_g, p_g = _train(True, 4, pts, lab)
+    tv_e, loss_e, p_e = _train(False, 4, pts, lab, DETERMINISTIC=True)
+    tv_g, loss_g, p_g = _train(True, 4, pts, lab, DETERMINISTIC=True)
     assert len(tv_g._graphs) == 1 and not tv_e._graphs            # one (shape, mode) -> one captured graph, replayed 6 times
-    # same dropout stream (the seed advances per tower call in both modes), same arithmetic.  Training is not bit-reproducible
-    # run to run (atomically accumulated BatchNorm sums -> last-bit feature differences -> a few different layer-1
-    # neighbour lists -> Adam amplifies): the graph run must sit within that noise, measured here by the second eager run.
-    np.testing.assert_allclose(loss_g[:2], loss_e[:2], rtol=0, atol=2e-5)     # before the first update: same seeds, same masks
-    np.testing.assert_allclose(loss_g, loss_e, rtol=0, atol=1.5e-3)           # (a wrong mask stream moves the loss by ~1e-2)
-    noise = np.abs(p_e2 - p_e)
+    np.testing.assert_allclose(loss_g, loss_e, rtol=0, atol=1e-6)             # (a wrong mask stream moves the loss by ~1e-2)
     d = np.abs(p_g - p_e)
-    print("graph vs eager: median |dp| %.2e, eager vs eager %.2e" % (np.median(d), np.median(noise)))
-    assert np.median(d) <= 3 * np.median(noise) + 1e-6 and d.max() <= max(3 * noise.max(), 5e-3), (np.median(d), np.median(noise))
+    print("graph vs eager (deterministic kernels): max |dp| %.2e" % d.max())
+    assert d.max() <= 1e-6, d.max()
     assert np.abs(p_g - dgcnn.trainval(_flags()).initialize()._ctx.flat_param.cpu().numpy()).max() > 1e-3   # it trained
+    # default kernels: the first two micro-steps (before any update) still agree to the atomics' noise
+    tv_e, loss_e, _ = _train(False, 1, pts, lab)
+    tv_g, loss_g, _ = _train(True, 1, pts, lab)
+    np.testing.assert_allclose(loss_g, loss_e, rtol=0, atol=2e-5)
 
 
 def test_graph_replay_draws_a_new_dropout_mask_and_accumulates():
@@ -65,10 +67,11 @@ def test_graph_replay_draws_a_new_dropout_mask_and_accumulates():
         grads.append(c.flat_grad.cpu().numpy().copy())
     assert len(tv._graphs) == 1
     assert len({round(l, 7) for l in losses}) == 4, losses        # same inputs, same weights: only the mask differs
-    # without dropout the replays are repeatable and two replays without zeroing accumulate 2x
+    # without dropout the replays are repeatable and two replays without zeroing accumulate 2x (deterministic kernels: with
+    # the atomically summed statistics two replays differ by a few flipped near-tie neighbours, ~2e-3 of the gradient norm)
     keep, E.DROPOUT_KEEP = E.DROPOUT_KEEP, 1.0
     try:
-        tv = dgcnn.trainval(_flags()).initialize().use_graph(True)
+        tv = dgcnn.trainval(_flags(DETERMINISTIC=True)).initialize().use_graph(True)
         c = dgcnn.ctx()
         for i in range(2):
             tv.zero_gradients(None)
@@ -76,9 +79,10 @@ def test_graph_replay_draws_a_new_dropout_mask_and_accumulates():
         g1 = c.flat_grad.cpu().numpy().copy()
         tv.accum_gradient(None, [pts[0]], [lab[0]])
         g2 = c.flat_grad.cpu().numpy().copy()
-        assert np.linalg.norm(g2 - 2 * g1) <= 2e-3 * np.linalg.norm(g1)
+        assert np.linalg.norm(g2 - 2 * g1) <= 1e-6 * np.linalg.norm(g1)
     finally:
         E.DROPOUT_KEEP = keep
+        E.DETERMINISTIC = E.DETERMINISTIC_ENV_DEFAULT
 
 
 def test_graph_replay_inference_and_new_shapes():
@@ -140,7 +144,8 @@ def test_graph_outputs_of_several_towers_and_micro_steps_do_not_alias():
 
 def test_graph_cache_is_bounded():
     """Variable-N sources: every distinct point count would otherwise pin a captured graph and its activations for ever."""
-    from dgcnn import trainval as TV
+    import importlib
+    TV = importlib.import_module("dgcnn.trainval")               # (the package attribute `dgcnn.trainval` is the class)
     tv = dgcnn.trainval(_flags(TRAIN=False)).initialize().use_graph(True)
     old = TV.GRAPH_CACHE_MAX
     TV.GRAPH_CACHE_MAX = 3
