@@ -51,9 +51,10 @@ def cpu_model():
     return "unknown CPU"
 
 
-def cpu_baseline(clouds=8, iters=5):
+def cpu_baseline(clouds=24, iters=3):
     """The reference graph restated op-for-op on torch-CPU (oracle/torch_twin.py), fwd+bwd, timed on
-    this host's cores on a bounded sample of the same workload (8 of the 24 clouds, MEDIAN of 5 iterations, ~15 s).
+    this host's cores on the SAME batch size as the GPU step (all 24 clouds: BatchNorm statistics over the whole batch, as in
+    the reference; MEDIAN of 3 iterations, ~25-30 s).
     torch's intra-op pool collapses when oversubscribed (256 threads: 0.14 clouds/s, 16 threads: 2.9 clouds/s on the
     2x EPYC 9575F GPU-box host, profiles/r01_cpu_threads.txt), so a short sweep picks the thread count first and
     `cores` reports the count actually used."""
@@ -82,7 +83,7 @@ def cpu_baseline(clouds=8, iters=5):
         ts.append(time.perf_counter() - t0)
     med = float(np.median(ts))
     return {"value": round(clouds / med, 3), "unit": "clouds/s", "cores": best_nt, "kind": "port", "cpu_model": cpu_model(),
-            "sample": "%d of the 24 clouds (N=2048,k=20,C=3, same model) fwd+bwd, median of %d iterations (%.1f s each), %d torch "
+            "sample": "all %d clouds of the batch (N=2048,k=20,C=3, same model) fwd+bwd, median of %d iterations (%.1f s each), %d torch "
                       "threads (best of a {8,16,32} sweep) on a %d-CPU host (%s); torch-CPU op-for-op restatement of the "
                       "TF1 graph (TF1 itself cannot run, BASELINE.md 2)" % (clouds, iters, med, best_nt, ncpu, cpu_model())}
 
@@ -141,8 +142,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--kernel-table", action="store_true", help="print per-kernel event timings to stderr")
-    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for the "
-                    "single-GPU-box sanity run of the N>1 logic, with --same-device)")
+    ap.add_argument("--backend", default="rccl", choices=["rccl", "nccl", "gloo"],
+                    help="N > 1: rccl (default) = the library's own RCCL communicator (dgcnn/rccl.py over csrc/comm.cc, no "
+                         "torch.distributed); nccl = RCCL through torch.distributed; gloo = only for the single-GPU-box sanity run "
+                         "of the N > 1 logic, with --same-device")
     ap.add_argument("--same-device", action="store_true", help="all ranks on cuda:0 (sanity runs only)")
     ap.add_argument("--graph", default="auto", choices=["0", "1", "auto"],
                     help="1: replay the forward+backward tower as a captured HIP graph (the reference replays a static TF graph "
@@ -164,18 +167,26 @@ def main():
     if args.same_device:
         local_rank = 0
     torch.cuda.set_device(local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.backend == "nccl":
-            dist.init_process_group(backend="nccl", rank=rank, world_size=world,
-                                    device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(backend=args.backend, rank=rank, world_size=world)
-
     import dgcnn
     from dgcnn import _hip as H
+    from dgcnn import parallel
+    dist = group = None
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        backend = args.backend
+        if backend == "rccl":
+            try:
+                group = parallel.init_rccl(rank=rank, world=world)
+            except Exception as e:          # every rank fails alike (no library / rendezvous): fall back together, loudly
+                sys.stderr.write("bench.py: own RCCL communicator unavailable (%s); using torch.distributed nccl\n" % e)
+                backend = "nccl"
+        if group is None:
+            import torch.distributed as dist
+            if backend == "nccl":
+                dist.init_process_group(backend="nccl", rank=rank, world_size=world,
+                                        device_id=torch.device("cuda", local_rank))
+            else:
+                dist.init_process_group(backend=backend, rank=rank, world_size=world)
     flags = make_flags(dgcnn)
     tv = dgcnn.trainval(flags).initialize()
     tv.use_graph(args.graph == "1")
@@ -186,13 +197,15 @@ def main():
 
     def step():
         tv.zero_gradients(None)
-        res = tv.accum_gradient(None, [pts], [lab])
+        res = tv.accum_gradient(None, [pts], [lab], last=True)        # one micro-step per update: the head bucket may go early
         tv.apply_gradient(None)
         return res
 
     def fence():
         torch.cuda.synchronize()
-        if dist is not None:
+        if group is not None:
+            group.barrier()
+        elif dist is not None:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -228,7 +241,10 @@ def main():
         step()                                  # sighting + capture
         t_graph = rate()
         use = t_graph < t_eager
-        if dist is not None:                    # every rank must make the same choice
+        if group is not None:                   # every rank must make the same choice
+            v = group.gather_scalars([t_eager, t_graph]).max(0).values
+            use = bool(v[1] < v[0])
+        elif dist is not None:
             v = torch.tensor([t_eager, t_graph], dtype=torch.float64, device="cuda")
             dist.all_reduce(v, op=dist.ReduceOp.MAX)
             use = bool(v[1] < v[0])
@@ -257,12 +273,17 @@ def main():
     tv.use_graph(use_graph)
     loss = float(res[2])
 
-    if dist is not None:
+    # replicas must hold identical parameters after identical Adam steps on the all-reduced gradient
+    chk = torch.stack([dgcnn.ctx().flat_param.double().sum(), dgcnn.ctx().flat_param.double().abs().sum()])
+    if group is not None:
+        allv = group.gather_scalars([elapsed] + [float(x) for x in chk.float()])      # (world, 3)
+        elapsed = float(allv[:, 0].max())
+        if not bool((allv[:, 1:] == allv[0, 1:]).all()):
+            raise SystemExit("replicas diverged: parameter checksums differ across ranks")
+    elif dist is not None:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
-        # replicas must hold identical parameters after identical Adam steps on the all-reduced gradient
-        chk = torch.stack([dgcnn.ctx().flat_param.double().sum(), dgcnn.ctx().flat_param.double().abs().sum()])
         lo, hi = chk.clone(), chk.clone()
         dist.all_reduce(lo, op=dist.ReduceOp.MIN)
         dist.all_reduce(hi, op=dist.ReduceOp.MAX)
@@ -270,8 +291,11 @@ def main():
             raise SystemExit("replicas diverged: parameter checksums differ across ranks")
 
     # the group the gradient all-reduce ran in: backend "nccl" IS RCCL on ROCm (gloo only in the one-device sanity run)
-    coll_backend = dist.get_backend() if dist is not None else None
-    rccl_ranks = dist.get_world_size() if (dist is not None and coll_backend == "nccl") else (1 if dist is None else 0)
+    if group is not None:
+        coll_backend, rccl_ranks = "rccl (dgcnn_allreduce_f32, own communicator)", group.world
+    else:
+        coll_backend = dist.get_backend() if dist is not None else None
+        rccl_ranks = dist.get_world_size() if (dist is not None and coll_backend == "nccl") else (1 if dist is None else 0)
     arith_name = {0: "native fp32 MFMA", 6: "exact 3-way bf16 split, 6 partial products on the bf16 MFMA pipe",
                   9: "exact 3-way bf16 split, 9 partial products on the bf16 MFMA pipe"}[H.gemm_arith()]
     if rank == 0:
@@ -313,6 +337,34 @@ def main():
                 roof["traffic"] = json.load(open(pmc)).get(dominant)
             except Exception:
                 pass
+        # north_star: "rocprof HBM GB/s on the distance/gather kernels and MFMA utilisation on the edge MLP": the other kernel
+        # families of the step, each timed ALONE (the serialised warm-up step above), against the ceiling that bounds it
+        extra = []
+        for t, (n, sec, work) in sorted(table.items(), key=lambda kv: -kv[1][1]):
+            if t == dominant or sec <= 0:
+                continue
+            if t.startswith("knn"):
+                c_in = int(t.split("<C")[1].split(",")[0])
+                extra.append({"kernel": t, "bound": "valu+mfma (fp32 MFMA and the selection share the vector pipe)",
+                              "achieved": round(work / sec / 1e12, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                              "frac": round(work / sec / 1e12 / PEAK_F32_MFMA_TFLOPS, 4), "launches": n,
+                              "avg_us": round(sec / n * 1e6, 1),
+                              "materialised_equiv_GBs": round(n * 2.0 * B * N * N * 4 / sec / 1e9, 1),
+                              "note": "flops = 2 B N^2 C (C = %d padded); materialised_equiv = the 2 B N^2 4-byte write+read of the "
+                                      "reference's (B,N,N) distance tensor that never touches HBM here" % c_in})
+            elif t.startswith("gemm"):
+                pk = PEAK_F32_MFMA_TFLOPS
+                if "bf16x" in t:
+                    pk = PEAK_BF16_MFMA_TFLOPS / int(t.rstrip(">").split("bf16x")[1])
+                if t.startswith("gemm_pl"):
+                    pk = PEAK_BF16_MFMA_TFLOPS / (3 if "f16x2" in t else 6)
+                extra.append({"kernel": t, "bound": "mfma", "achieved": round(work / sec / 1e12, 2), "peak": round(pk, 1),
+                              "unit": "TFLOP/s", "frac": round(work / sec / 1e12 / pk, 4), "launches": n,
+                              "avg_us": round(sec / n * 1e6, 1)})
+            elif work > 0:
+                extra.append({"kernel": t, "bound": "hbm", "achieved": round(work / sec / 1e9, 1), "peak": PEAK_HBM_GBS,
+                              "unit": "GB/s", "frac": round(work / sec / 1e9 / PEAK_HBM_GBS, 4), "launches": n,
+                              "avg_us": round(sec / n * 1e6, 1)})
         if args.kernel_table:
             tot = sum(v[1] for v in table.values())
             for t, (n, s, w) in sorted(table.items(), key=lambda kv: -kv[1][1]):
@@ -338,12 +390,15 @@ def main():
                        "final_loss": round(loss, 5), "host_enqueue_ms_per_step": round(t_issue / args.steps * 1e3, 3),
                        "launch_mode": "hip-graph replay" if use_graph else "eager", "launch_mode_calibration": calib},
             "roofline": roof,
+            "roofline_extra": extra[:14],
         }
         if world == 1:
             out["edgeconv_stack"] = edgeconv_stack_rate(dgcnn, pts)     # after the timed region; resets the engine context
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))
+    if group is not None:
+        parallel.shutdown_rccl()
     if dist is not None:
         dist.destroy_process_group()
 

@@ -17,10 +17,16 @@ def main(argv=None):
         local = int(os.environ.get("LOCAL_RANK", "0"))
         torch.cuda.set_device(local)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+        # data path (parameter broadcast, gradient all-reduce): the library's own RCCL communicator (dgcnn/rccl.py);
+        # control plane of the run loops (resume iteration, output gathering: host objects): a gloo group
+        dist.init_process_group(backend="gloo")
+        from dgcnn import parallel
+        if os.environ.get("DGCNN_COLLECTIVE", "rccl") == "rccl":
+            parallel.init_rccl()
     from dgcnn import DGCNN_FLAGS
     DGCNN_FLAGS().parse_args(argv)
     if world > 1:
+        parallel.shutdown_rccl()
         dist.destroy_process_group()
 
 

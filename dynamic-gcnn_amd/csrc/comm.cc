@@ -1,0 +1,101 @@
+// comm.cc -- the one collective of the path (dgcnn/trainval.py:64-73: gradients averaged over the towers), as a thin layer over
+// RCCL: libdgcnn_hip.so does not link librccl -- it is dlopen'ed on first use, so single-GPU use needs no RCCL at all.
+//   dgcnn_comm_unique_id  rank 0 draws the 128-byte id; the HOST side ships it to the other ranks (dgcnn/rccl.py: a socket on
+//                         MASTER_ADDR:MASTER_PORT + 1 -- no torch.distributed anywhere)
+//   dgcnn_comm_init       ncclCommInitRank (one process per GPU, the device already selected with hipSetDevice)
+//   dgcnn_allreduce_f32   in-place SUM all-reduce of a device buffer on the caller's stream (gradients: followed by a 1/world
+//                         scale in the caller's Adam launch); dgcnn_broadcast_f32: rank `root`'s buffer to everyone
+// One communicator serves several streams sequentially; the host orders the calls (a bucket per call).
+#include "common.h"
+#include <dlfcn.h>
+#include <stdlib.h>
+#include <string.h>
+
+namespace {
+
+typedef struct { char internal[128]; } UniqueId;           // ncclUniqueId (NCCL_UNIQUE_ID_BYTES = 128), passed BY VALUE
+typedef void* Comm;                                        // ncclComm_t
+enum { kFloat32 = 7, kSum = 0 };                           // ncclFloat32, ncclSum (rccl.h)
+
+struct Api {
+  void* lib = nullptr;
+  int (*GetUniqueId)(UniqueId*) = nullptr;
+  int (*CommInitRank)(Comm*, int, UniqueId, int) = nullptr;
+  int (*CommDestroy)(Comm) = nullptr;
+  int (*AllReduce)(const void*, void*, size_t, int, int, Comm, hipStream_t) = nullptr;
+  int (*Broadcast)(const void*, void*, size_t, int, int, Comm, hipStream_t) = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+} g;
+
+int load_api() {
+  if (g.lib) return DGCNN_OK;
+  const char* names[] = {getenv("DGCNN_RCCL_LIB"), "librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
+  void* h = nullptr;
+  for (const char* n : names) {
+    if (n && *n && (h = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
+  }
+  if (!h) {
+    dg::set_error("RCCL not found (librccl.so; set DGCNN_RCCL_LIB): %s", dlerror());
+    return DGCNN_EUNSUP;
+  }
+#define DG_SYM(field, name)                                             \
+  *(void**)(&g.field) = dlsym(h, name);                                 \
+  if (!g.field) { dg::set_error("librccl: missing symbol %s", name); dlclose(h); return DGCNN_EUNSUP; }
+  DG_SYM(GetUniqueId, "ncclGetUniqueId")
+  DG_SYM(CommInitRank, "ncclCommInitRank")
+  DG_SYM(CommDestroy, "ncclCommDestroy")
+  DG_SYM(AllReduce, "ncclAllReduce")
+  DG_SYM(Broadcast, "ncclBroadcast")
+  DG_SYM(GetErrorString, "ncclGetErrorString")
+#undef DG_SYM
+  g.lib = h;
+  return DGCNN_OK;
+}
+
+int check(int rc, const char* what) {
+  if (rc == 0) return DGCNN_OK;
+  dg::set_error("%s: RCCL error %d (%s)", what, rc, g.GetErrorString ? g.GetErrorString(rc) : "?");
+  return DGCNN_ELAUNCH;
+}
+
+}  // namespace
+
+extern "C" int dgcnn_comm_unique_id(void* id128) {
+  DG_REQUIRE(id128, DGCNN_EINVAL, "dgcnn_comm_unique_id: null pointer");
+  int rc = load_api();
+  if (rc) return rc;
+  UniqueId id;
+  memset(&id, 0, sizeof(id));
+  rc = check(g.GetUniqueId(&id), "ncclGetUniqueId");
+  if (rc) return rc;
+  memcpy(id128, &id, sizeof(id));
+  return DGCNN_OK;
+}
+
+extern "C" int dgcnn_comm_init(int world, int rank, const void* id128, void** comm_out) {
+  DG_REQUIRE(id128 && comm_out && world >= 1 && rank >= 0 && rank < world, DGCNN_EINVAL, "dgcnn_comm_init: bad args");
+  int rc = load_api();
+  if (rc) return rc;
+  UniqueId id;
+  memcpy(&id, id128, sizeof(id));
+  Comm c = nullptr;
+  rc = check(g.CommInitRank(&c, world, id, rank), "ncclCommInitRank");
+  if (rc) return rc;
+  *comm_out = c;
+  return DGCNN_OK;
+}
+
+extern "C" int dgcnn_comm_destroy(void* comm) {
+  if (!comm || !g.lib) return DGCNN_OK;
+  return check(g.CommDestroy((Comm)comm), "ncclCommDestroy");
+}
+
+extern "C" int dgcnn_allreduce_f32(float* buf, int64_t count, void* comm, void* stream) {
+  DG_REQUIRE(buf && comm && count > 0 && g.lib, DGCNN_EINVAL, "dgcnn_allreduce_f32: bad args (communicator from dgcnn_comm_init)");
+  return check(g.AllReduce(buf, buf, (size_t)count, kFloat32, kSum, (Comm)comm, (hipStream_t)stream), "ncclAllReduce");
+}
+
+extern "C" int dgcnn_broadcast_f32(float* buf, int64_t count, int root, void* comm, void* stream) {
+  DG_REQUIRE(buf && comm && count > 0 && root >= 0 && g.lib, DGCNN_EINVAL, "dgcnn_broadcast_f32: bad args");
+  return check(g.Broadcast(buf, buf, (size_t)count, kFloat32, root, (Comm)comm, (hipStream_t)stream), "ncclBroadcast");
+}

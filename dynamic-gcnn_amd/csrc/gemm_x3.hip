@@ -8,9 +8,10 @@
 //             (as it does in the native kernel)                               -> 9/16 of the native MFMA time
 //     NP = 6  drops a2*b3, a3*b2, a3*b3 (<= 2^-23 |a*b| together, the size of ONE fp32 rounding of the
 //             product -- what an unfused multiply-add chain commits anyway)    -> 6/16 of the native MFMA time
-//     NP = 1  only a1*b1: plain bf16 OPERANDS (round to nearest even), fp32 accumulate -- the "bf16 edge-MLP" mode of
-//             BASELINE configs[2]; NOT fp32-class (2^-9 relative per operand), selected per GEMM by the host for the
-//             EdgeConv conv0 / conv1 products only (EDGE_MLP_DTYPE = bf16)      -> 1/16 of the native MFMA time
+//     NP = 1  only a1*b1: plain bf16 OPERANDS (round to nearest even), fp32 accumulate; NOT fp32-class (2^-9 relative per
+//             operand).  Kept for measurements (dgcnn_gemm_set_arith(1)): as the "bf16 edge-MLP" of BASELINE configs[2] it was
+//             measured neither accurate (the folded conv0 rounds x_i and x_j separately: logits 0.6 off) nor faster, and the
+//             model no longer offers it                                -> 1/16 of the native MFMA time
 // Inputs, outputs and accumulators stay fp32; tests/test_gpu_parity.py::test_gemm_split_accuracy measures
 // the error of both against an fp64 product next to the native fp32-MFMA kernel (profiles/r01_gemm_arith.txt).
 // Inf/NaN inputs produce NaN (Inf - Inf in the split); the path's activations are finite.

@@ -53,7 +53,8 @@ DETERMINISTIC = DETERMINISTIC_ENV_DEFAULT      # trainval.initialize() sets it p
 
 # Head GEMMs (MergedEdgeConv, FC0, FC1: 98 % of the step's GEMM flops) from pre-split operand planes (csrc/gemm_pl.hip):
 #   "f16"  two fp16 planes per operand, 3 partial products   "bf16"  three bf16 planes, 6 partial products   "0"  off
-HEAD_PLANES = {"f16": PL.F16X2, "bf16": PL.BF16X3}.get(os.environ.get("DGCNN_HEAD_PLANES", "0").lower())
+HEAD_PLANES_ENV_DEFAULT = {"f16": PL.F16X2, "bf16": PL.BF16X3}.get(os.environ.get("DGCNN_HEAD_PLANES", "0").lower())
+HEAD_PLANES = HEAD_PLANES_ENV_DEFAULT          # trainval.initialize() sets it per instance (flag HEAD_PLANES, else this default)
 PLANES_MIN_ROWS = 8192
 
 
@@ -84,12 +85,12 @@ class Context(object):
         self.step_seed = 0
         self.seed_dev = None             # device uint64: the dropout seed of the running step (read by the kernels)
         self.capturing = False           # inside a HIP-graph capture: no host-side per-step state may be baked in
-        self.edge_mlp_arith = None       # 1: bf16 operands for the EdgeConv conv0 / conv1 products (EDGE_MLP_DTYPE = 'bf16')
         self.debug = False
         self.planes = {}                 # (data_ptr, rows, cols) of an fp32 2-D view -> PlaneSet holding it as GEMM operand planes (this step)
         self.pl_scales = None            # device float[2]: power-of-two scales of the step's activation / weight plane sets (fp16 planes)
         self.pl_scales_ready = False
         self.pl_ws = None
+        self.head_grads_hook = None      # called by the backward when every head gradient is final (trainval: bucketed all-reduce)
 
     # ---- device / scratch -------------------------------------------------------------
     @property
@@ -387,7 +388,7 @@ def _tile_m(M, N):
 
 def gemm(A, Bm, C, transA=False, transB=False, beta=0.0, gbias=None, rpg=0, stats=None, arith=None):
     """C (+)= op(A) op(B); shapes are those of the stored matrices.  arith: arithmetic of THIS product (None = the
-    process-wide setting; 1 = bf16 operands, the EDGE_MLP_DTYPE='bf16' mode of the EdgeConv conv0 / conv1 products)."""
+    process-wide setting; 1 = plain bf16 operands: measurements only, not fp32 class)."""
     if arith is not None and arith != H.gemm_arith():
         prev = H.gemm_arith()
         H.set_gemm_arith(arith)
@@ -603,7 +604,7 @@ def _point_gemm(c, x, W0, R, C, F, side):
         if Cp != C:
             H.call("dgcnn_copy2d_f32", x.data_ptr(), H.ld2(x), xg.data_ptr(), Cp, R, C, 0)
         H.call("dgcnn_edge_weight_split_f32", W0.data_ptr(), C, F, wcat.data_ptr())
-        gemm(xg, wcat, UV, arith=c.edge_mlp_arith)
+        gemm(xg, wcat, UV, arith=None)
     if side:
         with c.off_critical_path(xg, wcat, UV, rows=R):
             issue()
@@ -769,10 +770,10 @@ def edge_conv_block(x, B, N, k, num_filters, relu1=True, outs=None, net2=None):
                 # dUV / dwcat are locals of this closure allocated on the main stream: record them on the side stream,
                 # or the caching allocator may hand dUV's block to the next main-stream allocation while the side GEMM reads it
                 with c.off_critical_path(dwcat, dUV, rows=R):
-                    gemm(xg, dUV, dwcat, transA=True, arith=c.edge_mlp_arith)
+                    gemm(xg, dUV, dwcat, transA=True, arith=None)
                     H.call("dgcnn_edge_wgrad_combine_f32", dwcat.data_ptr(), C, F, dW0.data_ptr())
                 if dx is not None:
-                    gemm(dUV, wcat[:C], dx, transB=True, beta=1.0, arith=c.edge_mlp_arith)
+                    gemm(dUV, wcat[:C], dx, transB=True, beta=1.0, arith=None)
                 return
             if literal:
                 H.call("dgcnn_edge_mlp_wgrad_f32", x.data_ptr(), H.ld2(x), idx.data_ptr(), dY.data_ptr(), B, N, C, k, F,
@@ -809,7 +810,7 @@ def edge_conv_block(x, B, N, k, num_filters, relu1=True, outs=None, net2=None):
                     gemm(S, W0[C:], dx, transB=True, beta=1.0)
         c.tape.append(bwd)
 
-    net = conv_bn_act(mm, "conv1", 64, relu=relu1, out=net_out, out2=net2, arith=c.edge_mlp_arith)   # ops.py:62-70 (64 hard-coded)
+    net = conv_bn_act(mm, "conv1", 64, relu=relu1, out=net_out, out2=net2, arith=None)   # ops.py:62-70 (64 hard-coded)
     return mm, net, idx
 
 
@@ -907,6 +908,20 @@ def plain_gemm(a, leaf_scope_weight, w_rows, Cout):
 # ----------------------------------------------------------------------------------------------
 # dgcnn/trainval.py:39-52 softmax / accuracy / loss (+ the seed of the backward pass)
 # ----------------------------------------------------------------------------------------------
+def mark_head_gradients_complete():
+    """Tape marker placed (in forward order) right after the EdgeConv stack: in the backward it runs when every closure of
+    the head (MergedEdgeConv, FC*, Final) has run, i.e. when the head's share of the gradient bucket is final."""
+    c = ctx()
+    if not c.recording:
+        return
+
+    def bwd():
+        hook, c.head_grads_hook = c.head_grads_hook, None
+        if hook is not None:
+            hook()
+    c.tape.append(bwd)
+
+
 def softmax_loss(logits2d, labels, weight, want_grad):
     """-> (softmax (R,ncls), scal tensor [loss, accuracy] on device).  Seeds d(logits) if want_grad."""
     c = ctx()

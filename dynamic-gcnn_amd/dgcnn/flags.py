@@ -50,8 +50,9 @@ _OPTIONS = [
     ("CHECKPOINT_HOUR", "-chkh", float, 0.4, "t", "accepted for compatibility; unused"),
     ("WEIGHT_KEY", "-wkey", str, "", "tf", "keyword to fetch weight from file"),
     ("USE_GRAPH", "-ug", str, "auto", "ti", "replay the tower as a captured HIP graph: 0 | 1 | auto (launch-bound shapes only)"),
-    ("EDGE_MLP_DTYPE", "-emd", str, "f32", "ti", "operand type of the EdgeConv conv0 / conv1 products: f32 | bf16"),
     ("DETERMINISTIC", "-det", _BOOL, None, "ti", "fixed-order BatchNorm sums / sorted adjacency: bit-reproducible runs (slower)"),
+    ("HEAD_PLANES", "-hp", str, None, "ti", "head GEMMs (MergedEdgeConv, FC*) from operand planes written by the BatchNorm passes: "
+                                             "0 | f16 (2 fp16 planes, 3 products) | bf16 (3 bf16 planes, 6 products); default $DGCNN_HEAD_PLANES"),
 ]
 
 

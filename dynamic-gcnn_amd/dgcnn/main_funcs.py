@@ -188,7 +188,9 @@ def _replica_mean(h, values):
         return -1.0
     t = torch.stack([torch.as_tensor(v, dtype=torch.float32).reshape(()) for v in values]).mean()
     dist, _, world = parallel.dist_state()
-    if dist is not None and world > 1:
+    if world > 1 and parallel.rccl_group() is not None and t.is_cuda:
+        t = parallel.rccl_group().allreduce_sum_(t.clone().reshape(1)) / world
+    elif dist is not None and world > 1:
         t = t.clone()
         dist.all_reduce(t)
         t = t / world
@@ -203,6 +205,9 @@ def _gather_rows(h, softmax, idx):
     if h.world == 1:
         return [row for tower in softmax for row in tower.cpu().numpy()]
     dist = parallel.dist_state()[0]
+    if dist is None:
+        raise RuntimeError("OUTPUT_FILE with more than one replica needs torch.distributed for the control plane "
+                           "(bin/dgcnn.py initialises a gloo group next to the RCCL communicator)")
     dev = softmax[0].device
     mine = torch.as_tensor(np.asarray(idx, dtype=np.int64), device=dev)
     ref = mine.clone()
@@ -245,8 +250,10 @@ def train_loop(flags, h):
         t0 = time.time()
         losses, accs = [], []
         h.trainer.zero_gradients(h.sess)
-        for dv, lv, wv in _micro_batches(flags, h, data, label, weight):
-            res = h.trainer.accum_gradient(h.sess, dv, lv, wv, summary=summarize)
+        micro = list(_micro_batches(flags, h, data, label, weight))
+        for mi, (dv, lv, wv) in enumerate(micro):
+            # (last: the head's gradient bucket may start its all-reduce under this micro-step's EdgeConv backward)
+            res = h.trainer.accum_gradient(h.sess, dv, lv, wv, summary=summarize, last=(mi == len(micro) - 1))
             accs.append(res[1])
             losses.append(res[2])
         h.trainer.apply_gradient(h.sess)

@@ -63,6 +63,7 @@ def build(point_cloud, flags):
                                                 num_filters=num_edge_filters, trainable=is_training,
                                                 debug=debug, _plan=plan)
 
+    E.mark_head_gradients_complete()                               # (backward: the head's gradients are final from here on)
     if nofc:                                                       # model.py:45-58
         last, _, _ = E.as2d(tensors[-1])
         fin = E.conv_bn_act(last, "Final", num_class, relu=True)

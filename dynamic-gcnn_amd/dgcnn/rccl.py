@@ -1,0 +1,136 @@
+"""The path's one collective on RCCL, without torch.distributed: a ctypes view of the communicator entry points of
+libdgcnn_hip.so (csrc/comm.cc dlopens librccl.so) plus the rendezvous that ships rank 0's unique id to the other ranks.
+
+Reference: in-graph towers, gradients copied to the host and averaged there (dgcnn/trainval.py:16,64-73).  Here: one process per
+GPU (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT from the launcher's environment, as torch.distributed.run sets
+them); the 128-byte ncclUniqueId travels over a plain TCP socket on MASTER_ADDR:(MASTER_PORT + 1) (or $DGCNN_RCCL_PORT);
+collectives run on a dedicated HIP stream so that a bucket can be reduced while the backward pass is still producing the next."""
+from __future__ import annotations
+
+import ctypes
+import os
+import socket
+import time
+
+import torch
+
+from . import _hip as H
+
+ID_BYTES = 128
+
+
+def _exchange_id(rank, world, addr, port, make_id, timeout=180.0):
+    """rank 0: draw the id, serve it to world - 1 connections; others: connect (with retries) and read it."""
+    if rank == 0:
+        ident = make_id()
+        if world == 1:
+            return ident
+        srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+        srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+        srv.bind((addr if addr not in ("localhost",) else "127.0.0.1", port))
+        srv.listen(world)
+        srv.settimeout(timeout)
+        try:
+            for _ in range(world - 1):
+                conn, _ = srv.accept()
+                with conn:
+                    conn.sendall(ident)
+        finally:
+            srv.close()
+        return ident
+    deadline = time.time() + timeout
+    last = None
+    while time.time() < deadline:
+        try:
+            with socket.create_connection((addr, port), timeout=5.0) as s:
+                buf = b""
+                while len(buf) < ID_BYTES:
+                    chunk = s.recv(ID_BYTES - len(buf))
+                    if not chunk:
+                        break
+                    buf += chunk
+                if len(buf) == ID_BYTES:
+                    return buf
+        except OSError as e:            # rank 0 not listening yet
+            last = e
+        time.sleep(0.1)
+    raise H.HipError("RCCL rendezvous: rank %d could not fetch the unique id from %s:%d (%s)" % (rank, addr, port, last))
+
+
+class Group(object):
+    """One RCCL communicator for this process' current device."""
+
+    def __init__(self, rank=None, world=None, addr=None, port=None):
+        env = os.environ
+        self.rank = int(env.get("RANK", "0")) if rank is None else int(rank)
+        self.world = int(env.get("WORLD_SIZE", "1")) if world is None else int(world)
+        addr = env.get("MASTER_ADDR", "127.0.0.1") if addr is None else addr
+        if port is None:
+            port = int(env["DGCNN_RCCL_PORT"]) if "DGCNN_RCCL_PORT" in env else int(env.get("MASTER_PORT", "29500")) + 1
+        if not torch.cuda.is_available():
+            raise H.HipError("RCCL group needs a GPU")
+        self.lib = H.load()
+        self.device = torch.device("cuda", torch.cuda.current_device())
+
+        def make_id():
+            buf = ctypes.create_string_buffer(ID_BYTES)
+            self._check(self.lib.dgcnn_comm_unique_id(buf), "dgcnn_comm_unique_id")
+            return buf.raw
+        ident = _exchange_id(self.rank, self.world, addr, int(port), make_id)
+        comm = ctypes.c_void_p()
+        self._check(self.lib.dgcnn_comm_init(self.world, self.rank, ident, ctypes.byref(comm)), "dgcnn_comm_init")
+        self.comm = comm
+        self.stream = torch.cuda.Stream(device=self.device)          # collectives run here
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise H.HipError("%s failed (%d): %s" % (what, rc, self.lib.dgcnn_last_error().decode()))
+
+    # ---- collectives (in place, on self.stream, ordered after everything issued so far on the current stream) ----
+    def _on_comm_stream(self, fn, tensor):
+        cur = torch.cuda.current_stream()
+        self.stream.wait_stream(cur)
+        tensor.record_stream(self.stream)
+        fn(self.stream.cuda_stream)
+
+    def allreduce_sum_async(self, t):
+        """SUM over the ranks, in place; returns immediately.  `wait()` orders the current stream after it."""
+        assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()
+        self._on_comm_stream(lambda st: self._check(self.lib.dgcnn_allreduce_f32(t.data_ptr(), t.numel(), self.comm, st),
+                                                    "dgcnn_allreduce_f32"), t)
+
+    def broadcast_async(self, t, root=0):
+        assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()
+        self._on_comm_stream(lambda st: self._check(self.lib.dgcnn_broadcast_f32(t.data_ptr(), t.numel(), int(root), self.comm, st),
+                                                    "dgcnn_broadcast_f32"), t)
+
+    def wait(self):
+        torch.cuda.current_stream().wait_stream(self.stream)
+
+    def allreduce_sum_(self, t):
+        self.allreduce_sum_async(t)
+        self.wait()
+        return t
+
+    def broadcast_(self, t, root=0):
+        self.broadcast_async(t, root)
+        self.wait()
+        return t
+
+    def barrier(self):
+        one = torch.ones(1, dtype=torch.float32, device=self.device)
+        self.allreduce_sum_(one)
+        torch.cuda.synchronize()
+
+    def gather_scalars(self, values):
+        """Every rank's list of floats on every rank: (world, len(values)) via one SUM all-reduce of a one-hot-by-rank matrix."""
+        m = torch.zeros((self.world, len(values)), dtype=torch.float32, device=self.device)
+        m[self.rank] = torch.tensor(values, dtype=torch.float32, device=self.device)
+        self.allreduce_sum_(m)
+        return m.cpu()
+
+    def destroy(self):
+        if getattr(self, "comm", None):
+            torch.cuda.synchronize()
+            self.lib.dgcnn_comm_destroy(self.comm)
+            self.comm = None

@@ -76,6 +76,16 @@ class trainval(object):
         self._lr = float(f.LEARNING_RATE)
         self._dist, self._rank, self._world = parallel.dist_state()
         parallel.broadcast_(self._ctx.flat_param, self._dist, src=0)
+        # the head's variables (MergedEdgeConv, FC*, Final) sit at the END of the flat bucket (creation order, SURVEY
+        # Appendix B): [head_off, end) is the bucket that can be all-reduced while the EdgeConv backward is still running
+        self._head_off = 0
+        off = 0
+        for name, shape in param_specs(f, int(f.NUM_CHANNEL)):
+            if name.startswith("MergedEdgeConv/"):
+                self._head_off = off
+                break
+            off += int(np.prod(shape))
+        self._head_reduced = False
         # resolved on EVERY initialize (flag, else the DGCNN_DETERMINISTIC environment default): an instance never inherits
         # the mode of an earlier one.  The switch itself is process-wide, like the GEMM arithmetic.
         det = getattr(f, "DETERMINISTIC", None)
@@ -87,12 +97,13 @@ class trainval(object):
             if wide:
                 raise ValueError("DETERMINISTIC mode supports at most 1024 filters per layer (csrc/det.hip); too wide: %s"
                                  % ", ".join(wide))
-        emd = str(getattr(f, "EDGE_MLP_DTYPE", "f32")).lower()
-        if emd not in ("f32", "fp32", "float32", "bf16", "bfloat16"):
-            raise ValueError("EDGE_MLP_DTYPE must be 'f32' or 'bf16', got %r" % (emd,))
-        # BASELINE configs[2] "bf16 edge-MLP": the conv0 / conv1 products of every EdgeConv layer (forward, dgrad, wgrad) take
-        # bf16 OPERANDS with fp32 accumulation (one bf16 MFMA product instead of six); everything else stays fp32-class
-        self._ctx.edge_mlp_arith = 1 if emd.startswith("b") else None
+        hp = getattr(f, "HEAD_PLANES", None)             # per instance, like DETERMINISTIC: flag, else the environment default
+        if hp is None:
+            E.HEAD_PLANES = E.HEAD_PLANES_ENV_DEFAULT
+        else:
+            if str(hp).lower() not in ("0", "", "none", "off", "f16", "bf16"):
+                raise ValueError("HEAD_PLANES must be 0, f16 or bf16, got %r" % (hp,))
+            E.HEAD_PLANES = {"f16": E.PL.F16X2, "bf16": E.PL.BF16X3}.get(str(hp).lower())
         self._graphs, self._graph_seen = OrderedDict(), {}     # captured towers (LRU order) / sightings per key
         ug = str(getattr(f, "USE_GRAPH", "0")).lower()
         self._use_graph = "auto" if ug == "auto" else ug in ("1", "true", "yes", "on")
@@ -169,7 +180,7 @@ class trainval(object):
     def _tower_graph(self, pts, lab, wgt, train):
         c = self._ctx
         key = (tuple(pts.shape), bool(train), lab is not None, wgt is not None, float(E.DROPOUT_KEEP), H.gemm_arith(),
-               E.WGRAD_SIDE_STREAM, c.edge_mlp_arith, E.DETERMINISTIC)
+               E.WGRAD_SIDE_STREAM, E.HEAD_PLANES, E.DETERMINISTIC)
         ent = self._graphs.get(key)
         if ent is None:
             # first sightings run eagerly (the very first also allocates workspaces / arenas).  A variable-N source
@@ -245,14 +256,23 @@ class trainval(object):
             outs += [s[1], s[0]]
         return outs
 
-    def accum_gradient(self, sess, data, label, weight=None, summary=False):
+    def accum_gradient(self, sess, data, label, weight=None, summary=False, last=False):
         """trainval.py:110-119: [accum_results, accuracy, loss(, summary)]; tower-mean gradient is
-        ADDED to the accumulators (sum over micro-steps, trainval.py:79)."""
+        ADDED to the accumulators (sum over micro-steps, trainval.py:79).
+        last=True (not in the reference: its averaging happens inside apply_gradient's session run): this is the final
+        micro-step before apply_gradient, so the head's share of the gradient bucket may be all-reduced as soon as the head's
+        backward has produced it, underneath the EdgeConv backward (RCCL group registered, one tower per process)."""
         if not self._flags.TRAIN:
             raise NotImplementedError
         c = self._ctx
         fd = self.feed_dict(data, label, weight)
         T = len(fd["data"])
+        c.head_grads_hook = None
+        if last and T == 1 and parallel.rccl_group() is not None and 0 < self._head_off < c.flat_grad.numel() and not self._use_graph:
+            def hook():
+                c.join_side()                                   # the head's weight-gradient GEMMs (side stream) have landed
+                self._head_reduced = parallel.allreduce_sum_async(c.flat_grad[self._head_off:])
+            c.head_grads_hook = hook
         saved = None
         if T > 1:
             saved = c.flat_grad.clone()
@@ -282,7 +302,13 @@ class trainval(object):
             raise NotImplementedError
         c = self._ctx
         g = c.flat_grad
-        parallel.allreduce_mean_(g, self._dist, self._world)          # sum over replicas / world
+        if self._head_reduced:                                        # the head bucket is already travelling: send the rest, join
+            self._head_reduced = False
+            parallel.allreduce_sum_async(g[:self._head_off])
+            parallel.rccl_group().wait()
+            parallel.scale_(g, self._world)
+        else:
+            parallel.allreduce_mean_(g, self._dist, self._world)      # sum over replicas / world
         c.adam_t += 1
         b1, b2, eps = 0.9, 0.999, 1e-8                                # tf.train.AdamOptimizer defaults
         lr_t = self._lr * math.sqrt(1.0 - b2 ** c.adam_t) / (1.0 - b1 ** c.adam_t)

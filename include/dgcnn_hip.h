@@ -309,6 +309,17 @@ int dgcnn_axpby_f32(const float* x, float a, float* y, float b, int64_t n, void*
 int dgcnn_adam_f32(float* param, const float* grad, float* m, float* v, int64_t n,
                    float lr_t, float b1, float b2, float eps, void* stream);
 
+/* ---- the gradient collective (trainval.py:64-73 mean over the towers; here: one process per GPU, RCCL over xGMI) ----
+ * RCCL is dlopen'ed on first use (librccl.so, or $DGCNN_RCCL_LIB); no torch.distributed involved.
+ * dgcnn_comm_unique_id: rank 0 fills 128 bytes; the host ships them to the other ranks (dgcnn/rccl.py).
+ * dgcnn_comm_init: ncclCommInitRank for this process' current HIP device -> opaque communicator.
+ * dgcnn_allreduce_f32: in-place SUM over the ranks on `stream`;  dgcnn_broadcast_f32: root's buffer to every rank. */
+int dgcnn_comm_unique_id(void* id128);
+int dgcnn_comm_init(int world, int rank, const void* id128, void** comm_out);
+int dgcnn_comm_destroy(void* comm);
+int dgcnn_allreduce_f32(float* buf, int64_t count, void* comm, void* stream);
+int dgcnn_broadcast_f32(float* buf, int64_t count, int root, void* comm, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

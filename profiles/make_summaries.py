@@ -36,6 +36,9 @@ def tag_of(name):
     if m:
         kinds = {0: "KCONTIG", 1: "KSTRIDED"}
         return "gemm_x3_kernel<%s,%s,%s,bf16x%s>" % (kinds[int(m.group(1))], kinds[int(m.group(2))], m.group(3), m.group(4))
+    m = re.match(r"gemm_pl_kernel<(\d), (\d), (\d+), (\d+)>", n)
+    if m:
+        return "gemm_pl_kernel<%s,%s>" % ("KC" if m.group(1) == "0" else "TR", "bf16x3" if m.group(2) == "0" else "f16x2")
     m = re.match(r"knn_(mfma_)?kernel<(\d+), (\d+)(, \w+)?>", n)
     if m:
         return "knn_kernel<C%s,k%s>" % (m.group(2), m.group(3))

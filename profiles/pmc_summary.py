@@ -1,5 +1,8 @@
 #!/usr/bin/env python
 """Summarise rocprofv3 --pmc counter_collection.csv files per kernel (mean per dispatch).
+Derived columns (when the pass holds GRBM_GUI_ACTIVE / SQ_VALU_MFMA_BUSY_CYCLES):
+  clk_GHz  = GRBM_GUI_ACTIVE / 8 XCDs / avg_us          (effective shader clock under the power cap)
+  mfma_%   = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x avg_us x clk)   (share of SIMD-cycles with the matrix pipe busy)
 usage: pmc_summary.py <counter_collection.csv> [more.csv ...]"""
 import collections
 import csv
@@ -29,10 +32,13 @@ def main():
         rows.append((sum(v["_dur_us"]), k, len(v["_dur_us"]), dur, v))
     rows.sort(reverse=True, key=lambda r: r[0])
     ctrs = sorted({c for _, _, _, _, v in rows for c in v if not c.startswith("_")})
-    print("kernel | calls | avg_us | " + " | ".join(ctrs) + " | regs")
+    print("kernel | calls | avg_us | clk_GHz | mfma_% | " + " | ".join(ctrs) + " | regs")
     for tot, k, n, dur, v in rows[:30]:
         vals = ["%.4g" % (sum(v[c]) / len(v[c])) if c in v else "-" for c in ctrs]
-        print("%-58s %3d %8.1f  " % (k[:58], n, dur) + "  ".join(vals) + "  " + v["_regs"][0])
+        mean = lambda c: sum(v[c]) / len(v[c])
+        clk = mean("GRBM_GUI_ACTIVE") / 8.0 / dur / 1e3 if "GRBM_GUI_ACTIVE" in v and dur > 0 else 0.0
+        busy = 100.0 * mean("SQ_VALU_MFMA_BUSY_CYCLES") / (1024.0 * dur * 1e3 * clk) if ("SQ_VALU_MFMA_BUSY_CYCLES" in v and clk > 0) else 0.0
+        print("%-58s %3d %8.1f  %5.2f  %5.1f  " % (k[:58], n, dur, clk, busy) + "  ".join(vals) + "  " + v["_regs"][0])
 
 
 if __name__ == "__main__":

@@ -15,9 +15,10 @@ pytestmark = pytest.mark.gpu
 B, N, C = 4, 2048, 3
 
 
-def _flags(train):
+def _flags(train, mode=None):
+    hp = {None: None, P.F16X2: "f16", P.BF16X3: "bf16"}[mode]
     return dgcnn.DGCNN_FLAGS(MODEL_NAME="dgcnn", EDGE_CONV_LAYERS=2, EDGE_CONV_FILTERS=[64, 64], FC_LAYERS=2, FC_FILTERS=[512, 256],
-                             NUM_CLASS=3, KVALUE=12, NUM_CHANNEL=C, TRAIN=train, SEED=3)
+                             NUM_CLASS=3, KVALUE=12, NUM_CHANNEL=C, TRAIN=train, SEED=3, HEAD_PLANES=hp)
 
 
 @pytest.fixture(scope="module")
@@ -44,7 +45,7 @@ def _run(mode, case, train):
         return orig(form, A, Bm, Cm, **kw)
     P.gemm = spy
     try:
-        tv, res, layers = run_model(dgcnn, _flags(train), pts, params, train=train, labels=labels)
+        tv, res, layers = run_model(dgcnn, _flags(train, mode), pts, params, train=train, labels=labels)
         grads = {n: host(tv.gradients[n]).astype(np.float64) for n in params} if train else None
         out = [host(r) if isinstance(r, torch.Tensor) else r for r in res]
     finally:
@@ -85,9 +86,9 @@ def test_plane_mode_inference_logits(case, mode):
 
 def test_plane_mode_is_off_in_deterministic_mode_and_for_small_problems(case):
     old = E.HEAD_PLANES
-    E.HEAD_PLANES = P.F16X2
     try:
-        dgcnn.trainval(_flags(True)).initialize()
+        dgcnn.trainval(_flags(True, P.F16X2)).initialize()
+        assert E.HEAD_PLANES == P.F16X2
         assert E.planes_ok(8192, 128, 1024) and not E.planes_ok(4096, 128, 1024) and not E.planes_ok(8192, 100, 1024)
         E.DETERMINISTIC = True
         assert not E.planes_ok(8192, 128, 1024)

@@ -1,0 +1,84 @@
+"""The library's own RCCL communicator (csrc/comm.cc + dgcnn/rccl.py): the gradient collective of dgcnn/trainval.py:64-73 without
+torch.distributed.  The GPU box has ONE device and RCCL refuses two ranks on one device, so what runs here is a one-rank
+communicator created through the full path (dlopen librccl, unique id, ncclCommInitRank, collectives on the communicator's own
+stream) and the trainer's bucketed, overlapped reduction on top of it; the rendezvous is covered by tests/test_rccl_rendezvous.py."""
+import numpy as np
+import pytest
+import torch
+
+import dgcnn
+from dgcnn import _engine as E, parallel
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture()
+def group():
+    g = parallel.init_rccl(rank=0, world=1)
+    yield g
+    parallel.shutdown_rccl()
+    dgcnn.reset()
+
+
+def test_one_rank_communicator_runs_allreduce_and_broadcast_inside_rccl(group):
+    assert group.world == 1 and group.rank == 0 and group.comm
+    x = torch.arange(1 << 20, dtype=torch.float32, device="cuda") * 0.5
+    ref = x.clone()
+    group.allreduce_sum_(x)                       # SUM over one rank: the buffer goes through ncclAllReduce unchanged
+    group.broadcast_(x, root=0)
+    torch.cuda.synchronize()
+    assert torch.equal(x, ref)
+    m = group.gather_scalars([3.0, -1.5])
+    assert m.shape == (1, 2) and m[0, 0] == 3.0 and m[0, 1] == -1.5
+    group.barrier()
+    # asynchronous form: started on the communicator's stream, joined later
+    y = torch.ones(1797186, dtype=torch.float32, device="cuda")       # the 7.19 MB gradient bucket of configs[1]
+    assert parallel.allreduce_sum_async(y)
+    group.wait()
+    torch.cuda.synchronize()
+    assert float(y.sum()) == 1797186.0
+
+
+def _flags():
+    return dgcnn.DGCNN_FLAGS(MODEL_NAME="dgcnn", EDGE_CONV_LAYERS=2, EDGE_CONV_FILTERS=[64, 64], FC_LAYERS=2, FC_FILTERS=[128, 64],
+                             NUM_CLASS=2, KVALUE=10, NUM_CHANNEL=3, TRAIN=True, SEED=5, LEARNING_RATE=1e-3, DETERMINISTIC=True)
+
+
+def _two_steps(last):
+    rng = np.random.default_rng(0)
+    pts = torch.from_numpy(rng.random((2, 4, 512, 3), dtype=np.float32)).cuda()
+    lab = torch.from_numpy(rng.integers(0, 2, (2, 4, 512)).astype(np.int32)).cuda()
+    keep, E.DROPOUT_KEEP = E.DROPOUT_KEEP, 1.0
+    try:
+        tv = dgcnn.trainval(_flags()).initialize()
+        c = dgcnn.ctx()
+        hooked = []
+        for s in range(2):
+            tv.zero_gradients(None)
+            tv.accum_gradient(None, [pts[s]], [lab[s]])                       # a first micro-step: never reduced early
+            tv.accum_gradient(None, [pts[s]], [lab[s]], last=last)
+            hooked.append(tv._head_reduced)
+            tv.apply_gradient(None)
+        return c.flat_grad.cpu().numpy().copy(), c.flat_param.cpu().numpy().copy(), hooked, tv._head_off
+    finally:
+        E.DROPOUT_KEEP = keep
+        E.DETERMINISTIC = E.DETERMINISTIC_ENV_DEFAULT
+
+
+def test_bucketed_overlapped_reduction_equals_the_plain_path(group):
+    """accum_gradient(last=True): the head's gradients (MergedEdgeConv, FC*, Final: the end of the flat bucket) start their
+    all-reduce from inside the backward, the EdgeConv part follows in apply_gradient -- same gradients, same Adam step as the
+    single all-reduce after the backward (deterministic kernels: bit-identical)."""
+    g1, p1, hooked, off = _two_steps(last=True)
+    assert hooked == [True, True] and 0 < off < g1.size
+    g0, p0, hooked0, _ = _two_steps(last=False)
+    assert hooked0 == [False, False]
+    np.testing.assert_array_equal(g1, g0)
+    np.testing.assert_array_equal(p1, p0)
+
+
+def test_trainer_without_a_group_is_unchanged():
+    assert parallel.rccl_group() is None
+    g, p, hooked, _ = _two_steps(last=True)       # no communicator: the hint is ignored
+    assert hooked == [False, False] and np.isfinite(p).all()
+    dgcnn.reset()
