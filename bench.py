@@ -147,6 +147,10 @@ def main():
                          "torch.distributed); nccl = RCCL through torch.distributed; gloo = only for the single-GPU-box sanity run "
                          "of the N > 1 logic, with --same-device")
     ap.add_argument("--same-device", action="store_true", help="all ranks on cuda:0 (sanity runs only)")
+    ap.add_argument("--deterministic", action="store_true", help="run the deterministic kernels (fixed-order BatchNorm sums, sorted "
+                    "adjacency): bit-reproducible steps, ~1.7x slower (DESIGN 2)")
+    ap.add_argument("--no-edgeconv-stack", action="store_true", help="skip the EdgeConv-stack-only passes after the timed region "
+                    "(profiling runs)")
     ap.add_argument("--graph", default="auto", choices=["0", "1", "auto"],
                     help="1: replay the forward+backward tower as a captured HIP graph (the reference replays a static TF graph "
                          "with sess.run); 0: eager launches; auto (default): a few untimed steps of each during warm-up, then the "
@@ -188,6 +192,8 @@ def main():
             else:
                 dist.init_process_group(backend=backend, rank=rank, world_size=world)
     flags = make_flags(dgcnn)
+    if args.deterministic:
+        flags.DETERMINISTIC = True
     tv = dgcnn.trainval(flags).initialize()
     tv.use_graph(args.graph == "1")
 
@@ -392,7 +398,9 @@ def main():
             "roofline": roof,
             "roofline_extra": extra[:14],
         }
-        if world == 1:
+        if args.deterministic:
+            out["config"]["deterministic"] = True
+        if world == 1 and not args.no_edgeconv_stack:
             out["edgeconv_stack"] = edgeconv_stack_rate(dgcnn, pts)     # after the timed region; resets the engine context
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()

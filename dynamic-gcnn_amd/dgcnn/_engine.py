@@ -37,6 +37,8 @@ EDGE_MLP_LITERAL = False  # True: conv0 as the literal (B*N*k) x 2C GEMM over E 
 EDGE_MATERIALIZE_Y = False  # True: gather-add writes the (B*N*k, F) conv0 output and BatchNorm streams it (A/B switch);
                             # False: the BatchNorm passes recompute y = V[neighbour] + U[point] (no edge tensor in the forward)
 WGRAD_SIDE_STREAM = os.environ.get("DGCNN_SIDE_STREAM", "1") != "0"   # weight-gradient GEMMs on a second HIP stream
+WGRAD_AFTER_DGRAD = os.environ.get("DGCNN_WGRAD_AFTER_DGRAD", "1") != "0"   # side-stream weight gradients start behind the data gradient
+WEIGHT_PREP_AHEAD = os.environ.get("DGCNN_WPREP", "1") != "0"   # parameter-only kernels of the step go first, on the side stream
 EDGE_BWD_REDUCE_POINTS = True   # BN backward sums of conv0 from per-point data (False: a pass over the edges)
 SIDE_STREAM_MIN_ROWS = 16384   # below this many points the side stream is not used
 EDGE_MLP_NBR_GEMM = False  # True: factored conv0 with an edge-level neighbour GEMM instead of point-level GEMM + gather-add
@@ -90,6 +92,8 @@ class Context(object):
         self.pl_scales = None            # device float[2]: power-of-two scales of the step's activation / weight plane sets (fp16 planes)
         self.pl_scales_ready = False
         self.pl_ws = None
+        self.wprep = {}                  # weight-only work of the step, issued ahead on the side stream: key -> tensor / PlaneSet
+        self.wprep_event = None          # recorded behind it; the first consumer makes the main stream wait for it
         self.head_grads_hook = None      # called by the backward when every head gradient is final (trainval: bucketed all-reduce)
 
     # ---- device / scratch -------------------------------------------------------------
@@ -198,6 +202,8 @@ class Context(object):
         self.roots = []
         self.planes = {}
         self.pl_scales_ready = False
+        self.wprep = {}
+        self.wprep_event = None
         if self.stat_arena is not None:
             if self.capturing:
                 self.stat_arena.zero_()          # a captured step cannot know what ran before it: whole arena (8 MB memset)
@@ -482,7 +488,9 @@ def conv_bn_act(x, leaf_scope, num_outputs, relu=True, out=None, out2=None, gbia
     if use_pl:
         c.ensure_plane_scales(R)
         xp = c.planes_of(x)                                                # (R, Cin) activations
-        wt = c.new_planes(F, Cin, "w").fill_from(Wx, transpose=True)       # (F rows, Cin channels) = W^T
+        wt = prepared(("wT", Wx.data_ptr()))                               # (F rows, Cin channels) = W^T
+        if wt is None:
+            wt = c.new_planes(F, Cin, "w").fill_from(Wx, transpose=True)
         PL.gemm(PL.KC, xp, wt, T, gbias=gbias, rpg=rpg, stats=st)
     else:
         plane_out, f32_out = None, True
@@ -532,12 +540,18 @@ def conv_bn_act(x, leaf_scope, num_outputs, relu=True, out=None, out2=None, gbia
                        int(relu), dout.data_ptr(), H.ld2(dout), red.data_ptr(), maxbits.data_ptr(), HEAD_PLANES, sc.data_ptr(),
                        dTp.ptr(), dTp.plane_stride, dTp.ra, H._p(dT32), H._p(tmp), F, int(rpg), c.var_grads[bname].data_ptr(), 1.0,
                        tag="bn1_bwd_apply_planes_kernel", work=4.0 * R * F * 3)
-                with c.off_critical_path(dTp.buf, sc, rows=R):
-                    PL.gemm(PL.TR, xp, dTp, dWx, beta=1.0, ws=c.workspace())           # dW += x^T dT
+                # data gradient FIRST, on the critical path; the weight gradient is issued behind it on the side stream, so that it
+                # runs under the bandwidth-bound BatchNorm / gather passes that follow on the main stream -- not next to the data
+                # gradient, another matrix-pipe kernel at the package power cap (both then just run at half speed:
+                # profiles/r03/wgrad_order.txt)
                 dx, bx = c.grad_w(x)
                 if dx is not None:
-                    wd = c.new_planes(Wx.shape[0], F, "w").fill_from(Wx)                # (Cin rows, F channels)
+                    wd = prepared(("w", Wx.data_ptr()))                                  # (Cin rows, F channels)
+                    if wd is None:
+                        wd = c.new_planes(Wx.shape[0], F, "w").fill_from(Wx)
                     PL.gemm(PL.KC, dTp, wd, dx, beta=bx)                                 # dx (+)= dT W^T
+                with c.off_critical_path(dTp.buf, sc, rows=R):
+                    PL.gemm(PL.TR, xp, dTp, dWx, beta=1.0, ws=c.workspace())           # dW += x^T dT
                 if dgb is not None:                                                     # tf.tile^T: sum over the cloud
                     if not fused_gsum:
                         tmp = torch.empty_like(gbias)
@@ -550,10 +564,12 @@ def conv_bn_act(x, leaf_scope, num_outputs, relu=True, out=None, out2=None, gbia
                    int(relu), dout.data_ptr(), H.ld2(dout), 0, 0, 0, 0, 0, red.data_ptr(), T.data_ptr(), 0, 0,
                    c.var_grads[bname].data_ptr(), 1.0, tag="bn_bwd_apply_kernel<k=1>", work=4.0 * R * F * 3)
             dT = T
+            dx, bx = c.grad_w(x)
+            if WGRAD_AFTER_DGRAD and dx is not None:
+                gemm(dT, Wx, dx, transB=True, beta=bx, arith=arith)    # dx (+)= dT W^T
             with c.off_critical_path(rows=R):
                 gemm(x, dT, dWx, transA=True, beta=1.0, arith=arith)   # dW += x^T dT
-            dx, bx = c.grad_w(x)
-            if dx is not None:
+            if not WGRAD_AFTER_DGRAD and dx is not None:
                 gemm(dT, Wx, dx, transB=True, beta=bx, arith=arith)    # dx (+)= dT W^T
             if dgb is not None:                                         # tf.tile^T: sum over the cloud
                 tmp = torch.empty_like(gbias)
@@ -588,22 +604,66 @@ UV_UNDER_KNN = os.environ.get("DGCNN_UV_UNDER_KNN", "0") != "0"     # A/B switch
 #                                                                    configs[1]: the GEMM's 157 KB workgroups displace k-NN blocks)
 
 
+def prepare_step_weights(edge_w0, head_w):
+    """Everything that depends on the PARAMETERS only -- conv0's folded weights [Wa - Wb | Wb] of every EdgeConv layer and, in
+    plane mode, the head weights as operand planes in both orientations -- issued at the start of the step on the side stream,
+    where it runs under the first k-NN instead of as ~10 six-microsecond kernels on the critical path.
+    edge_w0: [(W0 (2C, F), C, F)]; head_w: [Wx views] (plane mode, else empty)."""
+    c = ctx()
+    if not (WGRAD_SIDE_STREAM and WEIGHT_PREP_AHEAD and c.flat_param is not None) or c.wprep:
+        return
+    dev = c.device
+    items, temps = [], []
+    for W0, C, F in edge_w0:
+        Cp = (C + 3) // 4 * 4
+        wcat = (torch.zeros if Cp != C else torch.empty)((Cp, 2 * F), dtype=torch.float32, device=dev)
+        items.append((("wcat", W0.data_ptr()), wcat, W0, C, F))
+        temps.append(wcat)
+    planes = []
+    for Wx in head_w:
+        wt = c.new_planes(Wx.shape[1], Wx.shape[0], "w")
+        wd = c.new_planes(Wx.shape[0], Wx.shape[1], "w")
+        planes.append((Wx, wt, wd))
+        temps += [wt.buf, wd.buf]
+    with c.off_critical_path(*temps):
+        for key, wcat, W0, C, F in items:
+            H.call("dgcnn_edge_weight_split_f32", W0.data_ptr(), C, F, wcat.data_ptr())
+            c.wprep[key] = wcat
+        for Wx, wt, wd in planes:
+            c.wprep[("wT", Wx.data_ptr())] = wt.fill_from(Wx, transpose=True)
+            c.wprep[("w", Wx.data_ptr())] = wd.fill_from(Wx)
+        if c.side is not None and torch.cuda.current_stream() == c.side:
+            c.wprep_event = c.side.record_event()
+
+
+def prepared(key):
+    """A tensor prepared by prepare_step_weights (the main stream is made to wait for the preparation once), or None."""
+    c = ctx()
+    v = c.wprep.get(key)
+    if v is not None and c.wprep_event is not None:
+        torch.cuda.current_stream().wait_event(c.wprep_event)
+        c.wprep_event = None
+    return v
+
+
 def _point_gemm(c, x, W0, R, C, F, side):
     """Wcat = [Wa - Wb | Wb] and [U | V] = X Wcat (conv0 folded to the points).  C = 3 (raw coordinates): the reduction
     dimension is padded to 4 with a zero column / zero weight row so that the GEMM takes the float4 path."""
     Cp = (C + 3) // 4 * 4
     xg = x
+    ready = prepared(("wcat", W0.data_ptr()))
     if Cp != C:
         xg = torch.zeros((R, Cp), dtype=torch.float32, device=x.device)
-        wcat = torch.zeros((Cp, 2 * F), dtype=torch.float32, device=x.device)
+        wcat = ready if ready is not None else torch.zeros((Cp, 2 * F), dtype=torch.float32, device=x.device)
     else:
-        wcat = torch.empty((C, 2 * F), dtype=torch.float32, device=x.device)
+        wcat = ready if ready is not None else torch.empty((C, 2 * F), dtype=torch.float32, device=x.device)
     UV = torch.empty((R, 2 * F), dtype=torch.float32, device=x.device)
 
     def issue():
         if Cp != C:
             H.call("dgcnn_copy2d_f32", x.data_ptr(), H.ld2(x), xg.data_ptr(), Cp, R, C, 0)
-        H.call("dgcnn_edge_weight_split_f32", W0.data_ptr(), C, F, wcat.data_ptr())
+        if ready is None:
+            H.call("dgcnn_edge_weight_split_f32", W0.data_ptr(), C, F, wcat.data_ptr())
         gemm(xg, wcat, UV, arith=None)
     if side:
         with c.off_critical_path(xg, wcat, UV, rows=R):
@@ -769,10 +829,12 @@ def edge_conv_block(x, B, N, k, num_filters, relu1=True, outs=None, net2=None):
                 dwcat = torch.empty((Cp, 2 * F), dtype=torch.float32, device=x.device)
                 # dUV / dwcat are locals of this closure allocated on the main stream: record them on the side stream,
                 # or the caching allocator may hand dUV's block to the next main-stream allocation while the side GEMM reads it
+                if WGRAD_AFTER_DGRAD and dx is not None:
+                    gemm(dUV, wcat[:C], dx, transB=True, beta=1.0, arith=None)
                 with c.off_critical_path(dwcat, dUV, rows=R):
                     gemm(xg, dUV, dwcat, transA=True, arith=None)
                     H.call("dgcnn_edge_wgrad_combine_f32", dwcat.data_ptr(), C, F, dW0.data_ptr())
-                if dx is not None:
+                if not WGRAD_AFTER_DGRAD and dx is not None:
                     gemm(dUV, wcat[:C], dx, transB=True, beta=1.0, arith=None)
                 return
             if literal:

@@ -55,6 +55,31 @@ def build(point_cloud, flags):
             f = ecf[i]
             return (big[:, o:o + 2 * f], big[:, o + 2 * f:o + 2 * f + 64]), merged_in[:, 64 * i:64 * (i + 1)]
 
+    # parameter-only work of the whole step (conv0's folded weights; the head's weight planes) goes first, on the side stream
+    pl_head = False
+    if not nofc:
+        fcf = ops._listify(num_fc_filters, num_fc, "num_filters")
+        pl_head = (num_fc >= 1 and E.planes_ok(R, 64 * num_edge_conv, 1024) and E.planes_ok(R, ctot, fcf[0]) and ctot % 32 == 0 and
+                   (num_fc < 2 or E.planes_ok(R, fcf[0], fcf[1])))
+    if c.flat_param is not None and R >= E.SIDE_STREAM_MIN_ROWS:
+        edge_w0, cin = [], x.shape[1]
+        for i, f in enumerate(ecf):
+            with E.variable_scope("EdgeConv%d" % i), E.variable_scope("conv0"):
+                edge_w0.append((c.get_variable("weights", (2 * cin, f))[1], cin, f))
+            cin = 64
+        head_w = []
+        if pl_head:
+            kmax = max(ops._listify(k, num_edge_conv, "k"))
+            c.ensure_plane_scales(R * kmax)
+            with E.variable_scope("MergedEdgeConv"):
+                head_w.append(c.get_variable("weights", (64 * num_edge_conv, 1024))[1])
+            with E.variable_scope("FC0"):
+                head_w.append(c.get_variable("weights", (1024 + ctot, fcf[0]))[1][1024:1024 + ctot])
+            if num_fc >= 2:
+                with E.variable_scope("FC1"):
+                    head_w.append(c.get_variable("weights", (fcf[0], fcf[1]))[1])
+        E.prepare_step_weights(edge_w0, head_w)
+
     if flags.MODEL_NAME == "dgcnn":
         tensors = ops.repeat_edge_conv(point_cloud, repeat=num_edge_conv, k=k, num_filters=num_edge_filters,
                                        trainable=is_training, debug=debug, _plan=plan)
@@ -77,8 +102,6 @@ def build(point_cloud, flags):
     # of `big`, and the conv1 copies) are split by one pass each; MergedEdgeConv's BatchNorm pass writes its 1024 channels
     # straight into big's plane set (the fp32 slice of `big` is never written: nothing else reads it -- the global max-pool
     # is taken on the GEMM output) and FC0's writes the planes FC1 reads.
-    pl_head = (E.planes_ok(R, 64 * num_edge_conv, 1024) and E.planes_ok(R, ctot, fcf[0]) and ctot % 32 == 0 and
-               (num_fc < 2 or E.planes_ok(R, fcf[0], fcf[1])))
     if pl_head:
         kmax = max(ops._listify(k, num_edge_conv, "k"))
         c.ensure_plane_scales(R * kmax)

@@ -14,6 +14,8 @@ def main():
         name = name.split("(")[0]
         d[name][0] += 1
         d[name][1] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+    if "adam_kernel" in d:            # one optimizer step per training step: the run's real step count (warm-up, timed,
+        steps = float(d["adam_kernel"][0])  # instrumented passes); the EdgeConv-stack-only passes of bench.py add launches without one
     tot = sum(v[1] for v in d.values())
     print("# total kernel time per step %.3f ms (%d steps in the run)" % (tot / steps / 1e3, steps))
     for k, v in sorted(d.items(), key=lambda kv: -kv[1][1]):
