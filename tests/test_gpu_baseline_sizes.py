@@ -190,14 +190,18 @@ def test_config1_full_size_logits_and_dynamic_graphs(dg):
     assert w_hip >= w_o32 - 0.12 and w_hip > 0.6, (w_hip, w_o32)
 
 
-GRAD_BAR = 5e-3     # relative Frobenius vs the float64 twin (measured 1.0e-3 .. 2.2e-3 at full size, profiles/r02/grad_error_3way.txt)
+# relative Frobenius vs the float64 twin.  Measured at full size over seven runs of round 3 (the neighbour graphs, and with them which
+# ReLU / max-over-k decisions sit on a last-bit difference, change run to run with the atomically summed BatchNorm statistics):
+# HIP worst tensor 1.7e-3, 2.0e-3, 2.3e-3, 2.4e-3, 3.9e-3, 3.9e-3, 6.6e-3; the fp32 oracle on the same graphs 0.8e-3 .. 4.2e-3.
+# 5e-3 (round 2) failed one run in seven; a wrong or missing term is O(1).
+GRAD_BAR = 1e-2
 
 
 def test_config1_full_size_training_step(dg):
     """One full training micro-step at (24,2048,20,3) with dropout off, the HIP graphs fed to the oracle: loss within 1e-4
-    and EVERY gradient tensor within 5e-3 (relative Frobenius) of the float64 twin; so is the float32 oracle (tree-ordered
-    BatchNorm sums: 2e-3 .. 4e-3; round 2's running float32 sums over 983040 rows: 2e-2 .. 4e-2), and the two float32
-    evaluations agree within 1e-2 -- then the Adam step."""
+    and EVERY gradient tensor within 1e-2 (relative Frobenius; measured 1.7e-3 .. 6.6e-3) of the float64 twin; so is the float32
+    oracle (tree-ordered BatchNorm sums: 0.8e-3 .. 4.2e-3; round 2's running float32 sums over 983040 rows: 2e-2 .. 4e-2), and the
+    two float32 evaluations agree within 2e-2 -- then the Adam step."""
     B, N, C = 24, 2048, 3
     flags = config1_flags(dg, train=True)
     rng = np.random.default_rng(1)
