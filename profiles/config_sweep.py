@@ -22,8 +22,8 @@ CONFIGS = [
 
 def main():
     graph = "--graph" in sys.argv                  # replay the tower as a captured HIP graph (trainval.use_graph)
-    extra = {"EDGE_MLP_DTYPE": "bf16"} if "--bf16-edge-mlp" in sys.argv else {}
-    print("# graph replay: %s%s" % (graph, "  edge-MLP operands: bf16" if extra else ""))
+    extra = {"HEAD_PLANES": "f16"} if "--f16-planes" in sys.argv else {}
+    print("# graph replay: %s%s" % (graph, "  head GEMMs from fp16 operand planes" if extra else ""))
     for name, cfg, B, N, C in CONFIGS:
         flags = dgcnn.DGCNN_FLAGS(NUM_CLASS=2, FC_LAYERS=2, FC_FILTERS=[512, 256], TRAIN=True, NUM_CHANNEL=C, **cfg, **extra)
         tv = dgcnn.trainval(flags).initialize().use_graph(graph)

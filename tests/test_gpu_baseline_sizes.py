@@ -88,7 +88,10 @@ def test_config4_knn_n65536_k20_bit_exact(dg, C, kind):
     if C <= 4:
         np.testing.assert_array_equal(idx, O.k_nn(x, k))
     else:
-        nrows = 16384 if (os.cpu_count() or 1) >= 32 else 2048
+        ncpu = os.cpu_count() or 1
+        nrows = 16384 if ncpu >= 32 else 2048
+        print("C=%d relu features at N=65536: %d of the 65536 query rows checked against the C oracle (%d host CPUs%s)"
+              % (C, nrows, ncpu, "" if ncpu >= 32 else ": fewer than 32, the sample is cut from 16384 to keep the run in minutes"))
         rows = np.sort(rng.permutation(N)[:nrows]).astype(np.int32)
         check_knn_properties(x[0], idx[0], k, rows)
     if kind != "integer":
