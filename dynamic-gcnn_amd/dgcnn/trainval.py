@@ -143,14 +143,17 @@ class trainval(object):
         wgt = self._to_dev(weight, torch.float32)
         if pts.dim() != 3:
             raise ValueError("points must be (MINIBATCH_SIZE, N, NUM_CHANNEL), got %s" % (tuple(pts.shape),))
-        use = self._use_graph
-        if use == "auto":                 # graphs pay where the step is launch bound (profiles/r02/config_sweep.txt)
-            use = pts.shape[0] * pts.shape[1] < E.SIDE_STREAM_MIN_ROWS
-        if use and H.TIMER is None:
+        if self._wants_graph(pts.shape[0] * pts.shape[1]):
             out = self._tower_graph(pts, lab, wgt, train)
             if out is not None:
                 return out
         return self._tower_eager(pts, lab, wgt, train)
+
+    def _wants_graph(self, rows):
+        use = self._use_graph
+        if use == "auto":                 # graphs pay where the step is launch bound (profiles/r02/config_sweep.txt)
+            use = rows < E.SIDE_STREAM_MIN_ROWS
+        return bool(use) and H.TIMER is None
 
     def _tower_body(self, pts, lab, wgt, train):
         c = self._ctx
@@ -268,7 +271,9 @@ class trainval(object):
         fd = self.feed_dict(data, label, weight)
         T = len(fd["data"])
         c.head_grads_hook = None
-        if last and T == 1 and parallel.rccl_group() is not None and 0 < self._head_off < c.flat_grad.numel() and not self._use_graph:
+        d0 = fd["data"][0]
+        eager = not self._wants_graph(int(d0.shape[0]) * int(d0.shape[1]))       # (a replayed graph cannot carry the RCCL call)
+        if last and T == 1 and eager and parallel.rccl_group() is not None and 0 < self._head_off < c.flat_grad.numel():
             def hook():
                 c.join_side()                                   # the head's weight-gradient GEMMs (side stream) have landed
                 self._head_reduced = parallel.allreduce_sum_async(c.flat_grad[self._head_off:])
