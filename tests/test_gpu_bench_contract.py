@@ -54,3 +54,17 @@ def test_bench_gpus_2_from_a_bare_shell_launches_two_ranks_itself():
     assert c["collective_backend"] == "gloo" and c["rccl_ranks"] == 0
     assert abs(d["value"] - 48 * 1e3 / d["ms_per_step"]) / d["value"] < 1e-3       # whole-job clouds/s over BOTH ranks
     assert "roofline" in d and "cpu_baseline" not in d and "edgeconv_stack" not in d
+
+
+def test_bench_deterministic_mode_gives_a_reproducible_line():
+    """bench.py --deterministic: the bit-reproducible kernels are reachable from the bench (two runs: the same final loss)."""
+    outs = []
+    for _ in range(2):
+        p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "2", "--no-cpu-baseline",
+                            "--no-edgeconv-stack", "--deterministic", "--graph", "0"],
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, cwd=ROOT)
+        assert p.returncode == 0, p.stderr.decode(errors="replace")[-2000:]
+        d = json.loads([l for l in p.stdout.decode().splitlines() if l.strip().startswith("{")][0])
+        assert d["config"]["deterministic"] is True and d["config"]["launch_mode"] == "eager" and "edgeconv_stack" not in d
+        outs.append(d["config"]["final_loss"])
+    assert outs[0] == outs[1], outs

@@ -95,3 +95,35 @@ def test_plane_mode_is_off_in_deterministic_mode_and_for_small_problems(case):
     finally:
         E.HEAD_PLANES, E.DETERMINISTIC = old, E.DETERMINISTIC_ENV_DEFAULT
         dgcnn.reset()
+
+
+def test_plane_mode_on_the_residual_architecture(case):
+    """configs[2]'s architecture (residual-dgcnn, 6 x 64, k = 40) at B=4, N=2048 in fp16 plane mode: the activation scale must
+    cover residual sums of two batch-normalised tensors (factor 2 in dgcnn_param_scales_f32); logits within 1e-3 of the twin."""
+    pts, labels, _ = case
+    f = dgcnn.DGCNN_FLAGS(MODEL_NAME="residual-dgcnn", EDGE_CONV_LAYERS=6, EDGE_CONV_FILTERS=64, FC_LAYERS=2, FC_FILTERS=[512, 256],
+                          NUM_CLASS=2, KVALUE=40, NUM_CHANNEL=C, TRAIN=False, SEED=3, HEAD_PLANES="f16")
+    rng = np.random.default_rng(8)
+    params = O.init_params(f, C, seed=6)
+    for n in params:
+        if n.endswith("beta"):
+            params[n] = rng.normal(0, 0.2, params[n].shape).astype(np.float32)
+    used = []
+    orig = P.gemm
+
+    def spy(form, A, Bm, Cm, **kw):
+        used.append(form)
+        return orig(form, A, Bm, Cm, **kw)
+    P.gemm = spy
+    try:
+        tv, res, layers = run_model(dgcnn, f, pts, params, train=False, labels=labels)
+    finally:
+        P.gemm = orig
+        E.HEAD_PLANES = E.HEAD_PLANES_ENV_DEFAULT
+        dgcnn.reset()
+    assert used == [P.KC] * 3
+    idx_list = [layers["EdgeConv%d" % i][1] for i in range(6)]
+    p64 = {n: v.astype(np.float64) for n, v in params.items()}
+    ref, _ = O.model_forward(pts.astype(np.float64), f, p64, idx_list=idx_list)
+    e = np.exp(ref - ref.max(-1, keepdims=True))
+    np.testing.assert_allclose(host(res[0]), e / e.sum(-1, keepdims=True), rtol=0, atol=1e-3)

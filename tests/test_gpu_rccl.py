@@ -82,3 +82,32 @@ def test_trainer_without_a_group_is_unchanged():
     g, p, hooked, _ = _two_steps(last=True)       # no communicator: the hint is ignored
     assert hooked == [False, False] and np.isfinite(p).all()
     dgcnn.reset()
+
+
+def test_train_loop_runs_on_the_registered_communicator(group, tmp_path, capsys):
+    """The run loop (main_funcs.train_loop) with the RCCL group registered: parameters are broadcast through it, the last
+    micro-step of every iteration starts the head bucket's all-reduce from inside the backward (USE_GRAPH=0: eager towers),
+    the loss mean over replicas goes through it -- and the run learns like the single-process run."""
+    from dgcnn import main_funcs as M
+    calls = {"async": 0}
+    orig = parallel.allreduce_sum_async
+
+    def spy(t):
+        calls["async"] += 1
+        return orig(t)
+    parallel.allreduce_sum_async = spy
+    try:
+        f = dgcnn.DGCNN_FLAGS(IO_TYPE="synthetic", NUM_ENTRIES=16, NUM_POINT=256, NUM_CHANNEL=3, BATCH_SIZE=8, MINIBATCH_SIZE=4,
+                              KVALUE=8, EDGE_CONV_LAYERS=2, EDGE_CONV_FILTERS=[32, 64], FC_LAYERS=1, FC_FILTERS=[64], NUM_CLASS=2,
+                              ITERATION=6, REPORT_STEP=3, SUMMARY_STEP=0, CHECKPOINT_STEP=0, SEED=5, SHUFFLE=1, LEARNING_RATE=1e-3,
+                              LOG_DIR=str(tmp_path / "log"), WEIGHT_PREFIX="", USE_GRAPH="0")
+        M.train(f)
+    finally:
+        parallel.allreduce_sum_async = orig
+    out = capsys.readouterr().out
+    assert out.count("Iteration ") == 2
+    # 6 iterations x 2 micro-steps: the head bucket once per iteration (last micro-step) + the EdgeConv bucket in apply_gradient
+    assert calls["async"] == 12, calls
+    import csv
+    rows = list(csv.DictReader(open(tmp_path / "log" / "train_log-0000000.csv")))
+    assert len(rows) == 6 and all(np.isfinite(float(r["loss"])) for r in rows)
