@@ -388,6 +388,108 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
   }
 }
 
+
+// ---- conv0 backward of an EdgeConv layer whose input needs NO gradient and has C <= 4 channels (the first layer: raw
+// coordinates): the whole edge-level backward collapses into this one pass.  Per edge it forms dY exactly as
+// bn_bwd_apply_kernel<4, true> does -- and consumes it on the spot: dW0 = E^T dY with E = [x_i, x_j - x_i] (ops.py:39-52),
+//   dW0[c]     += x_i[c] * sum_m dY[i, m]          dW0[C + c] += sum_m (x_j[c] - x_i[c]) * dY[i, m]
+// so no dY (252 MB at configs[1]) is written, no transposed adjacency is built or summed, and the two point-level GEMMs of
+// the folded form are not needed.  A thread owns one channel quad for its whole life (items_of<true>: the item stride is a
+// multiple of F / 4), accumulates 2 C x 4 partial sums in registers, the block reduces them through LDS into
+// partial[block][2 C][F]; reduce_partials_kernel (gemm.hip) adds the blocks up in fixed order.
+template <int CC>
+__global__ __launch_bounds__(256) void edge_bwd_apply_wgrad_kernel(
+    Src src, int64_t R, int k, int F, const float* __restrict__ mean, const float* __restrict__ rstd,
+    const float* __restrict__ beta, const float* __restrict__ dmax, int64_t lddmax, const float* __restrict__ dmean,
+    int64_t lddmean, const float* __restrict__ mx_in, int64_t ldmx, const float* __restrict__ cnt_in,
+    const double* __restrict__ red, const float* __restrict__ x, int64_t ldx, int C, float* __restrict__ partial, int fv_shift) {
+  constexpr int V = 4;
+  extern __shared__ float sh[];                   // [256 / FV row lanes][2 CC][F]
+  const int FV = F / V;
+  const Items its = items_of<true>(R, FV);
+  const float invk = 1.0f / (float)k;
+  const double inv_cnt = 1.0 / ((double)R * (double)k);
+  float wc[CC][V], wd[CC][V];
+#pragma unroll
+  for (int c = 0; c < CC; ++c)
+#pragma unroll
+    for (int v = 0; v < V; ++v) { wc[c][v] = 0.f; wd[c][v] = 0.f; }
+  const int fq_fixed = (int)((its.base + its.first) & (FV - 1));          // FV is a power of two here (checked by the host)
+  const int f = fq_fixed * V;
+  float mu[V], rs[V], be[V], c1[V], c2[V];
+  Vec<V>::ld(mean + f, mu); Vec<V>::ld(rstd + f, rs); Vec<V>::ld(beta + f, be);
+#pragma unroll
+  for (int v = 0; v < V; ++v) {
+    c1[v] = (float)(red[f + v] * inv_cnt);
+    c2[v] = (float)(red[F + f + v] * inv_cnt);
+  }
+  for (int64_t q = its.first; q < its.count; q += its.step) {
+    const int64_t r = (its.base + q) >> fv_shift;
+    float dmx[V], dmn[V];
+    Vec<V>::ld(dmax + r * lddmax + f, dmx);
+    Vec<V>::ld(dmean + r * lddmean + f, dmn);
+    Rows<V, true> rows;
+    rows.init(src, r, k, F, f);
+    KState<V> st;
+    Vec<V>::ld(mx_in + r * ldmx + f, st.mx);
+    Vec<V>::ld(cnt_in + r * F + f, st.cnt);
+#pragma unroll
+    for (int v = 0; v < V; ++v) st.cnt[v] -= (float)CNT_POS * floorf(st.cnt[v] * (1.0f / CNT_POS));
+    float xi[CC];
+#pragma unroll
+    for (int c = 0; c < CC; ++c) xi[c] = (c < C) ? x[r * ldx + c] : 0.f;
+    const int64_t cloud0 = (int64_t)((unsigned)r / src.npts) * src.npts;
+    float acc[V] = {0.f, 0.f, 0.f, 0.f};
+    for (int m = 0; m < k; m += NB) {
+      float yv[NB][V];
+      rows.load(m, k, yv);
+#pragma unroll
+      for (int b = 0; b < NB; ++b)
+        if (m + b < k) {
+          const float* xj = x + (cloud0 + rows.ip[m + b]) * ldx;
+          float dx[CC];
+#pragma unroll
+          for (int c = 0; c < CC; ++c) dx[c] = (c < C) ? xj[c] - xi[c] : 0.f;
+#pragma unroll
+          for (int v = 0; v < V; ++v) {
+            float xh;
+            const float z = bn_z(yv[b][v], mu[v], rs[v], be[v], 1, xh);
+            float dz = ((z == st.mx[v]) ? dmx[v] / st.cnt[v] : 0.f) + dmn[v] * invk;
+            if (!(z > 0.f)) dz = 0.f;
+            const float o = rs[v] * (dz - c1[v] - xh * c2[v]);
+            acc[v] += o;
+#pragma unroll
+            for (int c = 0; c < CC; ++c) wd[c][v] = fmaf(dx[c], o, wd[c][v]);
+          }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < CC; ++c)
+#pragma unroll
+      for (int v = 0; v < V; ++v) wc[c][v] = fmaf(xi[c], acc[v], wc[c][v]);
+  }
+  // block reduction: threads t and t + FV, t + 2 FV ... hold the same channel quad
+  const int lanes = 256 / FV;
+  const int rl = threadIdx.x / FV;
+#pragma unroll
+  for (int c = 0; c < CC; ++c)
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+      sh[(rl * 2 * CC + c) * F + f + v] = wc[c][v];
+      sh[(rl * 2 * CC + CC + c) * F + f + v] = wd[c][v];
+    }
+  __syncthreads();
+  float* out = partial + (int64_t)blockIdx.x * 2 * C * F;
+  for (int e = threadIdx.x; e < 2 * CC * F; e += 256) {
+    const int cr = e / F, ff = e % F;
+    const int c = cr < CC ? cr : cr - CC;
+    if (c >= C) continue;
+    float s = 0.f;
+    for (int l = 0; l < lanes; ++l) s += sh[(l * 2 * CC + cr) * F + ff];
+    out[(int64_t)(cr < CC ? c : C + c) * F + ff] = s;
+  }
+}
+
 // ---- k = 1 (per-point layers: conv1, shortcut, merged, FC, Final): column-fixed streaming kernels -------------
 // A thread keeps ONE channel quad for its whole life (mean / rstd / beta / the backward constants live in
 // registers) and walks rows with 4 independent row loads in flight; block = (256 / FVB rows) x FVB quads,
@@ -808,4 +910,40 @@ extern "C" int dgcnn_edge_bn_bwd_apply_f32(const float* V, int64_t ldv, const fl
   return launch_bwd_apply<true>("dgcnn_edge_bn_bwd_apply_f32", edge_src(V, ldv, U, ldu, idx, N), (int64_t)B * N, k, F, mean,
                                 rstd, beta, relu, dmax, lddmax, dmean, lddmean, mx_in, ldmx, cnt_in, red, dY, dYsum,
                                 lddysum, dbeta, dbeta_beta, (hipStream_t)stream);
+}
+
+namespace dg {
+void launch_reduce_partials(const float* part, int splits, int M, int N, float* C, int64_t ldc, float beta, hipStream_t st);
+}
+
+extern "C" int dgcnn_edge_bn_bwd_apply_wgrad_f32(const float* V, int64_t ldv, const float* U, int64_t ldu,
+                                                 const int32_t* idx, int B, int N, int k, int F,
+                                                 const float* mean, const float* rstd, const float* beta,
+                                                 const float* dmax, int64_t lddmax, const float* dmean, int64_t lddmean,
+                                                 const float* mx_in, int64_t ldmx, const float* cnt_in, double* red,
+                                                 const float* x, int64_t ldx, int C, float* dW0, float* dbeta,
+                                                 float dbeta_beta, void* ws, size_t ws_bytes, void* stream) {
+  int rc = check_edge("dgcnn_edge_bn_bwd_apply_wgrad_f32", V, ldv, U, ldu, idx, B, N, k, F);
+  if (rc) return rc;
+  DG_REQUIRE(mean && rstd && beta && dmax && dmean && mx_in && cnt_in && red && x && dW0 && ws, DGCNN_EINVAL,
+             "dgcnn_edge_bn_bwd_apply_wgrad_f32: null pointer");
+  DG_REQUIRE(C >= 1 && C <= 4, DGCNN_EUNSUP, "dgcnn_edge_bn_bwd_apply_wgrad_f32: C must be <= 4 (got %d)", C);
+  const int FV = F / 4;
+  DG_REQUIRE(shift_of(FV) >= 0 && FV <= 256 && lddmax % 4 == 0 && lddmean % 4 == 0 && ldmx % 4 == 0 && a16(dmax) && a16(dmean) &&
+                 a16(mx_in) && a16(cnt_in) && a16(mean) && a16(rstd) && a16(beta), DGCNN_EUNSUP,
+             "dgcnn_edge_bn_bwd_apply_wgrad_f32: F / 4 must be a power of two <= 256, operands 16-byte aligned");
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t R = (int64_t)B * N;
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)dg::cdiv(F, 128)), dim3(128), 0, st, red, F, dbeta, dbeta_beta);
+  const unsigned grid = grid8(grid_reduce(R * FV));                 // <= 1024 blocks: one partial tile each
+  const size_t need = (size_t)grid * 2 * C * F * sizeof(float);
+  DG_REQUIRE(ws_bytes >= need, DGCNN_ENOSPC, "dgcnn_edge_bn_bwd_apply_wgrad_f32: workspace too small (%zu < %zu)", ws_bytes, need);
+  const size_t shb = (size_t)(256 / FV) * 2 * 4 * F * sizeof(float);
+  hipLaunchKernelGGL((edge_bwd_apply_wgrad_kernel<4>), dim3(grid), dim3(256), shb, st, edge_src(V, ldv, U, ldu, idx, N), R, k, F,
+                     mean, rstd, beta, dmax, lddmax, dmean, lddmean, mx_in, ldmx, cnt_in, red, x, ldx, C,
+                     reinterpret_cast<float*>(ws), shift_of(FV));
+  rc = dg::check_launch("dgcnn_edge_bn_bwd_apply_wgrad_f32");
+  if (rc) return rc;
+  dg::launch_reduce_partials(reinterpret_cast<const float*>(ws), (int)grid, 2 * C, F, dW0, (int64_t)F, 1.0f, st);
+  return dg::check_launch("dgcnn_edge_bn_bwd_apply_wgrad_f32(reduce)");
 }

@@ -39,6 +39,7 @@ EDGE_MATERIALIZE_Y = False  # True: gather-add writes the (B*N*k, F) conv0 outpu
 WGRAD_SIDE_STREAM = os.environ.get("DGCNN_SIDE_STREAM", "1") != "0"   # weight-gradient GEMMs on a second HIP stream
 WGRAD_AFTER_DGRAD = os.environ.get("DGCNN_WGRAD_AFTER_DGRAD", "1") != "0"   # side-stream weight gradients start behind the data gradient
 WEIGHT_PREP_AHEAD = os.environ.get("DGCNN_WPREP", "1") != "0"   # parameter-only kernels of the step go first, on the side stream
+EDGE_BWD_FUSED_L0 = os.environ.get("DGCNN_EDGE_BWD_FUSED_L0", "1") != "0"   # input layer (C <= 4, no input gradient): one backward pass
 EDGE_BWD_REDUCE_POINTS = True   # BN backward sums of conv0 from per-point data (False: a pass over the edges)
 SIDE_STREAM_MIN_ROWS = 16384   # below this many points the side stream is not used
 EDGE_MLP_NBR_GEMM = False  # True: factored conv0 with an edge-level neighbour GEMM instead of point-level GEMM + gather-add
@@ -297,6 +298,13 @@ class Context(object):
                 assert H.ld2(v) == ld or v.shape[0] == 1, (v.shape, v.stride(), ld)
                 return slot[0][r0:r0 + v.shape[0], c0:c0 + v.shape[1]]
         return None
+
+    def tracked(self, v):
+        """True when `v` lies inside a buffer whose gradient is being tracked (no allocation, unlike grad())."""
+        if not self.recording:
+            return False
+        ptr = v.data_ptr()
+        return any(root.data_ptr() <= ptr < root.data_ptr() + root.numel() * 4 for root, _ in self.roots)
 
     def grad_w(self, v):
         """(gradient view, beta) for a GEMM that adds into d(v): beta = 0.0 -- and the buffer is left
@@ -750,8 +758,11 @@ def edge_conv_block(x, B, N, k, num_filters, relu1=True, outs=None, net2=None):
                mx.data_ptr(), H.ld2(mx), mn.data_ptr(), H.ld2(mn), 0, 0, H._p(cnt),
                tag="bn_act_kreduce_kernel", work=4.0 * (R * k * F + 2 * R * F))   # ops.py:54-58
 
+    fv = F // 4
+    fused_l0 = (c.recording and virtual and EDGE_BWD_FUSED_L0 and EDGE_BWD_REDUCE_POINTS and C <= 4 and F % 4 == 0 and
+                fv & (fv - 1) == 0 and fv <= 256 and not c.tracked(x))
     csr = None
-    if c.recording and gather and WGRAD_SIDE_STREAM and R >= SIDE_STREAM_MIN_ROWS:
+    if c.recording and gather and WGRAD_SIDE_STREAM and R >= SIDE_STREAM_MIN_ROWS and not fused_l0:
         # the transposed adjacency depends only on idx: build it now, off the critical path, for the backward
         cws = torch.empty(2 * R, dtype=torch.int32, device=x.device)
         off_t = torch.empty(R + 1, dtype=torch.int32, device=x.device)
@@ -784,6 +795,14 @@ def edge_conv_block(x, B, N, k, num_filters, relu1=True, outs=None, net2=None):
                 bn_bwd_reduce(Y, R, k, F, mean, rstd, beta0, 1, dmx, dmn, mx, cnt, red,
                               tag="bn_bwd_reduce_kernel", work=4.0 * (R * k * F + 2 * R * F))
             dx = c.grad(x)
+            if fused_l0 and dx is None:
+                # first layer (raw coordinates, nobody wants d(points)): dY is formed and consumed in one pass, straight into dW0
+                ws = c.workspace()
+                H.call("dgcnn_edge_bn_bwd_apply_wgrad_f32", *esrc, mean.data_ptr(), rstd.data_ptr(), beta0.data_ptr(),
+                       dmx.data_ptr(), H.ld2(dmx), dmn.data_ptr(), H.ld2(dmn), mx.data_ptr(), H.ld2(mx), cnt.data_ptr(),
+                       red.data_ptr(), x.data_ptr(), H.ld2(x), C, c.var_grads[w0name].data_ptr(), c.var_grads[b0name].data_ptr(), 1.0,
+                       ws.data_ptr(), ws.numel(), tag="edge_bwd_apply_wgrad_kernel", work=4.0 * (4 * R * F) + 4.0 * R * k)
+                return
             need_sum = (dx is not None) or not literal
             dUV = dysum = None
             if gather:

@@ -146,6 +146,19 @@ int dgcnn_edge_bn_bwd_apply_f32(const float* V, int64_t ldv, const float* U, int
                                 double* red, float* dY, float* dYsum, int64_t lddysum, float* dbeta,
                                 float dbeta_beta, void* stream);
 
+/* conv0 backward of a layer whose input needs no gradient and has C <= 4 channels (the first EdgeConv layer: raw coordinates),
+ * in ONE pass: dY is formed per edge exactly as in dgcnn_edge_bn_bwd_apply_f32 and consumed on the spot,
+ * dW0[2C][F] += [x_i, x_j - x_i]^T dY (ops.py:39-52) -- no dY tensor, no transposed adjacency, no point-level GEMMs.
+ * red: the sums of dgcnn_edge_bn_bwd_reduce(_points)_f32 (finalised here; dbeta as in the apply call); relu is implied (conv0).
+ * ws >= (<= 1024 blocks) * 2C * F floats.                                                                                    */
+int dgcnn_edge_bn_bwd_apply_wgrad_f32(const float* V, int64_t ldv, const float* U, int64_t ldu,
+                                      const int32_t* idx, int B, int N, int k, int F,
+                                      const float* mean, const float* rstd, const float* beta,
+                                      const float* dmax, int64_t lddmax, const float* dmean, int64_t lddmean,
+                                      const float* mx_in, int64_t ldmx, const float* cnt_in, double* red,
+                                      const float* x, int64_t ldx, int C, float* dW0, float* dbeta, float dbeta_beta,
+                                      void* ws, size_t ws_bytes, void* stream);
+
 /* ---- plain fp32 MFMA GEMM: every other slim.conv2d 1x1 (ops.py:62-70,125-133,153-160;
  * model.py:46-53,65-72,94-101) and their dgrad / wgrad --------------------------------------
  * C[M][N] = op(A)[M][K] op(B)[K][N] (+ beta*C) (+ gbias[row / rows_per_group][n]);

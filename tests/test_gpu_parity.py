@@ -895,3 +895,64 @@ def test_residual_add_relu_gradients_exact(dg, R, F, ld):
     gd = d * (ref > 0)
     np.testing.assert_array_equal(host(c.grad(ta)), gd)
     np.testing.assert_array_equal(host(c.grad(tb_full))[:, :F], gd)
+
+
+@pytest.mark.parametrize("B,N,C,k,F", [(2, 4096, 3, 20, 64), (3, 1500, 4, 9, 128), (1, 8192, 3, 12, 32)])
+def test_first_layer_fused_backward_matches_the_unfused_passes(dg, B, N, C, k, F):
+    """Input layer of the model (C <= 4, nobody asks for d(points)): dgcnn_edge_bn_bwd_apply_wgrad_f32 forms dY per edge and
+    consumes it in the same pass (dW0 += [x_i, x_j - x_i]^T dY) -- against the general path (dY written, transposed-adjacency
+    sum, two point-level GEMMs) on the same upstream gradients, and against the float64 oracle."""
+    from dgcnn import _engine as E
+    rng = np.random.default_rng(B * N + F)
+    pts = rng.random((B, N, C), dtype=np.float32)
+    P = {"conv0/weights": rng.normal(0, 0.5, (2 * C, F)).astype(np.float32),
+         "conv0/BatchNorm/beta": rng.normal(0, 0.3, F).astype(np.float32),
+         "conv1/weights": rng.normal(0, 0.3, (2 * F, 64)).astype(np.float32),
+         "conv1/BatchNorm/beta": rng.normal(0, 0.3, 64).astype(np.float32)}
+    ups = [rng.normal(size=(B * N, F)).astype(np.float32), rng.normal(size=(B * N, F)).astype(np.float32),
+           rng.normal(size=(B * N, 64)).astype(np.float32)]
+    got = {}
+    old = E.EDGE_BWD_FUSED_L0
+    calls = []
+    orig = E.H.call
+
+    def spy(name, *a, **kw):
+        calls.append(name)
+        return orig(name, *a, **kw)
+    try:
+        for fused in (True, False):
+            E.EDGE_BWD_FUSED_L0 = fused
+            dg.reset()
+            c = dg.ctx()
+            c.begin_step()
+            c.recording = True
+            for n, v in P.items():
+                c.get_variable(n, v.shape)
+            _set_vars(dg, P)
+            x = dev(pts)                                      # NOT a tracked buffer: no d(point_cloud) is requested
+            del calls[:]
+            E.H.call = spy
+            try:
+                outs = dg.ops.edge_conv(x, k, F, True)
+                for t, g in zip(outs, ups):
+                    v, _, _ = E.as2d(t)
+                    c.grad(v).copy_(dev(g))
+                c.backward()
+            finally:
+                E.H.call = orig
+            assert ("dgcnn_edge_bn_bwd_apply_wgrad_f32" in calls) == fused
+            assert ("dgcnn_edge_bn_bwd_apply_f32" in calls) == (not fused) and ("dgcnn_edge_csr_build" in calls) == (not fused)
+            got[fused] = {n: host(c.var_grads[n]).copy() for n in P}
+            idx = host(dg.ops.edge_conv.last_idx)
+    finally:
+        E.EDGE_BWD_FUSED_L0 = old
+        dg.reset()
+    for n in P:
+        a, b = got[True][n].astype(np.float64), got[False][n].astype(np.float64)
+        assert np.linalg.norm(a - b) <= 2e-5 * max(np.linalg.norm(b), 1e-9), (n, np.linalg.norm(a - b) / np.linalg.norm(b))
+    ref, cache = O.edge_conv(pts.astype(np.float64), k, *[P[n].astype(np.float64) for n in P], idx=idx)
+    d = [u.reshape(B, N, 1, -1).astype(np.float64) for u in ups]
+    _, g_ref = O.edge_conv_bwd(d[0], d[1], d[2], cache)
+    for n, key in (("conv0/weights", "W0"), ("conv0/BatchNorm/beta", "beta0")):
+        r = g_ref[key]
+        assert np.linalg.norm(got[True][n] - r) <= 2e-3 * np.linalg.norm(r), (n, np.linalg.norm(got[True][n] - r) / np.linalg.norm(r))
