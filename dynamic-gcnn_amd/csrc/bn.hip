@@ -513,9 +513,15 @@ __global__ __launch_bounds__(256) void bn1_act_kernel(const float* __restrict__ 
                                                       const float* __restrict__ mean, const float* __restrict__ rstd,
                                                       const float* __restrict__ beta, int relu,
                                                       float* __restrict__ out, int64_t ldo, float* __restrict__ out2,
-                                                      int64_t ldo2, float* __restrict__ cnt_out) {
+                                                      int64_t ldo2, float* __restrict__ cnt_out,
+                                                      const uint64_t* __restrict__ drop_seed, float drop_keep) {
   const K1Map m = k1_map(F, FVB, RP);
   if (!m.on) return;
+  // optional dropout fused behind the activation (model.py:90-91): element (row, f) of the (R, F) output keeps its value x 1/keep
+  // iff the counter-based mask of dropout_dev_kernel keeps flattened index row * F + f
+  const uint64_t dseed = drop_seed ? *drop_seed : 0ull;
+  const uint32_t dthr = dropout_threshold(drop_keep);
+  const float dscale = drop_seed ? 1.0f / drop_keep : 1.0f;
   float mu[4], rs[4], be[4];
   Vec<4>::ld(mean + m.f, mu); Vec<4>::ld(rstd + m.f, rs); Vec<4>::ld(beta + m.f, be);
   const float one[4] = {1.f, 1.f, 1.f, 1.f};
@@ -533,6 +539,10 @@ __global__ __launch_bounds__(256) void bn1_act_kernel(const float* __restrict__ 
         float z[4];
 #pragma unroll
         for (int v = 0; v < 4; ++v) { float xh; z[v] = bn_z(y[b][v], mu[v], rs[v], be[v], relu, xh); }
+        if (drop_seed) {
+#pragma unroll
+          for (int v = 0; v < 4; ++v) z[v] = dropout_keeps(dseed, (uint64_t)(rr * F + m.f + v), dthr) ? z[v] * dscale : 0.f;
+        }
         Vec<4>::st(out + rr * ldo + m.f, z);
         if (out2) Vec<4>::st(out2 + rr * ldo2 + m.f, z);
         if (cnt_out) Vec<4>::st(cnt_out + rr * F + m.f, one);
@@ -548,8 +558,11 @@ __global__ __launch_bounds__(256) void bn1_bwd_kernel(const float* T, int64_t R,
                                                       const float* __restrict__ beta, int relu,
                                                       const float* __restrict__ dout, int64_t lddo,
                                                       double* __restrict__ red, float* dT, float* __restrict__ dsum,
-                                                      int64_t lddsum) {
+                                                      int64_t lddsum, const uint64_t* __restrict__ drop_seed, float drop_keep) {
   extern __shared__ float lred[];   // reduce only: [2][min(F,1024)]
+  const uint64_t dseed = drop_seed ? *drop_seed : 0ull;      // dout is the gradient of the DROPPED output (fused dropout backward)
+  const uint32_t dthr = dropout_threshold(drop_keep);
+  const float dscale = drop_seed ? 1.0f / drop_keep : 1.0f;
   const K1Map m = k1_map(F, FVB, RP);
   const int fbase = blockIdx.y * 1024;
   const int fw = (F - fbase < 1024) ? (F - fbase) : 1024;
@@ -586,6 +599,7 @@ __global__ __launch_bounds__(256) void bn1_bwd_kernel(const float* T, int64_t R,
             float xh;
             const float z = bn_z(y[b][v], mu[v], rs[v], be[v], relu, xh);
             float dz = d[b][v];
+            if (drop_seed) dz = dropout_keeps(dseed, (uint64_t)(rr * F + m.f + v), dthr) ? dz * dscale : 0.f;
             if (relu && !(z > 0.f)) dz = 0.f;
             if (APPLY) o[v] = rs[v] * (dz - c1[v] - xh * c2[v]);
             else { s0[v] += dz; s1[v] += dz * xh; }
@@ -732,7 +746,7 @@ int launch_act_kreduce(const char* what, Src src, int64_t R, int k, int F, const
   } else if (vec && k == 1 && !mean_out) {
     const K1Grid g = k1_grid(R, F, 4096);
     hipLaunchKernelGGL(bn1_act_kernel, g.grid, dim3(256), 0, st, src.Y, R, F, g.FVB, g.RP, mean, rstd, beta, relu, max_out,
-                       ldmax, out2, ldout2, cnt_out);
+                       ldmax, out2, ldout2, cnt_out, (const uint64_t*)nullptr, 1.0f);
   } else if (vec) {
     hipLaunchKernelGGL((bn_act_kreduce_kernel<4, false>), dim3(grid_for(R * (F / 4))), dim3(256), 0, st, src, R, k, F, mean,
                        rstd, beta, relu, max_out, ldmax, mean_out, ldmean, out2, ldout2, cnt_out, shift_of(F / 4));
@@ -767,7 +781,7 @@ int launch_bwd_reduce(const char* what, Src src, int64_t R, int k, int F, const 
     const K1Grid g = k1_grid(R, F, mb);
     const size_t sh1 = sizeof(float) * 2 * (size_t)(F < 1024 ? F : 1024);
     hipLaunchKernelGGL((bn1_bwd_kernel<false>), g.grid, dim3(256), sh1, st, src.Y, R, F, g.FVB, g.RP, mean, rstd, beta, relu,
-                       dmax, lddmax, red, (float*)nullptr, (float*)nullptr, (int64_t)0);
+                       dmax, lddmax, red, (float*)nullptr, (float*)nullptr, (int64_t)0, (const uint64_t*)nullptr, 1.0f);
   } else if (vec) {
     hipLaunchKernelGGL((bn_bwd_reduce_kernel<4, false>), dim3(grid_reduce(R * (F / 4))), dim3(256), sh, st, src, R, k, F,
                        mean, rstd, beta, relu, dmax, lddmax, dmean, lddmean, mx_in, ldmx, cnt_in, red, shift_of(F / 4));
@@ -799,7 +813,7 @@ int launch_bwd_apply(const char* what, Src src, int64_t R, int k, int F, const f
   } else if (vec && k == 1 && !dmean) {
     const K1Grid g = k1_grid(R, F, 4096);
     hipLaunchKernelGGL((bn1_bwd_kernel<true>), g.grid, dim3(256), 0, st, src.Y, R, F, g.FVB, g.RP, mean, rstd, beta, relu,
-                       dmax, lddmax, red, dY, dYsum, lddysum);
+                       dmax, lddmax, red, dY, dYsum, lddysum, (const uint64_t*)nullptr, 1.0f);
   } else if (vec) {
     hipLaunchKernelGGL((bn_bwd_apply_kernel<4, false>), dim3(grid_for(R * (F / 4))), dim3(256), 0, st, src, R, k, F, mean,
                        rstd, beta, relu, dmax, lddmax, dmean, lddmean, mx_in, ldmx, cnt_in, red, dY, dYsum, lddysum,
@@ -910,6 +924,46 @@ extern "C" int dgcnn_edge_bn_bwd_apply_f32(const float* V, int64_t ldv, const fl
   return launch_bwd_apply<true>("dgcnn_edge_bn_bwd_apply_f32", edge_src(V, ldv, U, ldu, idx, N), (int64_t)B * N, k, F, mean,
                                 rstd, beta, relu, dmax, lddmax, dmean, lddmean, mx_in, ldmx, cnt_in, red, dY, dYsum,
                                 lddysum, dbeta, dbeta_beta, (hipStream_t)stream);
+}
+
+// ---- the last FC layer with tf.nn.dropout fused behind it (model.py:88-91): out = dropout(relu(bn(T))), and its backward
+// reading the gradient of the dropped output through the same mask.  (R, F) contiguous, F % 4 == 0.
+static int check_bn1_drop(const char* what, const float* T, int64_t R, int F, const float* mean, const float* rstd,
+                          const float* beta, float keep, const uint64_t* seed_dev) {
+  DG_REQUIRE(T && mean && rstd && beta && seed_dev && R > 0 && F > 0 && keep > 0.f && keep <= 1.f, DGCNN_EINVAL, "%s: bad args", what);
+  DG_REQUIRE(F % 4 == 0 && a16(T) && a16(mean) && a16(rstd) && a16(beta), DGCNN_EUNSUP, "%s: F %% 4 == 0 and 16-byte aligned operands required", what);
+  return DGCNN_OK;
+}
+
+extern "C" int dgcnn_bn1_act_dropout_f32(const float* T, int64_t R, int F, const float* mean, const float* rstd,
+                                         const float* beta, int relu, float keep, const uint64_t* seed_dev, float* out,
+                                         int64_t ldo, void* stream) {
+  int rc = check_bn1_drop("dgcnn_bn1_act_dropout_f32", T, R, F, mean, rstd, beta, keep, seed_dev);
+  if (rc) return rc;
+  DG_REQUIRE(out && ldo % 4 == 0 && a16(out), DGCNN_EINVAL, "dgcnn_bn1_act_dropout_f32: out must be 16-byte aligned, ld %% 4 == 0");
+  const K1Grid g = k1_grid(R, F, 4096);
+  hipLaunchKernelGGL(bn1_act_kernel, g.grid, dim3(256), 0, (hipStream_t)stream, T, R, F, g.FVB, g.RP, mean, rstd, beta, relu, out,
+                     ldo, (float*)nullptr, (int64_t)0, (float*)nullptr, seed_dev, keep);
+  return dg::check_launch("dgcnn_bn1_act_dropout_f32");
+}
+
+extern "C" int dgcnn_bn1_bwd_dropout_f32(const float* T, int64_t R, int F, const float* mean, const float* rstd,
+                                         const float* beta, int relu, float keep, const uint64_t* seed_dev,
+                                         const float* dout, int64_t lddo, double* red, float* dT, float* dbeta,
+                                         float dbeta_beta, void* stream) {
+  int rc = check_bn1_drop("dgcnn_bn1_bwd_dropout_f32", T, R, F, mean, rstd, beta, keep, seed_dev);
+  if (rc) return rc;
+  DG_REQUIRE(dout && red && dT && lddo % 4 == 0 && a16(dout) && a16(dT) && F <= 8192, DGCNN_EINVAL, "dgcnn_bn1_bwd_dropout_f32: bad args");
+  hipStream_t st = (hipStream_t)stream;
+  const K1Grid gr = k1_grid(R, F, 256);
+  const size_t sh1 = sizeof(float) * 2 * (size_t)(F < 1024 ? F : 1024);
+  hipLaunchKernelGGL((bn1_bwd_kernel<false>), gr.grid, dim3(256), sh1, st, T, R, F, gr.FVB, gr.RP, mean, rstd, beta, relu, dout, lddo,
+                     red, (float*)nullptr, (float*)nullptr, (int64_t)0, seed_dev, keep);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)dg::cdiv(F, 128)), dim3(128), 0, st, red, F, dbeta, dbeta_beta);
+  const K1Grid ga = k1_grid(R, F, 4096);
+  hipLaunchKernelGGL((bn1_bwd_kernel<true>), ga.grid, dim3(256), 0, st, T, R, F, ga.FVB, ga.RP, mean, rstd, beta, relu, dout, lddo, red,
+                     dT, (float*)nullptr, (int64_t)0, seed_dev, keep);
+  return dg::check_launch("dgcnn_bn1_bwd_dropout_f32");
 }
 
 namespace dg {

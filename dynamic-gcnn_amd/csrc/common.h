@@ -37,3 +37,20 @@ int x3_tile_m(int M, int N, int K);
 void launch_gemm_x3(int asrc, int bsrc, void* pv, hipStream_t st, int bn, int np);
 
 }  // namespace dg
+
+// ---- dropout (tf.nn.dropout(net, 0.7), model.py:91): counter-based mask, element i of the flattened tensor is kept iff
+// mix32(seed * K + i) < keep * 2^32; the backward regenerates the mask from the same seed (misc.hip, bn.hip)
+__device__ __forceinline__ uint32_t mix32(uint64_t z) {   // splitmix64 finaliser
+  z += 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z = z ^ (z >> 31);
+  return (uint32_t)(z >> 32);
+}
+
+__device__ __forceinline__ bool dropout_keeps(uint64_t seed, uint64_t i, uint32_t thr) {
+  return mix32(seed * 0xD1342543DE82EF95ull + i) < thr;
+}
+__device__ __forceinline__ uint32_t dropout_threshold(float keep) {
+  return (keep >= 1.f) ? 0xffffffffu : (uint32_t)((double)keep * 4294967296.0);
+}

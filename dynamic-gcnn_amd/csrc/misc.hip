@@ -346,14 +346,6 @@ __global__ __launch_bounds__(64 * RG) void group_colsum_kernel(const float* __re
   }
 }
 
-__device__ __forceinline__ uint32_t mix32(uint64_t z) {   // splitmix64 finaliser
-  z += 0x9E3779B97F4A7C15ull;
-  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-  z = z ^ (z >> 31);
-  return (uint32_t)(z >> 32);
-}
-
 __global__ void dropout_kernel(const float* x, float* y, int64_t n, float keep, uint64_t seed) {
   const float scale = 1.0f / keep;
   const uint32_t thr = (keep >= 1.f) ? 0xffffffffu : (uint32_t)((double)keep * 4294967296.0);

@@ -40,6 +40,7 @@ WGRAD_SIDE_STREAM = os.environ.get("DGCNN_SIDE_STREAM", "1") != "0"   # weight-g
 WGRAD_AFTER_DGRAD = os.environ.get("DGCNN_WGRAD_AFTER_DGRAD", "1") != "0"   # side-stream weight gradients start behind the data gradient
 WEIGHT_PREP_AHEAD = os.environ.get("DGCNN_WPREP", "1") != "0"   # parameter-only kernels of the step go first, on the side stream
 EDGE_BWD_FUSED_L0 = os.environ.get("DGCNN_EDGE_BWD_FUSED_L0", "1") != "0"   # input layer (C <= 4, no input gradient): one backward pass
+FUSE_DROPOUT = os.environ.get("DGCNN_FUSE_DROPOUT", "1") != "0"   # tf.nn.dropout inside the last FC layer's BatchNorm passes
 EDGE_BWD_REDUCE_POINTS = True   # BN backward sums of conv0 from per-point data (False: a pass over the edges)
 SIDE_STREAM_MIN_ROWS = 16384   # below this many points the side stream is not used
 EDGE_MLP_NBR_GEMM = False  # True: factored conv0 with an edge-level neighbour GEMM instead of point-level GEMM + gather-add
@@ -470,14 +471,16 @@ def bn_finalize(stats, F, count):
 # dgcnn/ops.py:62-70,125-133,153-160 ; dgcnn/model.py:46-53,65-72,94-101
 # ----------------------------------------------------------------------------------------------
 def conv_bn_act(x, leaf_scope, num_outputs, relu=True, out=None, out2=None, gbias=None, rpg=0, w_rows=None, arith=None,
-                plane_out=None, f32_out=True, gmax=None):
+                plane_out=None, f32_out=True, gmax=None, drop_keep=None):
     """x: (R,Cin) view.  Variables `<scope>/weights` [Cin(+extra), Cout], `<scope>/BatchNorm/beta`.
     w_rows: (lo, hi) row range of the weight that multiplies x (FC0 with the folded global feature).
     Returns the (R,Cout) output (a fresh tracked buffer unless `out` is given).
     Plane mode (HEAD_PLANES, planes_ok): the products run on the plane GEMM; plane_out = PlaneSet view that receives the
     activated output as operand planes of the NEXT product (f32_out = False: the fp32 `out` is then never written -- it only
     names the tensor and carries its gradient); gmax = (B, N): also return the per-cloud max over the points of the output
-    (model.py:76-77), taken on the GEMM output and normalised afterwards (BN + ReLU are monotone)."""
+    (model.py:76-77), taken on the GEMM output and normalised afterwards (BN + ReLU are monotone).
+    drop_keep: tf.nn.dropout(out, drop_keep) behind the layer (model.py:90-91), fused into the BatchNorm passes where the
+    kernels allow it (the returned tensor is the DROPPED output either way)."""
     c = ctx()
     R, Cin = x.shape
     with variable_scope(leaf_scope):
@@ -508,7 +511,15 @@ def conv_bn_act(x, leaf_scope, num_outputs, relu=True, out=None, out2=None, gbia
     mean, rstd = bn_finalize(st, F, R)
     if out is None:
         out = c.new_buffer(R, F)
-    if plane_out is not None:
+    fuse_drop = (drop_keep is not None and FUSE_DROPOUT and not use_pl and not DETERMINISTIC and F % 4 == 0 and out2 is None and
+                 gmax is None and plane_out is None)
+    if fuse_drop:
+        if c.seed_dev is None:
+            c.advance_seed()
+        seed = c.seed_dev                       # device-resident: the backward regenerates the mask from the same value
+        H.call("dgcnn_bn1_act_dropout_f32", T.data_ptr(), R, F, mean.data_ptr(), rstd.data_ptr(), beta.data_ptr(), int(relu),
+               float(drop_keep), seed.data_ptr(), out.data_ptr(), H.ld2(out), tag="bn_act_kreduce_kernel<k=1>", work=4.0 * R * F * 2)
+    elif plane_out is not None:
         H.call("dgcnn_bn_act_planes_f32", T.data_ptr(), F, R, F, mean.data_ptr(), rstd.data_ptr(), beta.data_ptr(), int(relu),
                plane_out.fmt, H._p(plane_out.scale), plane_out.ptr(), plane_out.plane_stride, plane_out.ra,
                out.data_ptr() if f32_out else 0, H.ld2(out), H._p(out2) if f32_out else 0, 0 if out2 is None else H.ld2(out2),
@@ -531,6 +542,24 @@ def conv_bn_act(x, leaf_scope, num_outputs, relu=True, out=None, out2=None, gbia
             red = c.stats(F)
             dWx = c.var_grads[wname] if w_rows is None else c.var_grads[wname][w_rows[0]:w_rows[1]]
             dgb = c.grad(gbias) if gbias is not None else None
+            if fuse_drop:
+                # sums, finalise (+ dbeta) and dT (in place of T), all reading d(dropped output) through the regenerated mask
+                H.call("dgcnn_bn1_bwd_dropout_f32", T.data_ptr(), R, F, mean.data_ptr(), rstd.data_ptr(), beta.data_ptr(), int(relu),
+                       float(drop_keep), seed.data_ptr(), dout.data_ptr(), H.ld2(dout), red.data_ptr(), T.data_ptr(),
+                       c.var_grads[bname].data_ptr(), 1.0, tag="bn_bwd_apply_kernel<k=1>", work=4.0 * R * F * 5)
+                dT = T
+                dx, bx = c.grad_w(x)
+                if WGRAD_AFTER_DGRAD and dx is not None:
+                    gemm(dT, Wx, dx, transB=True, beta=bx, arith=arith)
+                with c.off_critical_path(rows=R):
+                    gemm(x, dT, dWx, transA=True, beta=1.0, arith=arith)
+                if not WGRAD_AFTER_DGRAD and dx is not None:
+                    gemm(dT, Wx, dx, transB=True, beta=bx, arith=arith)
+                if dgb is not None:
+                    tmp = torch.empty_like(gbias)
+                    H.call("dgcnn_group_colsum_f32", dT.data_ptr(), H.ld2(dT), gbias.shape[0], rpg, F, tmp.data_ptr())
+                    H.call("dgcnn_axpby_f32", tmp.data_ptr(), 1.0, dgb.data_ptr(), 1.0, tmp.numel())
+                return
             if use_pl:
                 # sums + column maxima -> bound on |dT| -> the dT plane set's scale -> dT written as planes (never as fp32)
                 maxbits = c.stats_raw(F + 1)                              # uint32[2 F + 1]: column maxima + the tensor-wide bound
@@ -585,6 +614,8 @@ def conv_bn_act(x, leaf_scope, num_outputs, relu=True, out=None, out2=None, gbia
                 H.call("dgcnn_axpby_f32", tmp.data_ptr(), 1.0, dgb.data_ptr(), 1.0, tmp.numel())
         c.tape.append(bwd)
     if gmax is None:
+        if drop_keep is not None and not fuse_drop:
+            return dropout(out, drop_keep)         # (plane / deterministic modes: the separate pass)
         return out
     # model.py:76-77 max_pool over the points of each cloud, on the GEMM output: z = relu((t - mean) rstd + beta) is
     # non-decreasing in t, so max_n z[n] = z(max_n t[n]) and the first arg-max of t is an arg-max of z

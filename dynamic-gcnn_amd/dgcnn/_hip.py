@@ -53,6 +53,8 @@ PROTOTYPES = {
     "dgcnn_edge_bn_bwd_apply_wgrad_f32": [c_vp, c_i64, c_vp, c_i64, c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp,
                                           c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_int, c_vp, c_vp, c_f32,
                                           c_vp, c_sz, c_vp],
+    "dgcnn_bn1_act_dropout_f32": [c_vp, c_i64, c_int, c_vp, c_vp, c_vp, c_int, c_f32, c_vp, c_vp, c_i64, c_vp],
+    "dgcnn_bn1_bwd_dropout_f32": [c_vp, c_i64, c_int, c_vp, c_vp, c_vp, c_int, c_f32, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_f32, c_vp],
     "dgcnn_gemm_set_arith": [c_int],
     "dgcnn_gemm_get_arith": [],
     "dgcnn_gemm_f32": [c_int, c_int, c_int, c_int, c_int, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_f32,

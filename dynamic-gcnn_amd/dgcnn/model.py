@@ -119,14 +119,15 @@ def build(point_cloud, flags):
     with E.variable_scope("FC0"):
         wleaf = c.get_variable("weights", (1024 + ctot, fcf[0]))
     gb = E.plain_gemm(g, wleaf, (0, 1024), fcf[0])                 # per-cloud term (B, fcf0)
+    # model.py:90-91: tf.nn.dropout(net, 0.7) behind the LAST fc layer when training -- fused into that layer's BatchNorm passes
+    keep = E.DROPOUT_KEEP if is_training else None
     if pl_head and num_fc >= 2:
         net = E.conv_bn_act(big, "FC0", fcf[0], relu=True, gbias=gb, rpg=N, w_rows=(1024, 1024 + ctot, 1024 + ctot),
                             plane_out=c.new_planes(R, fcf[0], "act"), f32_out=False)
     else:
-        net = E.conv_bn_act(big, "FC0", fcf[0], relu=True, gbias=gb, rpg=N, w_rows=(1024, 1024 + ctot, 1024 + ctot))
+        net = E.conv_bn_act(big, "FC0", fcf[0], relu=True, gbias=gb, rpg=N, w_rows=(1024, 1024 + ctot, 1024 + ctot),
+                            drop_keep=keep if num_fc == 1 else None)
     for i in range(1, num_fc):                                     # ops.py:151-160
-        net = E.conv_bn_act(net, "FC%d" % i, fcf[i], relu=True)
-    if is_training:
-        net = E.dropout(net, E.DROPOUT_KEEP)                       # model.py:90-91
+        net = E.conv_bn_act(net, "FC%d" % i, fcf[i], relu=True, drop_keep=keep if i == num_fc - 1 else None)
     fin = E.conv_bn_act(net, "Final", num_class, relu=True)        # model.py:94-101 (BN + ReLU on the logits)
     return fin.view(B, N, num_class)                                # model.py:104 squeeze

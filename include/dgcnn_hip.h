@@ -146,6 +146,16 @@ int dgcnn_edge_bn_bwd_apply_f32(const float* V, int64_t ldv, const float* U, int
                                 double* red, float* dY, float* dYsum, int64_t lddysum, float* dbeta,
                                 float dbeta_beta, void* stream);
 
+/* The last FC layer with tf.nn.dropout fused behind it (model.py:88-91): out = dropout(relu?(bn(T)), keep) with the counter-based
+ * mask of dgcnn_dropout_dev_f32 (seed read from device memory), and its whole BatchNorm backward (sums, finalise + dbeta, dT in
+ * place or not) reading dout = d(dropped output) through the same mask: the activated tensor is never stored undropped and the
+ * separate dropout passes (forward and backward) disappear.  T, out, dT: (R, F) contiguous rows of F floats (out: leading dim ldo). */
+int dgcnn_bn1_act_dropout_f32(const float* T, int64_t R, int F, const float* mean, const float* rstd, const float* beta,
+                              int relu, float keep, const uint64_t* seed_dev, float* out, int64_t ldo, void* stream);
+int dgcnn_bn1_bwd_dropout_f32(const float* T, int64_t R, int F, const float* mean, const float* rstd, const float* beta,
+                              int relu, float keep, const uint64_t* seed_dev, const float* dout, int64_t lddo, double* red,
+                              float* dT, float* dbeta, float dbeta_beta, void* stream);
+
 /* conv0 backward of a layer whose input needs no gradient and has C <= 4 channels (the first EdgeConv layer: raw coordinates),
  * in ONE pass: dY is formed per edge exactly as in dgcnn_edge_bn_bwd_apply_f32 and consumed on the spot,
  * dW0[2C][F] += [x_i, x_j - x_i]^T dY (ops.py:39-52) -- no dY tensor, no transposed adjacency, no point-level GEMMs.
