@@ -763,11 +763,28 @@ void launch_reduce_partials(const float* part, int splits, int M, int N, float* 
 }
 }  // namespace dg
 
+__global__ void colmax_decode_kernel(const unsigned long long* __restrict__ keys, int64_t n, float* __restrict__ vals,
+                                     int32_t* __restrict__ arg) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const unsigned long long k = keys[i];
+  vals[i] = f32_from_ordered((unsigned)(k >> 32));
+  arg[i] = (int32_t)(0xffffffffu - (unsigned)(k & 0xffffffffu));
+}
+
+extern "C" int dgcnn_colmax_decode_f32(const void* keys, int64_t n, float* vals, int32_t* arg, void* stream) {
+  DG_REQUIRE(keys && vals && arg && n > 0, DGCNN_EINVAL, "dgcnn_colmax_decode_f32: bad args");
+  hipLaunchKernelGGL(colmax_decode_kernel, dim3((unsigned)dg::cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const unsigned long long*)keys, n, vals, arg);
+  return dg::check_launch("dgcnn_colmax_decode_f32");
+}
+
 extern "C" int dgcnn_gemm_f32(int transA, int transB, int M, int N, int K,
                               const float* A, int64_t lda, const float* B, int64_t ldb,
                               float* C, int64_t ldc, float beta,
                               const float* gbias, int64_t ldgbias, int rows_per_group,
-                              double* stats, void* ws, size_t ws_bytes, void* stream) {
+                              double* stats, void* colmax_keys, int colmax_rows_per_group,
+                              void* ws, size_t ws_bytes, void* stream) {
   DG_REQUIRE(A && B && C, DGCNN_EINVAL, "dgcnn_gemm_f32: null pointer");
   DG_REQUIRE(M > 0 && N > 0 && K > 0, DGCNN_EINVAL, "dgcnn_gemm_f32: bad shape %d %d %d", M, N, K);
   DG_REQUIRE(!(transA && transB), DGCNN_EUNSUP, "dgcnn_gemm_f32: transA && transB unsupported");
@@ -778,6 +795,9 @@ extern "C" int dgcnn_gemm_f32(int transA, int transB, int M, int N, int K,
   p.gbias = gbias; p.ldgbias = ldgbias; p.rpg = rows_per_group > 0 ? rows_per_group : 1;
   p.stats = stats;
   p.splits = 1; p.kchunk = K;
+  DG_REQUIRE(!colmax_keys || (colmax_rows_per_group > 0 && colmax_rows_per_group % 256 == 0 && !transA && N > 4), DGCNN_EUNSUP,
+             "dgcnn_gemm_f32: the column-maximum epilogue needs rows_per_group %% 256 == 0 (a tile inside one group), no transA, N > 4");
+  p.colmax = reinterpret_cast<unsigned long long*>(colmax_keys); p.colmax_rpg = colmax_rows_per_group;
   p.gbvec = gbias && (ldgbias % 4 == 0) && aligned16(gbias);
   p.avec = (lda % 4 == 0) && aligned16(A);
   p.bvec = (ldb % 4 == 0) && aligned16(B);
@@ -820,7 +840,7 @@ extern "C" int dgcnn_gemm_f32(int transA, int transB, int M, int N, int K,
   }
   p.bm = tile_m(M, N, 1);
   // a handful of output tiles with a long reduction (per-cloud rows: M = B): split K so the chip is not idle
-  if (!gbias && !stats && ws && K >= 512 && dg::cdiv(M, 128) * dg::cdiv(N, 128) <= 32) {
+  if (!gbias && !stats && !colmax_keys && ws && K >= 512 && dg::cdiv(M, 128) * dg::cdiv(N, 128) <= 32) {
     int rc = plan_splits(p, ws, ws_bytes, "dgcnn_gemm_f32");
     if (rc) return rc;
     p.bm = 128;

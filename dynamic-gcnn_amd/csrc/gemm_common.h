@@ -37,7 +37,20 @@ struct GemmP {
   int edge_nbr;   // A_EDGE / A_EDGE_T rows are the raw neighbour features x_j (K or M = C) instead of [x_i, x_j - x_i]
   int gbvec;      // per-group bias rows are float4-loadable
   int zmajor;     // split-K launches of the bf16-split kernels: 1-D grid, XCD x (= block id % 8) owns the k-chunks z = x (mod 8)
+  // per-group column maximum of the output (model.py:76-77 max-pool over the points of a cloud, taken in the epilogue of the GEMM
+  // that produces the tensor): keys[group][N] <- atomicMax(order-preserving bits of the value << 32 | ~row-in-group), i.e. the
+  // largest value and, among ties, the FIRST row.  Needs rows_per_group % tile rows == 0 (checked by the host).
+  unsigned long long* colmax; int colmax_rpg;
 };
+
+// order-preserving map float -> uint32 (larger float <=> larger unsigned), and back
+__device__ __forceinline__ unsigned f32_ordered(float v) {
+  const unsigned u = __float_as_uint(v);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float f32_from_ordered(unsigned u) {
+  return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u);
+}
 
 // Block -> (mt, nt, z).  MI355X hands workgroup b to XCD b % 8 (each XCD has a private 4 MB L2).
 //   zmajor    (split-K: few output tiles, long reduction) every k-chunk z is pinned to ONE XCD: all mtiles x ntiles tiles
@@ -130,6 +143,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[TM][
       if (gcol + q < p.N) gbu[q] = p.gbias[(int64_t)(m0 / p.rpg) * p.ldgbias + gcol + q];
   }
   float cs[4] = {0.f, 0.f, 0.f, 0.f}, cq[4] = {0.f, 0.f, 0.f, 0.f};
+  float cmx[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+  int cmr[4] = {0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff};
+  const bool want_max = (p.colmax != nullptr) && !split;
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
     __syncthreads();
@@ -184,24 +200,57 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[TM][
           for (int q = 0; q < 4; ++q)
             if (gcol + q < p.N) { dst[q] = v[q]; cs[q] += v[q]; cq[q] += v[q] * v[q]; }
         }
+        if (want_max) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            if (v[q] > cmx[q] || (v[q] == cmx[q] && grow < cmr[q])) { cmx[q] = v[q]; cmr[q] = grow; }
+        }
       }
     }
   }
-  if (p.stats && !split) {
+  if ((p.stats || want_max) && !split) {
+    // Column reductions of the tile.  The NTH / QV threads that share a column quad park their partial results as float4
+    // slots [thread row l][kind][quad] (conflict-free ds_write_b128), one thread per column then walks down the l's (round 2
+    // used 8 LDS float atomics per thread, 16 threads deep on every address).
     __syncthreads();
-    float* red = smem;  // [2][BN]
-    for (int e = t; e < 2 * BN; e += NTH) red[e] = 0.f;
-    __syncthreads();
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      atomicAdd(&red[c4 + q], cs[q]);
-      atomicAdd(&red[BN + c4 + q], cq[q]);
+    constexpr int L = NTH / QV;
+    float4* park = reinterpret_cast<float4*>(smem);          // [L][4 kinds][QV]
+    const int l = t / QV, qd = t % QV;
+    park[(l * 4 + 0) * QV + qd] = make_float4(cs[0], cs[1], cs[2], cs[3]);
+    park[(l * 4 + 1) * QV + qd] = make_float4(cq[0], cq[1], cq[2], cq[3]);
+    if (want_max) {
+      park[(l * 4 + 2) * QV + qd] = make_float4(cmx[0], cmx[1], cmx[2], cmx[3]);
+      park[(l * 4 + 3) * QV + qd] = make_float4(__int_as_float(cmr[0]), __int_as_float(cmr[1]), __int_as_float(cmr[2]), __int_as_float(cmr[3]));
     }
     __syncthreads();
-    const int slot = mt % DGCNN_STAT_SLOTS;
-    for (int e = t; e < 2 * BN; e += NTH) {
-      const int which = e / BN, c = n0 + (e % BN);
-      if (c < p.N) atomicAdd(p.stats + ((int64_t)slot * 2 + which) * p.N + c, (double)red[e]);
+    const float* pk = smem;
+    if (t < BN) {
+      const int c = n0 + t;
+      float s0 = 0.f, s1 = 0.f, mx = -INFINITY;
+      int mr = 0x7fffffff;
+#pragma unroll 4
+      for (int ll = 0; ll < L; ++ll) {
+        s0 += pk[((ll * 4 + 0) * QV) * 4 + t];
+        s1 += pk[((ll * 4 + 1) * QV) * 4 + t];
+        if (want_max) {
+          const float v = pk[((ll * 4 + 2) * QV) * 4 + t];
+          const int r = __float_as_int(pk[((ll * 4 + 3) * QV) * 4 + t]);
+          if (v > mx || (v == mx && r < mr)) { mx = v; mr = r; }
+        }
+      }
+      if (c < p.N) {
+        if (p.stats) {
+          const int slot = mt % DGCNN_STAT_SLOTS;
+          atomicAdd(p.stats + ((int64_t)slot * 2 + 0) * p.N + c, (double)s0);
+          atomicAdd(p.stats + ((int64_t)slot * 2 + 1) * p.N + c, (double)s1);
+        }
+        if (want_max && mr != 0x7fffffff) {
+          const int grp = m0 / p.colmax_rpg;                  // the tile lies inside one group (host check)
+          const unsigned long long key = ((unsigned long long)f32_ordered(mx) << 32) |
+                                         (unsigned long long)(0xffffffffu - (unsigned)(mr - grp * p.colmax_rpg));
+          atomicMax(p.colmax + (int64_t)grp * p.N + c, key);
+        }
+      }
     }
   }
 }

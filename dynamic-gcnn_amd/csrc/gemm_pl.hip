@@ -442,7 +442,8 @@ extern "C" int dgcnn_gemm_planes_f32(int form, int fmt, int M, int N, int K,
                                      const float* a_scale_dev, const float* b_scale_dev,
                                      float* C, int64_t ldc, float beta,
                                      const float* gbias, int64_t ldgbias, int rows_per_group,
-                                     double* stats, void* ws, size_t ws_bytes, void* stream) {
+                                     double* stats, void* colmax_keys, int colmax_rows_per_group,
+                                     void* ws, size_t ws_bytes, void* stream) {
   DG_REQUIRE(A && B && C && M > 0 && N > 0 && K > 0, DGCNN_EINVAL, "dgcnn_gemm_planes_f32: bad args");
   DG_REQUIRE(form == DGCNN_PL_KC || form == DGCNN_PL_TR, DGCNN_EINVAL, "dgcnn_gemm_planes_f32: unknown form %d", form);
   DG_REQUIRE(fmt == DGCNN_PLANES_BF16X3 || fmt == DGCNN_PLANES_F16X2, DGCNN_EINVAL, "dgcnn_gemm_planes_f32: unknown format %d", fmt);
@@ -455,6 +456,9 @@ extern "C" int dgcnn_gemm_planes_f32(int form, int fmt, int M, int N, int K,
   p.gbias = gbias; p.ldgbias = ldgbias; p.rpg = rows_per_group > 0 ? rows_per_group : 1;
   p.gbvec = gbias && (ldgbias % 4 == 0) && aligned16p(gbias);
   p.stats = stats;
+  DG_REQUIRE(!colmax_keys || (form == DGCNN_PL_KC && colmax_rows_per_group > 0 && colmax_rows_per_group % 256 == 0), DGCNN_EUNSUP,
+             "dgcnn_gemm_planes_f32: the column-maximum epilogue needs the KC form and rows_per_group %% 256 == 0");
+  p.colmax = reinterpret_cast<unsigned long long*>(colmax_keys); p.colmax_rpg = colmax_rows_per_group;
   p.splits = 1; p.kchunk = K; p.bm = 256;
   q.Ap = (const char*)A; q.a_ps = a_plane_stride; q.a_rows = a_rows_alloc;
   q.Bp = (const char*)B; q.b_ps = b_plane_stride; q.b_rows = b_rows_alloc;

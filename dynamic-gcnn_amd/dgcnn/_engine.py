@@ -41,6 +41,7 @@ WGRAD_AFTER_DGRAD = os.environ.get("DGCNN_WGRAD_AFTER_DGRAD", "1") != "0"   # si
 WEIGHT_PREP_AHEAD = os.environ.get("DGCNN_WPREP", "1") != "0"   # parameter-only kernels of the step go first, on the side stream
 EDGE_BWD_FUSED_L0 = os.environ.get("DGCNN_EDGE_BWD_FUSED_L0", "1") != "0"   # input layer (C <= 4, no input gradient): one backward pass
 FUSE_DROPOUT = os.environ.get("DGCNN_FUSE_DROPOUT", "1") != "0"   # tf.nn.dropout inside the last FC layer's BatchNorm passes
+COLMAX_IN_EPILOGUE = os.environ.get("DGCNN_COLMAX_EPILOGUE", "1") != "0"   # the global max-pool comes out of MergedEdgeConv's GEMM epilogue
 EDGE_BWD_REDUCE_POINTS = True   # BN backward sums of conv0 from per-point data (False: a pass over the edges)
 SIDE_STREAM_MIN_ROWS = 16384   # below this many points the side stream is not used
 EDGE_MLP_NBR_GEMM = False  # True: factored conv0 with an edge-level neighbour GEMM instead of point-level GEMM + gather-add
@@ -401,14 +402,14 @@ def _tile_m(M, N):
     return 128
 
 
-def gemm(A, Bm, C, transA=False, transB=False, beta=0.0, gbias=None, rpg=0, stats=None, arith=None):
+def gemm(A, Bm, C, transA=False, transB=False, beta=0.0, gbias=None, rpg=0, stats=None, arith=None, colmax=None, colmax_rpg=0):
     """C (+)= op(A) op(B); shapes are those of the stored matrices.  arith: arithmetic of THIS product (None = the
     process-wide setting; 1 = plain bf16 operands: measurements only, not fp32 class)."""
     if arith is not None and arith != H.gemm_arith():
         prev = H.gemm_arith()
         H.set_gemm_arith(arith)
         try:
-            return gemm(A, Bm, C, transA, transB, beta, gbias, rpg, stats)
+            return gemm(A, Bm, C, transA, transB, beta, gbias, rpg, stats, None, colmax, colmax_rpg)
         finally:
             H.set_gemm_arith(prev)
     M = A.shape[1] if transA else A.shape[0]
@@ -437,7 +438,7 @@ def gemm(A, Bm, C, transA=False, transB=False, beta=0.0, gbias=None, rpg=0, stat
                                                       _tile_m(M, N), bn)
     H.call("dgcnn_gemm_f32", int(transA), int(transB), M, N, K, A.data_ptr(), H.ld2(A), Bm.data_ptr(), H.ld2(Bm),
            C.data_ptr(), H.ld2(C), float(beta), H._p(gbias), 0 if gbias is None else H.ld2(gbias), int(rpg),
-           H._p(stats), ws.data_ptr(), ws.numel(), tag=tag, work=2.0 * M * N * K)
+           H._p(stats), H._p(colmax), int(colmax_rpg), ws.data_ptr(), ws.numel(), tag=tag, work=2.0 * M * N * K)
 
 
 def colstats_det(T, st):
@@ -496,16 +497,22 @@ def conv_bn_act(x, leaf_scope, num_outputs, relu=True, out=None, out2=None, gbia
     st = c.stats(F)
     use_pl = arith is None and planes_ok(R, Cin, F)
     xp = None
+    # the per-cloud column maximum (model.py:76-77), when asked for, comes out of the GEMM's epilogue as packed (value, first row)
+    # keys -- a tile of 256 rows must lie inside one cloud; otherwise a separate pass over T below
+    keys = None
+    if gmax is not None and COLMAX_IN_EPILOGUE and gmax[1] % 256 == 0 and gmax[0] * gmax[1] == R and F > 4:
+        keys = c.stats_raw(gmax[0] * F)                                    # zeroed uint64[B][F]
     if use_pl:
         c.ensure_plane_scales(R)
         xp = c.planes_of(x)                                                # (R, Cin) activations
         wt = prepared(("wT", Wx.data_ptr()))                               # (F rows, Cin channels) = W^T
         if wt is None:
             wt = c.new_planes(F, Cin, "w").fill_from(Wx, transpose=True)
-        PL.gemm(PL.KC, xp, wt, T, gbias=gbias, rpg=rpg, stats=st)
+        PL.gemm(PL.KC, xp, wt, T, gbias=gbias, rpg=rpg, stats=st, colmax=keys, colmax_rpg=0 if keys is None else gmax[1])
     else:
         plane_out, f32_out = None, True
-        gemm(x, Wx, T, gbias=gbias, rpg=rpg, stats=None if DETERMINISTIC else st, arith=arith)
+        gemm(x, Wx, T, gbias=gbias, rpg=rpg, stats=None if DETERMINISTIC else st, arith=arith,
+             colmax=keys, colmax_rpg=0 if keys is None else gmax[1])
     if DETERMINISTIC:
         colstats_det(T, st)
     mean, rstd = bn_finalize(st, F, R)
@@ -622,7 +629,10 @@ def conv_bn_act(x, leaf_scope, num_outputs, relu=True, out=None, out2=None, gbia
     Bc, Nc = gmax
     graw = torch.empty((Bc, F), dtype=torch.float32, device=x.device)
     arg = torch.empty((Bc, F), dtype=torch.int32, device=x.device)
-    H.call("dgcnn_global_max_f32", T.data_ptr(), F, Bc, Nc, F, graw.data_ptr(), arg.data_ptr())
+    if keys is not None:
+        H.call("dgcnn_colmax_decode_f32", keys.data_ptr(), Bc * F, graw.data_ptr(), arg.data_ptr())
+    else:
+        H.call("dgcnn_global_max_f32", T.data_ptr(), F, Bc, Nc, F, graw.data_ptr(), arg.data_ptr())
     g = c.new_buffer(Bc, F)
     H.call("dgcnn_bn_act_kreduce_f32", graw.data_ptr(), Bc, 1, F, mean.data_ptr(), rstd.data_ptr(), beta.data_ptr(),
            int(relu), g.data_ptr(), F, 0, 0, 0, 0, 0)

@@ -58,11 +58,12 @@ PROTOTYPES = {
     "dgcnn_gemm_set_arith": [c_int],
     "dgcnn_gemm_get_arith": [],
     "dgcnn_gemm_f32": [c_int, c_int, c_int, c_int, c_int, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_f32,
-                       c_vp, c_i64, c_int, c_vp, c_vp, c_sz, c_vp],
+                       c_vp, c_i64, c_int, c_vp, c_vp, c_int, c_vp, c_sz, c_vp],
+    "dgcnn_colmax_decode_f32": [c_vp, c_i64, c_vp, c_vp, c_vp],
     "dgcnn_split_planes_f32": [c_vp, c_i64, c_i64, c_i64, c_int, c_int, c_vp, c_vp, c_i64, c_i64, c_vp],
     "dgcnn_planes_scale_f32": [c_vp, c_i64, c_i64, c_int, c_f32, c_vp, c_vp, c_vp],
     "dgcnn_gemm_planes_f32": [c_int, c_int, c_int, c_int, c_int, c_vp, c_i64, c_i64, c_vp, c_i64, c_i64, c_vp, c_vp, c_vp, c_i64, c_f32,
-                              c_vp, c_i64, c_int, c_vp, c_vp, c_sz, c_vp],
+                              c_vp, c_i64, c_int, c_vp, c_vp, c_int, c_vp, c_sz, c_vp],
     "dgcnn_param_scales_f32": [c_vp, c_i64, c_f64, c_f32, c_vp, c_vp, c_vp],
     "dgcnn_bn_act_planes_f32": [c_vp, c_i64, c_i64, c_int, c_vp, c_vp, c_vp, c_int, c_int, c_vp, c_vp, c_i64, c_i64, c_vp, c_i64,
                                 c_vp, c_i64, c_vp],

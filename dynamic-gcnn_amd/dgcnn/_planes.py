@@ -84,7 +84,7 @@ def from_f32(src, fmt=BF16X3, transpose=False):
     return PlaneSet(r, c, fmt, device=src.device).fill_from(src, transpose)
 
 
-def gemm(form, A, B, C, beta=0.0, gbias=None, rpg=0, stats=None, ws=None):
+def gemm(form, A, B, C, beta=0.0, gbias=None, rpg=0, stats=None, ws=None, colmax=None, colmax_rpg=0):
     """C (+)= A B^T-style product of two plane sets.  KC: C is (A.rows, B.rows), reduction over the channels;
     TR: C is (A.cols, B.cols), reduction over the rows (X^T dY)."""
     if A.fmt != B.fmt:
@@ -100,6 +100,6 @@ def gemm(form, A, B, C, beta=0.0, gbias=None, rpg=0, stats=None, ws=None):
     assert tuple(C.shape) == (M, N), (tuple(C.shape), M, N)
     H.call("dgcnn_gemm_planes_f32", form, A.fmt, M, N, K, A.ptr(), A.plane_stride, A.ra, B.ptr(), B.plane_stride, B.ra,
            H._p(A.scale), H._p(B.scale), C.data_ptr(), H.ld2(C), float(beta), H._p(gbias), 0 if gbias is None else H.ld2(gbias), int(rpg),
-           H._p(stats), H._p(ws), 0 if ws is None else ws.numel(),
+           H._p(stats), H._p(colmax), int(colmax_rpg), H._p(ws), 0 if ws is None else ws.numel(),
            tag="gemm_pl_kernel<%s,%s>" % ("KC" if form == KC else "TR", "bf16x3" if A.fmt == BF16X3 else "f16x2"),
            work=2.0 * M * N * K)

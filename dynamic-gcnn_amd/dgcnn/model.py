@@ -111,8 +111,9 @@ def build(point_cloud, flags):
                                   plane_out=bigP.cols_view(ctot - 1024, ctot), f32_out=False, gmax=(B, N))   # model.py:65-77
         c.planes[c.plane_key(big)] = bigP
     else:
-        merged = E.conv_bn_act(merged_in, "MergedEdgeConv", 1024, relu=True, out=big[:, ctot - 1024:])  # model.py:65-72
-        g = E.global_max(merged, B, N)                             # model.py:76-77 (B,1024)
+        # model.py:65-77: MergedEdgeConv, then the max-pool over the points of each cloud -- taken on the GEMM output (in its
+        # epilogue where the tile shape allows) and normalised afterwards: BN + ReLU are non-decreasing
+        merged, g = E.conv_bn_act(merged_in, "MergedEdgeConv", 1024, relu=True, out=big[:, ctot - 1024:], gmax=(B, N))
     tensors.append(E.rank4(merged, B, N))                          # model.py:74
 
     # model.py:80-88: concat([tile(g)] + tensors) -> fc.  FC0 is split as described in the docstring.

@@ -183,11 +183,16 @@ int dgcnn_edge_bn_bwd_apply_wgrad_f32(const float* V, int64_t ldv, const float* 
  * Default 6, or $DGCNN_GEMM_ARITH = f32 | bf16x6 | bf16x9 | bf16x1.  Process-wide.                     */
 int dgcnn_gemm_set_arith(int mode);
 int dgcnn_gemm_get_arith(void);
+/* colmax_keys (optional, uint64[M / colmax_rows_per_group][N], zeroed): the per-group column maximum of C and its FIRST row
+ * (model.py:76-77: max-pool over the points of a cloud, taken in the epilogue of the GEMM that produces the tensor), as packed
+ * keys decoded by dgcnn_colmax_decode_f32 -> value[g][n], row-in-group[g][n].  rows_per_group % 256 == 0, no transA.       */
 int dgcnn_gemm_f32(int transA, int transB, int M, int N, int K,
                    const float* A, int64_t lda, const float* B, int64_t ldb,
                    float* C, int64_t ldc, float beta,
                    const float* gbias, int64_t ldgbias, int rows_per_group,
-                   double* stats, void* ws, size_t ws_bytes, void* stream);
+                   double* stats, void* colmax_keys, int colmax_rows_per_group,
+                   void* ws, size_t ws_bytes, void* stream);
+int dgcnn_colmax_decode_f32(const void* keys, int64_t n, float* vals, int32_t* arg, void* stream);
 
 /* ---- GEMM from PRE-SPLIT operand planes (gemm_pl.hip) -------------------------------------------
  * The same 1x1 convolutions and their dgrad / wgrad (ops.py:62-70,153-160; model.py:65-72) when the
@@ -219,7 +224,8 @@ int dgcnn_gemm_planes_f32(int form, int fmt, int M, int N, int K,
                           const float* a_scale_dev, const float* b_scale_dev,
                           float* C, int64_t ldc, float beta,
                           const float* gbias, int64_t ldgbias, int rows_per_group,
-                          double* stats, void* ws, size_t ws_bytes, void* stream);
+                          double* stats, void* colmax_keys, int colmax_rows_per_group,
+                          void* ws, size_t ws_bytes, void* stream);
 
 /* ---- BatchNorm passes that WRITE operand planes (planes_bn.hip) ------------------------------------
  * The per-point conv + BN + ReLU layers of the head (model.py:65-72, ops.py:153-160): the pass that normalises a GEMM

@@ -1020,3 +1020,28 @@ def test_dropout_fused_into_the_last_fc_layer_equals_the_separate_passes(dg):
         E.FUSE_DROPOUT = old
         dg.reset()
     assert 0.3 <= seen["frac0"] <= 0.9, seen          # 30 % dropped + the ReLU's own zeros
+
+
+@pytest.mark.parametrize("B,N,Cin,F", [(3, 512, 64, 128), (2, 1024, 192, 1024), (5, 256, 32, 96)])
+def test_column_maximum_from_the_gemm_epilogue(dg, B, N, Cin, F):
+    """model.py:76-77 (max_pool_v2 over the points of a cloud): the per-cloud column maximum and its FIRST row come out of the
+    epilogue of the GEMM that produces the tensor (packed keys + dgcnn_colmax_decode_f32) -- against numpy, ties included."""
+    from dgcnn import _engine as E
+    rng = np.random.default_rng(B * N + F)
+    X = rng.normal(size=(B * N, Cin)).astype(np.float32)
+    X[rng.integers(0, B * N, 200)] = X[0]                       # duplicate rows: exact ties of whole output rows
+    W = rng.normal(0, 0.2, size=(Cin, F)).astype(np.float32)
+    W[:, :3] = 0.0                                              # all-equal columns: every row ties, the first must win
+    T = torch.empty((B * N, F), device="cuda")
+    keys = torch.zeros(B * F, dtype=torch.int64, device="cuda")
+    st = torch.zeros(E.H.STAT_SLOTS * 2 * F, dtype=torch.float64, device="cuda")
+    E.gemm(dev(X), dev(W), T, stats=st, colmax=keys, colmax_rpg=N)
+    vals = torch.empty((B, F), device="cuda")
+    arg = torch.empty((B, F), dtype=torch.int32, device="cuda")
+    E.H.call("dgcnn_colmax_decode_f32", keys.data_ptr(), B * F, vals.data_ptr(), arg.data_ptr())
+    Th = host(T).reshape(B, N, F)
+    np.testing.assert_array_equal(host(vals), Th.max(1))
+    np.testing.assert_array_equal(host(arg), Th.argmax(1))          # numpy's argmax is the first maximum too
+    s = host(st).reshape(E.H.STAT_SLOTS, 2, F).sum(0)               # the BatchNorm column sums of the same epilogue
+    np.testing.assert_allclose(s[0], Th.reshape(-1, F).astype(np.float64).sum(0), rtol=1e-5, atol=1e-2)
+    np.testing.assert_allclose(s[1], (Th.reshape(-1, F).astype(np.float64) ** 2).sum(0), rtol=1e-5, atol=1e-2)
