@@ -190,10 +190,9 @@ struct Stage {
   }
 };
 
-template <int AKIND, int BKIND, int BN, int NP>
-__global__ __launch_bounds__(NT, 2) void gemm_x3_kernel(GemmP p) {
-  constexpr int BM = 128;
-  constexpr int TM = 2;
+template <int AKIND, int BKIND, int BN, int NP, int BM = 128>
+__global__ __launch_bounds__(NT, (BM == 64 ? 3 : 2)) void gemm_x3_kernel(GemmP p) {
+  constexpr int TM = BM / 64;
   constexpr int TN = BN / 64;
   using IA = Img<BM>;
   using IB = Img<BN>;
@@ -237,7 +236,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_x3_kernel(GemmP p) {
   // operand addresses of this lane: tile row (wave base + 32 i + l31), chunk = 2*kstep + lh
   unsigned a_off[TM], b_off[TN];
 #pragma unroll
-  for (int i = 0; i < TM; ++i) a_off[i] = IA::at(wr * 64 + i * 32 + l31, lh);
+  for (int i = 0; i < TM; ++i) a_off[i] = IA::at(wr * (BM / 2) + i * 32 + l31, lh);
 #pragma unroll
   for (int j = 0; j < TN; ++j) b_off[j] = IB::at(wc * (BN / 2) + j * 32 + l31, lh);
 
@@ -610,6 +609,11 @@ void launch_kind(GemmP& p, hipStream_t st, int bn, int np, dim3 grid) {
     else hipLaunchKernelGGL((gemm_x3w2_kernel<AKIND, BKIND, 6>), grid, dim3(768), 0, st, p);
     return;
   }
+  if (p.bm == 64) {          // short reductions over many rows (conv1, the point-level [U|V] product and their data gradients)
+    if (bn == 64) hipLaunchKernelGGL((gemm_x3_kernel<AKIND, BKIND, 64, 6, 64>), grid, dim3(NT), 0, st, p);
+    else hipLaunchKernelGGL((gemm_x3_kernel<AKIND, BKIND, 128, 6, 64>), grid, dim3(NT), 0, st, p);
+    return;
+  }
   if (bn == 64) {
     if (np == 9) hipLaunchKernelGGL((gemm_x3_kernel<AKIND, BKIND, 64, 9>), grid, dim3(NT), 0, st, p);
     else if (np == 1) hipLaunchKernelGGL((gemm_x3_kernel<AKIND, BKIND, 64, 1>), grid, dim3(NT), 0, st, p);
@@ -643,6 +647,11 @@ int x3_tile_m(int M, int N, int K) {
   static int v = -1;
   if (v < 0) { const char* e = getenv("DGCNN_GEMM_X3_BM"); v = e ? atoi(e) : 0; }   // A/B switch: 128 forces the small tile
   if (v == 128) return 128;
+  static int v64 = -1;
+  if (v64 < 0) { const char* e = getenv("DGCNN_GEMM_X3_BM64"); v64 = e ? atoi(e) : 1; }         // A/B switch
+  // short reduction, many rows, one or two column tiles: the kernel is bound by the latency of its few slabs -- 64-row tiles put
+  // twice the workgroups (and loads in flight) on a CU
+  if (v64 && dg::gemm_arith() == 6 && K <= 256 && N <= 256 && M >= 8192 && cdiv(M, 128) * cdiv(N, 128) <= 1024) return 64;
   // small problems (configs[0]: 1024 rows, K ~ 1000): a 256 x 128 tiling, even split over K, leaves most CUs without work
   if (cdiv(M, 256) * cdiv(N, 128) * cdiv(K, 256) < 256) return 128;
   return (M > 128 && N > 64) ? 256 : 128;

@@ -1,0 +1,10 @@
+cd /root/repo
+python -m pytest tests/test_gpu_parity.py -x -q -k "gemm" 2>&1 | grep -v amdgpu.ids | tail -3
+for fl in 0 1; do DGCNN_GEMM_X3_BM64=$fl python profiles/r03/small_gemm_bench.py 2>&1 | grep -v amdgpu.ids; done
+J='import sys,json
+for l in sys.stdin:
+    if l.startswith("{"):
+        d=json.loads(l); c=d["config"]; print(d["ms_per_step"], "host", c["host_enqueue_ms_per_step"], c["launch_mode"])'
+for rep in 1 2; do for fl in 0 1; do
+echo "BM64=$fl"; DGCNN_GEMM_X3_BM64=$fl python bench.py --steps 30 --warmup 5 --no-cpu-baseline --graph 0 --no-edgeconv-stack 2>/dev/null | python -c "$J"
+done; done

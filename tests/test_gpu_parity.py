@@ -176,7 +176,8 @@ def _gemm(dg, A, B, C, **kw):
 
 
 @pytest.mark.parametrize("M,N,K", [(128, 64, 16), (300, 70, 50), (1024, 512, 192), (257, 2, 256), (640, 128, 6),
-                                   (129, 130, 131)])
+                                   (129, 130, 131),
+                                   (8200, 64, 128), (9000, 256, 64), (8192, 100, 256)])   # 64-row tiles (short reduction, many rows)
 def test_gemm_nn_nt(dg, arith, M, N, K):
     rng = np.random.default_rng(M + N + K)
     A = rng.normal(size=(M, K)).astype(np.float32)
