@@ -557,6 +557,7 @@ __global__ __launch_bounds__(256) void bn1_bwd_kernel(const float* T, int64_t R,
                                                       const float* __restrict__ mean, const float* __restrict__ rstd,
                                                       const float* __restrict__ beta, int relu,
                                                       const float* __restrict__ dout, int64_t lddo,
+                                                      const float* __restrict__ dout2, int64_t lddo2,
                                                       double* __restrict__ red, float* dT, float* __restrict__ dsum,
                                                       int64_t lddsum, const uint64_t* __restrict__ drop_seed, float drop_keep) {
   extern __shared__ float lred[];   // reduce only: [2][min(F,1024)]
@@ -587,7 +588,15 @@ __global__ __launch_bounds__(256) void bn1_bwd_kernel(const float* T, int64_t R,
 #pragma unroll
       for (int b = 0; b < 4; ++b) {
         const int64_t rr = r + b * m.rstep;
-        if (rr < R) { Vec<4>::ld(T + rr * F + m.f, y[b]); Vec<4>::ld(dout + rr * lddo + m.f, d[b]); }
+        if (rr < R) {
+          Vec<4>::ld(T + rr * F + m.f, y[b]); Vec<4>::ld(dout + rr * lddo + m.f, d[b]);
+          if (dout2) {               // the output had two consumers (conv1: the concat slice and MergedEdgeConv's input): dz = d + d2
+            float e[4];
+            Vec<4>::ld(dout2 + rr * lddo2 + m.f, e);
+#pragma unroll
+            for (int v = 0; v < 4; ++v) d[b][v] += e[v];
+          }
+        }
       }
 #pragma unroll
       for (int b = 0; b < 4; ++b) {
@@ -773,7 +782,7 @@ int launch_bwd_reduce(const char* what, Src src, int64_t R, int k, int F, const 
     DG_REQUIRE(vec, DGCNN_EINVAL, "%s: operands must be 16-byte aligned with leading dimensions %% 4 == 0", what);
     hipLaunchKernelGGL((bn_bwd_reduce_kernel<4, true>), dim3(grid8(grid_reduce(R * (F / 4)))), dim3(256), sh, st, src, R, k,
                        F, mean, rstd, beta, relu, dmax, lddmax, dmean, lddmean, mx_in, ldmx, cnt_in, red, shift_of(F / 4));
-  } else if (vec && k == 1 && !dmean) {
+  } else if (vec && k == 1 && !mx_in) {          // k = 1: dz = dmax + dmean / 1 -- `dmean` is the gradient of a second copy of the output
     static int mb = -1;
     if (mb < 0) { const char* e = getenv("DGCNN_BN1_RED_BLOCKS"); mb = e ? atoi(e) : 256; }   // experiments
     // the kernel ends with 2F double atomics per workgroup, which dominate above ~1 workgroup per CU
@@ -781,7 +790,7 @@ int launch_bwd_reduce(const char* what, Src src, int64_t R, int k, int F, const 
     const K1Grid g = k1_grid(R, F, mb);
     const size_t sh1 = sizeof(float) * 2 * (size_t)(F < 1024 ? F : 1024);
     hipLaunchKernelGGL((bn1_bwd_kernel<false>), g.grid, dim3(256), sh1, st, src.Y, R, F, g.FVB, g.RP, mean, rstd, beta, relu,
-                       dmax, lddmax, red, (float*)nullptr, (float*)nullptr, (int64_t)0, (const uint64_t*)nullptr, 1.0f);
+                       dmax, lddmax, dmean, lddmean, red, (float*)nullptr, (float*)nullptr, (int64_t)0, (const uint64_t*)nullptr, 1.0f);
   } else if (vec) {
     hipLaunchKernelGGL((bn_bwd_reduce_kernel<4, false>), dim3(grid_reduce(R * (F / 4))), dim3(256), sh, st, src, R, k, F,
                        mean, rstd, beta, relu, dmax, lddmax, dmean, lddmean, mx_in, ldmx, cnt_in, red, shift_of(F / 4));
@@ -810,10 +819,10 @@ int launch_bwd_apply(const char* what, Src src, int64_t R, int k, int F, const f
     hipLaunchKernelGGL((bn_bwd_apply_kernel<4, true>), dim3(grid8(grid_for(R * (F / 4)))), dim3(256), 0, st, src, R, k, F,
                        mean, rstd, beta, relu, dmax, lddmax, dmean, lddmean, mx_in, ldmx, cnt_in, red, dY, dYsum, lddysum,
                        shift_of(F / 4));
-  } else if (vec && k == 1 && !dmean) {
+  } else if (vec && k == 1 && !mx_in) {
     const K1Grid g = k1_grid(R, F, 4096);
     hipLaunchKernelGGL((bn1_bwd_kernel<true>), g.grid, dim3(256), 0, st, src.Y, R, F, g.FVB, g.RP, mean, rstd, beta, relu,
-                       dmax, lddmax, red, dY, dYsum, lddysum, (const uint64_t*)nullptr, 1.0f);
+                       dmax, lddmax, dmean, lddmean, red, dY, dYsum, lddysum, (const uint64_t*)nullptr, 1.0f);
   } else if (vec) {
     hipLaunchKernelGGL((bn_bwd_apply_kernel<4, false>), dim3(grid_for(R * (F / 4))), dim3(256), 0, st, src, R, k, F, mean,
                        rstd, beta, relu, dmax, lddmax, dmean, lddmean, mx_in, ldmx, cnt_in, red, dY, dYsum, lddysum,
@@ -958,11 +967,11 @@ extern "C" int dgcnn_bn1_bwd_dropout_f32(const float* T, int64_t R, int F, const
   const K1Grid gr = k1_grid(R, F, 256);
   const size_t sh1 = sizeof(float) * 2 * (size_t)(F < 1024 ? F : 1024);
   hipLaunchKernelGGL((bn1_bwd_kernel<false>), gr.grid, dim3(256), sh1, st, T, R, F, gr.FVB, gr.RP, mean, rstd, beta, relu, dout, lddo,
-                     red, (float*)nullptr, (float*)nullptr, (int64_t)0, seed_dev, keep);
+                     (const float*)nullptr, (int64_t)0, red, (float*)nullptr, (float*)nullptr, (int64_t)0, seed_dev, keep);
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)dg::cdiv(F, 128)), dim3(128), 0, st, red, F, dbeta, dbeta_beta);
   const K1Grid ga = k1_grid(R, F, 4096);
-  hipLaunchKernelGGL((bn1_bwd_kernel<true>), ga.grid, dim3(256), 0, st, T, R, F, ga.FVB, ga.RP, mean, rstd, beta, relu, dout, lddo, red,
-                     dT, (float*)nullptr, (int64_t)0, seed_dev, keep);
+  hipLaunchKernelGGL((bn1_bwd_kernel<true>), ga.grid, dim3(256), 0, st, T, R, F, ga.FVB, ga.RP, mean, rstd, beta, relu, dout, lddo,
+                     (const float*)nullptr, (int64_t)0, red, dT, (float*)nullptr, (int64_t)0, seed_dev, keep);
   return dg::check_launch("dgcnn_bn1_bwd_dropout_f32");
 }
 

@@ -41,6 +41,7 @@ WGRAD_AFTER_DGRAD = os.environ.get("DGCNN_WGRAD_AFTER_DGRAD", "1") != "0"   # si
 WEIGHT_PREP_AHEAD = os.environ.get("DGCNN_WPREP", "1") != "0"   # parameter-only kernels of the step go first, on the side stream
 EDGE_BWD_FUSED_L0 = os.environ.get("DGCNN_EDGE_BWD_FUSED_L0", "1") != "0"   # input layer (C <= 4, no input gradient): one backward pass
 FUSE_DROPOUT = os.environ.get("DGCNN_FUSE_DROPOUT", "1") != "0"   # tf.nn.dropout inside the last FC layer's BatchNorm passes
+BN1_BWD_TWO_SOURCES = os.environ.get("DGCNN_BN1_BWD_TWO_SOURCES", "1") != "0"   # conv1's backward reads both output gradients (no add pass)
 COLMAX_IN_EPILOGUE = os.environ.get("DGCNN_COLMAX_EPILOGUE", "1") != "0"   # the global max-pool comes out of MergedEdgeConv's GEMM epilogue
 EDGE_BWD_REDUCE_POINTS = True   # BN backward sums of conv0 from per-point data (False: a pass over the edges)
 SIDE_STREAM_MIN_ROWS = 16384   # below this many points the side stream is not used
@@ -542,10 +543,11 @@ def conv_bn_act(x, leaf_scope, num_outputs, relu=True, out=None, out2=None, gbia
             dout = c.grad(out)
             if dout is None:
                 return
-            if out2 is not None:
-                d2 = c.grad(out2)
-                if d2 is not None:      # the second copy's gradient joins the first
-                    H.call("dgcnn_copy2d_f32", d2.data_ptr(), H.ld2(d2), dout.data_ptr(), H.ld2(dout), R, F, 1)
+            d2 = c.grad(out2) if out2 is not None else None
+            if d2 is not None and (fuse_drop or use_pl or DETERMINISTIC or F % 4 != 0 or not BN1_BWD_TWO_SOURCES):
+                # the second copy's gradient joins the first (the default passes below read both instead)
+                H.call("dgcnn_copy2d_f32", d2.data_ptr(), H.ld2(d2), dout.data_ptr(), H.ld2(dout), R, F, 1)
+                d2 = None
             red = c.stats(F)
             dWx = c.var_grads[wname] if w_rows is None else c.var_grads[wname][w_rows[0]:w_rows[1]]
             dgb = c.grad(gbias) if gbias is not None else None
@@ -602,11 +604,12 @@ def conv_bn_act(x, leaf_scope, num_outputs, relu=True, out=None, out2=None, gbia
                         H.call("dgcnn_group_colsum_f32", dT32.data_ptr(), F, gbias.shape[0], rpg, F, tmp.data_ptr())
                     H.call("dgcnn_axpby_f32", tmp.data_ptr(), 1.0, dgb.data_ptr(), 1.0, tmp.numel())
                 return
-            bn_bwd_reduce(T, R, 1, F, mean, rstd, beta, relu, dout, None, None, None, red,
-                          tag="bn_bwd_reduce_kernel<k=1>", work=4.0 * R * F * 2)
+            nsrc = 1 if d2 is None else 2                                  # k = 1: dz = dout + d2 (the kernels' dmax + dmean / k)
+            bn_bwd_reduce(T, R, 1, F, mean, rstd, beta, relu, dout, d2, None, None, red,
+                          tag="bn_bwd_reduce_kernel<k=1>", work=4.0 * R * F * (1 + nsrc))
             H.call("dgcnn_bn_bwd_apply_f32", T.data_ptr(), R, 1, F, mean.data_ptr(), rstd.data_ptr(), beta.data_ptr(),
-                   int(relu), dout.data_ptr(), H.ld2(dout), 0, 0, 0, 0, 0, red.data_ptr(), T.data_ptr(), 0, 0,
-                   c.var_grads[bname].data_ptr(), 1.0, tag="bn_bwd_apply_kernel<k=1>", work=4.0 * R * F * 3)
+                   int(relu), dout.data_ptr(), H.ld2(dout), H._p(d2), 0 if d2 is None else H.ld2(d2), 0, 0, 0, red.data_ptr(),
+                   T.data_ptr(), 0, 0, c.var_grads[bname].data_ptr(), 1.0, tag="bn_bwd_apply_kernel<k=1>", work=4.0 * R * F * (2 + nsrc))
             dT = T
             dx, bx = c.grad_w(x)
             if WGRAD_AFTER_DGRAD and dx is not None:
