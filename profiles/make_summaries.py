@@ -32,7 +32,7 @@ def tag_of(name):
     if m:
         kinds = {0: "KCONTIG", 1: "KSTRIDED"}
         return "gemm_x3w2_kernel<%s,%s,bf16x%s>" % (kinds[int(m.group(1))], kinds[int(m.group(2))], m.group(3))
-    m = re.match(r"gemm_x3_kernel<(\d), (\d), (\d+), (\d+)>", n)
+    m = re.match(r"gemm_x3_kernel<(\d), (\d), (\d+), (\d+)(?:, \d+)?>", n)
     if m:
         kinds = {0: "KCONTIG", 1: "KSTRIDED"}
         return "gemm_x3_kernel<%s,%s,%s,bf16x%s>" % (kinds[int(m.group(1))], kinds[int(m.group(2))], m.group(3), m.group(4))
@@ -55,7 +55,7 @@ def per_launch(path, counter):
 
 def main():
     src, tag = sys.argv[1], sys.argv[2]
-    one = lambda pat: glob.glob(os.path.join(src, pat))[0]
+    one = lambda pat: max(glob.glob(os.path.join(src, pat)), key=os.path.getmtime)   # gpurun MERGES runs into the directory: newest
     steps = 10.0   # collect.sh: --steps 8 --warmup 2
     with open(os.path.join(HERE, "%s_kernel_trace.txt" % tag), "w") as f:
         f.write("# rocprofv3 --kernel-trace --stats -- python bench.py --steps 8 --warmup 2 --no-cpu-baseline --graph 0 (1x MI355X); per step = per\n"
