@@ -798,6 +798,14 @@ extern "C" int dgcnn_gemm_f32(int transA, int transB, int M, int N, int K,
   DG_REQUIRE(!colmax_keys || (colmax_rows_per_group > 0 && colmax_rows_per_group % 256 == 0 && !transA && N > 4), DGCNN_EUNSUP,
              "dgcnn_gemm_f32: the column-maximum epilogue needs rows_per_group %% 256 == 0 (a tile inside one group), no transA, N > 4");
   p.colmax = reinterpret_cast<unsigned long long*>(colmax_keys); p.colmax_rpg = colmax_rows_per_group;
+  {
+    static int nt = -1;
+    // A/B switch, default off: alone the head GEMMs gain 2-4 % (FC0 dgrad 509 -> 493 us, Merged fwd fetch 76 -> 45 MB), in the step
+    // nothing (4.716 vs 4.725 ms over five alternating pairs): the consumer of C then misses where it used to hit
+    // (profiles/r03/nt_store.txt).  1: outputs of >= 4 M elements, 2: always
+    if (nt < 0) { const char* e = getenv("DGCNN_GEMM_NT_STORE"); nt = e ? atoi(e) : 0; }
+    p.nt_store = (nt == 2 || (nt == 1 && (int64_t)M * N >= (int64_t)(4 << 20))) ? 1 : 0;
+  }
   p.gbvec = gbias && (ldgbias % 4 == 0) && aligned16(gbias);
   p.avec = (lda % 4 == 0) && aligned16(A);
   p.bvec = (ldb % 4 == 0) && aligned16(B);

@@ -41,7 +41,17 @@ struct GemmP {
   // that produces the tensor): keys[group][N] <- atomicMax(order-preserving bits of the value << 32 | ~row-in-group), i.e. the
   // largest value and, among ties, the FIRST row.  Needs rows_per_group % tile rows == 0 (checked by the host).
   unsigned long long* colmax; int colmax_rpg;
+  // 1: the output tile is stored with nontemporal (streaming) stores.  A GEMM with many column tiles per row panel (FC0's data
+  // gradient: 14) writes hundreds of MB through the XCD's 4 MB L2 while its workgroups re-read the shared A panel and B tiles from
+  // it: the write stream evicted them (FC0 dgrad fetched 452 MB for 104 MB of operands, profiles/r03_pmc_hbm_bytes.txt)
+  int nt_store;
 };
+
+__device__ __forceinline__ void st4_nt(float* p, float a, float b, float c, float d) {
+  typedef float f4v __attribute__((ext_vector_type(4)));
+  f4v v = {a, b, c, d};
+  __builtin_nontemporal_store(v, reinterpret_cast<f4v*>(p));
+}
 
 // order-preserving map float -> uint32 (larger float <=> larger unsigned), and back
 __device__ __forceinline__ unsigned f32_ordered(float v) {
@@ -192,7 +202,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[TM][
           }
         }
         if (vec_st) {
-          *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+          if (p.nt_store) st4_nt(dst, v[0], v[1], v[2], v[3]);
+          else *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
 #pragma unroll
           for (int q = 0; q < 4; ++q) { cs[q] += v[q]; cq[q] += v[q] * v[q]; }
         } else {
