@@ -676,3 +676,5 @@ extern "C" int dgcnn_gemm_set_arith(int mode) {
 }
 
 extern "C" int dgcnn_gemm_get_arith(void) { return dg::gemm_arith(); }
+
+extern "C" int dgcnn_gemm_x3_tile_rows(int M, int N, int K) { return dg::x3_tile_m(M, N, K); }

@@ -430,7 +430,7 @@ def gemm(A, Bm, C, transA=False, transB=False, beta=0.0, gbias=None, rpg=0, stat
         bn = 64 if (N <= 64 or small) else 128
         if vec and arith:
             kinds = ("KSTRIDED" if transA else "KCONTIG", "KCONTIG" if transB else "KSTRIDED")
-            if M > 128 and N > 64 and cd(M, 256) * cd(N, 128) * cd(K, 256) >= 256:   # dg::x3_tile_m: 256 x 128 wave-specialised kernel
+            if H.load().dgcnn_gemm_x3_tile_rows(M, N, K) == 256:     # dg::x3_tile_m: the 256 x 128 wave-specialised kernel
                 tag = "gemm_x3w2_kernel<%s,%s,bf16x%d>" % (kinds + (arith,))
             else:
                 tag = "gemm_x3_kernel<%s,%s,%d,bf16x%d>" % (kinds + (bn, arith))
