@@ -325,6 +325,27 @@ __global__ void global_max_bwd_kernel(const float* __restrict__ dout, const int3
   }
 }
 
+// the same scatter, plus its share of the BatchNorm-backward sums that dgcnn_gemm_bn_bwd_f32 took BEFORE this gradient arrived:
+// the sums are linear in dz, so the (b, f) entries add  m dg  and  m dg xhat  (m = relu mask at the arg-max row) to slot 0
+__global__ void global_max_bwd_bn_kernel(const float* __restrict__ dout, const int32_t* __restrict__ arg, int N, int F,
+                                         int64_t total, float* __restrict__ dx, int64_t lddx, const float* __restrict__ T,
+                                         int64_t ldT, const float* __restrict__ mean, const float* __restrict__ rstd,
+                                         const float* __restrict__ beta, int relu, double* __restrict__ red) {
+  GRID_STRIDE(i, total) {
+    const int64_t b = i / F;
+    const int f = (int)(i % F);
+    const int64_t row = b * N + arg[i];
+    const float g = dout[i];
+    dx[row * lddx + f] += g;
+    const float xh = (T[row * ldT + f] - mean[f]) * rstd[f];
+    float z = xh + beta[f];
+    if (relu) z = fmaxf(z, 0.f);
+    const float dz = (relu && !(z > 0.f)) ? 0.f : g;
+    atomicAdd(red + f, (double)dz);
+    atomicAdd(red + F + f, (double)(dz * xh));
+  }
+}
+
 __global__ __launch_bounds__(64 * RG) void group_colsum_kernel(const float* __restrict__ x, int64_t ldx, int rows,
                                                                int F, float* __restrict__ out) {
   __shared__ float sv[RG][64];
@@ -560,6 +581,17 @@ extern "C" int dgcnn_global_max_bwd_f32(const float* dout, const int32_t* arg, i
   const int64_t total = (int64_t)B * F;
   hipLaunchKernelGGL(global_max_bwd_kernel, dim3(grid1d(total)), dim3(256), 0, ST, dout, arg, N, F, total, dx, lddx);
   return dg::check_launch("dgcnn_global_max_bwd_f32");
+}
+
+extern "C" int dgcnn_global_max_bwd_bn_f32(const float* dout, const int32_t* arg, int B, int N, int F, float* dx, int64_t lddx,
+                                           const float* T, int64_t ldT, const float* mean, const float* rstd, const float* beta,
+                                           int relu, double* red, void* stream) {
+  DG_REQUIRE(dout && arg && dx && T && mean && rstd && beta && red && B > 0 && N > 0 && F > 0, DGCNN_EINVAL,
+             "dgcnn_global_max_bwd_bn_f32: bad args");
+  const int64_t total = (int64_t)B * F;
+  hipLaunchKernelGGL(global_max_bwd_bn_kernel, dim3(grid1d(total)), dim3(256), 0, ST, dout, arg, N, F, total, dx, lddx, T, ldT, mean,
+                     rstd, beta, relu, red);
+  return dg::check_launch("dgcnn_global_max_bwd_bn_f32");
 }
 
 extern "C" int dgcnn_group_colsum_f32(const float* x, int64_t ldx, int G, int rows_per_group, int F, float* out,

@@ -41,6 +41,7 @@ WGRAD_AFTER_DGRAD = os.environ.get("DGCNN_WGRAD_AFTER_DGRAD", "1") != "0"   # si
 WEIGHT_PREP_AHEAD = os.environ.get("DGCNN_WPREP", "1") != "0"   # parameter-only kernels of the step go first, on the side stream
 EDGE_BWD_FUSED_L0 = os.environ.get("DGCNN_EDGE_BWD_FUSED_L0", "1") != "0"   # input layer (C <= 4, no input gradient): one backward pass
 FUSE_DROPOUT = os.environ.get("DGCNN_FUSE_DROPOUT", "1") != "0"   # tf.nn.dropout inside the last FC layer's BatchNorm passes
+BN_BWD_IN_DGRAD = os.environ.get("DGCNN_BN_BWD_IN_DGRAD", "1") != "0"   # BatchNorm-backward sums of a layer from the dgrad GEMM above it
 BN1_BWD_TWO_SOURCES = os.environ.get("DGCNN_BN1_BWD_TWO_SOURCES", "1") != "0"   # conv1's backward reads both output gradients (no add pass)
 COLMAX_IN_EPILOGUE = os.environ.get("DGCNN_COLMAX_EPILOGUE", "1") != "0"   # the global max-pool comes out of MergedEdgeConv's GEMM epilogue
 EDGE_BWD_REDUCE_POINTS = True   # BN backward sums of conv0 from per-point data (False: a pass over the edges)
@@ -93,6 +94,7 @@ class Context(object):
         self.capturing = False           # inside a HIP-graph capture: no host-side per-step state may be baked in
         self.debug = False
         self.planes = {}                 # (data_ptr, rows, cols) of an fp32 2-D view -> PlaneSet holding it as GEMM operand planes (this step)
+        self.bn_hooks = {}               # data_ptr of a BatchNorm layer's output view -> BnBwdHook (this step)
         self.pl_scales = None            # device float[2]: power-of-two scales of the step's activation / weight plane sets (fp16 planes)
         self.pl_scales_ready = False
         self.pl_ws = None
@@ -205,6 +207,7 @@ class Context(object):
         self.tape = []
         self.roots = []
         self.planes = {}
+        self.bn_hooks = {}
         self.pl_scales_ready = False
         self.wprep = {}
         self.wprep_event = None
@@ -403,6 +406,25 @@ def _tile_m(M, N):
     return 128
 
 
+def _gemm_tag(M, N, K, transA, transB, A, Bm):
+    """Kernel identity of a dgcnn_gemm_f32 launch for bench.py's table (mirrors the C dispatch); None when nobody is timing."""
+    if H.TIMER is None:
+        return None
+    lda, ldb = H.ld2(A), H.ld2(Bm)
+    vec = (lda % 4 == 0 and ldb % 4 == 0 and A.data_ptr() % 16 == 0 and Bm.data_ptr() % 16 == 0 and
+           ((M if transA else K) % 4 == 0) and ((K if transB else N) % 4 == 0))
+    arith = H.gemm_arith()
+    cd = lambda a, b: -(-a // b)
+    small = cd(M, 128) * cd(N, 128) * cd(K, 256) < 256       # gemm.hip:tile_n
+    bn = 64 if (N <= 64 or small) else 128
+    if vec and arith:
+        kinds = ("KSTRIDED" if transA else "KCONTIG", "KCONTIG" if transB else "KSTRIDED")
+        if H.load().dgcnn_gemm_x3_tile_rows(M, N, K) == 256:     # dg::x3_tile_m: the 256 x 128 wave-specialised kernel
+            return "gemm_x3w2_kernel<%s,%s,bf16x%d>" % (kinds + (arith,))
+        return "gemm_x3_kernel<%s,%s,%d,bf16x%d>" % (kinds + (bn, arith))
+    return "gemm_kernel<%s,%s,STORE,%d,%d>" % ("A_COL" if transA else "A_ROW", "B_COL" if transB else "B_ROW", _tile_m(M, N), bn)
+
+
 def gemm(A, Bm, C, transA=False, transB=False, beta=0.0, gbias=None, rpg=0, stats=None, arith=None, colmax=None, colmax_rpg=0):
     """C (+)= op(A) op(B); shapes are those of the stored matrices.  arith: arithmetic of THIS product (None = the
     process-wide setting; 1 = plain bf16 operands: measurements only, not fp32 class)."""
@@ -419,24 +441,7 @@ def gemm(A, Bm, C, transA=False, transB=False, beta=0.0, gbias=None, rpg=0, stat
     Kb = Bm.shape[1] if transB else Bm.shape[0]
     assert K == Kb and tuple(C.shape) == (M, N), (A.shape, Bm.shape, C.shape, transA, transB)
     ws = ctx().workspace()
-    tag = None
-    if H.TIMER is not None:                  # kernel identity for bench.py's table (mirrors the C dispatch)
-        lda, ldb = H.ld2(A), H.ld2(Bm)
-        vec = (lda % 4 == 0 and ldb % 4 == 0 and A.data_ptr() % 16 == 0 and Bm.data_ptr() % 16 == 0 and
-               ((M if transA else K) % 4 == 0) and ((K if transB else N) % 4 == 0))
-        arith = H.gemm_arith()
-        cd = lambda a, b: -(-a // b)
-        small = cd(M, 128) * cd(N, 128) * cd(K, 256) < 256       # gemm.hip:tile_n
-        bn = 64 if (N <= 64 or small) else 128
-        if vec and arith:
-            kinds = ("KSTRIDED" if transA else "KCONTIG", "KCONTIG" if transB else "KSTRIDED")
-            if H.load().dgcnn_gemm_x3_tile_rows(M, N, K) == 256:     # dg::x3_tile_m: the 256 x 128 wave-specialised kernel
-                tag = "gemm_x3w2_kernel<%s,%s,bf16x%d>" % (kinds + (arith,))
-            else:
-                tag = "gemm_x3_kernel<%s,%s,%d,bf16x%d>" % (kinds + (bn, arith))
-        else:
-            tag = "gemm_kernel<%s,%s,STORE,%d,%d>" % ("A_COL" if transA else "A_ROW", "B_COL" if transB else "B_ROW",
-                                                      _tile_m(M, N), bn)
+    tag = _gemm_tag(M, N, K, transA, transB, A, Bm)
     H.call("dgcnn_gemm_f32", int(transA), int(transB), M, N, K, A.data_ptr(), H.ld2(A), Bm.data_ptr(), H.ld2(Bm),
            C.data_ptr(), H.ld2(C), float(beta), H._p(gbias), 0 if gbias is None else H.ld2(gbias), int(rpg),
            H._p(stats), H._p(colmax), int(colmax_rpg), ws.data_ptr(), ws.numel(), tag=tag, work=2.0 * M * N * K)
@@ -461,6 +466,57 @@ def bn_bwd_reduce(Y, R, k, F, mean, rstd, beta, relu, dmx, dmn, mx, cnt, red, ta
                H._p(cnt), red.data_ptr(), tag=tag, work=work)
 
 
+class BnBwdHook(object):
+    """A BatchNorm layer offers the two sums of its backward (sum dz, sum dz*xhat) to whoever produces d(its output): the data-
+    gradient GEMM of the layer ABOVE takes them in its epilogue (dgcnn_gemm_bn_bwd_f32) while the tile of dz is still in registers,
+    and the layer's own pass over (dz, T) is dropped.  served: `red` holds the sums (slots), not finalised."""
+    __slots__ = ("out", "T", "mean", "rstd", "beta", "relu", "F", "red", "served")
+
+    def __init__(self, out, T, mean, rstd, beta, relu):
+        self.out, self.T, self.mean, self.rstd, self.beta, self.relu = out, T, mean, rstd, beta, bool(relu)
+        self.F = out.shape[1]
+        self.red = None
+        self.served = False
+
+
+def bn_hook_inside(x):
+    """The widest unserved hook whose output view is a column range of the 2-D view x (same rows, same leading dimension):
+    (hook, first column) or (None, 0)."""
+    c = ctx()
+    best, best_c0 = None, 0
+    px, ld = x.data_ptr(), H.ld2(x)
+    for h in c.bn_hooks.values():
+        if h.served or h.out.shape[0] != x.shape[0] or H.ld2(h.out) != ld:
+            continue
+        off = (h.out.data_ptr() - px) // 4
+        if off < 0 or off >= x.shape[1] or off + h.F > x.shape[1]:
+            continue
+        if best is None or h.F > best.F:
+            best, best_c0 = h, int(off)
+    return best, best_c0
+
+
+def dgrad_gemm(dT, W, x, dx, beta, arith=None):
+    """dx (+)= dT W^T for the layer input x; when a BatchNorm layer's output is a column range of x and offered a hook, the GEMM's
+    epilogue also reduces that layer's backward sums (BN_BWD_IN_DGRAD)."""
+    h, c0 = (None, 0)
+    if BN_BWD_IN_DGRAD and not DETERMINISTIC and arith is None and H.gemm_arith() != 0:
+        h, c0 = bn_hook_inside(x)
+    if h is not None:
+        M, K = dT.shape
+        N = W.shape[0]
+        al = lambda t: t.data_ptr() % 16 == 0 and H.ld2(t) % 4 == 0
+        if (c0 % 4 == 0 and h.F % 4 == 0 and N % 4 == 0 and K % 4 == 0 and N > 4 and K > 4 and al(dT) and al(W) and al(dx) and
+                al(h.T) and tuple(dx.shape) == (M, N) and W.shape[1] == K):
+            h.red = ctx().stats(h.F)
+            H.call("dgcnn_gemm_bn_bwd_f32", M, N, K, dT.data_ptr(), H.ld2(dT), W.data_ptr(), H.ld2(W), dx.data_ptr(), H.ld2(dx),
+                   float(beta), h.T.data_ptr(), H.ld2(h.T), h.mean.data_ptr(), h.rstd.data_ptr(), h.beta.data_ptr(), int(h.relu),
+                   c0, h.F, h.red.data_ptr(), tag=_gemm_tag(M, N, K, False, True, dT, W), work=2.0 * M * N * K)
+            h.served = True
+            return
+    gemm(dT, W, dx, transB=True, beta=beta, arith=arith)
+
+
 def bn_finalize(stats, F, count):
     dev = stats.device
     mr = torch.empty((2, F), dtype=torch.float32, device=dev)
@@ -473,7 +529,7 @@ def bn_finalize(stats, F, count):
 # dgcnn/ops.py:62-70,125-133,153-160 ; dgcnn/model.py:46-53,65-72,94-101
 # ----------------------------------------------------------------------------------------------
 def conv_bn_act(x, leaf_scope, num_outputs, relu=True, out=None, out2=None, gbias=None, rpg=0, w_rows=None, arith=None,
-                plane_out=None, f32_out=True, gmax=None, drop_keep=None):
+                plane_out=None, f32_out=True, gmax=None, drop_keep=None, offer_bwd_sums=False):
     """x: (R,Cin) view.  Variables `<scope>/weights` [Cin(+extra), Cout], `<scope>/BatchNorm/beta`.
     w_rows: (lo, hi) row range of the weight that multiplies x (FC0 with the folded global feature).
     Returns the (R,Cout) output (a fresh tracked buffer unless `out` is given).
@@ -481,6 +537,9 @@ def conv_bn_act(x, leaf_scope, num_outputs, relu=True, out=None, out2=None, gbia
     activated output as operand planes of the NEXT product (f32_out = False: the fp32 `out` is then never written -- it only
     names the tensor and carries its gradient); gmax = (B, N): also return the per-cloud max over the points of the output
     (model.py:76-77), taken on the GEMM output and normalised afterwards (BN + ReLU are monotone).
+    offer_bwd_sums: the caller guarantees that d(out) is COMPLETE once the data-gradient GEMM of the one layer that consumes `out`
+    has run (apart from the gmax gradient, which adds its own share): that GEMM then takes this layer's BatchNorm-backward sums in
+    its epilogue (BnBwdHook) and the pass over (d(out), T) is skipped.
     drop_keep: tf.nn.dropout(out, drop_keep) behind the layer (model.py:90-91), fused into the BatchNorm passes where the
     kernels allow it (the returned tensor is the DROPPED output either way)."""
     c = ctx()
@@ -538,6 +597,12 @@ def conv_bn_act(x, leaf_scope, num_outputs, relu=True, out=None, out2=None, gbia
                int(relu), out.data_ptr(), H.ld2(out), 0, 0, H._p(out2), 0 if out2 is None else H.ld2(out2), 0,
                tag="bn_act_kreduce_kernel<k=1>", work=4.0 * R * F * (2 if out2 is None else 3))
 
+    hook = None
+    if (offer_bwd_sums and c.recording and BN_BWD_IN_DGRAD and not use_pl and not DETERMINISTIC and not fuse_drop and out2 is None and
+            F % 4 == 0 and drop_keep is None):
+        # whoever computes d(out) with a data-gradient GEMM may take this layer's backward sums along (dgrad_gemm)
+        hook = c.bn_hooks[out.data_ptr()] = BnBwdHook(out, T, mean, rstd, beta, relu)
+
     if c.recording:
         def bwd():
             dout = c.grad(out)
@@ -559,11 +624,11 @@ def conv_bn_act(x, leaf_scope, num_outputs, relu=True, out=None, out2=None, gbia
                 dT = T
                 dx, bx = c.grad_w(x)
                 if WGRAD_AFTER_DGRAD and dx is not None:
-                    gemm(dT, Wx, dx, transB=True, beta=bx, arith=arith)
+                    dgrad_gemm(dT, Wx, x, dx, bx, arith)
                 with c.off_critical_path(rows=R):
                     gemm(x, dT, dWx, transA=True, beta=1.0, arith=arith)
                 if not WGRAD_AFTER_DGRAD and dx is not None:
-                    gemm(dT, Wx, dx, transB=True, beta=bx, arith=arith)
+                    dgrad_gemm(dT, Wx, x, dx, bx, arith)
                 if dgb is not None:
                     tmp = torch.empty_like(gbias)
                     H.call("dgcnn_group_colsum_f32", dT.data_ptr(), H.ld2(dT), gbias.shape[0], rpg, F, tmp.data_ptr())
@@ -605,19 +670,22 @@ def conv_bn_act(x, leaf_scope, num_outputs, relu=True, out=None, out2=None, gbia
                     H.call("dgcnn_axpby_f32", tmp.data_ptr(), 1.0, dgb.data_ptr(), 1.0, tmp.numel())
                 return
             nsrc = 1 if d2 is None else 2                                  # k = 1: dz = dout + d2 (the kernels' dmax + dmean / k)
-            bn_bwd_reduce(T, R, 1, F, mean, rstd, beta, relu, dout, d2, None, None, red,
-                          tag="bn_bwd_reduce_kernel<k=1>", work=4.0 * R * F * (1 + nsrc))
+            if hook is not None and hook.served:
+                red = hook.red                                             # taken by the GEMM that wrote dout (dgrad_gemm)
+            else:
+                bn_bwd_reduce(T, R, 1, F, mean, rstd, beta, relu, dout, d2, None, None, red,
+                              tag="bn_bwd_reduce_kernel<k=1>", work=4.0 * R * F * (1 + nsrc))
             H.call("dgcnn_bn_bwd_apply_f32", T.data_ptr(), R, 1, F, mean.data_ptr(), rstd.data_ptr(), beta.data_ptr(),
                    int(relu), dout.data_ptr(), H.ld2(dout), H._p(d2), 0 if d2 is None else H.ld2(d2), 0, 0, 0, red.data_ptr(),
                    T.data_ptr(), 0, 0, c.var_grads[bname].data_ptr(), 1.0, tag="bn_bwd_apply_kernel<k=1>", work=4.0 * R * F * (2 + nsrc))
             dT = T
             dx, bx = c.grad_w(x)
             if WGRAD_AFTER_DGRAD and dx is not None:
-                gemm(dT, Wx, dx, transB=True, beta=bx, arith=arith)    # dx (+)= dT W^T
+                dgrad_gemm(dT, Wx, x, dx, bx, arith)                   # dx (+)= dT W^T (+ the BatchNorm-backward sums of the layer below)
             with c.off_critical_path(rows=R):
                 gemm(x, dT, dWx, transA=True, beta=1.0, arith=arith)   # dW += x^T dT
             if not WGRAD_AFTER_DGRAD and dx is not None:
-                gemm(dT, Wx, dx, transB=True, beta=bx, arith=arith)    # dx (+)= dT W^T
+                dgrad_gemm(dT, Wx, x, dx, bx, arith)
             if dgb is not None:                                         # tf.tile^T: sum over the cloud
                 tmp = torch.empty_like(gbias)
                 H.call("dgcnn_group_colsum_f32", dT.data_ptr(), H.ld2(dT), gbias.shape[0], rpg, F, tmp.data_ptr())
@@ -644,7 +712,11 @@ def conv_bn_act(x, leaf_scope, num_outputs, relu=True, out=None, out2=None, gbia
             dg_, dout = c.grad(g), c.grad(out)
             if dg_ is None or dout is None:
                 return
-            H.call("dgcnn_global_max_bwd_f32", dg_.data_ptr(), arg.data_ptr(), Bc, Nc, F, dout.data_ptr(), H.ld2(dout))
+            if hook is not None and hook.served:      # the sums of this layer's BatchNorm backward were taken before dg arrives: add its share
+                H.call("dgcnn_global_max_bwd_bn_f32", dg_.data_ptr(), arg.data_ptr(), Bc, Nc, F, dout.data_ptr(), H.ld2(dout),
+                       T.data_ptr(), H.ld2(T), mean.data_ptr(), rstd.data_ptr(), beta.data_ptr(), int(relu), hook.red.data_ptr())
+            else:
+                H.call("dgcnn_global_max_bwd_f32", dg_.data_ptr(), arg.data_ptr(), Bc, Nc, F, dout.data_ptr(), H.ld2(dout))
         c.tape.append(bwd_g)
     return out, g
 
