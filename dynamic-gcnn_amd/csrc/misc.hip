@@ -196,9 +196,12 @@ __global__ __launch_bounds__(256) void csr_gather_sum_kernel(const float* __rest
 // holds at any moment are few.
 __global__ __launch_bounds__(256) void edge_gather_add_kernel(const float* __restrict__ V, int64_t ldv,
                                                               const float* __restrict__ U, int64_t ldu,
-                                                              const int32_t* __restrict__ idx, unsigned rows,
+                                                              const int32_t* __restrict__ idx, unsigned pts,
                                                               unsigned npts, unsigned knn, int F,
                                                               float* __restrict__ Y, double* __restrict__ stats) {
+  // Point-major (round 3): a group of F/4 lanes owns a point, keeps its U quad in registers and walks the point's k neighbour
+  // rows four at a time.  (The edge-major version spent ~60 VALU operations per gathered float4 on two integer divisions and
+  // the per-edge U reload: it was issue-bound at 18 % of the L1/L2 gather bandwidth.)
   __shared__ float red[2 * 1024];
   const int FV = F >> 2;
   const unsigned RP = 256u / (unsigned)FV;
@@ -207,33 +210,34 @@ __global__ __launch_bounds__(256) void edge_gather_add_kernel(const float* __res
   const unsigned r = (unsigned)t / (unsigned)FV;
   const int f = (t % FV) * 4;
   const unsigned xcd = blockIdx.x & 7, l = blockIdx.x >> 3, nl = gridDim.x >> 3;
-  const unsigned per = (rows + 7) / 8;
+  const unsigned per = (pts + 7) / 8;
   const unsigned xbeg = xcd * per;
-  const unsigned xend = (xbeg + per < rows) ? (xbeg + per) : rows;
+  const unsigned xend = (xbeg + per < pts) ? (xbeg + per) : pts;
   float cs[4] = {0.f, 0.f, 0.f, 0.f}, cq[4] = {0.f, 0.f, 0.f, 0.f};
   if (active) {
     const unsigned step = nl * RP;
-    for (unsigned e0 = xbeg + l * RP + r; e0 < xend; e0 += 4 * step) {
-      float4 v[4], u[4];
-      bool ok[4];
+    for (unsigned i = xbeg + l * RP + r; i < xend; i += step) {
+      const unsigned b = i / npts;
+      const float* vb = V + (int64_t)b * npts * ldv + f;
+      const int32_t* ip = idx + (int64_t)i * knn;
+      const float4 u = *reinterpret_cast<const float4*>(U + (int64_t)i * ldu + f);
+      float* yp = Y ? (Y + (int64_t)i * knn * F + f) : nullptr;
+      for (unsigned m = 0; m < knn; m += 4) {
+        int row[4];
+        float4 v[4];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const unsigned e = e0 + q * step;
-        ok[q] = e < xend;
-        const unsigned ec = ok[q] ? e : e0;
-        const unsigned i = ec / knn;
-        const unsigned b = i / npts;
-        v[q] = *reinterpret_cast<const float4*>(V + ((int64_t)b * npts + idx[ec]) * ldv + f);
-        u[q] = *reinterpret_cast<const float4*>(U + (int64_t)i * ldu + f);
+        for (int q = 0; q < 4; ++q) row[q] = ip[(m + q < knn) ? (m + q) : (knn - 1)];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = *reinterpret_cast<const float4*>(vb + (int64_t)row[q] * ldv);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (m + q < knn) {
+            const float4 y = make_float4(v[q].x + u.x, v[q].y + u.y, v[q].z + u.z, v[q].w + u.w);
+            if (yp) *reinterpret_cast<float4*>(yp + (int64_t)(m + q) * F) = y;
+            cs[0] += y.x; cs[1] += y.y; cs[2] += y.z; cs[3] += y.w;
+            cq[0] += y.x * y.x; cq[1] += y.y * y.y; cq[2] += y.z * y.z; cq[3] += y.w * y.w;
+          }
       }
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-        if (ok[q]) {
-          const float4 y = make_float4(v[q].x + u[q].x, v[q].y + u[q].y, v[q].z + u[q].z, v[q].w + u[q].w);
-          if (Y) *reinterpret_cast<float4*>(Y + (int64_t)(e0 + q * step) * F + f) = y;
-          cs[0] += y.x; cs[1] += y.y; cs[2] += y.z; cs[3] += y.w;
-          cq[0] += y.x * y.x; cq[1] += y.y * y.y; cq[2] += y.z * y.z; cq[3] += y.w * y.w;
-        }
     }
   }
   if (!stats) return;
@@ -546,11 +550,13 @@ extern "C" int dgcnn_edge_gather_add_f32(const float* V, int64_t ldv, const floa
   auto a16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
   DG_REQUIRE(a16(V) && a16(U) && (!Y || a16(Y)) && ldv % 4 == 0 && ldu % 4 == 0 && ldv >= F && ldu >= F, DGCNN_EINVAL,
              "dgcnn_edge_gather_add_f32: V, U, Y must be 16-byte aligned with leading dimensions %% 4 == 0");
-  const unsigned rp = 256u / (unsigned)(F / 4);
-  int64_t g = dg::cdiv(dg::cdiv(rows, 8), (int64_t)rp * 4);      // blocks per XCD so that each thread makes >= 1 trip
-  if (g > 256) g = 256;                                          // 2048 blocks = 8 per CU
+  const unsigned rp = 256u / (unsigned)(F / 4);                   // points per block pass
+  const int64_t pts = (int64_t)B * N;
+  const int64_t passes_x = dg::cdiv(dg::cdiv(pts, 8), (int64_t)rp);      // block passes one XCD's eighth of the points needs
+  const int64_t trips = dg::cdiv(passes_x, 256);                         // <= 256 blocks per XCD (8 per CU), every block the same trips
+  int64_t g = dg::cdiv(passes_x, trips);
   if (g < 1) g = 1;
-  hipLaunchKernelGGL(edge_gather_add_kernel, dim3((unsigned)g * 8), dim3(256), 0, ST, V, ldv, U, ldu, idx, (unsigned)rows,
+  hipLaunchKernelGGL(edge_gather_add_kernel, dim3((unsigned)g * 8), dim3(256), 0, ST, V, ldv, U, ldu, idx, (unsigned)pts,
                      (unsigned)N, (unsigned)k, F, Y, stats);
   return dg::check_launch("dgcnn_edge_gather_add_f32");
 }
