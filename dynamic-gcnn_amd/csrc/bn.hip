@@ -7,17 +7,36 @@
 
 namespace {
 
-constexpr int SLOTS = DGCNN_STAT_SLOTS;
-
-__global__ void bn_finalize_kernel(const double* __restrict__ stats, int F, double count, float eps,
-                                   float* __restrict__ mean, float* __restrict__ rstd) {
-  const int f = blockIdx.x * blockDim.x + threadIdx.x;
-  if (f >= F) return;
-  double s = 0.0, q = 0.0;
-  for (int sl = 0; sl < SLOTS; ++sl) {
-    s += stats[((int64_t)sl * 2 + 0) * F + f];
-    q += stats[((int64_t)sl * 2 + 1) * F + f];
+// Slot reduction shared by the two finalize kernels: 8 columns x 32 slot lanes per workgroup; lane z adds slots z, z + 32, ...
+// (ascending), the 32 partial sums of a column are then added in lane order by its first lane: one fixed order for a given
+// slot count, whatever wrote the slots.
+constexpr int FIN_COLS = 8, FIN_LANES = 32;
+__device__ __forceinline__ bool slot_sums(const double* __restrict__ acc, int F, int nslots, int& f, double& s, double& q) {
+  __shared__ double part[2][FIN_COLS][FIN_LANES];
+  const int c = threadIdx.x / FIN_LANES, z = threadIdx.x % FIN_LANES;
+  f = blockIdx.x * FIN_COLS + c;
+  double a = 0.0, b = 0.0;
+  if (f < F) {
+    for (int sl = z; sl < nslots; sl += FIN_LANES) {
+      a += acc[((int64_t)sl * 2 + 0) * F + f];
+      b += acc[((int64_t)sl * 2 + 1) * F + f];
+    }
   }
+  part[0][c][z] = a;
+  part[1][c][z] = b;
+  __syncthreads();
+  if (z != 0 || f >= F) return false;
+  s = 0.0; q = 0.0;
+  for (int l = 0; l < FIN_LANES; ++l) { s += part[0][c][l]; q += part[1][c][l]; }
+  return true;
+}
+
+__global__ __launch_bounds__(FIN_COLS * FIN_LANES) void bn_finalize_kernel(const double* __restrict__ stats, int F, int nslots,
+                                                                           double count, float eps, float* __restrict__ mean,
+                                                                           float* __restrict__ rstd) {
+  int f;
+  double s, q;
+  if (!slot_sums(stats, F, nslots, f, s, q)) return;
   const double mu = s / count;
   double var = q / count - mu * mu;   // biased variance, in double: no fp32 cancellation
   if (var < 0.0) var = 0.0;
@@ -26,15 +45,11 @@ __global__ void bn_finalize_kernel(const double* __restrict__ stats, int F, doub
 }
 
 // reduce the slots of a backward reduction in place into slot 0, and emit dbeta
-__global__ void bn_bwd_finalize_kernel(double* __restrict__ red, int F, float* __restrict__ dbeta,
-                                       float dbeta_beta) {
-  const int f = blockIdx.x * blockDim.x + threadIdx.x;
-  if (f >= F) return;
-  double s = 0.0, q = 0.0;
-  for (int sl = 0; sl < SLOTS; ++sl) {
-    s += red[((int64_t)sl * 2 + 0) * F + f];
-    q += red[((int64_t)sl * 2 + 1) * F + f];
-  }
+__global__ __launch_bounds__(FIN_COLS * FIN_LANES) void bn_bwd_finalize_kernel(double* __restrict__ red, int F, int nslots,
+                                                                               float* __restrict__ dbeta, float dbeta_beta) {
+  int f;
+  double s, q;
+  if (!slot_sums(red, F, nslots, f, s, q)) return;
   red[f] = s;
   red[F + f] = q;
   if (dbeta) dbeta[f] = (dbeta_beta != 0.f) ? (float)s + dbeta_beta * dbeta[f] : (float)s;
@@ -249,7 +264,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
     const float* __restrict__ rstd, const float* __restrict__ beta, int relu,
     const float* __restrict__ dmax, int64_t lddmax, const float* __restrict__ dmean, int64_t lddmean,
     const float* __restrict__ mx_in, int64_t ldmx, const float* __restrict__ cnt_in, double* __restrict__ red,
-    int fv_shift) {
+    int fv_shift, int nslots) {
   extern __shared__ float lred[];  // [2][F]
   for (int e = threadIdx.x; e < 2 * F; e += blockDim.x) lred[e] = 0.f;
   __syncthreads();
@@ -316,7 +331,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
     for (int v = 0; v < V; ++v) { atomicAdd(&lred[curf + v], s0[v]); atomicAdd(&lred[F + curf + v], s1[v]); }
   }
   __syncthreads();
-  const int slot = blockIdx.x % SLOTS;
+  const int slot = blockIdx.x % nslots;
   for (int e = threadIdx.x; e < 2 * F; e += blockDim.x)
     atomicAdd(red + (int64_t)slot * 2 * F + e, (double)lred[e]);
 }
@@ -509,6 +524,35 @@ __device__ __forceinline__ K1Map k1_map(int F, int FVB, int RP) {   // RP = bloc
   return m;
 }
 
+// Column sums of a K1-mapped workgroup in a FIXED order: every (row group rp, column quad) thread parks its two partial quads in
+// lpark[rp][2][4 FVB] (2048 floats), then one thread per (sum, column) adds the RP row groups in ascending order and hands the
+// result to slot (blockIdx.x % nslots) -- no LDS float atomics, whose order changed from run to run.
+constexpr int K1_PARK_FLOATS = 2048;
+__device__ __forceinline__ void k1_block_sums(float* lpark, const K1Map& m, int F, int FVB, int RP, const float (&s0)[4],
+                                              const float (&s1)[4], double* __restrict__ red, int nslots) {
+  const int t = threadIdx.x;
+  const int W = 4 * FVB;
+  if (t < RP * FVB) {
+    const int rp = t / FVB, cb = (t % FVB) * 4;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      lpark[(rp * 2 + 0) * W + cb + v] = m.on ? s0[v] : 0.f;
+      lpark[(rp * 2 + 1) * W + cb + v] = m.on ? s1[v] : 0.f;
+    }
+  }
+  __syncthreads();
+  const int fbase = blockIdx.y * 1024;
+  const int slot = blockIdx.x % nslots;
+  for (int e = t; e < 2 * W; e += blockDim.x) {
+    const int which = e / W, cb = e % W;
+    if (fbase + cb < F) {
+      float a = 0.f;
+      for (int rp = 0; rp < RP; ++rp) a += lpark[(rp * 2 + which) * W + cb];
+      atomicAdd(red + ((int64_t)slot * 2 + which) * F + fbase + cb, (double)a);
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void bn1_act_kernel(const float* __restrict__ T, int64_t R, int F, int FVB, int RP,
                                                       const float* __restrict__ mean, const float* __restrict__ rstd,
                                                       const float* __restrict__ beta, int relu,
@@ -559,18 +603,13 @@ __global__ __launch_bounds__(256) void bn1_bwd_kernel(const float* T, int64_t R,
                                                       const float* __restrict__ dout, int64_t lddo,
                                                       const float* __restrict__ dout2, int64_t lddo2,
                                                       double* __restrict__ red, float* dT, float* __restrict__ dsum,
-                                                      int64_t lddsum, const uint64_t* __restrict__ drop_seed, float drop_keep) {
-  extern __shared__ float lred[];   // reduce only: [2][min(F,1024)]
+                                                      int64_t lddsum, const uint64_t* __restrict__ drop_seed, float drop_keep,
+                                                      int nslots) {
+  extern __shared__ float lred[];   // reduce only: K1_PARK_FLOATS
   const uint64_t dseed = drop_seed ? *drop_seed : 0ull;      // dout is the gradient of the DROPPED output (fused dropout backward)
   const uint32_t dthr = dropout_threshold(drop_keep);
   const float dscale = drop_seed ? 1.0f / drop_keep : 1.0f;
   const K1Map m = k1_map(F, FVB, RP);
-  const int fbase = blockIdx.y * 1024;
-  const int fw = (F - fbase < 1024) ? (F - fbase) : 1024;
-  if (!APPLY) {
-    for (int e = threadIdx.x; e < 2 * fw; e += blockDim.x) lred[e] = 0.f;
-    __syncthreads();
-  }
   float mu[4] = {0, 0, 0, 0}, rs[4] = {0, 0, 0, 0}, be[4] = {0, 0, 0, 0}, c1[4] = {0, 0, 0, 0}, c2[4] = {0, 0, 0, 0};
   float s0[4] = {0, 0, 0, 0}, s1[4] = {0, 0, 0, 0};
   if (m.on) {
@@ -621,18 +660,7 @@ __global__ __launch_bounds__(256) void bn1_bwd_kernel(const float* T, int64_t R,
       }
     }
   }
-  if (!APPLY) {
-    if (m.on) {
-#pragma unroll
-      for (int v = 0; v < 4; ++v) { atomicAdd(&lred[m.f - fbase + v], s0[v]); atomicAdd(&lred[fw + m.f - fbase + v], s1[v]); }
-    }
-    __syncthreads();
-    const int slot = blockIdx.x % SLOTS;
-    for (int e = threadIdx.x; e < 2 * fw; e += blockDim.x) {
-      const int which = e / fw, c = fbase + (e % fw);
-      atomicAdd(red + ((int64_t)slot * 2 + which) * F + c, (double)lred[e]);
-    }
-  }
+  if (!APPLY) k1_block_sums(lred, m, F, FVB, RP, s0, s1, red, nslots);
 }
 
 // Backward BN reduction of an EdgeConv conv0 WITHOUT touching the edges.  With relu and dz_e = [z_e = max_i]
@@ -645,15 +673,12 @@ __global__ __launch_bounds__(256) void edge_bwd_reduce_points_kernel(
     const float* __restrict__ mx, int64_t ldmx, const float* __restrict__ mn, int64_t ldmn,
     const float* __restrict__ cntpos, const float* __restrict__ dmax, int64_t lddmax,
     const float* __restrict__ dmean, int64_t lddmean, const float* __restrict__ beta, int64_t R, int k, int F,
-    int FVB, int RP, double* __restrict__ red) {
-  extern __shared__ float lred[];
+    int FVB, int RP, double* __restrict__ red, int nslots) {
+  extern __shared__ float lred[];          // K1_PARK_FLOATS
   const K1Map m = k1_map(F, FVB, RP);
-  const int fbase = blockIdx.y * 1024;
-  const int fw = (F - fbase < 1024) ? (F - fbase) : 1024;
-  for (int e = threadIdx.x; e < 2 * fw; e += 256) lred[e] = 0.f;
-  __syncthreads();
+  float s0[4] = {0, 0, 0, 0}, s1[4] = {0, 0, 0, 0};
   if (m.on) {
-    float be[4], s0[4] = {0, 0, 0, 0}, s1[4] = {0, 0, 0, 0};
+    float be[4];
     Vec<4>::ld(beta + m.f, be);
     const float invk = 1.0f / (float)k, kf = (float)k;
     for (int64_t r = m.r0; r < R; r += m.rstep) {
@@ -669,15 +694,8 @@ __global__ __launch_bounds__(256) void edge_bwd_reduce_points_kernel(
         s1[v] += g1 * (a[v] - be[v]) + g2 * (kf * b[v] - be[v] * npos);
       }
     }
-#pragma unroll
-    for (int v = 0; v < 4; ++v) { atomicAdd(&lred[m.f - fbase + v], s0[v]); atomicAdd(&lred[fw + m.f - fbase + v], s1[v]); }
   }
-  __syncthreads();
-  const int slot = blockIdx.x % SLOTS;
-  for (int e = threadIdx.x; e < 2 * fw; e += 256) {
-    const int which = e / fw, c = fbase + (e % fw);
-    atomicAdd(red + ((int64_t)slot * 2 + which) * F + c, (double)lred[e]);
-  }
+  k1_block_sums(lred, m, F, FVB, RP, s0, s1, red, nslots);
 }
 
 struct K1Grid { dim3 grid; int FVB, RP; };
@@ -781,22 +799,23 @@ int launch_bwd_reduce(const char* what, Src src, int64_t R, int k, int F, const 
   if (G) {
     DG_REQUIRE(vec, DGCNN_EINVAL, "%s: operands must be 16-byte aligned with leading dimensions %% 4 == 0", what);
     hipLaunchKernelGGL((bn_bwd_reduce_kernel<4, true>), dim3(grid8(grid_reduce(R * (F / 4)))), dim3(256), sh, st, src, R, k,
-                       F, mean, rstd, beta, relu, dmax, lddmax, dmean, lddmean, mx_in, ldmx, cnt_in, red, shift_of(F / 4));
+                       F, mean, rstd, beta, relu, dmax, lddmax, dmean, lddmean, mx_in, ldmx, cnt_in, red, shift_of(F / 4), dg::stat_slots());
   } else if (vec && k == 1 && !mx_in) {          // k = 1: dz = dmax + dmean / 1 -- `dmean` is the gradient of a second copy of the output
     static int mb = -1;
     if (mb < 0) { const char* e = getenv("DGCNN_BN1_RED_BLOCKS"); mb = e ? atoi(e) : 256; }   // experiments
     // the kernel ends with 2F double atomics per workgroup, which dominate above ~1 workgroup per CU
     // (F = 256: 19 us at 256 workgroups, 32 us at 2048; 1024-thread workgroups are slower: profiles/bn1_bench.py)
     const K1Grid g = k1_grid(R, F, mb);
-    const size_t sh1 = sizeof(float) * 2 * (size_t)(F < 1024 ? F : 1024);
+    const size_t sh1 = sizeof(float) * K1_PARK_FLOATS;
     hipLaunchKernelGGL((bn1_bwd_kernel<false>), g.grid, dim3(256), sh1, st, src.Y, R, F, g.FVB, g.RP, mean, rstd, beta, relu,
-                       dmax, lddmax, dmean, lddmean, red, (float*)nullptr, (float*)nullptr, (int64_t)0, (const uint64_t*)nullptr, 1.0f);
+                       dmax, lddmax, dmean, lddmean, red, (float*)nullptr, (float*)nullptr, (int64_t)0, (const uint64_t*)nullptr, 1.0f,
+                       dg::stat_slots());
   } else if (vec) {
     hipLaunchKernelGGL((bn_bwd_reduce_kernel<4, false>), dim3(grid_reduce(R * (F / 4))), dim3(256), sh, st, src, R, k, F,
-                       mean, rstd, beta, relu, dmax, lddmax, dmean, lddmean, mx_in, ldmx, cnt_in, red, shift_of(F / 4));
+                       mean, rstd, beta, relu, dmax, lddmax, dmean, lddmean, mx_in, ldmx, cnt_in, red, shift_of(F / 4), dg::stat_slots());
   } else {
     hipLaunchKernelGGL((bn_bwd_reduce_kernel<1, false>), dim3(grid_reduce(R * F)), dim3(256), sh, st, src, R, k, F, mean,
-                       rstd, beta, relu, dmax, lddmax, dmean, lddmean, mx_in, ldmx, cnt_in, red, shift_of(F));
+                       rstd, beta, relu, dmax, lddmax, dmean, lddmean, mx_in, ldmx, cnt_in, red, shift_of(F), dg::stat_slots());
   }
   return dg::check_launch(what);
 }
@@ -808,7 +827,7 @@ int launch_bwd_apply(const char* what, Src src, int64_t R, int k, int F, const f
                      float* dYsum, int64_t lddysum, float* dbeta, float dbeta_beta, hipStream_t st) {
   DG_REQUIRE(mean && rstd && beta && dmax && red && dY, DGCNN_EINVAL, "%s: null pointer", what);
   DG_REQUIRE(!dYsum || lddysum >= F, DGCNN_EINVAL, "%s: lddysum < F", what);
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)dg::cdiv(F, 128)), dim3(128), 0, st, red, F, dbeta,
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)dg::cdiv(F, FIN_COLS)), dim3(FIN_COLS * FIN_LANES), 0, st, red, F, dg::stat_slots(), dbeta,
                      dbeta_beta);
   const bool vec = (F % 4 == 0) && (lddmax % 4 == 0) && (G || a16(src.Y)) && a16(dY) && a16(dmax) && a16(mean) &&
                    a16(rstd) && a16(beta) && (!dmean || ((lddmean % 4 == 0) && a16(dmean))) &&
@@ -822,7 +841,7 @@ int launch_bwd_apply(const char* what, Src src, int64_t R, int k, int F, const f
   } else if (vec && k == 1 && !mx_in) {
     const K1Grid g = k1_grid(R, F, 4096);
     hipLaunchKernelGGL((bn1_bwd_kernel<true>), g.grid, dim3(256), 0, st, src.Y, R, F, g.FVB, g.RP, mean, rstd, beta, relu,
-                       dmax, lddmax, dmean, lddmean, red, dY, dYsum, lddysum, (const uint64_t*)nullptr, 1.0f);
+                       dmax, lddmax, dmean, lddmean, red, dY, dYsum, lddysum, (const uint64_t*)nullptr, 1.0f, dg::stat_slots());
   } else if (vec) {
     hipLaunchKernelGGL((bn_bwd_apply_kernel<4, false>), dim3(grid_for(R * (F / 4))), dim3(256), 0, st, src, R, k, F, mean,
                        rstd, beta, relu, dmax, lddmax, dmean, lddmean, mx_in, ldmx, cnt_in, red, dY, dYsum, lddysum,
@@ -839,8 +858,8 @@ int launch_bwd_apply(const char* what, Src src, int64_t R, int k, int F, const f
 extern "C" int dgcnn_bn_finalize_f32(const double* stats, int F, double count, float eps,
                                      float* mean, float* rstd, void* stream) {
   DG_REQUIRE(stats && mean && rstd && F > 0 && count > 0, DGCNN_EINVAL, "dgcnn_bn_finalize_f32: bad args");
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)dg::cdiv(F, 128)), dim3(128), 0, (hipStream_t)stream,
-                     stats, F, count, eps, mean, rstd);
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)dg::cdiv(F, FIN_COLS)), dim3(FIN_COLS * FIN_LANES), 0, (hipStream_t)stream,
+                     stats, F, dg::stat_slots(), count, eps, mean, rstd);
   return dg::check_launch("dgcnn_bn_finalize_f32");
 }
 
@@ -915,9 +934,9 @@ extern "C" int dgcnn_edge_bn_bwd_reduce_points_f32(const float* mx, int64_t ldmx
                  lddmax % 4 == 0 && lddmean % 4 == 0, DGCNN_EINVAL,
              "dgcnn_edge_bn_bwd_reduce_points_f32: operands must be 16-byte aligned with leading dimensions %% 4 == 0");
   const K1Grid g = k1_grid(R, F, 256);
-  const size_t sh = sizeof(float) * 2 * (size_t)(F < 1024 ? F : 1024);
+  const size_t sh = sizeof(float) * K1_PARK_FLOATS;
   hipLaunchKernelGGL(edge_bwd_reduce_points_kernel, g.grid, dim3(256), sh, (hipStream_t)stream, mx, ldmx, mn, ldmn, cntpos,
-                     dmax, lddmax, dmean, lddmean, beta, R, k, F, g.FVB, g.RP, red);
+                     dmax, lddmax, dmean, lddmean, beta, R, k, F, g.FVB, g.RP, red, dg::stat_slots());
   return dg::check_launch("dgcnn_edge_bn_bwd_reduce_points_f32");
 }
 
@@ -965,13 +984,13 @@ extern "C" int dgcnn_bn1_bwd_dropout_f32(const float* T, int64_t R, int F, const
   DG_REQUIRE(dout && red && dT && lddo % 4 == 0 && a16(dout) && a16(dT) && F <= 8192, DGCNN_EINVAL, "dgcnn_bn1_bwd_dropout_f32: bad args");
   hipStream_t st = (hipStream_t)stream;
   const K1Grid gr = k1_grid(R, F, 256);
-  const size_t sh1 = sizeof(float) * 2 * (size_t)(F < 1024 ? F : 1024);
+  const size_t sh1 = sizeof(float) * K1_PARK_FLOATS;
   hipLaunchKernelGGL((bn1_bwd_kernel<false>), gr.grid, dim3(256), sh1, st, T, R, F, gr.FVB, gr.RP, mean, rstd, beta, relu, dout, lddo,
-                     (const float*)nullptr, (int64_t)0, red, (float*)nullptr, (float*)nullptr, (int64_t)0, seed_dev, keep);
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)dg::cdiv(F, 128)), dim3(128), 0, st, red, F, dbeta, dbeta_beta);
+                     (const float*)nullptr, (int64_t)0, red, (float*)nullptr, (float*)nullptr, (int64_t)0, seed_dev, keep, dg::stat_slots());
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)dg::cdiv(F, FIN_COLS)), dim3(FIN_COLS * FIN_LANES), 0, st, red, F, dg::stat_slots(), dbeta, dbeta_beta);
   const K1Grid ga = k1_grid(R, F, 4096);
   hipLaunchKernelGGL((bn1_bwd_kernel<true>), ga.grid, dim3(256), 0, st, T, R, F, ga.FVB, ga.RP, mean, rstd, beta, relu, dout, lddo,
-                     (const float*)nullptr, (int64_t)0, red, dT, (float*)nullptr, (int64_t)0, seed_dev, keep);
+                     (const float*)nullptr, (int64_t)0, red, dT, (float*)nullptr, (int64_t)0, seed_dev, keep, dg::stat_slots());
   return dg::check_launch("dgcnn_bn1_bwd_dropout_f32");
 }
 
@@ -997,7 +1016,7 @@ extern "C" int dgcnn_edge_bn_bwd_apply_wgrad_f32(const float* V, int64_t ldv, co
              "dgcnn_edge_bn_bwd_apply_wgrad_f32: F / 4 must be a power of two <= 256, operands 16-byte aligned");
   hipStream_t st = (hipStream_t)stream;
   const int64_t R = (int64_t)B * N;
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)dg::cdiv(F, 128)), dim3(128), 0, st, red, F, dbeta, dbeta_beta);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)dg::cdiv(F, FIN_COLS)), dim3(FIN_COLS * FIN_LANES), 0, st, red, F, dg::stat_slots(), dbeta, dbeta_beta);
   const unsigned grid = grid8(grid_reduce(R * FV));                 // <= 1024 blocks: one partial tile each
   const size_t need = (size_t)grid * 2 * C * F * sizeof(float);
   DG_REQUIRE(ws_bytes >= need, DGCNN_ENOSPC, "dgcnn_edge_bn_bwd_apply_wgrad_f32: workspace too small (%zu < %zu)", ws_bytes, need);

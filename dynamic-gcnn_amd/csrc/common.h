@@ -29,6 +29,16 @@ inline int check_launch(const char* what) {
 
 static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// Accumulation slots of every `stats` / `red` buffer (double[slots][2][F]): a producer workgroup adds its partial sums to slot
+// (writer index % slots).  Default DGCNN_STAT_SLOTS; dgcnn_set_stat_slots(n) with n >= the number of writers gives every slot a
+// single writer -- the sums then do not depend on the order in which workgroups finish (bit-reproducible runs), api.cc.
+int stat_slots();
+// a grid of `g` writers, capped so that every slot keeps a single writer when the reproducible configuration is on
+static inline int64_t cap_writers(int64_t g) {
+  const int64_t n = stat_slots();
+  return (n > DGCNN_STAT_SLOTS && g > n) ? n : g;
+}
+
 // gemm_x3.hip: arithmetic of the plain GEMMs (0 native fp32 MFMA, 6 / 9 = partial products of the exact
 // three-way bf16 split on the bf16 matrix pipe) and its launcher (pv = GemmP*, tiles already planned)
 int gemm_arith();

@@ -419,11 +419,11 @@ __global__ __launch_bounds__(64 * RL) void reduce_partials_kernel(const float* _
 template <int N>
 __global__ __launch_bounds__(256) void skinny_nn_kernel(const float* __restrict__ A, int64_t lda,
                                                         const float* __restrict__ B, int64_t ldb, float* __restrict__ C,
-                                                        int64_t ldc, int M, int K, float beta, double* __restrict__ stats) {
-  extern __shared__ float bs[];                  // [K][N] then [2][N] for the statistics
+                                                        int64_t ldc, int M, int K, float beta, double* __restrict__ stats,
+                                                        int nslots) {
+  extern __shared__ float bs[];                  // [K][N] then [4 waves][2][N] for the statistics
   float* red = bs + (size_t)K * N;
   for (int e = threadIdx.x; e < K * N; e += 256) bs[e] = B[(int64_t)(e / N) * ldb + (e % N)];
-  if (threadIdx.x < 2 * N) red[threadIdx.x] = 0.f;
   __syncthreads();
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int nw = gridDim.x * 4;
@@ -456,14 +456,15 @@ __global__ __launch_bounds__(256) void skinny_nn_kernel(const float* __restrict_
     }
   }
   if (stats) {
-    if (lane == 0) {
+    if (lane == 0) {                             // the four waves' partial sums, added below in wave order (fixed)
 #pragma unroll
-      for (int n = 0; n < N; ++n) { atomicAdd(&red[n], cs[n]); atomicAdd(&red[N + n], cq[n]); }
+      for (int n = 0; n < N; ++n) { red[wv * 2 * N + n] = cs[n]; red[wv * 2 * N + N + n] = cq[n]; }
     }
     __syncthreads();
     if (threadIdx.x < 2 * N) {
       const int which = threadIdx.x / N, n = threadIdx.x % N;
-      atomicAdd(stats + ((int64_t)(blockIdx.x % DGCNN_STAT_SLOTS) * 2 + which) * N + n, (double)red[threadIdx.x]);
+      const float a = ((red[threadIdx.x] + red[2 * N + threadIdx.x]) + red[4 * N + threadIdx.x]) + red[6 * N + threadIdx.x];
+      atomicAdd(stats + ((int64_t)(blockIdx.x % nslots) * 2 + which) * N + n, (double)a);
     }
   }
 }
@@ -790,6 +791,7 @@ extern "C" int dgcnn_gemm_f32(int transA, int transB, int M, int N, int K,
   DG_REQUIRE(!(transA && transB), DGCNN_EUNSUP, "dgcnn_gemm_f32: transA && transB unsupported");
   DG_REQUIRE(!gbias || rows_per_group > 0, DGCNN_EINVAL, "dgcnn_gemm_f32: rows_per_group");
   GemmP p = {};
+  p.stat_slots = dg::stat_slots();
   p.A = A; p.lda = lda; p.B = B; p.ldb = ldb; p.C = C; p.ldc = ldc;
   p.M = M; p.N = N; p.K = K; p.beta = beta;
   p.gbias = gbias; p.ldgbias = ldgbias; p.rpg = rows_per_group > 0 ? rows_per_group : 1;
@@ -812,9 +814,9 @@ extern "C" int dgcnn_gemm_f32(int transA, int transB, int M, int N, int K,
   hipStream_t st = (hipStream_t)stream;
   // ---- skinny shapes (class dimension): streaming kernels instead of 95 %-padded MFMA tiles
   if (!gbias && !transA && !transB && N <= 4 && K % 4 == 0 && K <= 4096 && p.avec) {
-    const size_t sh = sizeof(float) * ((size_t)K * N + 2 * N);
-    const unsigned g = (unsigned)(dg::cdiv(M, 4) < 2048 ? dg::cdiv(M, 4) : 2048);
-#define DG_SK_NN(NN) hipLaunchKernelGGL((skinny_nn_kernel<NN>), dim3(g), dim3(256), sh, st, A, lda, B, ldb, C, ldc, M, K, beta, stats)
+    const size_t sh = sizeof(float) * ((size_t)K * N + 8 * N);
+    const unsigned g = (unsigned)dg::cap_writers(dg::cdiv(M, 4) < 2048 ? dg::cdiv(M, 4) : 2048);
+#define DG_SK_NN(NN) hipLaunchKernelGGL((skinny_nn_kernel<NN>), dim3(g), dim3(256), sh, st, A, lda, B, ldb, C, ldc, M, K, beta, stats, dg::stat_slots())
     if (N == 1) DG_SK_NN(1); else if (N == 2) DG_SK_NN(2); else if (N == 3) DG_SK_NN(3); else DG_SK_NN(4);
 #undef DG_SK_NN
     return dg::check_launch("dgcnn_gemm_f32(NN skinny)");
@@ -866,6 +868,7 @@ extern "C" int dgcnn_gemm_bn_bwd_f32(int M, int N, int K, const float* A, int64_
   DG_REQUIRE(A && B && C && T && mean && rstd && bn_beta && red, DGCNN_EINVAL, "dgcnn_gemm_bn_bwd_f32: null pointer");
   DG_REQUIRE(M > 0 && N > 0 && K > 0 && F > 0 && c0 >= 0 && c0 + F <= N, DGCNN_EINVAL, "dgcnn_gemm_bn_bwd_f32: bad shape");
   GemmP p = {};
+  p.stat_slots = dg::stat_slots();
   p.A = A; p.lda = lda; p.B = B; p.ldb = ldb; p.C = C; p.ldc = ldc;
   p.M = M; p.N = N; p.K = K; p.beta = beta; p.rpg = 1;
   p.splits = 1; p.kchunk = K;
@@ -889,6 +892,7 @@ extern "C" int dgcnn_edge_mlp_f32(const float* x, int64_t ldx, const int32_t* id
   const int64_t Me = (int64_t)B * N * k;
   DG_REQUIRE(Me < (1ll << 31), DGCNN_EUNSUP, "dgcnn_edge_mlp_f32: B*N*k >= 2^31");
   GemmP p = {};
+  p.stat_slots = dg::stat_slots();
   p.x = x; p.ldx = ldx; p.idx = idx; p.npts = N; p.cch = C; p.knn = k;
   p.B = W0; p.ldb = F; p.C = Y; p.ldc = F;
   p.M = (int)Me; p.N = F; p.K = 2 * C; p.beta = 0.f; p.rpg = 1;
@@ -906,6 +910,7 @@ extern "C" int dgcnn_edge_mlp_wgrad_f32(const float* x, int64_t ldx, const int32
   const int64_t Me = (int64_t)B * N * k;
   DG_REQUIRE(Me < (1ll << 31), DGCNN_EUNSUP, "dgcnn_edge_mlp_wgrad_f32: B*N*k >= 2^31");
   GemmP p = {};
+  p.stat_slots = dg::stat_slots();
   p.x = x; p.ldx = ldx; p.idx = idx; p.npts = N; p.cch = C; p.knn = k;
   p.B = dY; p.ldb = F; p.C = dW0; p.ldc = F;
   p.M = 2 * C; p.N = F; p.K = (int)Me; p.beta = beta; p.rpg = 1;
@@ -938,6 +943,7 @@ extern "C" int dgcnn_edge_mlp_dgrad_scatter_f32(const float* dY, const float* W0
   const int64_t Me = (int64_t)B * N * k;
   DG_REQUIRE(Me < (1ll << 31), DGCNN_EUNSUP, "dgcnn_edge_mlp_dgrad_scatter_f32: B*N*k >= 2^31");
   GemmP p = {};
+  p.stat_slots = dg::stat_slots();
   // G[e][c] = sum_f dY[e][f] * W0[C + c][f]  (B stored [n][k] = rows C..2C of W0), scattered to dx[nbr(e)]
   p.A = dY; p.lda = F; p.B = W0 + (int64_t)C * F; p.ldb = F;
   p.M = (int)Me; p.N = C; p.K = F; p.rpg = 1;
@@ -961,6 +967,7 @@ extern "C" int dgcnn_edge_nbr_gemm_f32(const float* x, int64_t ldx, const int32_
   const int64_t Me = (int64_t)B * N * k;
   DG_REQUIRE(Me < (1ll << 31), DGCNN_EUNSUP, "dgcnn_edge_nbr_gemm_f32: B*N*k >= 2^31");
   GemmP p = {};
+  p.stat_slots = dg::stat_slots();
   p.x = x; p.ldx = ldx; p.idx = idx; p.npts = N; p.cch = C; p.knn = k; p.edge_nbr = 1;
   p.B = Wb; p.ldb = F; p.C = Y; p.ldc = F;
   p.M = (int)Me; p.N = F; p.K = C; p.beta = 0.f;
@@ -995,6 +1002,7 @@ extern "C" int dgcnn_edge_nbr_wgrad_f32(const float* x, int64_t ldx, const int32
     return dg::check_launch("dgcnn_edge_nbr_wgrad_f32(small C reduce)");
   }
   GemmP p = {};
+  p.stat_slots = dg::stat_slots();
   p.x = x; p.ldx = ldx; p.idx = idx; p.npts = N; p.cch = C; p.knn = k; p.edge_nbr = 1;
   p.B = dY; p.ldb = F; p.C = dWb; p.ldc = F;
   p.M = C; p.N = F; p.K = (int)Me; p.beta = beta; p.rpg = 1;

@@ -45,6 +45,7 @@ struct GemmP {
   // gradient: 14) writes hundreds of MB through the XCD's 4 MB L2 while its workgroups re-read the shared A panel and B tiles from
   // it: the write stream evicted them (FC0 dgrad fetched 452 MB for 104 MB of operands, profiles/r03_pmc_hbm_bytes.txt)
   int nt_store;
+  int stat_slots; // slots of p.stats / p.bnb_red (dg::stat_slots() at launch)
   // BatchNorm-backward sums of the layer BELOW, taken in the epilogue of the data-gradient GEMM that produces that layer's output
   // gradient (dgcnn_gemm_bn_bwd_f32): for output columns c in [bnb_c0, bnb_c0 + bnb_F), f = c - bnb_c0, the layer's pre-BN tensor
   // t = bnb_T[row][f]:  xhat = (t - mean) rstd, z = xhat + beta (relu'ed), dz = (relu && z <= 0) ? 0 : C[row][c];
@@ -281,12 +282,12 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[TM][
       }
       if (c < p.N) {
         if (p.stats) {
-          const int slot = mt % DGCNN_STAT_SLOTS;
+          const int slot = mt % p.stat_slots;
           atomicAdd(p.stats + ((int64_t)slot * 2 + 0) * p.N + c, (double)s0);
           atomicAdd(p.stats + ((int64_t)slot * 2 + 1) * p.N + c, (double)s1);
         }
         if (bnb && c >= p.bnb_c0 && c < p.bnb_c0 + p.bnb_F) {
-          const int slot = mt % DGCNN_STAT_SLOTS;
+          const int slot = mt % p.stat_slots;
           atomicAdd(p.bnb_red + ((int64_t)slot * 2 + 0) * p.bnb_F + (c - p.bnb_c0), (double)s0);
           atomicAdd(p.bnb_red + ((int64_t)slot * 2 + 1) * p.bnb_F + (c - p.bnb_c0), (double)s1);
         }

@@ -459,7 +459,7 @@ extern "C" int dgcnn_gemm_planes_f32(int form, int fmt, int M, int N, int K,
   DG_REQUIRE(!colmax_keys || (form == DGCNN_PL_KC && colmax_rows_per_group > 0 && colmax_rows_per_group % 256 == 0), DGCNN_EUNSUP,
              "dgcnn_gemm_planes_f32: the column-maximum epilogue needs the KC form and rows_per_group %% 256 == 0");
   p.colmax = reinterpret_cast<unsigned long long*>(colmax_keys); p.colmax_rpg = colmax_rows_per_group;
-  p.splits = 1; p.kchunk = K; p.bm = 256;
+  p.splits = 1; p.kchunk = K; p.bm = 256; p.stat_slots = dg::stat_slots();
   q.Ap = (const char*)A; q.a_ps = a_plane_stride; q.a_rows = a_rows_alloc;
   q.Bp = (const char*)B; q.b_ps = b_plane_stride; q.b_rows = b_rows_alloc;
   q.a_scale = a_scale_dev; q.b_scale = b_scale_dev;

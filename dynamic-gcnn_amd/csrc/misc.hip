@@ -198,7 +198,7 @@ __global__ __launch_bounds__(256) void edge_gather_add_kernel(const float* __res
                                                               const float* __restrict__ U, int64_t ldu,
                                                               const int32_t* __restrict__ idx, unsigned pts,
                                                               unsigned npts, unsigned knn, int F,
-                                                              float* __restrict__ Y, double* __restrict__ stats) {
+                                                              float* __restrict__ Y, double* __restrict__ stats, int nslots) {
   // Point-major (round 3): a group of F/4 lanes owns a point, keeps its U quad in registers and walks the point's k neighbour
   // rows four at a time.  (The edge-major version spent ~60 VALU operations per gathered float4 on two integer divisions and
   // the per-edge U reload: it was issue-bound at 18 % of the L1/L2 gather bandwidth.)
@@ -241,19 +241,23 @@ __global__ __launch_bounds__(256) void edge_gather_add_kernel(const float* __res
     }
   }
   if (!stats) return;
-  for (int e = t; e < 2 * F; e += 256) red[e] = 0.f;
-  __syncthreads();
+  // fixed order: the RP point groups park their partial quads ([r][2][F], RP * 2 * F = 2048 floats), one thread per (sum, column)
+  // adds them in ascending r (LDS float atomics added them in whatever order the waves arrived)
   if (active) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      atomicAdd(&red[f + q], cs[q]);
-      atomicAdd(&red[F + f + q], cq[q]);
+      red[(r * 2 + 0) * F + f + q] = cs[q];
+      red[(r * 2 + 1) * F + f + q] = cq[q];
     }
   }
   __syncthreads();
-  const int slot = blockIdx.x % DGCNN_STAT_SLOTS;
-  for (int e = t; e < 2 * F; e += 256)
-    atomicAdd(stats + ((int64_t)slot * 2 + e / F) * F + (e % F), (double)red[e]);
+  const int slot = blockIdx.x % nslots;
+  for (int e = t; e < 2 * F; e += 256) {
+    const int which = e / F, c = e % F;
+    float a = 0.f;
+    for (unsigned g = 0; g < RP; ++g) a += red[(g * 2 + which) * F + c];
+    atomicAdd(stats + ((int64_t)slot * 2 + which) * F + c, (double)a);
+  }
 }
 
 // Wcat = [Wa - Wb | Wb] (C x 2F) from W0 = [Wa ; Wb] (2C x F), and the matching gradient fold
@@ -331,23 +335,27 @@ __global__ void global_max_bwd_kernel(const float* __restrict__ dout, const int3
 
 // the same scatter, plus its share of the BatchNorm-backward sums that dgcnn_gemm_bn_bwd_f32 took BEFORE this gradient arrived:
 // the sums are linear in dz, so the (b, f) entries add  m dg  and  m dg xhat  (m = relu mask at the arg-max row) to slot 0
-__global__ void global_max_bwd_bn_kernel(const float* __restrict__ dout, const int32_t* __restrict__ arg, int N, int F,
-                                         int64_t total, float* __restrict__ dx, int64_t lddx, const float* __restrict__ T,
+__global__ void global_max_bwd_bn_kernel(const float* __restrict__ dout, const int32_t* __restrict__ arg, int B, int N, int F,
+                                         float* __restrict__ dx, int64_t lddx, const float* __restrict__ T,
                                          int64_t ldT, const float* __restrict__ mean, const float* __restrict__ rstd,
                                          const float* __restrict__ beta, int relu, double* __restrict__ red) {
-  GRID_STRIDE(i, total) {
-    const int64_t b = i / F;
-    const int f = (int)(i % F);
-    const int64_t row = b * N + arg[i];
-    const float g = dout[i];
+  const int f = blockIdx.x * blockDim.x + threadIdx.x;          // one thread per channel, clouds in ascending order: fixed order
+  if (f >= F) return;
+  const float mu = mean[f], rs = rstd[f], be = beta[f];
+  double s0 = 0.0, s1 = 0.0;
+  for (int b = 0; b < B; ++b) {
+    const int64_t row = (int64_t)b * N + arg[(int64_t)b * F + f];
+    const float g = dout[(int64_t)b * F + f];
     dx[row * lddx + f] += g;
-    const float xh = (T[row * ldT + f] - mean[f]) * rstd[f];
-    float z = xh + beta[f];
+    const float xh = (T[row * ldT + f] - mu) * rs;
+    float z = xh + be;
     if (relu) z = fmaxf(z, 0.f);
     const float dz = (relu && !(z > 0.f)) ? 0.f : g;
-    atomicAdd(red + f, (double)dz);
-    atomicAdd(red + F + f, (double)(dz * xh));
+    s0 += (double)dz;
+    s1 += (double)(dz * xh);
   }
+  atomicAdd(red + f, s0);              // slot 0 has one other writer at most (the GEMM's first row tile), and that kernel is complete
+  atomicAdd(red + F + f, s1);
 }
 
 __global__ __launch_bounds__(64 * RG) void group_colsum_kernel(const float* __restrict__ x, int64_t ldx, int rows,
@@ -555,9 +563,10 @@ extern "C" int dgcnn_edge_gather_add_f32(const float* V, int64_t ldv, const floa
   const int64_t passes_x = dg::cdiv(dg::cdiv(pts, 8), (int64_t)rp);      // block passes one XCD's eighth of the points needs
   const int64_t trips = dg::cdiv(passes_x, 256);                         // <= 256 blocks per XCD (8 per CU), every block the same trips
   int64_t g = dg::cdiv(passes_x, trips);
+  g = dg::cap_writers(g * 8) / 8;                                         // (reproducible configuration: one writer per slot)
   if (g < 1) g = 1;
   hipLaunchKernelGGL(edge_gather_add_kernel, dim3((unsigned)g * 8), dim3(256), 0, ST, V, ldv, U, ldu, idx, (unsigned)pts,
-                     (unsigned)N, (unsigned)k, F, Y, stats);
+                     (unsigned)N, (unsigned)k, F, Y, stats, dg::stat_slots());
   return dg::check_launch("dgcnn_edge_gather_add_f32");
 }
 
@@ -594,9 +603,8 @@ extern "C" int dgcnn_global_max_bwd_bn_f32(const float* dout, const int32_t* arg
                                            int relu, double* red, void* stream) {
   DG_REQUIRE(dout && arg && dx && T && mean && rstd && beta && red && B > 0 && N > 0 && F > 0, DGCNN_EINVAL,
              "dgcnn_global_max_bwd_bn_f32: bad args");
-  const int64_t total = (int64_t)B * F;
-  hipLaunchKernelGGL(global_max_bwd_bn_kernel, dim3(grid1d(total)), dim3(256), 0, ST, dout, arg, N, F, total, dx, lddx, T, ldT, mean,
-                     rstd, beta, relu, red);
+  hipLaunchKernelGGL(global_max_bwd_bn_kernel, dim3((unsigned)dg::cdiv(F, 64)), dim3(64), 0, ST, dout, arg, B, N, F, dx, lddx, T, ldT,
+                     mean, rstd, beta, relu, red);
   return dg::check_launch("dgcnn_global_max_bwd_bn_f32");
 }
 

@@ -146,14 +146,30 @@ class Context(object):
     def stats(self, F):
         """Zeroed double[SLOTS][2][F] carved from one arena that is memset once per step."""
         n = H.STAT_SLOTS * 2 * F
-        if self.stat_arena is None or self.stat_arena.device != self.device:
-            self.stat_arena = torch.zeros(1 << 20, dtype=torch.float64, device=self.device)
+        want = (1 << 20) if H.STAT_SLOTS <= 32 else (1 << 19) * (H.STAT_SLOTS // 32)   # 8 MB at 32 slots, 128 MB at 1024
+        if self.stat_arena is None or self.stat_arena.device != self.device or self.stat_arena.numel() < want:
+            self.stat_arena = torch.zeros(want, dtype=torch.float64, device=self.device)
             self.stat_off = 0
         if self.stat_off + n > self.stat_arena.numel():
             return torch.zeros(n, dtype=torch.float64, device=self.device)
         s = self.stat_arena[self.stat_off:self.stat_off + n]
         self.stat_off += n
         return s
+
+    def configure_slots(self, rows=0):
+        """DETERMINISTIC: every stats / red slot gets a single writer -- as many slots as the producer with the most workgroups has
+        (a GEMM over `rows` rows in 64-row tiles; the reduction kernels cap their grids at the slot count) -- so that no sum
+        depends on the order in which workgroups finish.  Default mode: DGCNN_STAT_SLOTS (32) slots, several writers each."""
+        if DETERMINISTIC:
+            need = max(256, -(-int(rows) // 64))
+            n = 256
+            while n < need:
+                n *= 2
+            n = max(n, H.STAT_SLOTS if H.STAT_SLOTS > 32 else 0)       # never shrink inside a run: buffers of this step exist already
+        else:
+            n = 32
+        if n != H.STAT_SLOTS:
+            H.set_stat_slots(n)
 
     # ---- operand planes of the head GEMMs (csrc/gemm_pl.hip, planes_bn.hip) ------------------------------
     @staticmethod
@@ -211,6 +227,10 @@ class Context(object):
         self.pl_scales_ready = False
         self.wprep = {}
         self.wprep_event = None
+        if not DETERMINISTIC and H.STAT_SLOTS != 32:
+            H.set_stat_slots(32)
+        elif DETERMINISTIC and H.STAT_SLOTS < 256:
+            self.configure_slots(0)
         if self.stat_arena is not None:
             if self.capturing:
                 self.stat_arena.zero_()          # a captured step cannot know what ran before it: whole arena (8 MB memset)
@@ -344,6 +364,8 @@ def reset():
     """Forget all variables / state (tf.reset_default_graph analogue)."""
     global _CTX
     _CTX = Context()
+    if H.STAT_SLOTS != 32 and not DETERMINISTIC:
+        H.set_stat_slots(32)
     return _CTX
 
 
@@ -454,8 +476,12 @@ def colstats_det(T, st):
 
 
 def bn_bwd_reduce(Y, R, k, F, mean, rstd, beta, relu, dmx, dmn, mx, cnt, red, tag, work):
-    """sum dZ / sum dZ*xhat of a materialised Y: the atomically accumulated kernel, or its fixed-order twin."""
-    if DETERMINISTIC:
+    """sum dZ / sum dZ*xhat of a materialised Y.  DETERMINISTIC: the column-fixed k = 1 kernel (float4 channels) reduces in a fixed
+    order by itself; every other shape (the class dimension, materialised edge tensors) takes the fixed-order twin of det.hip."""
+    k1 = (k == 1 and F % 4 == 0 and mx is None and Y.data_ptr() % 16 == 0 and dmx.data_ptr() % 16 == 0 and H.ld2(dmx) % 4 == 0 and
+          mean.data_ptr() % 16 == 0 and rstd.data_ptr() % 16 == 0 and beta.data_ptr() % 16 == 0 and
+          (dmn is None or (dmn.data_ptr() % 16 == 0 and H.ld2(dmn) % 4 == 0)))
+    if DETERMINISTIC and not k1:
         ws = ctx().workspace()
         H.call("dgcnn_bn_bwd_reduce_det_f32", Y.data_ptr(), R, k, F, mean.data_ptr(), rstd.data_ptr(), beta.data_ptr(), int(relu),
                dmx.data_ptr(), H.ld2(dmx), H._p(dmn), 0 if dmn is None else H.ld2(dmn), H._p(mx), 0 if mx is None else H.ld2(mx),
@@ -500,7 +526,7 @@ def dgrad_gemm(dT, W, x, dx, beta, arith=None):
     """dx (+)= dT W^T for the layer input x; when a BatchNorm layer's output is a column range of x and offered a hook, the GEMM's
     epilogue also reduces that layer's backward sums (BN_BWD_IN_DGRAD)."""
     h, c0 = (None, 0)
-    if BN_BWD_IN_DGRAD and not DETERMINISTIC and arith is None and H.gemm_arith() != 0:
+    if BN_BWD_IN_DGRAD and arith is None and H.gemm_arith() != 0:
         h, c0 = bn_hook_inside(x)
     if h is not None:
         M, K = dT.shape
@@ -571,14 +597,11 @@ def conv_bn_act(x, leaf_scope, num_outputs, relu=True, out=None, out2=None, gbia
         PL.gemm(PL.KC, xp, wt, T, gbias=gbias, rpg=rpg, stats=st, colmax=keys, colmax_rpg=0 if keys is None else gmax[1])
     else:
         plane_out, f32_out = None, True
-        gemm(x, Wx, T, gbias=gbias, rpg=rpg, stats=None if DETERMINISTIC else st, arith=arith,
-             colmax=keys, colmax_rpg=0 if keys is None else gmax[1])
-    if DETERMINISTIC:
-        colstats_det(T, st)
+        gemm(x, Wx, T, gbias=gbias, rpg=rpg, stats=st, arith=arith, colmax=keys, colmax_rpg=0 if keys is None else gmax[1])
     mean, rstd = bn_finalize(st, F, R)
     if out is None:
         out = c.new_buffer(R, F)
-    fuse_drop = (drop_keep is not None and FUSE_DROPOUT and not use_pl and not DETERMINISTIC and F % 4 == 0 and out2 is None and
+    fuse_drop = (drop_keep is not None and FUSE_DROPOUT and not use_pl and F % 4 == 0 and out2 is None and
                  gmax is None and plane_out is None)
     if fuse_drop:
         if c.seed_dev is None:
@@ -598,7 +621,7 @@ def conv_bn_act(x, leaf_scope, num_outputs, relu=True, out=None, out2=None, gbia
                tag="bn_act_kreduce_kernel<k=1>", work=4.0 * R * F * (2 if out2 is None else 3))
 
     hook = None
-    if (offer_bwd_sums and c.recording and BN_BWD_IN_DGRAD and not use_pl and not DETERMINISTIC and not fuse_drop and out2 is None and
+    if (offer_bwd_sums and c.recording and BN_BWD_IN_DGRAD and not use_pl and not fuse_drop and out2 is None and
             F % 4 == 0 and drop_keep is None):
         # whoever computes d(out) with a data-gradient GEMM may take this layer's backward sums along (dgrad_gemm)
         hook = c.bn_hooks[out.data_ptr()] = BnBwdHook(out, T, mean, rstd, beta, relu)
@@ -609,7 +632,7 @@ def conv_bn_act(x, leaf_scope, num_outputs, relu=True, out=None, out2=None, gbia
             if dout is None:
                 return
             d2 = c.grad(out2) if out2 is not None else None
-            if d2 is not None and (fuse_drop or use_pl or DETERMINISTIC or F % 4 != 0 or not BN1_BWD_TWO_SOURCES):
+            if d2 is not None and (fuse_drop or use_pl or F % 4 != 0 or not BN1_BWD_TWO_SOURCES):
                 # the second copy's gradient joins the first (the default passes below read both instead)
                 H.call("dgcnn_copy2d_f32", d2.data_ptr(), H.ld2(d2), dout.data_ptr(), H.ld2(dout), R, F, 1)
                 d2 = None
@@ -817,7 +840,7 @@ def edge_conv_block(x, B, N, k, num_filters, relu1=True, outs=None, net2=None):
     idx = knn(x, B, N, k)                                               # ops.py:8-19
     if uv_early:
         c.join_side()
-    virtual = gather and not EDGE_MATERIALIZE_Y and not DETERMINISTIC and k < 256   # conv0 output never written: recomputed from (V, U, idx)
+    virtual = gather and not EDGE_MATERIALIZE_Y and k < 256   # conv0 output never written: recomputed from (V, U, idx)
     #                                                           (the edge BN passes pack tie / positive counts: k < 256)
     Y = None if virtual else torch.empty((R * k, F), dtype=torch.float32, device=x.device)
     wd = wcat = UV = None
@@ -836,10 +859,8 @@ def edge_conv_block(x, B, N, k, num_filters, relu1=True, outs=None, net2=None):
         # the point-level GEMMs take the float4 path (the generic scalar kernel costs ~10x more on them)
         Cp, xg, wcat, UV = pre if pre is not None else _point_gemm(c, x, W0, R, C, F, side=False)
         H.call("dgcnn_edge_gather_add_f32", UV[:, F:].data_ptr(), 2 * F, UV.data_ptr(), 2 * F, idx.data_ptr(),
-               B, N, k, F, H._p(Y), 0 if DETERMINISTIC else st.data_ptr(),
+               B, N, k, F, H._p(Y), st.data_ptr(),
                tag="edge_gather_add_kernel", work=4.0 * ((0 if virtual else R * k * F) + 2 * R * F) + 4.0 * R * k)   # ops.py:21-52
-        if DETERMINISTIC:
-            colstats_det(Y, st)
         if not virtual:
             UV = None
     else:

@@ -55,6 +55,8 @@ PROTOTYPES = {
                                           c_vp, c_sz, c_vp],
     "dgcnn_bn1_act_dropout_f32": [c_vp, c_i64, c_int, c_vp, c_vp, c_vp, c_int, c_f32, c_vp, c_vp, c_i64, c_vp],
     "dgcnn_bn1_bwd_dropout_f32": [c_vp, c_i64, c_int, c_vp, c_vp, c_vp, c_int, c_f32, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_f32, c_vp],
+    "dgcnn_set_stat_slots": [c_int],
+    "dgcnn_get_stat_slots": [],
     "dgcnn_gemm_set_arith": [c_int],
     "dgcnn_gemm_get_arith": [],
     "dgcnn_gemm_x3_tile_rows": [c_int, c_int, c_int],
@@ -132,6 +134,15 @@ def set_gemm_arith(mode):
     lib = load()
     if lib.dgcnn_gemm_set_arith(int(mode)) != 0:
         raise ValueError(lib.dgcnn_last_error().decode())
+
+
+def set_stat_slots(n):
+    """Slots of every stats / red buffer from now on (include/dgcnn_hip.h: dgcnn_set_stat_slots); mirrored in STAT_SLOTS."""
+    global STAT_SLOTS
+    lib = load()
+    if lib.dgcnn_set_stat_slots(int(n)) != 0:
+        raise ValueError(lib.dgcnn_last_error().decode())
+    STAT_SLOTS = int(n)
 
 
 def gemm_arith():

@@ -32,6 +32,7 @@ def build(point_cloud, flags):
 
     x, B, N = E.as2d(point_cloud)
     R = B * N
+    c.configure_slots(R)                                           # (DETERMINISTIC: one writer per statistics slot)
     ecf = ops._listify(num_edge_filters, num_edge_conv, "num_filters")
     nofc = flags.MODEL_NAME == "residual-dgcnn-nofc"
 

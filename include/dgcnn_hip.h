@@ -14,8 +14,9 @@
  *     keeps no state), tensors are dense row-major fp32 unless a leading dimension `ld*`
  *     (in elements) is given; indices are batch-local int32;
  *   - every call is asynchronous on the caller-supplied hipStream_t (passed as void*);
- *   - `stats` buffers are double[DGCNN_STAT_SLOTS][2][F] (sum, sum of squares), zeroed by the
- *     caller, accumulated by the producing kernel's epilogue, reduced by dgcnn_bn_finalize_f32.
+ *   - `stats` buffers are double[slots][2][F] (sum, sum of squares), zeroed by the
+ *     caller, accumulated by the producing kernel's epilogue, reduced by dgcnn_bn_finalize_f32;
+ *     slots = DGCNN_STAT_SLOTS unless dgcnn_set_stat_slots() changed it.
  */
 #ifndef DGCNN_HIP_H_
 #define DGCNN_HIP_H_
@@ -34,6 +35,13 @@ extern "C" {
 #define DGCNN_EUNSUP (-4)   /* shape not supported by this build */
 
 #define DGCNN_STAT_SLOTS 32
+/* Slots of every stats / red buffer from now on (process-wide; default DGCNN_STAT_SLOTS).  A producer workgroup adds its partial
+ * sums -- themselves formed in a fixed order -- to slot (writer index mod slots) with a double atomic; with slots >= the number of
+ * writers (the library then also caps the grids of its reduction kernels at `slots`) every slot has ONE writer, and the finalize
+ * kernels add the slots in a fixed order: sums, hence whole training steps, are bit-reproducible run to run at the speed of the
+ * default kernels (the host's DETERMINISTIC mode: 1024 slots for 49152 rows).  Buffers must be sized for the value in force. */
+int dgcnn_set_stat_slots(int n);
+int dgcnn_get_stat_slots(void);
 
 int dgcnn_version(void);
 const char* dgcnn_last_error(void);
