@@ -147,8 +147,8 @@ def main():
                          "torch.distributed); nccl = RCCL through torch.distributed; gloo = only for the single-GPU-box sanity run "
                          "of the N > 1 logic, with --same-device")
     ap.add_argument("--same-device", action="store_true", help="all ranks on cuda:0 (sanity runs only)")
-    ap.add_argument("--deterministic", action="store_true", help="run the deterministic kernels (fixed-order BatchNorm sums, sorted "
-                    "adjacency): bit-reproducible steps, ~1.7x slower (DESIGN 2)")
+    ap.add_argument("--deterministic", action="store_true", help="deterministic mode (one writer per statistics slot, fixed-order "
+                    "finalize, sorted adjacency): bit-reproducible steps, ~6 %% slower (DESIGN 2)")
     ap.add_argument("--no-edgeconv-stack", action="store_true", help="skip the EdgeConv-stack-only passes after the timed region "
                     "(profiling runs)")
     ap.add_argument("--graph", default="auto", choices=["0", "1", "auto"],
