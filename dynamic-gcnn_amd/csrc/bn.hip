@@ -7,17 +7,29 @@
 
 namespace {
 
-// Slot reduction shared by the two finalize kernels: 8 columns x 32 slot lanes per workgroup; lane z adds slots z, z + 32, ...
-// (ascending), the 32 partial sums of a column are then added in lane order by its first lane: one fixed order for a given
+// Slot reduction shared by the two finalize kernels: 4 columns x 64 slot lanes per workgroup; lane z adds slots z, z + 64, ...
+// (ascending), the 64 partial sums of a column are then added in lane order by its first lane: one fixed order for a given
 // slot count, whatever wrote the slots.
-constexpr int FIN_COLS = 8, FIN_LANES = 32;
+constexpr int FIN_COLS = 4, FIN_LANES = 64;
 __device__ __forceinline__ bool slot_sums(const double* __restrict__ acc, int F, int nslots, int& f, double& s, double& q) {
   __shared__ double part[2][FIN_COLS][FIN_LANES];
   const int c = threadIdx.x / FIN_LANES, z = threadIdx.x % FIN_LANES;
   f = blockIdx.x * FIN_COLS + c;
   double a = 0.0, b = 0.0;
   if (f < F) {
-    for (int sl = z; sl < nslots; sl += FIN_LANES) {
+    // four slots in flight per lane (slots z, z + 64, z + 128, z + 192 of every group of 256), added in that order
+    int sl = z;
+    for (; sl + 3 * FIN_LANES < nslots; sl += 4 * FIN_LANES) {
+      double va[4], vb[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        va[u] = acc[((int64_t)(sl + u * FIN_LANES) * 2 + 0) * F + f];
+        vb[u] = acc[((int64_t)(sl + u * FIN_LANES) * 2 + 1) * F + f];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { a += va[u]; b += vb[u]; }
+    }
+    for (; sl < nslots; sl += FIN_LANES) {
       a += acc[((int64_t)sl * 2 + 0) * F + f];
       b += acc[((int64_t)sl * 2 + 1) * F + f];
     }

@@ -343,16 +343,28 @@ __global__ void global_max_bwd_bn_kernel(const float* __restrict__ dout, const i
   if (f >= F) return;
   const float mu = mean[f], rs = rstd[f], be = beta[f];
   double s0 = 0.0, s1 = 0.0;
-  for (int b = 0; b < B; ++b) {
-    const int64_t row = (int64_t)b * N + arg[(int64_t)b * F + f];
-    const float g = dout[(int64_t)b * F + f];
-    dx[row * lddx + f] += g;
-    const float xh = (T[row * ldT + f] - mu) * rs;
-    float z = xh + be;
-    if (relu) z = fmaxf(z, 0.f);
-    const float dz = (relu && !(z > 0.f)) ? 0.f : g;
-    s0 += (double)dz;
-    s1 += (double)(dz * xh);
+  for (int b0 = 0; b0 < B; b0 += 8) {                  // 8 clouds' loads in flight, sums still in ascending b
+    int64_t row[8];
+    float g[8], t[8], old[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int b = (b0 + u < B) ? (b0 + u) : (B - 1);
+      row[u] = (int64_t)b * N + arg[(int64_t)b * F + f];
+      g[u] = dout[(int64_t)b * F + f];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { t[u] = T[row[u] * ldT + f]; old[u] = dx[row[u] * lddx + f]; }
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (b0 + u < B) {
+        dx[row[u] * lddx + f] = old[u] + g[u];
+        const float xh = (t[u] - mu) * rs;
+        float z = xh + be;
+        if (relu) z = fmaxf(z, 0.f);
+        const float dz = (relu && !(z > 0.f)) ? 0.f : g[u];
+        s0 += (double)dz;
+        s1 += (double)(dz * xh);
+      }
   }
   atomicAdd(red + f, s0);              // slot 0 has one other writer at most (the GEMM's first row tile), and that kernel is complete
   atomicAdd(red + F + f, s1);

@@ -146,7 +146,7 @@ class Context(object):
     def stats(self, F):
         """Zeroed double[SLOTS][2][F] carved from one arena that is memset once per step."""
         n = H.STAT_SLOTS * 2 * F
-        want = (1 << 20) if H.STAT_SLOTS <= 32 else (1 << 19) * (H.STAT_SLOTS // 32)   # 8 MB at 32 slots, 128 MB at 1024
+        want = (1 << 20) if H.STAT_SLOTS <= 32 else (1 << 19) * -(-H.STAT_SLOTS // 32)   # 8 MB at 32 slots, 96 MB at 768
         if self.stat_arena is None or self.stat_arena.device != self.device or self.stat_arena.numel() < want:
             self.stat_arena = torch.zeros(want, dtype=torch.float64, device=self.device)
             self.stat_off = 0
@@ -161,10 +161,8 @@ class Context(object):
         (a GEMM over `rows` rows in 64-row tiles; the reduction kernels cap their grids at the slot count) -- so that no sum
         depends on the order in which workgroups finish.  Default mode: DGCNN_STAT_SLOTS (32) slots, several writers each."""
         if DETERMINISTIC:
-            need = max(256, -(-int(rows) // 64))
-            n = 256
-            while n < need:
-                n *= 2
+            n = max(256, -(-int(rows) // 64))                              # (the finalize kernels walk all of them: no rounding up)
+            n = -(-n // 64) * 64
             n = max(n, H.STAT_SLOTS if H.STAT_SLOTS > 32 else 0)       # never shrink inside a run: buffers of this step exist already
         else:
             n = 32
