@@ -39,7 +39,7 @@ extern "C" {
  * sums -- themselves formed in a fixed order -- to slot (writer index mod slots) with a double atomic; with slots >= the number of
  * writers (the library then also caps the grids of its reduction kernels at `slots`) every slot has ONE writer, and the finalize
  * kernels add the slots in a fixed order: sums, hence whole training steps, are bit-reproducible run to run at the speed of the
- * default kernels (the host's DETERMINISTIC mode: 1024 slots for 49152 rows).  Buffers must be sized for the value in force. */
+ * default kernels (the host's DETERMINISTIC mode: 768 slots for 49152 rows).  Buffers must be sized for the value in force. */
 int dgcnn_set_stat_slots(int n);
 int dgcnn_get_stat_slots(void);
 
