@@ -306,7 +306,7 @@ def main():
                   9: "exact 3-way bf16 split, 9 partial products on the bf16 MFMA pipe"}[H.gemm_arith()]
     if rank == 0:
         is_gemm = dominant.startswith("gemm") or dominant.startswith("knn")
-        launches, secs, work = dom
+        launches, secs, work = dom[:3]
         if is_gemm:
             achieved = work / secs / 1e12          # algorithmic fp32 flops (2 M N K per GEMM)
             peak, note = PEAK_F32_MFMA_TFLOPS, "fp32 MFMA dense peak"
@@ -331,7 +331,7 @@ def main():
                     "unit": "GB/s", "frac": round(achieved / PEAK_HBM_GBS, 4), "traffic": None,
                     "launches": launches, "avg_us": round(secs / launches * 1e6, 1)}
         if side and is_gemm:
-            n1, s1, w1 = table[dominant]
+            n1, s1, w1 = table[dominant][:3]
             roof["achieved_serialized"] = round(w1 / s1 / 1e12, 2)
             roof["frac_serialized"] = round(w1 / s1 / 1e12 / roof["peak"], 4)
             roof["note"] = ("achieved/frac: HIP events around every launch of this kernel in eager steps right after the timed "
@@ -346,7 +346,7 @@ def main():
         # north_star: "rocprof HBM GB/s on the distance/gather kernels and MFMA utilisation on the edge MLP": the other kernel
         # families of the step, each timed ALONE (the serialised warm-up step above), against the ceiling that bounds it
         extra = []
-        for t, (n, sec, work) in sorted(table.items(), key=lambda kv: -kv[1][1]):
+        for t, (n, sec, work, nbytes) in sorted(table.items(), key=lambda kv: -kv[1][1]):
             if t == dominant or sec <= 0:
                 continue
             if t.startswith("knn"):
@@ -364,16 +364,24 @@ def main():
                     pk = PEAK_BF16_MFMA_TFLOPS / int(t.rstrip(">").split("bf16x")[1])
                 if t.startswith("gemm_pl"):
                     pk = PEAK_BF16_MFMA_TFLOPS / (3 if "f16x2" in t else 6)
-                extra.append({"kernel": t, "bound": "mfma", "achieved": round(work / sec / 1e12, 2), "peak": round(pk, 1),
-                              "unit": "TFLOP/s", "frac": round(work / sec / 1e12 / pk, 4), "launches": n,
-                              "avg_us": round(sec / n * 1e6, 1)})
+                # which roof: flops per compulsory byte against the ridge of this arithmetic (peak flops / HBM peak)
+                if nbytes > 0 and work / nbytes < pk * 1e12 / (PEAK_HBM_GBS * 1e9):
+                    extra.append({"kernel": t, "bound": "hbm", "achieved": round(nbytes / sec / 1e9, 1), "peak": PEAK_HBM_GBS,
+                                  "unit": "GB/s", "frac": round(nbytes / sec / 1e9 / PEAK_HBM_GBS, 4), "launches": n,
+                                  "avg_us": round(sec / n * 1e6, 1), "mfma_frac": round(work / sec / 1e12 / pk, 4),
+                                  "note": "short reduction: %.0f flops per operand/result byte, below the ridge of %.0f" % (
+                                      work / nbytes, pk * 1e12 / (PEAK_HBM_GBS * 1e9))})
+                else:
+                    extra.append({"kernel": t, "bound": "mfma", "achieved": round(work / sec / 1e12, 2), "peak": round(pk, 1),
+                                  "unit": "TFLOP/s", "frac": round(work / sec / 1e12 / pk, 4), "launches": n,
+                                  "avg_us": round(sec / n * 1e6, 1)})
             elif work > 0:
                 extra.append({"kernel": t, "bound": "hbm", "achieved": round(work / sec / 1e9, 1), "peak": PEAK_HBM_GBS,
                               "unit": "GB/s", "frac": round(work / sec / 1e9 / PEAK_HBM_GBS, 4), "launches": n,
                               "avg_us": round(sec / n * 1e6, 1)})
         if args.kernel_table:
             tot = sum(v[1] for v in table.values())
-            for t, (n, s, w) in sorted(table.items(), key=lambda kv: -kv[1][1]):
+            for t, (n, s, w, _b) in sorted(table.items(), key=lambda kv: -kv[1][1]):
                 sys.stderr.write("%-46s launches %3d  %8.3f ms  %5.1f%%  work/s %.3e\n" % (t, n, s * 1e3, 100 * s / tot, w / s))
         out = {
             "metric": "point-clouds/sec fwd+bwd at (B,N,k,C)=(24,2048,20,3), 1/2/4/8 MI355X",

@@ -464,7 +464,8 @@ def gemm(A, Bm, C, transA=False, transB=False, beta=0.0, gbias=None, rpg=0, stat
     tag = _gemm_tag(M, N, K, transA, transB, A, Bm)
     H.call("dgcnn_gemm_f32", int(transA), int(transB), M, N, K, A.data_ptr(), H.ld2(A), Bm.data_ptr(), H.ld2(Bm),
            C.data_ptr(), H.ld2(C), float(beta), H._p(gbias), 0 if gbias is None else H.ld2(gbias), int(rpg),
-           H._p(stats), H._p(colmax), int(colmax_rpg), ws.data_ptr(), ws.numel(), tag=tag, work=2.0 * M * N * K)
+           H._p(stats), H._p(colmax), int(colmax_rpg), ws.data_ptr(), ws.numel(), tag=tag, work=2.0 * M * N * K,
+           nbytes=4.0 * (M * K + K * N + (2 if beta != 0.0 else 1) * M * N))
 
 
 def colstats_det(T, st):
@@ -535,7 +536,8 @@ def dgrad_gemm(dT, W, x, dx, beta, arith=None):
             h.red = ctx().stats(h.F)
             H.call("dgcnn_gemm_bn_bwd_f32", M, N, K, dT.data_ptr(), H.ld2(dT), W.data_ptr(), H.ld2(W), dx.data_ptr(), H.ld2(dx),
                    float(beta), h.T.data_ptr(), H.ld2(h.T), h.mean.data_ptr(), h.rstd.data_ptr(), h.beta.data_ptr(), int(h.relu),
-                   c0, h.F, h.red.data_ptr(), tag=_gemm_tag(M, N, K, False, True, dT, W), work=2.0 * M * N * K)
+                   c0, h.F, h.red.data_ptr(), tag=_gemm_tag(M, N, K, False, True, dT, W), work=2.0 * M * N * K,
+                   nbytes=4.0 * (M * K + K * N + (2 if beta != 0.0 else 1) * M * N + M * h.F))
             h.served = True
             return
     gemm(dT, W, dx, transB=True, beta=beta, arith=arith)

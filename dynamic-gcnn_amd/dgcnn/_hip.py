@@ -164,25 +164,27 @@ class Timer(object):
 
     def __init__(self, watch=None):
         self.watch = watch          # None = every tagged call, else a set of tags
-        self.records = []           # (tag, start_event, stop_event, work)
+        self.records = []           # (tag, start_event, stop_event, work, bytes)
 
     def summary(self):
         torch.cuda.synchronize()
         out = {}
-        for tag, a, b, work in self.records:
-            d = out.setdefault(tag, [0, 0.0, 0.0])
+        for tag, a, b, work, nbytes in self.records:
+            d = out.setdefault(tag, [0, 0.0, 0.0, 0.0])
             d[0] += 1
             d[1] += a.elapsed_time(b) * 1e-3
             d[2] += work
-        return out                  # tag -> [launches, seconds, work]
+            d[3] += nbytes
+        return out                  # tag -> [launches, seconds, work, operand + result bytes (GEMMs; 0 where not given)]
 
 
 TIMER = None
 
 
-def call(name, *args, tag=None, work=0.0):
+def call(name, *args, tag=None, work=0.0, nbytes=0.0):
     """Invoke an entry point on the current stream; raise ValueError/HipError on a negative code.
-    tag/work: kernel identity and algorithmic flops-or-bytes of this launch, for bench.py's roofline."""
+    tag/work: kernel identity and algorithmic flops-or-bytes of this launch, for bench.py's roofline; nbytes: the compulsory
+    operand + result bytes of a GEMM launch (its `work` is flops), which decide whether HBM or the matrix pipe bounds it."""
     lib = load()
     tm = TIMER
     if tm is not None and tag is not None and (tm.watch is None or tag in tm.watch):
@@ -191,7 +193,7 @@ def call(name, *args, tag=None, work=0.0):
         a.record()
         rc = getattr(lib, name)(*args, _stream())
         b.record()
-        tm.records.append((tag, a, b, work))
+        tm.records.append((tag, a, b, work, nbytes))
     else:
         rc = getattr(lib, name)(*args, _stream())
     if rc != 0:

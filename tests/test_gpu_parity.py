@@ -1129,3 +1129,34 @@ def test_bn_backward_sums_in_the_dgrad_epilogue_leave_the_gradients_unchanged(dg
     assert abs(out[True][0] - out[False][0]) < 2e-6, (out[True][0], out[False][0])
     ga, gb = out[True][1].astype(np.float64), out[False][1].astype(np.float64)
     assert np.linalg.norm(ga - gb) <= 3e-3 * np.linalg.norm(gb), np.linalg.norm(ga - gb) / np.linalg.norm(gb)
+
+
+@pytest.mark.parametrize("M,N,K,transB", [(8200, 64, 128, False), (8200, 64, 256, True), (12345, 128, 64, False), (9000, 256, 64, True),
+                                          (4100, 64, 64, False), (49152, 256, 64, False)])
+def test_short_reduction_gemms_of_the_edgeconv_blocks(dg, M, N, K, transB):
+    """conv1 / the point-level [U|V] product / their data gradients (ops.py:47-70): K <= 256, N <= 256 over many rows (64-row
+    tiles) -- product, beta accumulate, the BatchNorm column sums against float64, and output into a column slice."""
+    from dgcnn import _engine as E
+    rng = np.random.default_rng(M + N + K)
+    A = rng.normal(size=(M, K)).astype(np.float32)
+    A[rng.integers(0, M, 50)] = 0.0
+    W = rng.normal(0, 0.3, size=(N, K) if transB else (K, N)).astype(np.float32)
+    ref = A.astype(np.float64) @ (W.T if transB else W).astype(np.float64)
+    tol = 2e-6 * K ** 0.5 * 4 + 1e-5
+    Ad, Wd = dev(A), dev(W)
+    C = torch.empty((M, N), device="cuda")
+    st = torch.zeros(E.H.STAT_SLOTS * 2 * N, dtype=torch.float64, device="cuda")
+    E.gemm(Ad, Wd, C, transB=transB, stats=st)
+    np.testing.assert_allclose(host(C), ref, rtol=1e-5, atol=tol)
+    s = host(st).reshape(E.H.STAT_SLOTS, 2, N).sum(0)
+    np.testing.assert_allclose(s[0], ref.sum(0), rtol=1e-5, atol=2e-2)
+    np.testing.assert_allclose(s[1], (ref ** 2).sum(0), rtol=1e-5, atol=2e-2)
+    old = rng.normal(size=(M, N)).astype(np.float32)
+    C2 = dev(old)
+    E.gemm(Ad, Wd, C2, transB=transB, beta=1.0)
+    np.testing.assert_allclose(host(C2), ref + old, rtol=1e-5, atol=tol)
+    # into a column slice of a wider tensor (the concat buffer of model.build): leading dimension != N
+    wide = torch.zeros((M, N + 40), device="cuda")
+    E.gemm(Ad, Wd, wide[:, 8:8 + N], transB=transB)
+    np.testing.assert_allclose(host(wide[:, 8:8 + N]), ref, rtol=1e-5, atol=tol)
+    assert float(wide[:, :8].abs().max()) == 0.0 and float(wide[:, 8 + N:].abs().max()) == 0.0
