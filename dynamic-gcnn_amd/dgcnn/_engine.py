@@ -41,7 +41,10 @@ WGRAD_AFTER_DGRAD = os.environ.get("DGCNN_WGRAD_AFTER_DGRAD", "1") != "0"   # si
 WEIGHT_PREP_AHEAD = os.environ.get("DGCNN_WPREP", "1") != "0"   # parameter-only kernels of the step go first, on the side stream
 EDGE_BWD_FUSED_L0 = os.environ.get("DGCNN_EDGE_BWD_FUSED_L0", "1") != "0"   # input layer (C <= 4, no input gradient): one backward pass
 FUSE_DROPOUT = os.environ.get("DGCNN_FUSE_DROPOUT", "1") != "0"   # tf.nn.dropout inside the last FC layer's BatchNorm passes
-BN_BWD_IN_DGRAD = os.environ.get("DGCNN_BN_BWD_IN_DGRAD", "1") != "0"   # BatchNorm-backward sums of a layer from the dgrad GEMM above it
+# BatchNorm-backward sums of MergedEdgeConv / FC0 from the epilogue of the data-gradient GEMM above them (dgcnn_gemm_bn_bwd_f32).
+# Off by default: -350 MB and two launches per step, but no step time (profiles/r03/bnb_epilogue.txt: those passes ran under the
+# side stream's weight-gradient GEMMs anyway) -- and the data-gradient GEMMs, the step's dominant kernel, get 4-19 us longer.
+BN_BWD_IN_DGRAD = os.environ.get("DGCNN_BN_BWD_IN_DGRAD", "0") != "0"
 BN1_BWD_TWO_SOURCES = os.environ.get("DGCNN_BN1_BWD_TWO_SOURCES", "1") != "0"   # conv1's backward reads both output gradients (no add pass)
 COLMAX_IN_EPILOGUE = os.environ.get("DGCNN_COLMAX_EPILOGUE", "1") != "0"   # the global max-pool comes out of MergedEdgeConv's GEMM epilogue
 EDGE_BWD_REDUCE_POINTS = True   # BN backward sums of conv0 from per-point data (False: a pass over the edges)

@@ -86,7 +86,14 @@ def main():
             gbs = v / 1e3 / us if us > 0 else 0.0
             f.write("%-48s fetch_KB %12.0f  write_KB %12.0f  hbm_MB %10.1f  avg_us %8.1f  GB/s %7.0f  of_peak %5.3f\n"
                     % (k, fetch.get(k, 0), write.get(k, 0), v / 1e6, us, gbs, gbs / 8000.0))
-    json.dump(json.load(open(os.path.join(src, "bench.json"))), open(os.path.join(HERE, "%s_bench.json" % tag), "w"), indent=1)
+    # the bench line of the same collect run; its roofline.traffic was read from the PREVIOUS pmc_traffic.json when it printed:
+    # replace it with this run's own counter passes so that the committed line and tables describe one build
+    b = json.load(open(os.path.join(src, "bench.json")))
+    k = b.get("roofline", {}).get("kernel")
+    if k in traffic:
+        b["roofline"]["traffic"] = traffic[k]
+        b["roofline"]["traffic_note"] = "HBM bytes per launch of this tag from the --pmc passes of the same profiles collect run (FETCH_SIZE*1024*2 + WRITE_SIZE*1024)"
+    json.dump(b, open(os.path.join(HERE, "%s_bench.json" % tag), "w"), indent=1)
 
 
 if __name__ == "__main__":
