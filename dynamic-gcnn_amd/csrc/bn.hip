@@ -148,11 +148,14 @@ struct Rows {
   // them).  Dense rows (mostly k = 1): rows past k-1 are skipped (k, m are wave-uniform: scalar branches).
   __device__ __forceinline__ void load(int m, int k, float (&y)[NB][V]) const {
     if constexpr (G) {
-      int64_t row[NB];
+      // row offset in ONE full-rate multiply (v_mul_u32_u24): index < N <= 2^24 and N * ld < 2^32 elements (check_edge); the
+      // 64-bit form cost a v_mad_u64_u32 and two v_mul_lo_u32 -- quarter rate each -- per gathered row, a quarter of the vector
+      // time of the forward max/mean pass (profiles/r03/kreduce_probe.txt)
+      unsigned row[NB];
 #pragma unroll
-      for (int b = 0; b < NB; ++b) row[b] = (int64_t)ip[(m + b < k) ? (m + b) : (k - 1)];
+      for (int b = 0; b < NB; ++b) row[b] = __umul24((unsigned)ip[(m + b < k) ? (m + b) : (k - 1)], (unsigned)ld);
 #pragma unroll
-      for (int b = 0; b < NB; ++b) Vec<V>::ld(base + row[b] * ld, y[b]);
+      for (int b = 0; b < NB; ++b) Vec<V>::ld(base + row[b], y[b]);
 #pragma unroll
       for (int b = 0; b < NB; ++b)
 #pragma unroll
@@ -765,6 +768,8 @@ int check_edge(const char* what, const float* V, int64_t ldv, const float* U, in
   DG_REQUIRE(F % 4 == 0, DGCNN_EUNSUP, "%s: F must be a multiple of 4 (got %d)", what, F);
   DG_REQUIRE((int64_t)B * N * k < (1ll << 31), DGCNN_EUNSUP, "%s: B*N*k >= 2^31", what);
   DG_REQUIRE(k < CNT_POS, DGCNN_EUNSUP, "%s: k must be < %d", what, CNT_POS);
+  DG_REQUIRE(N < (1 << 24) && ldv < (1 << 24) && (int64_t)N * ldv < (1ll << 32), DGCNN_EUNSUP,
+             "%s: N * ldv must be < 2^32 elements (32-bit row offsets inside a cloud)", what);
   DG_REQUIRE(a16(V) && a16(U) && ldv % 4 == 0 && ldu % 4 == 0 && ldv >= F && ldu >= F, DGCNN_EINVAL,
              "%s: V, U must be 16-byte aligned with leading dimensions %% 4 == 0", what);
   return DGCNN_OK;

@@ -228,7 +228,7 @@ __global__ __launch_bounds__(256) void edge_gather_add_kernel(const float* __res
 #pragma unroll
         for (int q = 0; q < 4; ++q) row[q] = ip[(m + q < knn) ? (m + q) : (knn - 1)];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) v[q] = *reinterpret_cast<const float4*>(vb + (int64_t)row[q] * ldv);
+        for (int q = 0; q < 4; ++q) v[q] = *reinterpret_cast<const float4*>(vb + __umul24((unsigned)row[q], (unsigned)ldv));   // (full-rate 24-bit multiply: N, ldv < 2^24, N * ldv < 2^32: host check)
 #pragma unroll
         for (int q = 0; q < 4; ++q)
           if (m + q < knn) {
@@ -567,6 +567,8 @@ extern "C" int dgcnn_edge_gather_add_f32(const float* V, int64_t ldv, const floa
   DG_REQUIRE(F % 4 == 0 && F <= 1024, DGCNN_EUNSUP, "dgcnn_edge_gather_add_f32: F must be a multiple of 4, <= 1024 (got %d)", F);
   const int64_t rows = (int64_t)B * N * k;
   DG_REQUIRE(rows < (1ll << 31), DGCNN_EUNSUP, "dgcnn_edge_gather_add_f32: B*N*k >= 2^31");
+  DG_REQUIRE(N < (1 << 24) && ldv < (1 << 24) && (int64_t)N * ldv < (1ll << 32), DGCNN_EUNSUP,
+             "dgcnn_edge_gather_add_f32: N * ldv must be < 2^32 elements (32-bit row offsets inside a cloud)");
   auto a16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
   DG_REQUIRE(a16(V) && a16(U) && (!Y || a16(Y)) && ldv % 4 == 0 && ldu % 4 == 0 && ldv >= F && ldu >= F, DGCNN_EINVAL,
              "dgcnn_edge_gather_add_f32: V, U, Y must be 16-byte aligned with leading dimensions %% 4 == 0");
