@@ -61,3 +61,22 @@ def test_host_logic_errors_without_gpu():
     from dgcnn.trainval import param_specs
     specs = param_specs(f, 3)
     assert sum(int(__import__("numpy").prod(s)) for _, s in specs) == 1797186
+
+
+def test_stat_slots_setter_and_gemm_tile_query_work_without_a_gpu():
+    """Process-wide modes behind the C ABI are plain host state: the slot count of the statistics buffers (deterministic mode:
+    one writer per slot) and the tile the bf16-split GEMM picks for a shape (tools name kernel instances with it)."""
+    from dgcnn import _hip as H
+    lib = H.load()
+    assert lib.dgcnn_get_stat_slots() == H.STAT_SLOTS
+    try:
+        H.set_stat_slots(768)
+        assert lib.dgcnn_get_stat_slots() == 768 and H.STAT_SLOTS == 768
+        with pytest.raises(ValueError):
+            H.set_stat_slots(8)                                   # fewer than DGCNN_STAT_SLOTS: buffers of the plane kernels assume 32
+        assert lib.dgcnn_get_stat_slots() == 768
+    finally:
+        H.set_stat_slots(32)
+    assert lib.dgcnn_gemm_x3_tile_rows(49152, 512, 1728) == 256     # FC0 forward: the wave-specialised 256 x 128 kernel
+    assert lib.dgcnn_gemm_x3_tile_rows(49152, 64, 128) == 64        # conv1: short reduction over many rows
+    assert lib.dgcnn_gemm_x3_tile_rows(1024, 512, 192) == 128       # configs[0]-sized problems
