@@ -228,7 +228,11 @@ def main():
     table = H.TIMER.summary()
     H.TIMER = None
     E.WGRAD_SIDE_STREAM = side
-    dominant = max(table, key=lambda t: table[t][1])
+    # the kernel with the largest time in that step.  The three operand layouts of the head GEMM (forward / data gradient / weight
+    # gradient: the same flops each) are within a few per cent of each other, so "largest" flipped from run to run; among tags within
+    # 5 % of the largest the choice is fixed (first in name order) so that successive bench lines report the same kernel
+    tmax = max(v[1] for v in table.values())
+    dominant = sorted(t for t in table if table[t][1] >= 0.95 * tmax)[0]
     for _ in range(max(args.warmup - 2, 0)):
         step()
     calib = None
