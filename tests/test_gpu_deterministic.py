@@ -145,3 +145,32 @@ def test_deterministic_mode_runs_the_default_kernels(det):
     E.DETERMINISTIC = False
     dgcnn.reset()
     assert H.STAT_SLOTS == 32
+
+
+def test_two_full_size_steps_are_bit_identical(det):
+    """BASELINE configs[1] (24 clouds x 2048 points, k = 20, filters 64/64/128, FC 512/256): the producer with the most workgroups
+    is a GEMM over 49152 rows in 64-row tiles -- 768 writers, 768 slots; the statistics pass and the class-dimension kernel cap
+    their grids at that.  Two runs of the same two steps: identical gradients and parameters, bit for bit."""
+    rng = np.random.default_rng(7)
+    pts = torch.from_numpy(rng.random((2, 24, 2048, 3), dtype=np.float32)).cuda()
+    lab = torch.from_numpy(rng.integers(0, 2, (2, 24, 2048)).astype(np.int32)).cuda()
+
+    def run():
+        f = dgcnn.DGCNN_FLAGS(MODEL_NAME="dgcnn", EDGE_CONV_LAYERS=3, EDGE_CONV_FILTERS=[64, 64, 128], KVALUE=20, FC_LAYERS=2,
+                              FC_FILTERS=[512, 256], NUM_CLASS=2, NUM_CHANNEL=3, TRAIN=True, SEED=3, LEARNING_RATE=1e-3,
+                              DETERMINISTIC=True)
+        tv = dgcnn.trainval(f).initialize()
+        c = dgcnn.ctx()
+        grads = []
+        for s in range(2):
+            tv.zero_gradients(None)
+            tv.accum_gradient(None, [pts[s]], [lab[s]])
+            grads.append(c.flat_grad.clone())
+            tv.apply_gradient(None)
+        return c.flat_param.clone(), grads, H.STAT_SLOTS
+    p1, g1, slots = run()
+    p2, g2, _ = run()
+    assert slots == 768
+    for a, b in zip(g1, g2):
+        assert torch.equal(a, b)
+    assert torch.equal(p1, p2)
