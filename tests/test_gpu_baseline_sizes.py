@@ -198,15 +198,21 @@ def test_config1_full_size_logits_and_dynamic_graphs(dg):
 # HIP worst tensor 1.7e-3, 2.0e-3, 2.3e-3, 2.4e-3, 3.9e-3, 3.9e-3, 6.6e-3; the fp32 oracle on the same graphs 0.8e-3 .. 4.2e-3.
 # 5e-3 (round 2) failed one run in seven; a wrong or missing term is O(1).
 GRAD_BAR = 1e-2
+# DETERMINISTIC mode: the HIP run is bit-reproducible, so the figure is ONE number per seed (round 3, this seed, every run: HIP
+# worst tensor 1.47e-3, fp32 oracle on the same graphs 1.43e-3, HIP vs fp32 oracle 1.54e-3) and the bar can sit at twice that
+GRAD_BAR_DET = 3e-3
 
 
-def test_config1_full_size_training_step(dg):
+@pytest.mark.parametrize("det", [False, True])
+def test_config1_full_size_training_step(dg, det):
     """One full training micro-step at (24,2048,20,3) with dropout off, the HIP graphs fed to the oracle: loss within 1e-4
     and EVERY gradient tensor within 1e-2 (relative Frobenius; measured 1.7e-3 .. 6.6e-3) of the float64 twin; so is the float32
     oracle (tree-ordered BatchNorm sums: 0.8e-3 .. 4.2e-3; round 2's running float32 sums over 983040 rows: 2e-2 .. 4e-2), and the
     two float32 evaluations agree within 2e-2 -- then the Adam step."""
     B, N, C = 24, 2048, 3
     flags = config1_flags(dg, train=True)
+    flags.DETERMINISTIC = det
+    bar = GRAD_BAR_DET if det else GRAD_BAR
     rng = np.random.default_rng(1)
     pts = rng.random((B, N, C), dtype=np.float32)
     labels = rng.integers(0, 2, (B, N)).astype(np.int32)
@@ -217,6 +223,7 @@ def test_config1_full_size_training_step(dg):
         tv, res, cap = run_model(dg, flags, pts, params, train=True, labels=labels)
     finally:
         E.DROPOUT_KEEP = keep
+        E.DETERMINISTIC = False
     idx_list = [cap["EdgeConv%d" % i][1] for i in range(3)]
     p64 = {n: v.astype(np.float64) for n, v in params.items()}
     G64, loss64, _, _ = O.train_step_grads(pts.astype(np.float64), labels, flags, p64, idx_list=idx_list)
@@ -227,11 +234,11 @@ def test_config1_full_size_training_step(dg):
     r_o32 = {n: rel(G32[n].astype(np.float64), G64[n]) for n in params}
     print("configs[1] full size, relative Frobenius gradient error vs the fp64 twin: HIP worst %.2e (%s) | fp32 oracle worst %.2e"
           % (max(r_hip.values()), max(r_hip, key=r_hip.get), max(r_o32.values())))
-    assert max(r_hip.values()) < GRAD_BAR, r_hip
-    assert max(r_o32.values()) < GRAD_BAR, r_o32          # the fp32 oracle is a credible target itself (round 2: 2e-2 .. 4e-2)
+    assert max(r_hip.values()) < bar, r_hip
+    assert max(r_o32.values()) < bar, r_o32               # the fp32 oracle is a credible target itself (round 2: 2e-2 .. 4e-2)
     r_h32 = {n: rel(host(tv.gradients[n]).astype(np.float64), G32[n].astype(np.float64)) for n in params}
     print("HIP vs fp32 oracle: worst %.2e (%s)" % (max(r_h32.values()), max(r_h32, key=r_h32.get)))
-    assert max(r_h32.values()) < 2 * GRAD_BAR, r_h32      # two fp32 evaluations, each within GRAD_BAR of exact arithmetic
+    assert max(r_h32.values()) < 2 * bar, r_h32           # two fp32 evaluations, each within the bar of exact arithmetic
     before = host(dg.ctx().flat_param).copy()
     tv.apply_gradient(None)
     after = host(dg.ctx().flat_param)
