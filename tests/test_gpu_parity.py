@@ -1169,3 +1169,54 @@ def test_short_reduction_gemms_of_the_edgeconv_blocks(dg, M, N, K, transB):
     E.gemm(Ad, Wd, wide[:, 8:8 + N], transB=transB)
     np.testing.assert_allclose(host(wide[:, 8:8 + N]), ref, rtol=1e-5, atol=tol)
     assert float(wide[:, :8].abs().max()) == 0.0 and float(wide[:, 8 + N:].abs().max()) == 0.0
+
+
+def test_training_trajectory_of_eight_adam_steps_follows_the_oracle(dg):
+    """trainval.py:75-80 (zero -> accumulate -> apply) eight times on fresh batches, dropout off: at EVERY step the loss the HIP path
+    reports agrees with the float64 oracle that is stepped alongside it (same Adam, same neighbour graphs as the HIP path built
+    from its own current features), and after the eight steps the accumulated parameter movement agrees where it is not noise.
+    (The oracle follows its OWN parameter trajectory: an error in any gradient or in the optimizer would separate the two.)"""
+    from gpu_helpers import capture_layers
+    import dgcnn._engine as E
+    flags = dg.DGCNN_FLAGS(MODEL_NAME="dgcnn", EDGE_CONV_LAYERS=2, EDGE_CONV_FILTERS=[32, 32], KVALUE=8, FC_LAYERS=2,
+                           FC_FILTERS=[64, 32], NUM_CLASS=2, NUM_CHANNEL=3, TRAIN=True, SEED=11, LEARNING_RATE=1e-3,
+                           DETERMINISTIC=True)
+    rng = np.random.default_rng(21)
+    keep, E.DROPOUT_KEEP = E.DROPOUT_KEEP, 1.0
+    try:
+        tv = dg.trainval(flags).initialize()
+        p64 = {n: host(v).astype(np.float64) for n, v in tv.variables.items()}
+        init = {n: v.copy() for n, v in p64.items()}
+        m = {n: np.zeros_like(v) for n, v in p64.items()}
+        vv = {n: np.zeros_like(v) for n, v in p64.items()}
+        losses = []
+        for step in range(1, 9):
+            pts = rng.random((3, 256, 3), dtype=np.float32)
+            lab = (pts[..., 0] + 0.3 * pts[..., 1] > 0.6).astype(np.int32)          # a learnable rule
+            tv.zero_gradients(None)
+            with capture_layers(keep_inputs=False) as cap:
+                res = tv.accum_gradient(None, [pts], [lab])
+            tv.apply_gradient(None)
+            idx_list = [cap.layers["EdgeConv%d" % i][1] for i in range(2)]
+            G, loss64, _, _ = O.train_step_grads(pts.astype(np.float64), lab, flags, p64, idx_list=idx_list)
+            for n in p64:
+                O.adam_step(p64[n], G[n], m[n], vv[n], step, flags.LEARNING_RATE)
+            losses.append((float(res[2]), float(loss64)))
+        for step, (lh, lo) in enumerate(losses, 1):
+            assert abs(lh - lo) < 2e-5 * max(1.0, abs(lo)), (step, lh, lo)            # measured 2.8e-6 over the eight steps
+        assert losses[-1][1] < losses[0][1]                                          # and it learns
+        worst = 0.0
+        for n in p64:
+            moved_o = p64[n] - init[n]
+            moved_h = host(tv.variables[n]).astype(np.float64) - init[n]
+            big = np.abs(moved_o) >= 0.25 * np.abs(moved_o).max()                    # Adam's normalised step amplifies noise where the gradient is ~0
+            assert big.any()
+            err = np.abs(moved_h - moved_o)[big].max() / np.abs(moved_o).max()
+            worst = max(worst, err)
+            assert err < 1e-1, (n, err)                   # measured 4.7e-2 (Adam's sign-like step where a gradient is small); a wrong gradient is O(1)
+        print("8 Adam steps: loss %.5f -> %.5f, max |loss_hip - loss_oracle| %.2e, worst parameter-movement error %.2e of the largest movement"
+              % (losses[0][1], losses[-1][1], max(abs(a - b) for a, b in losses), worst))
+    finally:
+        E.DROPOUT_KEEP = keep
+        E.DETERMINISTIC = False
+        dg.reset()
