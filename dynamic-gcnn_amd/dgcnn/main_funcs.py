@@ -230,66 +230,82 @@ def _gather_rows(h, softmax, idx):
 
 
 def train_loop(flags, h):
+    """main_funcs.py:96-167.  The loss / accuracy of iteration t are read back from the device AFTER iteration t + 1 has been put on
+    the queue (`resolve` below): the host never drains the GPU between two steps, which cost 0.35 ms of a 5.07 ms iteration at
+    configs[1] (profiles/r03_cli_train).  The CSV rows and report lines are the reference's, one iteration late; `titer` is the
+    period of the loop (start of iteration t to start of t + 1 -- in steady state the device time of a step, since each pass
+    blocks on the previous iteration's scalars), `ttrain` that period minus IO / save / summary time."""
     if h.csv_logger:
         h.csv_logger.write(TRAIN_COLUMNS + "\n")
     tsum = dict(iter=0.0, train=0.0, io=0.0, save=0.0, summary=0.0)
-    while h.iteration < int(flags.ITERATION):
-        it = h.iteration
-        stamp = datetime.datetime.fromtimestamp(time.time()).strftime("%Y-%m-%d %H:%M:%S")
-        t_iter = time.time()
-        report = bool(flags.REPORT_STEP) and (it + 1) % flags.REPORT_STEP == 0
-        summarize = bool(getattr(flags, "SUMMARY_STEP", 0)) and h.train_logger is not None and \
-            (it + 1) % flags.SUMMARY_STEP == 0
-        checkpoint = bool(getattr(flags, "CHECKPOINT_STEP", 0)) and bool(getattr(flags, "WEIGHT_PREFIX", "")) and \
-            (it + 1) % flags.CHECKPOINT_STEP == 0                           # main_funcs.py:131: no prefix, no snapshot
 
+    def resolve(p, t_next):
+        """Finish iteration p: scalars to the host (syncs on p's kernels only), summary / CSV / report lines."""
+        it = p["it"]
+        loss, acc = _replica_mean(h, p["losses"]), _replica_mean(h, p["accs"])
         t0 = time.time()
-        idx, data, label, weight = h.data_io.next()
-        t_io = time.time() - t0
-
-        t0 = time.time()
-        losses, accs = [], []
-        h.trainer.zero_gradients(h.sess)
-        micro = list(_micro_batches(flags, h, data, label, weight))
-        for mi, (dv, lv, wv) in enumerate(micro):
-            # (last: the head's gradient bucket may start its all-reduce under this micro-step's EdgeConv backward)
-            res = h.trainer.accum_gradient(h.sess, dv, lv, wv, summary=summarize, last=(mi == len(micro) - 1))
-            accs.append(res[1])
-            losses.append(res[2])
-        h.trainer.apply_gradient(h.sess)
-        loss, acc = _replica_mean(h, losses), _replica_mean(h, accs)     # syncs: ttrain is device time too
-        t_train = time.time() - t0
-
-        t0 = time.time()
-        if summarize:
+        if p["summarize"]:
             h.train_logger.write("%d,%g,%g\n" % (it, acc, loss))
         t_summary = time.time() - t0
-
-        t0 = time.time()
-        if checkpoint:
-            h.weight_io.save(h.trainer, flags.WEIGHT_PREFIX, global_step=it)
-        t_save = time.time() - t0
-
-        epoch = it * float(flags.BATCH_SIZE) / h.data_io.num_entries()
-        t_spent = time.time() - t_iter
-        for k, v in (("iter", t_spent), ("train", t_train), ("io", t_io), ("save", t_save), ("summary", t_summary)):
+        t_spent = t_next - p["t_iter"]
+        t_train = max(t_spent - p["t_io"] - p["t_save"] - t_summary, 0.0)
+        for k, v in (("iter", t_spent), ("train", t_train), ("io", p["t_io"]), ("save", p["t_save"]), ("summary", t_summary)):
             tsum[k] += v
         if h.csv_logger:
             h.csv_logger.write("%d,%g,%g,%g,%g,%g,%g,%g,%g,%g,%g,%g,%g,%g\n" % (
-                it, epoch, t_spent, t_train, t_io, t_save, t_summary,
+                it, p["epoch"], t_spent, t_train, p["t_io"], p["t_save"], t_summary,
                 tsum["iter"], tsum["train"], tsum["io"], tsum["save"], tsum["summary"], loss, acc))
-        if report and h.rank == 0:
+        if p["report"] and h.rank == 0:
             mem = torch.cuda.max_memory_allocated() if torch.cuda.is_available() else 0
             print("Iteration %d (epoch %g) @ %s ... train time fraction %g%% max mem. %g ... loss %g accuracy %g"
-                  % (it, round_decimals(epoch, 2), stamp, round_decimals(t_train / t_spent * 100.0, 2), mem,
+                  % (it, round_decimals(p["epoch"], 2), p["stamp"], round_decimals(t_train / max(t_spent, 1e-12) * 100.0, 2), mem,
                      round_decimals(loss, 4), round_decimals(acc, 4)))
             sys.stdout.flush()
             if h.csv_logger:
                 h.csv_logger.flush()
             if h.train_logger:
                 h.train_logger.flush()
+
+    pending = None
+    while h.iteration < int(flags.ITERATION):
+        it = h.iteration
+        t_iter = time.time()
+        p = dict(it=it, t_iter=t_iter, stamp=datetime.datetime.fromtimestamp(t_iter).strftime("%Y-%m-%d %H:%M:%S"),
+                 report=bool(flags.REPORT_STEP) and (it + 1) % flags.REPORT_STEP == 0,
+                 summarize=bool(getattr(flags, "SUMMARY_STEP", 0)) and h.train_logger is not None and
+                 (it + 1) % flags.SUMMARY_STEP == 0,
+                 epoch=it * float(flags.BATCH_SIZE) / h.data_io.num_entries())
+        checkpoint = bool(getattr(flags, "CHECKPOINT_STEP", 0)) and bool(getattr(flags, "WEIGHT_PREFIX", "")) and \
+            (it + 1) % flags.CHECKPOINT_STEP == 0                           # main_funcs.py:131: no prefix, no snapshot
+
+        t0 = time.time()
+        idx, data, label, weight = h.data_io.next()
+        p["t_io"] = time.time() - t0
+
+        losses, accs = [], []
+        h.trainer.zero_gradients(h.sess)
+        micro = list(_micro_batches(flags, h, data, label, weight))
+        for mi, (dv, lv, wv) in enumerate(micro):
+            # (last: the head's gradient bucket may start its all-reduce under this micro-step's EdgeConv backward)
+            res = h.trainer.accum_gradient(h.sess, dv, lv, wv, summary=p["summarize"], last=(mi == len(micro) - 1))
+            accs.append(res[1])
+            losses.append(res[2])
+        h.trainer.apply_gradient(h.sess)
+        p["losses"], p["accs"] = losses, accs
+
+        # iteration `it` is on the queue: now read back the iteration before it
+        if pending is not None:
+            resolve(pending, t_iter)
+        pending = p
+
+        t0 = time.time()
+        if checkpoint:
+            h.weight_io.save(h.trainer, flags.WEIGHT_PREFIX, global_step=it)      # (copies the state to the host: syncs)
+        p["t_save"] = time.time() - t0
         h.iteration += 1
 
+    if pending is not None:
+        resolve(pending, time.time())
     for f in (h.train_logger, h.csv_logger):
         if f:
             f.close()
