@@ -19,7 +19,7 @@ from . import _hip as H
 ID_BYTES = 128
 
 
-def _exchange_id(rank, world, addr, port, make_id, timeout=180.0):
+def _exchange_id(rank, world, addr, port, make_id, timeout=90.0):
     """rank 0: draw the id, serve it to world - 1 connections; others: connect (with retries) and read it."""
     if rank == 0:
         ident = make_id()
