@@ -635,7 +635,8 @@ def conv_bn_act(x, leaf_scope, num_outputs, relu=True, out=None, out2=None, gbia
             if dout is None:
                 return
             d2 = c.grad(out2) if out2 is not None else None
-            if d2 is not None and (fuse_drop or use_pl or F % 4 != 0 or not BN1_BWD_TWO_SOURCES):
+            # (DETERMINISTIC: unaligned parameter slices send the reduce to the fixed-order twin, which takes one gradient)
+            if d2 is not None and (fuse_drop or use_pl or DETERMINISTIC or F % 4 != 0 or not BN1_BWD_TWO_SOURCES):
                 # the second copy's gradient joins the first (the default passes below read both instead)
                 H.call("dgcnn_copy2d_f32", d2.data_ptr(), H.ld2(d2), dout.data_ptr(), H.ld2(dout), R, F, 1)
                 d2 = None

@@ -97,6 +97,11 @@ class trainval(object):
             if wide:
                 raise ValueError("DETERMINISTIC mode supports at most 1024 filters per layer (csrc/det.hip); too wide: %s"
                                  % ", ".join(wide))
+            # EdgeConv filter counts that are not multiples of 4 send the neighbour gradient through an atomic scatter
+            # (dgcnn_edge_mlp_dgrad_scatter_f32: no float4 rows for the transposed-adjacency sum): not order-independent
+            odd = [n for n, shp in param_specs(f, int(f.NUM_CHANNEL)) if n.endswith("conv0/weights") and shp[1] % 4]
+            if odd:
+                raise ValueError("DETERMINISTIC mode needs EdgeConv filter counts that are multiples of 4; got %s" % ", ".join(odd))
         hp = getattr(f, "HEAD_PLANES", None)             # per instance, like DETERMINISTIC: flag, else the environment default
         if hp is None:
             E.HEAD_PLANES = E.HEAD_PLANES_ENV_DEFAULT

@@ -174,3 +174,24 @@ def test_two_full_size_steps_are_bit_identical(det):
     for a, b in zip(g1, g2):
         assert torch.equal(a, b)
     assert torch.equal(p1, p2)
+
+
+def test_odd_filter_counts_are_refused_in_deterministic_mode(det):
+    """Filter counts that are not multiples of 4 (6, 10) take conv0's edge-level form, whose neighbour gradient is an atomic
+    scatter: the mode says so at initialize() instead of returning sums that depend on the order of the atomics."""
+    f = dgcnn.DGCNN_FLAGS(MODEL_NAME="dgcnn", EDGE_CONV_LAYERS=2, EDGE_CONV_FILTERS=[6, 10], KVALUE=3, FC_LAYERS=2,
+                          FC_FILTERS=[512, 256], NUM_CLASS=2, NUM_CHANNEL=3, TRAIN=True, SEED=2, DETERMINISTIC=True)
+    with pytest.raises(ValueError, match="multiples of 4"):
+        dgcnn.trainval(f).initialize()
+    f.EDGE_CONV_FILTERS = [8, 12]                      # multiples of 4 that are not powers of two: fine, and repeatable
+    rng = np.random.default_rng(5)
+    pts = torch.from_numpy(rng.random((2, 96, 3), dtype=np.float32)).cuda()
+    lab = torch.from_numpy(rng.integers(0, 2, (2, 96)).astype(np.int32)).cuda()
+
+    def run():
+        tv = dgcnn.trainval(f).initialize()
+        tv.zero_gradients(None)
+        tv.accum_gradient(None, [pts], [lab])
+        return dgcnn.ctx().flat_grad.clone()
+    a, b = run(), run()
+    assert torch.equal(a, b) and float(a.abs().sum()) > 0
