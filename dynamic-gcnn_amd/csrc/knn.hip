@@ -449,8 +449,8 @@ __global__ __launch_bounds__(256, (KC <= 20 ? 3 : 2)) void knn_mfma_kernel(const
         for (int e = 0; e < 4; ++e) {
           const int r = 4 * q + e;
           const float tt = si + sv[e];
-          const float tp = 2.0f * acc[r];
-          const float d = tt - tp;
+          // (tt - 2 p in ONE rounding: 2 p is exact, so the fused form equals the oracle's  tt - fl(2 p)  bit for bit)
+          const float d = __builtin_fmaf(-2.0f, acc[r], tt);
           dq[r * 256 + tid] = d;
           mask |= sel_01(m_flt(d, thr)) << r;
         }
