@@ -135,6 +135,105 @@ def self_launch(ngpus):
     return subprocess.call(cmd, env=env)
 
 
+def comm_fields(group, dist, world, per_rank_elapsed, steps, exposed_ms, bucket_elems):
+    """The multi-rank evidence of a bench line (rank 0): how many ranks the gradient all-reduce ran on ACCORDING TO RCCL
+    (ncclCommCount / ncclCommUserRank through dgcnn_comm_info -- not what the launcher said), every rank's own ms/step, and the
+    part of the all-reduce the step had to wait for."""
+    src = None
+    if group is not None:
+        info = group.info()
+        backend, ranks, myrank, src = "rccl (dgcnn_allreduce_f32, own communicator)", info["nranks"], info["rank"], \
+            "ncclCommCount / ncclCommUserRank (dgcnn_comm_info)"
+    elif dist is not None:
+        backend = dist.get_backend()
+        ranks, myrank = (dist.get_world_size(), dist.get_rank()) if backend == "nccl" else (0, 0)
+        src = "torch.distributed (launcher's world size)"
+    else:
+        backend, ranks, myrank = None, None, None
+    ms = [round(t / steps * 1e3, 3) for t in per_rank_elapsed]
+    ar = {"bucket_MB": round(bucket_elems * 4 / 1e6, 2),
+          "exposed_ms_per_step": {"median": round(exposed_ms[len(exposed_ms) // 2], 4), "max": round(exposed_ms[-1], 4),
+                                  "steps": len(exposed_ms)} if exposed_ms else None,
+          "note": "event pair on the step's stream around the all-reduce section of apply_gradient in eager steps right after the "
+                  "timed region: with the own communicator the head bucket (97 % of the bytes) is already travelling when that "
+                  "section starts, so this is the EXPOSED part of the collective (+ the 1/world scale); at N = 1 there is no "
+                  "collective in the step and it reads ~0"}
+    return {"collective_backend": backend, "rccl_ranks": ranks, "rccl_rank": myrank, "rccl_ranks_source": src,
+            "per_rank_ms_per_step": {"min": min(ms), "max": max(ms), "all": ms}, "allreduce": ar}
+
+
+def one_rank_rccl_probe(bucket_elems, iters=20):
+    """N = 1 carries no collective in its step; so that the line still shows what RCCL says on this box, a ONE-rank communicator
+    is created AFTER the timed region through the product path (dlopen, unique id, ncclCommInitRank), asked for its size / rank
+    (dgcnn_comm_info) and timed on the gradient bucket, then destroyed.  None when RCCL is not usable here."""
+    from dgcnn import rccl
+    try:
+        g = rccl.Group(rank=0, world=1)
+    except Exception as e:          # noqa: BLE001
+        return {"error": str(e)[:200]}
+    try:
+        info = g.info()
+        buf = torch.ones(bucket_elems, dtype=torch.float32, device="cuda")
+        g.allreduce_sum_(buf)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            g.allreduce_sum_(buf)
+        torch.cuda.synchronize()
+        info["bucket_allreduce_us"] = round((time.perf_counter() - t0) / iters * 1e6, 1)
+        info["source"] = "ncclCommCount / ncclCommUserRank / ncclCommCuDevice on a one-rank communicator created after the timed region"
+        return info
+    finally:
+        g.destroy()
+
+
+def dry_run(args, rank, world):
+    """No GPU: everything of an N-rank bench run that is NOT the model -- launcher environment, the communicator's rendezvous, the
+    barrier + max-over-ranks timing of exactly K steps, the replica checksum guard, comm_fields, ONE JSON line on rank 0 -- with a
+    stand-in step (a host-side all-reduce of a bucket-sized buffer through the communicator class $DGCNN_BENCH_GROUP names)."""
+    import importlib
+    mod, cls = os.environ["DGCNN_BENCH_GROUP"].split(":")
+    group = getattr(importlib.import_module(mod), cls)(rank=rank, world=world)
+    bucket = torch.full((1797186,), float(rank + 1))
+    state = {"sum": 0.0}
+
+    def step():
+        g = bucket.clone()
+        group.allreduce_sum_(g)                      # every rank must issue the same collectives
+        state["sum"] += float(g[0])
+
+    for _ in range(args.warmup):
+        step()
+    group.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    group.barrier()
+    elapsed = time.perf_counter() - t0
+    allv = group.gather_scalars([elapsed, state["sum"]])
+    per_rank = [float(x) for x in allv[:, 0]]
+    if not bool((allv[:, 1] == allv[0, 1]).all()):
+        raise SystemExit("replicas diverged: checksums differ across ranks")
+    want = (args.steps + args.warmup) * world * (world + 1) / 2.0
+    if abs(state["sum"] - want) > 1e-3:
+        raise SystemExit("stand-in all-reduce returned %r, expected %r" % (state["sum"], want))
+    comm = comm_fields_dry(group, per_rank, args.steps)
+    if rank == 0:
+        print(json.dumps({"metric": "point-clouds/sec fwd+bwd at (B,N,k,C)=(24,2048,20,3), 1/2/4/8 MI355X", "dry_run": True,
+                          "value": None, "unit": "clouds/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": round(max(per_rank) / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+                          "vs_baseline": None, "dtype": "f32", "data": "none (dry run: no model, no GPU)",
+                          "config": dict(comm, workload="dry run", global_batch=world * B, parallelism="dp%d" % world)}))
+    group.destroy()
+    return 0
+
+
+def comm_fields_dry(group, per_rank, steps):
+    f = comm_fields(group, None, group.world, per_rank, steps, [], 1797186)
+    f["collective_backend"] = "stand-in (%s)" % type(group).__name__
+    return f
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -156,6 +255,10 @@ def main():
                          "with sess.run); 0: eager launches; auto (default): a few untimed steps of each during warm-up, then the "
                          "faster mode for the timed region (eager wins on a fast host, replay when the host cannot enqueue "
                          "~150 launches per step as fast as the GPU retires them)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="plumbing check WITHOUT a GPU (tests/test_bench_launch.py): the launch / rendezvous / fence / timing / "
+                         "gather / JSON path of an N-rank run with a stand-in step and the communicator class named by "
+                         "$DGCNN_BENCH_GROUP (module:Class); the line says dry_run and measures nothing")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -168,6 +271,8 @@ def main():
     if args.gpus != world:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: start one rank per GPU (`python bench.py --gpus N` does it itself)"
                          % (args.gpus, world))
+    if args.dry_run:
+        return dry_run(args, rank, world)
     if args.same_device:
         local_rank = 0
     torch.cuda.set_device(local_rank)
@@ -280,20 +385,31 @@ def main():
         step()
     dom = H.TIMER.summary()[dominant]
     H.TIMER = None
+    # ---- the collective, live: event pairs around the part of the all-reduce the step's stream has to WAIT for (the head bucket
+    # travels under the EdgeConv backward; what is left is the exposed cost), same eager steps, after the timed region ----
+    tv._ar_events = []
+    for _ in range(max(args.steps // 4, 3)):
+        step()
+    torch.cuda.synchronize()
+    exposed_ms = sorted(a.elapsed_time(b) for a, b in tv._ar_events)
+    tv._ar_events = None
     tv.use_graph(use_graph)
     loss = float(res[2])
 
     # replicas must hold identical parameters after identical Adam steps on the all-reduced gradient
     chk = torch.stack([dgcnn.ctx().flat_param.double().sum(), dgcnn.ctx().flat_param.double().abs().sum()])
+    per_rank = [elapsed]
     if group is not None:
         allv = group.gather_scalars([elapsed] + [float(x) for x in chk.float()])      # (world, 3)
+        per_rank = [float(x) for x in allv[:, 0]]
         elapsed = float(allv[:, 0].max())
         if not bool((allv[:, 1:] == allv[0, 1:]).all()):
             raise SystemExit("replicas diverged: parameter checksums differ across ranks")
     elif dist is not None:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+        box = [torch.zeros(1, dtype=torch.float64, device="cuda") for _ in range(world)]
+        dist.all_gather(box, torch.tensor([elapsed], dtype=torch.float64, device="cuda"))
+        per_rank = [float(x.item()) for x in box]
+        elapsed = max(per_rank)
         lo, hi = chk.clone(), chk.clone()
         dist.all_reduce(lo, op=dist.ReduceOp.MIN)
         dist.all_reduce(hi, op=dist.ReduceOp.MAX)
@@ -301,11 +417,7 @@ def main():
             raise SystemExit("replicas diverged: parameter checksums differ across ranks")
 
     # the group the gradient all-reduce ran in: backend "nccl" IS RCCL on ROCm (gloo only in the one-device sanity run)
-    if group is not None:
-        coll_backend, rccl_ranks = "rccl (dgcnn_allreduce_f32, own communicator)", group.world
-    else:
-        coll_backend = dist.get_backend() if dist is not None else None
-        rccl_ranks = dist.get_world_size() if (dist is not None and coll_backend == "nccl") else (1 if dist is None else 0)
+    comm = comm_fields(group, dist, world, per_rank, args.steps, exposed_ms, dgcnn.ctx().flat_grad.numel())
     arith_name = {0: "native fp32 MFMA", 6: "exact 3-way bf16 split, 6 partial products on the bf16 MFMA pipe",
                   9: "exact 3-way bf16 split, 9 partial products on the bf16 MFMA pipe"}[H.gemm_arith()]
     if rank == 0:
@@ -404,7 +516,9 @@ def main():
                                    "FC (512,256) + Final, fp32 in/out/accumulate (GEMM arithmetic: %s), dropout on; step = zero-grad + fwd + loss + bwd + "
                                    "(RCCL all-reduce) + Adam" % arith_name,
                        "global_batch": world * B, "points_per_cloud": N, "parallelism": "dp%d" % world,
-                       "collective_backend": coll_backend, "rccl_ranks": rccl_ranks,
+                       "collective_backend": comm["collective_backend"], "rccl_ranks": comm["rccl_ranks"],
+                       "rccl_rank": comm["rccl_rank"], "rccl_ranks_source": comm["rccl_ranks_source"],
+                       "per_rank_ms_per_step": comm["per_rank_ms_per_step"], "allreduce": comm["allreduce"],
                        "final_loss": round(loss, 5), "host_enqueue_ms_per_step": round(t_issue / args.steps * 1e3, 3),
                        "launch_mode": "hip-graph replay" if use_graph else "eager", "launch_mode_calibration": calib},
             "roofline": roof,
@@ -412,6 +526,11 @@ def main():
         }
         if args.deterministic:
             out["config"]["deterministic"] = True
+        if world == 1:
+            probe = one_rank_rccl_probe(dgcnn.ctx().flat_grad.numel())
+            out["config"]["rccl_probe"] = probe
+            if probe and "nranks" in probe:
+                out["config"].update(rccl_ranks=probe["nranks"], rccl_rank=probe["rank"], rccl_ranks_source=probe["source"])
         if world == 1 and not args.no_edgeconv_stack:
             out["edgeconv_stack"] = edgeconv_stack_rate(dgcnn, pts)     # after the timed region; resets the engine context
         if world == 1 and not args.no_cpu_baseline:

@@ -3,6 +3,7 @@
 //   dgcnn_comm_unique_id  rank 0 draws the 128-byte id; the HOST side ships it to the other ranks (dgcnn/rccl.py: a socket on
 //                         MASTER_ADDR:MASTER_PORT + 1 -- no torch.distributed anywhere)
 //   dgcnn_comm_init       ncclCommInitRank (one process per GPU, the device already selected with hipSetDevice)
+//   dgcnn_comm_info       ncclCommCount / ncclCommUserRank / ncclCommCuDevice: the communicator as RCCL sees it
 //   dgcnn_allreduce_f32   in-place SUM all-reduce of a device buffer on the caller's stream (gradients: followed by a 1/world
 //                         scale in the caller's Adam launch); dgcnn_broadcast_f32: rank `root`'s buffer to everyone
 // One communicator serves several streams sequentially; the host orders the calls (a bucket per call).
@@ -25,6 +26,9 @@ struct Api {
   int (*AllReduce)(const void*, void*, size_t, int, int, Comm, hipStream_t) = nullptr;
   int (*Broadcast)(const void*, void*, size_t, int, int, Comm, hipStream_t) = nullptr;
   const char* (*GetErrorString)(int) = nullptr;
+  int (*CommCount)(Comm, int*) = nullptr;
+  int (*CommUserRank)(Comm, int*) = nullptr;
+  int (*CommCuDevice)(Comm, int*) = nullptr;
 } g;
 
 int load_api() {
@@ -47,6 +51,9 @@ int load_api() {
   DG_SYM(AllReduce, "ncclAllReduce")
   DG_SYM(Broadcast, "ncclBroadcast")
   DG_SYM(GetErrorString, "ncclGetErrorString")
+  DG_SYM(CommCount, "ncclCommCount")
+  DG_SYM(CommUserRank, "ncclCommUserRank")
+  DG_SYM(CommCuDevice, "ncclCommCuDevice")
 #undef DG_SYM
   g.lib = h;
   return DGCNN_OK;
@@ -98,4 +105,15 @@ extern "C" int dgcnn_allreduce_f32(float* buf, int64_t count, void* comm, void* 
 extern "C" int dgcnn_broadcast_f32(float* buf, int64_t count, int root, void* comm, void* stream) {
   DG_REQUIRE(buf && comm && count > 0 && root >= 0 && g.lib, DGCNN_EINVAL, "dgcnn_broadcast_f32: bad args");
   return check(g.Broadcast(buf, buf, (size_t)count, kFloat32, root, (Comm)comm, (hipStream_t)stream), "ncclBroadcast");
+}
+
+// What RCCL ITSELF says about the communicator (ncclCommCount / ncclCommUserRank / ncclCommCuDevice) -- not what the launcher
+// claimed: bench.py reports these as config.rccl_ranks / rccl_rank, the evidence that a line at --gpus N ran on N ranks.
+extern "C" int dgcnn_comm_info(void* comm, int* nranks, int* rank, int* device) {
+  DG_REQUIRE(comm && nranks && rank && device && g.lib, DGCNN_EINVAL, "dgcnn_comm_info: bad args (communicator from dgcnn_comm_init)");
+  int rc = check(g.CommCount((Comm)comm, nranks), "ncclCommCount");
+  if (rc) return rc;
+  rc = check(g.CommUserRank((Comm)comm, rank), "ncclCommUserRank");
+  if (rc) return rc;
+  return check(g.CommCuDevice((Comm)comm, device), "ncclCommCuDevice");
 }

@@ -769,6 +769,13 @@ __global__ void colmax_decode_kernel(const unsigned long long* __restrict__ keys
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const unsigned long long k = keys[i];
+  if (k == 0ull) {
+    // no row ever beat the zero-initialised key: every value of the column compared false (NaN).  The pass this epilogue
+    // replaces (dgcnn_global_max_f32) always reports an in-range row: NaN at row 0, so the backward scatters inside the cloud
+    vals[i] = __builtin_nanf("");
+    arg[i] = 0;
+    return;
+  }
   vals[i] = f32_from_ordered((unsigned)(k >> 32));
   arg[i] = (int32_t)(0xffffffffu - (unsigned)(k & 0xffffffffu));
 }

@@ -92,6 +92,7 @@ class Context(object):
         self._rng = None
         self.stat_arena = None
         self.stat_off = 0
+        self.arena_gen = 0               # bumped whenever the statistics arena is (re)allocated
         self.step_seed = 0
         self.seed_dev = None             # device uint64: the dropout seed of the running step (read by the kernels)
         self.capturing = False           # inside a HIP-graph capture: no host-side per-step state may be baked in
@@ -151,13 +152,29 @@ class Context(object):
         n = H.STAT_SLOTS * 2 * F
         want = (1 << 20) if H.STAT_SLOTS <= 32 else (1 << 19) * -(-H.STAT_SLOTS // 32)   # 8 MB at 32 slots, 96 MB at 768
         if self.stat_arena is None or self.stat_arena.device != self.device or self.stat_arena.numel() < want:
+            # a captured HIP graph has the arena's address (and the slot count) baked into its launches: trainval keys its
+            # graphs on arena_key() and drops those recorded against an arena that no longer exists
             self.stat_arena = torch.zeros(want, dtype=torch.float64, device=self.device)
             self.stat_off = 0
+            self.arena_gen += 1
         if self.stat_off + n > self.stat_arena.numel():
             return torch.zeros(n, dtype=torch.float64, device=self.device)
         s = self.stat_arena[self.stat_off:self.stat_off + n]
         self.stat_off += n
         return s
+
+    def arena_key(self):
+        """What a captured step depends on besides its inputs: the statistics arena it zeroes / writes and the slot count its
+        launches carry as arguments."""
+        return (self.arena_gen, H.STAT_SLOTS, 0 if self.stat_arena is None else self.stat_arena.data_ptr())
+
+    def ensure_arena(self, rows):
+        """Slot count and arena for a step over `rows` points, settled OUTSIDE a capture (so that the capture neither allocates
+        the arena inside its private pool nor changes the slot count half way)."""
+        self.configure_slots(rows)
+        off = self.stat_off
+        self.stats(1)
+        self.stat_off = off
 
     def configure_slots(self, rows=0):
         """DETERMINISTIC: every stats / red slot gets a single writer -- as many slots as the producer with the most workgroups has

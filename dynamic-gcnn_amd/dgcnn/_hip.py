@@ -102,6 +102,7 @@ PROTOTYPES = {
     "dgcnn_comm_unique_id": [c_vp],
     "dgcnn_comm_init": [c_int, c_int, c_vp, c_vp],
     "dgcnn_comm_destroy": [c_vp],
+    "dgcnn_comm_info": [c_vp, c_vp, c_vp, c_vp],
     "dgcnn_allreduce_f32": [c_vp, c_i64, c_vp, c_vp],
     "dgcnn_broadcast_f32": [c_vp, c_i64, c_int, c_vp, c_vp],
 }

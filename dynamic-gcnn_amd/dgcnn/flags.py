@@ -47,7 +47,7 @@ _OPTIONS = [
     ("SUMMARY_STEP", "-ss", int, 20, "t", "period (steps) to store a summary line"),
     ("CHECKPOINT_STEP", "-chks", int, 500, "t", "period (steps) to store a snapshot of weights"),
     ("CHECKPOINT_NUM", "-chkn", int, 10, "t", "number of latest checkpoints to keep"),
-    ("CHECKPOINT_HOUR", "-chkh", float, 0.4, "t", "accepted for compatibility; unused"),
+    ("CHECKPOINT_HOUR", "-chkh", float, 0.4, "t", "period (hours) at which a checkpoint leaving the -chkn window is kept for good"),
     ("WEIGHT_KEY", "-wkey", str, "", "tf", "keyword to fetch weight from file"),
     ("USE_GRAPH", "-ug", str, "auto", "ti", "replay the tower as a captured HIP graph: 0 | 1 | auto (launch-bound shapes only)"),
     ("DETERMINISTIC", "-det", _BOOL, None, "ti", "fixed-order BatchNorm sums / sorted adjacency: bit-reproducible runs (slower)"),

@@ -50,18 +50,29 @@ class Saver(object):
     """The slice of tf.train.Saver the loops use (main_funcs.py:83-84,91,183): save with a
     global_step suffix, keep the newest `max_to_keep`, restore by name."""
 
-    def __init__(self, max_to_keep=10):
+    def __init__(self, max_to_keep=10, keep_checkpoint_every_n_hours=0.0, clock=time.time):
+        """keep_checkpoint_every_n_hours (main_funcs.py:82 passes CHECKPOINT_HOUR): as in tf.train.Saver, a checkpoint that
+        falls out of the `max_to_keep` window is KEPT for good when at least that many hours have passed since the last one
+        kept this way (0 / negative: off)."""
         self._keep = int(max_to_keep)
-        self._written = []
+        self._every = float(keep_checkpoint_every_n_hours or 0.0) * 3600.0
+        self._clock = clock
+        self._next_keep = self._clock() + self._every
+        self._written = []            # [(name, time written)] still inside the retention window
+        self.kept_forever = []
 
     def save(self, trainer, prefix, global_step):
         name = trainer.save(prefix, global_step)
         if trainer._rank == 0:
-            self._written.append(name)
+            self._written.append((name, self._clock()))
             while self._keep > 0 and len(self._written) > self._keep:
-                old = self._written.pop(0) + ".npz"
-                if os.path.exists(old):
-                    os.remove(old)
+                old, t_old = self._written.pop(0)
+                if self._every > 0.0 and t_old >= self._next_keep:
+                    self._next_keep = t_old + self._every
+                    self.kept_forever.append(old)
+                    continue
+                if os.path.exists(old + ".npz"):
+                    os.remove(old + ".npz")
             with open(os.path.join(os.path.dirname(name) or ".", "checkpoint"), "w") as f:
                 f.write('model_checkpoint_path: "%s"\n' % os.path.basename(name))
         return name
@@ -132,7 +143,8 @@ def prepare(flags):
 
     h.trainer = trainval(flags)
     h.trainer.initialize()
-    h.weight_io = Saver(max_to_keep=getattr(flags, "CHECKPOINT_NUM", 10))
+    h.weight_io = Saver(max_to_keep=getattr(flags, "CHECKPOINT_NUM", 10),
+                        keep_checkpoint_every_n_hours=getattr(flags, "CHECKPOINT_HOUR", 0.0))
 
     h.iteration = 0
     loaded = 0
@@ -182,11 +194,14 @@ def _micro_batches(flags, h, data, label, weight):
         yield dv, lv, wv
 
 
-def _replica_mean(h, values):
-    """Mean over micro-steps (device scalars, one sync) and over replicas."""
+def _replica_mean(h, values, local_only=False):
+    """Mean over micro-steps (device scalars, one sync) and over replicas (local_only: this replica's mean, no collective --
+    the error path, where the other replicas may not be there to answer)."""
     if not values:
         return -1.0
     t = torch.stack([torch.as_tensor(v, dtype=torch.float32).reshape(()) for v in values]).mean()
+    if local_only:
+        return float(t)
     dist, _, world = parallel.dist_state()
     if world > 1 and parallel.rccl_group() is not None and t.is_cuda:
         t = parallel.rccl_group().allreduce_sum_(t.clone().reshape(1)) / world
@@ -201,7 +216,9 @@ def _gather_rows(h, softmax, idx):
     """Softmax rows of the whole batch on rank 0, in batch order.  Every replica holds the towers of its own shard
     [lo, hi) (main_funcs.py:264-268 stores from the one process the reference has).  The entry indices `idx` must be the
     same on every rank (each rank draws them from an identically seeded source): checked against rank 0's.  Equal-shaped
-    rows travel as ONE device all_gather (RCCL); ragged batches (-np -1 -mbs 1) go through a host object gather."""
+    rows travel as ONE all_gather on the torch.distributed CONTROL-PLANE group (bin/dgcnn.py creates it with gloo next to the
+    RCCL communicator: device tensors are staged through the host there -- output rows are not on the training hot path);
+    ragged batches (-np -1 -mbs 1) go through a host object gather."""
     if h.world == 1:
         return [row for tower in softmax for row in tower.cpu().numpy()]
     dist = parallel.dist_state()[0]
@@ -234,15 +251,17 @@ def train_loop(flags, h):
     the queue (`resolve` below): the host never drains the GPU between two steps, which cost 0.35 ms of a 5.07 ms iteration at
     configs[1] (profiles/r03_cli_train).  The CSV rows and report lines are the reference's, one iteration late; `titer` is the
     period of the loop (start of iteration t to start of t + 1 -- in steady state the device time of a step, since each pass
-    blocks on the previous iteration's scalars), `ttrain` that period minus IO / save / summary time."""
+    blocks on the previous iteration's scalars), `ttrain` that period minus IO / save / summary time.  An iteration that writes a
+    checkpoint is logged at once (never a snapshot without its rows), and the row of the last completed iteration is written
+    even when the loop leaves through an exception."""
     if h.csv_logger:
         h.csv_logger.write(TRAIN_COLUMNS + "\n")
     tsum = dict(iter=0.0, train=0.0, io=0.0, save=0.0, summary=0.0)
 
-    def resolve(p, t_next):
+    def resolve(p, t_next, local_only=False):
         """Finish iteration p: scalars to the host (syncs on p's kernels only), summary / CSV / report lines."""
         it = p["it"]
-        loss, acc = _replica_mean(h, p["losses"]), _replica_mean(h, p["accs"])
+        loss, acc = _replica_mean(h, p["losses"], local_only), _replica_mean(h, p["accs"], local_only)
         t0 = time.time()
         if p["summarize"]:
             h.train_logger.write("%d,%g,%g\n" % (it, acc, loss))
@@ -267,48 +286,62 @@ def train_loop(flags, h):
                 h.train_logger.flush()
 
     pending = None
-    while h.iteration < int(flags.ITERATION):
-        it = h.iteration
-        t_iter = time.time()
-        p = dict(it=it, t_iter=t_iter, stamp=datetime.datetime.fromtimestamp(t_iter).strftime("%Y-%m-%d %H:%M:%S"),
-                 report=bool(flags.REPORT_STEP) and (it + 1) % flags.REPORT_STEP == 0,
-                 summarize=bool(getattr(flags, "SUMMARY_STEP", 0)) and h.train_logger is not None and
-                 (it + 1) % flags.SUMMARY_STEP == 0,
-                 epoch=it * float(flags.BATCH_SIZE) / h.data_io.num_entries())
-        checkpoint = bool(getattr(flags, "CHECKPOINT_STEP", 0)) and bool(getattr(flags, "WEIGHT_PREFIX", "")) and \
-            (it + 1) % flags.CHECKPOINT_STEP == 0                           # main_funcs.py:131: no prefix, no snapshot
+    try:
+        while h.iteration < int(flags.ITERATION):
+            it = h.iteration
+            t_iter = time.time()
+            p = dict(it=it, t_iter=t_iter, stamp=datetime.datetime.fromtimestamp(t_iter).strftime("%Y-%m-%d %H:%M:%S"),
+                     report=bool(flags.REPORT_STEP) and (it + 1) % flags.REPORT_STEP == 0,
+                     summarize=bool(getattr(flags, "SUMMARY_STEP", 0)) and h.train_logger is not None and
+                     (it + 1) % flags.SUMMARY_STEP == 0,
+                     epoch=it * float(flags.BATCH_SIZE) / h.data_io.num_entries(), t_save=0.0)
+            checkpoint = bool(getattr(flags, "CHECKPOINT_STEP", 0)) and bool(getattr(flags, "WEIGHT_PREFIX", "")) and \
+                (it + 1) % flags.CHECKPOINT_STEP == 0                           # main_funcs.py:131: no prefix, no snapshot
 
-        t0 = time.time()
-        idx, data, label, weight = h.data_io.next()
-        p["t_io"] = time.time() - t0
+            t0 = time.time()
+            idx, data, label, weight = h.data_io.next()
+            p["t_io"] = time.time() - t0
 
-        losses, accs = [], []
-        h.trainer.zero_gradients(h.sess)
-        micro = list(_micro_batches(flags, h, data, label, weight))
-        for mi, (dv, lv, wv) in enumerate(micro):
-            # (last: the head's gradient bucket may start its all-reduce under this micro-step's EdgeConv backward)
-            res = h.trainer.accum_gradient(h.sess, dv, lv, wv, summary=p["summarize"], last=(mi == len(micro) - 1))
-            accs.append(res[1])
-            losses.append(res[2])
-        h.trainer.apply_gradient(h.sess)
-        p["losses"], p["accs"] = losses, accs
+            losses, accs = [], []
+            h.trainer.zero_gradients(h.sess)
+            micro = list(_micro_batches(flags, h, data, label, weight))
+            for mi, (dv, lv, wv) in enumerate(micro):
+                # (last: the head's gradient bucket may start its all-reduce under this micro-step's EdgeConv backward)
+                res = h.trainer.accum_gradient(h.sess, dv, lv, wv, summary=p["summarize"], last=(mi == len(micro) - 1))
+                accs.append(res[1])
+                losses.append(res[2])
+            h.trainer.apply_gradient(h.sess)
+            p["losses"], p["accs"] = losses, accs
 
-        # iteration `it` is on the queue: now read back the iteration before it
+            # iteration `it` is on the queue: now read back the iteration before it
+            if pending is not None:
+                done, pending = pending, None
+                resolve(done, t_iter)
+            pending = p
+
+            if checkpoint:
+                # a snapshot is never on disk ahead of its own log rows: the pending iteration (this one) is written first
+                # (the save copies the state to the host and drains the queue anyway)
+                t0 = time.time()
+                h.weight_io.save(h.trainer, flags.WEIGHT_PREFIX, global_step=it)
+                p["t_save"] = time.time() - t0
+                pending = None
+                resolve(p, time.time())
+            h.iteration += 1
         if pending is not None:
-            resolve(pending, t_iter)
-        pending = p
-
-        t0 = time.time()
-        if checkpoint:
-            h.weight_io.save(h.trainer, flags.WEIGHT_PREFIX, global_step=it)      # (copies the state to the host: syncs)
-        p["t_save"] = time.time() - t0
-        h.iteration += 1
-
-    if pending is not None:
-        resolve(pending, time.time())
-    for f in (h.train_logger, h.csv_logger):
-        if f:
-            f.close()
+            done, pending = pending, None
+            resolve(done, time.time())
+    finally:
+        # a step that raised (or an interrupt) must not lose the row of the last COMPLETED iteration; its replica mean is
+        # taken locally -- the other replicas may be gone
+        if pending is not None and "losses" in pending:
+            try:
+                resolve(pending, time.time(), local_only=True)
+            except Exception as e:      # noqa: BLE001 -- (the device may be the reason we are here; never mask the original error)
+                sys.stderr.write("dgcnn: could not write the log row of iteration %d (%s)\n" % (pending["it"], e))
+        for f in (h.train_logger, h.csv_logger):
+            if f:
+                f.close()
     h.data_io.finalize()
 
 

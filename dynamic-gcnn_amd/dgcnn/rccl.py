@@ -81,6 +81,17 @@ class Group(object):
         self._check(self.lib.dgcnn_comm_init(self.world, self.rank, ident, ctypes.byref(comm)), "dgcnn_comm_init")
         self.comm = comm
         self.stream = torch.cuda.Stream(device=self.device)          # collectives run here
+        # what RCCL itself reports for this communicator must match what the launcher said -- checked once, loudly
+        info = self.info()
+        if (info["nranks"], info["rank"]) != (self.world, self.rank):
+            raise H.HipError("RCCL communicator reports rank %d of %d, the launcher said rank %d of %d"
+                             % (info["rank"], info["nranks"], self.rank, self.world))
+
+    def info(self):
+        """{'nranks', 'rank', 'device'} from ncclCommCount / ncclCommUserRank / ncclCommCuDevice (dgcnn_comm_info)."""
+        n, r, d = ctypes.c_int(-1), ctypes.c_int(-1), ctypes.c_int(-1)
+        self._check(self.lib.dgcnn_comm_info(self.comm, ctypes.byref(n), ctypes.byref(r), ctypes.byref(d)), "dgcnn_comm_info")
+        return {"nranks": int(n.value), "rank": int(r.value), "device": int(d.value)}
 
     def _check(self, rc, what):
         if rc != 0:

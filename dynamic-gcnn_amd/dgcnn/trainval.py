@@ -86,6 +86,7 @@ class trainval(object):
                 break
             off += int(np.prod(shape))
         self._head_reduced = False
+        self._ar_events = None        # a list: apply_gradient appends one (start, end) event pair around the exposed part of the all-reduce
         # resolved on EVERY initialize (flag, else the DGCNN_DETERMINISTIC environment default): an instance never inherits
         # the mode of an earlier one.  The switch itself is process-wide, like the GEMM arithmetic.
         det = getattr(f, "DETERMINISTIC", None)
@@ -113,6 +114,11 @@ class trainval(object):
         ug = str(getattr(f, "USE_GRAPH", "0")).lower()
         self._use_graph = "auto" if ug == "auto" else ug in ("1", "true", "yes", "on")
         return self
+
+    def _split_reduce(self):
+        """The gradient bucket is reduced as [head piece, rest piece] on the library's RCCL communicator.  A function of the
+        model and of the group's existence only -- never of a batch's shape -- so that every rank issues the same collectives."""
+        return parallel.rccl_group() is not None and 0 < self._head_off < self._ctx.flat_grad.numel()
 
     @property
     def variables(self):
@@ -190,6 +196,14 @@ class trainval(object):
         key = (tuple(pts.shape), bool(train), lab is not None, wgt is not None, float(E.DROPOUT_KEEP), H.gemm_arith(),
                E.WGRAD_SIDE_STREAM, E.HEAD_PLANES, E.DETERMINISTIC)
         ent = self._graphs.get(key)
+        if ent is not None:
+            # DETERMINISTIC mode grows the slot count (and with it the statistics arena) when a larger cloud arrives: a graph
+            # captured before that replays launches that zero and write the OLD arena -- memory the allocator may have handed
+            # to someone else by now.  Such a graph is dropped and the shape captured again.
+            c.ensure_arena(int(pts.shape[0]) * int(pts.shape[1]))
+            if ent["arena"] != c.arena_key():
+                self._drop_graph(key)
+                ent = None
         if ent is None:
             # first sightings run eagerly (the very first also allocates workspaces / arenas).  A variable-N source
             # (-np -1 -mbs 1) shows thousands of distinct point counts: under "auto" a shape must come back a few times
@@ -219,6 +233,8 @@ class trainval(object):
         c = self._ctx
         ent = {"pts": pts.clone(), "lab": None if lab is None else lab.clone(), "wgt": None if wgt is None else wgt.clone()}
         try:
+            c.ensure_arena(int(pts.shape[0]) * int(pts.shape[1]))
+            ent["arena"] = c.arena_key()
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
             c.capturing = True
@@ -237,12 +253,19 @@ class trainval(object):
             c.side_busy = False
         if ent is not None:
             self._graphs[key] = ent
+            if ent["arena"] != c.arena_key():                    # (cannot happen after ensure_arena; never replay such a graph)
+                self._drop_graph(key)
+                return None
             while len(self._graphs) > GRAPH_CACHE_MAX:           # least recently replayed first; frees its private pool
-                _, old = self._graphs.popitem(last=False)
-                torch.cuda.current_stream().synchronize()        # (a replay of it may still be in flight)
-                old["graph"].reset()
-                old.clear()
+                self._drop_graph(next(iter(self._graphs)))
         return ent
+
+    def _drop_graph(self, key):
+        old = self._graphs.pop(key, None)
+        if old is not None:
+            torch.cuda.current_stream().synchronize()            # (a replay of it may still be in flight)
+            old["graph"].reset()
+            old.clear()
 
     def make_summary(self, sess, data, label, weight):
         if not self._flags.TRAIN:
@@ -277,8 +300,12 @@ class trainval(object):
         T = len(fd["data"])
         c.head_grads_hook = None
         d0 = fd["data"][0]
+        # Whether the head bucket starts early is a LOCAL matter (this rank's shape decides between eager launches and a
+        # replayed graph, which cannot carry the RCCL call); the SEQUENCE of collectives is not: with an RCCL group the bucket
+        # always travels as [head piece, rest piece] (apply_gradient sends whatever the hook did not), so ranks holding clouds
+        # of different sizes (-np -1 -mbs 1) issue identical calls.
         eager = not self._wants_graph(int(d0.shape[0]) * int(d0.shape[1]))       # (a replayed graph cannot carry the RCCL call)
-        if last and T == 1 and eager and parallel.rccl_group() is not None and 0 < self._head_off < c.flat_grad.numel():
+        if last and T == 1 and eager and self._split_reduce():
             def hook():
                 c.join_side()                                   # the head's weight-gradient GEMMs (side stream) have landed
                 self._head_reduced = parallel.allreduce_sum_async(c.flat_grad[self._head_off:])
@@ -312,13 +339,25 @@ class trainval(object):
             raise NotImplementedError
         c = self._ctx
         g = c.flat_grad
-        if self._head_reduced:                                        # the head bucket is already travelling: send the rest, join
+        ev = self._ar_events
+        if ev is not None:            # measurement only (bench.py): how long the step's stream waits for the collective
+            e0 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+        if self._split_reduce():
+            # two pieces, ALWAYS in this order on every rank: head (97 % of the bytes; already travelling when the backward's
+            # hook could start it under the EdgeConv backward), then the rest
+            if not self._head_reduced:
+                parallel.allreduce_sum_async(g[self._head_off:])
             self._head_reduced = False
             parallel.allreduce_sum_async(g[:self._head_off])
             parallel.rccl_group().wait()
             parallel.scale_(g, self._world)
         else:
             parallel.allreduce_mean_(g, self._dist, self._world)      # sum over replicas / world
+        if ev is not None:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()
+            ev.append((e0, e1))
         c.adam_t += 1
         b1, b2, eps = 0.9, 0.999, 1e-8                                # tf.train.AdamOptimizer defaults
         lr_t = self._lr * math.sqrt(1.0 - b2 ** c.adam_t) / (1.0 - b1 ** c.adam_t)

@@ -373,6 +373,8 @@ int dgcnn_adam_f32(float* param, const float* grad, float* m, float* v, int64_t 
 int dgcnn_comm_unique_id(void* id128);
 int dgcnn_comm_init(int world, int rank, const void* id128, void** comm_out);
 int dgcnn_comm_destroy(void* comm);
+/* ranks / this rank / HIP device of the communicator as RCCL reports them (ncclCommCount, ncclCommUserRank, ncclCommCuDevice) */
+int dgcnn_comm_info(void* comm, int* nranks, int* rank, int* device);
 int dgcnn_allreduce_f32(float* buf, int64_t count, void* comm, void* stream);
 int dgcnn_broadcast_f32(float* buf, int64_t count, int root, void* comm, void* stream);
 

@@ -41,3 +41,32 @@ def test_a_bare_gpus_n_invocation_takes_the_self_launch_path(monkeypatch):
         assert e.code == 48
     else:
         raise AssertionError("main() should exit with the launcher's code")
+
+
+def test_gpus_8_end_to_end_with_a_stand_in_communicator():
+    """`python bench.py --gpus 8 --dry-run` from a bare shell, no GPU: self-launch through torch.distributed.run, 8 ranks meet
+    over the product's id rendezvous (rank 0 AND rank 5 arrive late), every rank issues the same collectives, the timed region
+    is fenced by barriers, rank 0 prints ONE JSON line whose rccl_ranks comes from the communicator and which carries every
+    rank's ms/step."""
+    import json
+    import subprocess
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "DGCNN_BENCH_SELF_LAUNCHED"):
+        env.pop(k, None)
+    env["PYTHONPATH"] = os.pathsep.join([ROOT, os.path.join(ROOT, "dynamic-gcnn_amd"), os.path.join(ROOT, "tests")] +
+                                        [p for p in env.get("PYTHONPATH", "").split(os.pathsep) if p])
+    env["DGCNN_BENCH_GROUP"] = "stub_rccl:StubGroup"
+    env["STUB_RCCL_DELAY_RANK0"] = "1.0"
+    env["STUB_RCCL_DELAY_RANK5"] = "2.0"
+    env["OMP_NUM_THREADS"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "4", "--warmup", "1", "--dry-run"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["dry_run"] is True and out["n_gpus"] == 8 and out["steps"] == 4 and out["value"] is None
+    cfg = out["config"]
+    assert cfg["rccl_ranks"] == 8 and cfg["rccl_rank"] == 0 and cfg["parallelism"] == "dp8" and cfg["global_batch"] == 192
+    pr = cfg["per_rank_ms_per_step"]
+    assert len(pr["all"]) == 8 and pr["min"] <= pr["max"] and abs(out["ms_per_step"] - pr["max"]) < 1e-6

@@ -111,3 +111,46 @@ def test_train_loop_runs_on_the_registered_communicator(group, tmp_path, capsys)
     import csv
     rows = list(csv.DictReader(open(tmp_path / "log" / "train_log-0000000.csv")))
     assert len(rows) == 6 and all(np.isfinite(float(r["loss"])) for r in rows)
+
+
+def test_the_communicator_reports_its_own_size_and_rank(group):
+    """bench.py's config.rccl_ranks / rccl_rank come from ncclCommCount / ncclCommUserRank (dgcnn_comm_info), not from the
+    launcher's environment."""
+    info = group.info()
+    assert info["nranks"] == 1 and info["rank"] == 0 and info["device"] == torch.cuda.current_device()
+
+
+def test_collective_sequence_does_not_depend_on_the_batch_shape(group):
+    """Ranks of one job hold clouds of different sizes (-np -1 -mbs 1): one rank replays a captured graph (the backward hook
+    cannot start the head bucket early), another launches eagerly (it can).  Both must issue the SAME collectives: the bucket
+    always travels as [head piece, rest piece] (a rank-local choice between one and two all-reduces deadlocks
+    or corrupts gradients)."""
+    seen = []
+    orig = parallel.allreduce_sum_async
+
+    def spy(t):
+        seen.append(int(t.numel()))
+        return orig(t)
+    parallel.allreduce_sum_async = spy
+    try:
+        per_shape = {}
+        for graph, (B, N) in (("1", (2, 512)), ("0", (2, 512)), ("auto", (1, 16384)), ("auto", (4, 256))):
+            f = _flags()
+            f.USE_GRAPH = graph
+            tv = dgcnn.trainval(f).initialize()
+            rng = np.random.default_rng(1)
+            pts = torch.from_numpy(rng.random((B, N, 3), dtype=np.float32)).cuda()
+            lab = torch.from_numpy(rng.integers(0, 2, (B, N)).astype(np.int32)).cuda()
+            del seen[:]
+            for _ in range(5):                      # (the graph modes capture on the way: sightings, capture, replays)
+                tv.zero_gradients(None)
+                tv.accum_gradient(None, [pts], [lab], last=True)
+                tv.apply_gradient(None)
+            torch.cuda.synchronize()
+            n, off = dgcnn.ctx().flat_grad.numel(), tv._head_off
+            per_shape[(graph, B, N)] = list(seen)
+            assert seen == [n - off, off] * 5, (graph, B, N, seen)
+        assert len({tuple(v) for v in per_shape.values()}) == 1
+    finally:
+        parallel.allreduce_sum_async = orig
+        E.DETERMINISTIC = E.DETERMINISTIC_ENV_DEFAULT

@@ -264,3 +264,33 @@ def test_micro_batches_of_a_ragged_batch():
         list(M._micro_batches(_flags(BATCH_SIZE=4, MINIBATCH_SIZE=2), h, data, label, None))
     same = list(M._micro_batches(_flags(BATCH_SIZE=2, MINIBATCH_SIZE=2), h, [data[0], data[2]], [label[0], label[2]], None))
     assert same[0][0][0].shape == (2, 300, 4)                            # equal N stacks
+
+
+def test_saver_keeps_a_checkpoint_every_n_hours(tmp_path):
+    """tf.train.Saver(max_to_keep, keep_checkpoint_every_n_hours) as main_funcs.py:82-84 builds it: the newest CHECKPOINT_NUM
+    stay; one that leaves that window survives when CHECKPOINT_HOUR hours have passed since the last survivor."""
+    from dgcnn import main_funcs as M
+
+    class FakeTrainer(object):
+        _rank = 0
+
+        def save(self, prefix, step):
+            name = "%s-%d" % (prefix, step)
+            open(name + ".npz", "w").close()
+            return name
+
+    now = [0.0]
+    sv = M.Saver(max_to_keep=2, keep_checkpoint_every_n_hours=1.0, clock=lambda: now[0])
+    prefix = str(tmp_path / "snap")
+    for step in range(8):                       # one checkpoint every 30 minutes
+        now[0] = step * 1800.0
+        sv.save(FakeTrainer(), prefix, step)
+    left = sorted(int(f.name.split("-")[-1][:-4]) for f in tmp_path.iterdir() if f.name.endswith(".npz"))
+    assert left == [2, 4, 6, 7], left            # window {6, 7} + one per hour from the first full hour on
+    assert (tmp_path / "checkpoint").read_text().strip().endswith('snap-7"')
+    sv0 = M.Saver(max_to_keep=2, keep_checkpoint_every_n_hours=0.0, clock=lambda: now[0])
+    prefix = str(tmp_path / "plain")
+    for step in range(5):
+        now[0] += 7200.0
+        sv0.save(FakeTrainer(), prefix, step)
+    assert sorted(f.name for f in tmp_path.iterdir() if f.name.startswith("plain")) == ["plain-3.npz", "plain-4.npz"]
