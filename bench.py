@@ -135,6 +135,22 @@ def self_launch(ngpus):
     return subprocess.call(cmd, env=env)
 
 
+class stdout_to_stderr(object):
+    """RCCL prints a version banner to STDOUT when a communicator comes up; this script's contract is ONE JSON line there.  The
+    library's own communicator handles it inside dgcnn_comm_init; this guards the torch.distributed fallback path."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+        return False
+
+
 def comm_fields(group, dist, world, per_rank_elapsed, steps, exposed_ms, bucket_elems):
     """The multi-rank evidence of a bench line (rank 0): how many ranks the gradient all-reduce ran on ACCORDING TO RCCL
     (ncclCommCount / ncclCommUserRank through dgcnn_comm_info -- not what the launcher said), every rank's own ms/step, and the
@@ -291,11 +307,14 @@ def main():
                 backend = "nccl"
         if group is None:
             import torch.distributed as dist
-            if backend == "nccl":
-                dist.init_process_group(backend="nccl", rank=rank, world_size=world,
-                                        device_id=torch.device("cuda", local_rank))
-            else:
-                dist.init_process_group(backend=backend, rank=rank, world_size=world)
+            with stdout_to_stderr():
+                if backend == "nccl":
+                    dist.init_process_group(backend="nccl", rank=rank, world_size=world,
+                                            device_id=torch.device("cuda", local_rank))
+                    dist.barrier()                     # (RCCL initialises lazily: bring the communicator up inside the guard)
+                    torch.cuda.synchronize()
+                else:
+                    dist.init_process_group(backend=backend, rank=rank, world_size=world)
     flags = make_flags(dgcnn)
     if args.deterministic:
         flags.DETERMINISTIC = True

@@ -9,8 +9,10 @@
 // One communicator serves several streams sequentially; the host orders the calls (a bucket per call).
 #include "common.h"
 #include <dlfcn.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <unistd.h>
 
 namespace {
 
@@ -59,6 +61,24 @@ int load_api() {
   return DGCNN_OK;
 }
 
+// This RCCL build prints a banner ("RCCL version : ...", HIP / ROCm versions, host name, library path) to STDOUT when a
+// communicator is initialised.  A library must not write to its host's stdout (bench.py's contract is ONE JSON line there):
+// while RCCL initialises, file descriptor 1 points at stderr; C stdio is flushed on both sides of the switch.
+struct StdoutToStderr {
+  int saved;
+  StdoutToStderr() {
+    fflush(stdout);
+    saved = dup(1);
+    if (saved >= 0) dup2(2, 1);
+  }
+  ~StdoutToStderr() {
+    fflush(stdout);
+    if (saved >= 0) { dup2(saved, 1); close(saved); }
+  }
+};
+
+bool g_first_collective = true;      // (lazy initialisation inside RCCL may print as well: the first collective is quiet too)
+
 int check(int rc, const char* what) {
   if (rc == 0) return DGCNN_OK;
   dg::set_error("%s: RCCL error %d (%s)", what, rc, g.GetErrorString ? g.GetErrorString(rc) : "?");
@@ -86,7 +106,10 @@ extern "C" int dgcnn_comm_init(int world, int rank, const void* id128, void** co
   UniqueId id;
   memcpy(&id, id128, sizeof(id));
   Comm c = nullptr;
-  rc = check(g.CommInitRank(&c, world, id, rank), "ncclCommInitRank");
+  {
+    StdoutToStderr quiet;
+    rc = check(g.CommInitRank(&c, world, id, rank), "ncclCommInitRank");
+  }
   if (rc) return rc;
   *comm_out = c;
   return DGCNN_OK;
@@ -94,16 +117,27 @@ extern "C" int dgcnn_comm_init(int world, int rank, const void* id128, void** co
 
 extern "C" int dgcnn_comm_destroy(void* comm) {
   if (!comm || !g.lib) return DGCNN_OK;
+  StdoutToStderr quiet;
   return check(g.CommDestroy((Comm)comm), "ncclCommDestroy");
 }
 
 extern "C" int dgcnn_allreduce_f32(float* buf, int64_t count, void* comm, void* stream) {
   DG_REQUIRE(buf && comm && count > 0 && g.lib, DGCNN_EINVAL, "dgcnn_allreduce_f32: bad args (communicator from dgcnn_comm_init)");
+  if (g_first_collective) {
+    g_first_collective = false;
+    StdoutToStderr quiet;
+    return check(g.AllReduce(buf, buf, (size_t)count, kFloat32, kSum, (Comm)comm, (hipStream_t)stream), "ncclAllReduce");
+  }
   return check(g.AllReduce(buf, buf, (size_t)count, kFloat32, kSum, (Comm)comm, (hipStream_t)stream), "ncclAllReduce");
 }
 
 extern "C" int dgcnn_broadcast_f32(float* buf, int64_t count, int root, void* comm, void* stream) {
   DG_REQUIRE(buf && comm && count > 0 && root >= 0 && g.lib, DGCNN_EINVAL, "dgcnn_broadcast_f32: bad args");
+  if (g_first_collective) {
+    g_first_collective = false;
+    StdoutToStderr quiet;
+    return check(g.Broadcast(buf, buf, (size_t)count, kFloat32, root, (Comm)comm, (hipStream_t)stream), "ncclBroadcast");
+  }
   return check(g.Broadcast(buf, buf, (size_t)count, kFloat32, root, (Comm)comm, (hipStream_t)stream), "ncclBroadcast");
 }
 
