@@ -154,3 +154,20 @@ def test_collective_sequence_does_not_depend_on_the_batch_shape(group):
     finally:
         parallel.allreduce_sum_async = orig
         E.DETERMINISTIC = E.DETERMINISTIC_ENV_DEFAULT
+
+
+def test_rccl_start_up_prints_nothing_on_stdout():
+    """RCCL's version banner goes to stdout by default; bench.py's contract is ONE JSON line there.  A fresh process creates a
+    communicator, runs a collective, destroys it: its stdout holds only what the script printed."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, %r); import torch; torch.cuda.set_device(0)\n"
+            "from dgcnn import rccl\n"
+            "g = rccl.Group(rank=0, world=1)\n"
+            "x = torch.ones(1024, device='cuda'); g.allreduce_sum_(x); g.broadcast_(x); torch.cuda.synchronize()\n"
+            "g.destroy(); print('OK %d' % int(x.sum()))\n") % os.path.join(root, "dynamic-gcnn_amd")
+    p = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert p.returncode == 0, p.stderr.decode(errors="replace")[-2000:]
+    assert p.stdout.decode().strip() == "OK 1024", p.stdout.decode()
