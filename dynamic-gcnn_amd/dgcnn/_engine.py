@@ -49,6 +49,11 @@ BN1_BWD_TWO_SOURCES = os.environ.get("DGCNN_BN1_BWD_TWO_SOURCES", "1") != "0"   
 COLMAX_IN_EPILOGUE = os.environ.get("DGCNN_COLMAX_EPILOGUE", "1") != "0"   # the global max-pool comes out of MergedEdgeConv's GEMM epilogue
 EDGE_BWD_REDUCE_POINTS = True   # BN backward sums of conv0 from per-point data (False: a pass over the edges)
 SIDE_STREAM_MIN_ROWS = 16384   # below this many points the side stream is not used
+# conv0 of every EdgeConv layer with bf16 OPERANDS (BASELINE.json configs[2] "bf16 edge-MLP MFMA"): E = [x_i, x_j - x_i] is formed
+# in fp32, E and W0 are rounded to bf16 once, the literal (B*N*k) x 2C x F product runs on v_mfma_f32_32x32x16_bf16 with fp32
+# accumulation; the two gradient products round their operands the same way.  "f32" (default): the fp32-class folded form.
+# trainval.initialize() sets it per instance from flags.EDGE_MLP_DTYPE.
+EDGE_MLP_DTYPE = "f32"
 EDGE_MLP_NBR_GEMM = False  # True: factored conv0 with an edge-level neighbour GEMM instead of point-level GEMM + gather-add
 SCATTER_ATOMICS = False  # True: dx_j += dY W^T by fp32 atomics in the GEMM epilogue (A/B switch)
 # Deterministic mode: run-to-run bit-reproducible results.  The default kernels sum the BatchNorm statistics (forward and the
@@ -853,7 +858,8 @@ def edge_conv_block(x, B, N, k, num_filters, relu1=True, outs=None, net2=None):
         w0name, W0 = c.get_variable("weights", (2 * C, F))
         b0name, beta0 = c.get_variable("BatchNorm/beta", (F,))
     st = c.stats(F)
-    literal = EDGE_MLP_LITERAL
+    bf16 = EDGE_MLP_DTYPE == "bf16"
+    literal = EDGE_MLP_LITERAL or bf16
     gather = (not literal) and (not EDGE_MLP_NBR_GEMM) and F % 4 == 0 and F <= 1024
     # the point-level GEMM [U|V] = X Wcat needs only x: it CAN be issued on the side stream under the k-NN kernel (switch)
     uv_early = gather and UV_UNDER_KNN and WGRAD_SIDE_STREAM and R >= SIDE_STREAM_MIN_ROWS
@@ -865,7 +871,29 @@ def edge_conv_block(x, B, N, k, num_filters, relu1=True, outs=None, net2=None):
     #                                                           (the edge BN passes pack tie / positive counts: k < 256)
     Y = None if virtual else torch.empty((R * k, F), dtype=torch.float32, device=x.device)
     wd = wcat = UV = None
-    if literal:
+    Ee = W0p = None
+    if bf16:
+        # the literal edge tensor, formed in fp32 (the difference x_j - x_i BEFORE any rounding), then ONE product whose operands
+        # the GEMM rounds to bf16 (arith = 1: v_cvt_pk_bf16_f32, round to nearest even) with fp32 accumulation on the bf16 MFMA pipe.
+        # Raw coordinates (C = 3): channels padded to 4 so that the product takes the float4 path (zero columns / zero weight rows)
+        Cp = (C + 3) // 4 * 4
+        xg = x
+        if Cp != C:
+            xg = torch.zeros((R, Cp), dtype=torch.float32, device=x.device)
+            H.call("dgcnn_copy2d_f32", x.data_ptr(), H.ld2(x), xg.data_ptr(), Cp, R, C, 0)
+            W0p = torch.zeros((2 * Cp, F), dtype=torch.float32, device=x.device)
+            H.call("dgcnn_copy2d_f32", W0[:C].data_ptr(), F, W0p[:C].data_ptr(), F, C, F, 0)
+            H.call("dgcnn_copy2d_f32", W0[C:].data_ptr(), F, W0p[Cp:Cp + C].data_ptr(), F, C, F, 0)
+        else:
+            W0p = W0
+        Ee = torch.empty((R * k, 2 * Cp), dtype=torch.float32, device=x.device)
+        H.call("dgcnn_edge_gather_f32", xg.data_ptr(), H.ld2(xg), idx.data_ptr(), B, N, Cp, k, Ee.data_ptr())   # ops.py:21-40
+        gemm(Ee, W0p, Y, stats=None if DETERMINISTIC else st, arith=1)                                          # ops.py:47-52
+        if DETERMINISTIC:
+            colstats_det(Y, st)
+        if not c.recording:
+            Ee = None
+    elif literal:
         H.call("dgcnn_edge_mlp_f32", x.data_ptr(), H.ld2(x), idx.data_ptr(), W0.data_ptr(), B, N, C, k, F,
                Y.data_ptr(), 0 if DETERMINISTIC else st.data_ptr(),
                tag="gemm_kernel<A_EDGE,B_ROW,STORE,%d,%d>" % (_tile_m(R * k, F), 64 if F <= 64 else 128),
@@ -1013,6 +1041,23 @@ def edge_conv_block(x, B, N, k, num_filters, relu1=True, outs=None, net2=None):
                     H.call("dgcnn_edge_wgrad_combine_f32", dwcat.data_ptr(), C, F, dW0.data_ptr())
                 if not WGRAD_AFTER_DGRAD and dx is not None:
                     gemm(dUV, wcat[:C], dx, transB=True, beta=1.0, arith=None)
+                return
+            if bf16:
+                # dW0 = E^T dY and dE = dY W0^T with bf16 operands (the same rounding of E and W0 as the forward, dY rounded once)
+                if W0p is W0:
+                    gemm(Ee, dY, dW0, transA=True, beta=1.0, arith=1)
+                else:
+                    dWp = torch.empty_like(W0p)
+                    gemm(Ee, dY, dWp, transA=True, arith=1)
+                    H.call("dgcnn_copy2d_f32", dWp[:C].data_ptr(), F, dW0[:C].data_ptr(), F, C, F, 1)
+                    H.call("dgcnn_copy2d_f32", dWp[Cp:Cp + C].data_ptr(), F, dW0[C:].data_ptr(), F, C, F, 1)
+                if dx is not None:
+                    dE = torch.empty((R * k, 2 * Cp), dtype=torch.float32, device=x.device)
+                    gemm(dY, W0p, dE, transB=True, arith=1)
+                    if Cp != C:
+                        raise H.HipError("bf16 edge-MLP: an input gradient for a channel count that is not a multiple of 4 "
+                                         "is not implemented (C = %d)" % C)
+                    H.call("dgcnn_edge_gather_bwd_f32", dE.data_ptr(), idx.data_ptr(), B, N, C, k, dx.data_ptr(), H.ld2(dx))
                 return
             if literal:
                 H.call("dgcnn_edge_mlp_wgrad_f32", x.data_ptr(), H.ld2(x), idx.data_ptr(), dY.data_ptr(), B, N, C, k, F,

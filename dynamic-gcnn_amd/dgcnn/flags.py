@@ -51,6 +51,8 @@ _OPTIONS = [
     ("WEIGHT_KEY", "-wkey", str, "", "tf", "keyword to fetch weight from file"),
     ("USE_GRAPH", "-ug", str, "auto", "ti", "replay the tower as a captured HIP graph: 0 | 1 | auto (launch-bound shapes only)"),
     ("DETERMINISTIC", "-det", _BOOL, None, "ti", "fixed-order BatchNorm sums / sorted adjacency: bit-reproducible runs (slower)"),
+    ("EDGE_MLP_DTYPE", "-emd", str, "f32", "ti", "operands of the edge MLP (conv0 of every EdgeConv layer): f32 | bf16 (literal edge-level "
+                                                 "product on the bf16 MFMA pipe, fp32 accumulate: BASELINE configs[2])"),
     ("HEAD_PLANES", "-hp", str, None, "ti", "head GEMMs (MergedEdgeConv, FC*) from operand planes written by the BatchNorm passes: "
                                              "0 | f16 (2 fp16 planes, 3 products) | bf16 (3 bf16 planes, 6 products); default $DGCNN_HEAD_PLANES"),
 ]

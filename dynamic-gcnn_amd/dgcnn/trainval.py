@@ -103,6 +103,12 @@ class trainval(object):
             odd = [n for n, shp in param_specs(f, int(f.NUM_CHANNEL)) if n.endswith("conv0/weights") and shp[1] % 4]
             if odd:
                 raise ValueError("DETERMINISTIC mode needs EdgeConv filter counts that are multiples of 4; got %s" % ", ".join(odd))
+        emd = str(getattr(f, "EDGE_MLP_DTYPE", "f32") or "f32").lower()
+        if emd not in ("f32", "bf16"):
+            raise ValueError("EDGE_MLP_DTYPE must be f32 or bf16, got %r" % (getattr(f, "EDGE_MLP_DTYPE"),))
+        if emd == "bf16" and E.DETERMINISTIC:
+            raise ValueError("EDGE_MLP_DTYPE=bf16 with DETERMINISTIC: the neighbour gradient of the bf16 edge-MLP is an atomic scatter")
+        E.EDGE_MLP_DTYPE = emd                           # per instance, like DETERMINISTIC
         hp = getattr(f, "HEAD_PLANES", None)             # per instance, like DETERMINISTIC: flag, else the environment default
         if hp is None:
             E.HEAD_PLANES = E.HEAD_PLANES_ENV_DEFAULT
@@ -194,7 +200,7 @@ class trainval(object):
     def _tower_graph(self, pts, lab, wgt, train):
         c = self._ctx
         key = (tuple(pts.shape), bool(train), lab is not None, wgt is not None, float(E.DROPOUT_KEEP), H.gemm_arith(),
-               E.WGRAD_SIDE_STREAM, E.HEAD_PLANES, E.DETERMINISTIC)
+               E.WGRAD_SIDE_STREAM, E.HEAD_PLANES, E.DETERMINISTIC, E.EDGE_MLP_DTYPE)
         ent = self._graphs.get(key)
         if ent is not None:
             # DETERMINISTIC mode grows the slot count (and with it the statistics arena) when a larger cloud arrives: a graph

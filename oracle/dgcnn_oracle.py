@@ -182,11 +182,27 @@ def tree_colmean(a):
     return tree_colsum(a) / a.dtype.type(n)
 
 
-def conv_bn_act(x, W, beta, relu=True, eps=BN_EPS):
+def bf16_round(a):
+    """Round every element to the nearest bfloat16 (ties to even) and return it IN THE ARRAY'S OWN DTYPE: the operand
+    rounding of the `bf16 edge-MLP` mode (BASELINE.json configs[2]; what v_cvt_pk_bf16_f32 does on the device).  A float64
+    input goes through float32 first, as it would on the device, where the operands exist in float32 before they are rounded."""
+    f = np.ascontiguousarray(a, np.float32)
+    u = f.view(np.uint32)
+    r = ((u + np.uint32(0x7FFF) + ((u >> np.uint32(16)) & np.uint32(1))) & np.uint32(0xFFFF0000)).view(np.float32)
+    r = np.where(np.isfinite(f), r, f)
+    return r.astype(a.dtype)
+
+
+def conv_bn_act(x, W, beta, relu=True, eps=BN_EPS, operand_round=None):
     """x (..., Cin) @ W (Cin,Cout); BN over all axes but the last with batch statistics
     (biased variance), +beta, no gamma; optional ReLU.  Returns (out, cache).
-    Reductions over the BatchNorm axes: tree_colsum (fold-in-half pairwise, in the working dtype)."""
+    Reductions over the BatchNorm axes: tree_colsum (fold-in-half pairwise, in the working dtype).
+    operand_round: None, or a function applied to BOTH operands of the product (and, in the backward, to the three operands of
+    the two gradient products) before they are multiplied -- products and sums stay in the working dtype.  `bf16_round` makes
+    this the bf16 edge-MLP of BASELINE.json configs[2]: bf16 operands, wide accumulate."""
     dt = x.dtype
+    if operand_round is not None:
+        x, W = operand_round(x), operand_round(W)
     y = np.matmul(x, W)
     mu = tree_colmean(y)
     var = tree_colmean(np.square(y - mu))
@@ -194,7 +210,7 @@ def conv_bn_act(x, W, beta, relu=True, eps=BN_EPS):
     xhat = (y - mu) * rstd
     z = xhat + beta
     out = np.maximum(z, 0) if relu else z
-    return out, dict(x=x, W=W, xhat=xhat, rstd=rstd, out=out, relu=relu)
+    return out, dict(x=x, W=W, xhat=xhat, rstd=rstd, out=out, relu=relu, operand_round=operand_round)
 
 
 def conv_bn_act_bwd(dout, cache):
@@ -205,6 +221,8 @@ def conv_bn_act_bwd(dout, cache):
     m1 = dbeta / dz.dtype.type(dz.size // dz.shape[-1])
     m2 = tree_colmean(dz * xhat)
     dy = rstd * (dz - m1 - xhat * m2)
+    if cache.get("operand_round") is not None:       # (x and W in the cache are the rounded operands of the forward)
+        dy = cache["operand_round"](dy.astype(x.dtype))
     Cin, Cout = W.shape
     dW = np.matmul(x.reshape(-1, Cin).T, dy.reshape(-1, Cout))
     dx = np.matmul(dy, W.T)
@@ -214,13 +232,20 @@ def conv_bn_act_bwd(dout, cache):
 # ----------------------------------------------------------------------------------------
 # dgcnn/ops.py:42-73  edge_conv
 # ----------------------------------------------------------------------------------------
-def edge_conv(point_cloud, k, W0, beta0, W1, beta1, relu1=True, idx=None):
+def edge_conv(point_cloud, k, W0, beta0, W1, beta1, relu1=True, idx=None, edge_mlp_dtype="f32"):
     """Returns ([net_max, net_mean, net], cache), each (B,N,1,ch) as ops.py:73.
-    `idx` may be forced (tests feed the HIP path's own indices for layers >= 1)."""
+    `idx` may be forced (tests feed the HIP path's own indices for layers >= 1).
+    edge_mlp_dtype = "bf16" (BASELINE.json configs[2] "bf16 edge-MLP MFMA"; the reference itself has no such switch -- TF1
+    computes conv0 in float32): the operands of conv0's product, E = [x_i, x_j - x_i] (formed in the working dtype FIRST)
+    and W0, are rounded to bfloat16 once; accumulation, BatchNorm and everything else stay in the working dtype; the two
+    gradient products of conv0 round their operands (dy, E, W0) the same way.  conv1 is not part of the edge MLP."""
     if idx is None:
         idx = k_nn(point_cloud, k)
+    if edge_mlp_dtype not in ("f32", "bf16"):
+        raise ValueError("edge_mlp_dtype must be f32 or bf16, got %r" % (edge_mlp_dtype,))
     E = edges(point_cloud, k, idx)                                       # ops.py:45
-    y, c0 = conv_bn_act(E, W0, beta0, relu=True)                         # ops.py:47-54
+    y, c0 = conv_bn_act(E, W0, beta0, relu=True,                         # ops.py:47-54
+                        operand_round=bf16_round if edge_mlp_dtype == "bf16" else None)
     net_max = y.max(axis=-2, keepdims=True)                              # ops.py:56
     net_mean = y.mean(axis=-2, keepdims=True, dtype=y.dtype)             # ops.py:57
     cat = np.concatenate([net_max, net_mean], axis=-1)                   # ops.py:58
@@ -326,7 +351,8 @@ def model_forward(point_cloud, flags, params, idx_list=None, dropout_mask=None):
         relu1 = not (residual and shortcut is not None)                      # ops.py:123 activation=None
         outs, c = edge_conv(net, kv[i], P[s + "conv0/weights"], P[s + "conv0/BatchNorm/beta"],
                             P[s + "conv1/weights"], P[s + "conv1/BatchNorm/beta"], relu1=relu1,
-                            idx=None if idx_list is None else idx_list[i])
+                            idx=None if idx_list is None else idx_list[i],
+                            edge_mlp_dtype=str(getattr(flags, "EDGE_MLP_DTYPE", "f32")))
         rec = dict(ec=c, sc=None, pre=None)
         if residual and shortcut is not None:
             sc_in = shortcut
@@ -481,6 +507,7 @@ class Flags(object):
     MINIBATCH_SIZE = 1
     NUM_CHANNEL = 3
     WEIGHT_KEY = ""
+    EDGE_MLP_DTYPE = "f32"
 
     def __init__(self, **kw):
         for k, v in kw.items():

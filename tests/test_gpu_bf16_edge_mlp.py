@@ -1,0 +1,163 @@
+"""EDGE_MLP_DTYPE='bf16' -- BASELINE.json configs[2] in its named mode ("bf16 edge-MLP MFMA"): conv0 of every EdgeConv layer as the
+literal (B*N*k) x 2C x F product with bf16 OPERANDS (E = [x_i, x_j - x_i] formed in fp32 first, E and W0 rounded once, RNE) and
+fp32 accumulation on v_mfma_f32_32x32x16_bf16; the two gradient products round their operands the same way.
+
+The checker is the oracle IN THE SAME MODE (oracle.edge_conv(edge_mlp_dtype='bf16'): operands through oracle.bf16_round,
+products and sums in float64): with operands that are exactly representable the only difference left is the accumulation
+order, so the bars are the fp32 ones (1e-3 on the logits).  The distance to the UNROUNDED fp64 twin -- what the rounding itself
+costs -- is printed, not asserted (it is a property of the mode, 2^-9 per operand, not of the implementation)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import dgcnn_oracle as O
+from gpu_helpers import capture_layers, dev, host, run_model, set_vars
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture()
+def dg():
+    import dgcnn
+    from dgcnn import _engine as E
+    dgcnn.reset()
+    yield dgcnn
+    E.EDGE_MLP_DTYPE = "f32"
+    dgcnn.reset()
+
+
+@pytest.mark.parametrize("B,N,C,k,F", [(2, 64, 3, 5, 8), (2, 128, 64, 20, 64), (1, 96, 4, 7, 128), (2, 64, 64, 10, 32)])
+def test_edge_conv_bf16_forward_backward(dg, B, N, C, k, F):
+    """One edge_conv block in bf16 mode against the oracle in bf16 mode (same graph): [max, mean, net] within 1e-4 and the
+    gradients w.r.t. X (C % 4 == 0), W0, beta0, W1, beta1 within 2e-3 -- the bars of the fp32 block test
+    (test_gpu_parity.py::test_edge_conv_forward_backward)."""
+    from dgcnn import _engine as E
+    E.EDGE_MLP_DTYPE = "bf16"
+    rng = np.random.default_rng(C * 10 + F)
+    pts = rng.random((B, N, C), dtype=np.float32)
+    P = {"conv0/weights": rng.normal(0, 0.5, (2 * C, F)).astype(np.float32),
+         "conv0/BatchNorm/beta": rng.normal(0, 0.3, F).astype(np.float32),
+         "conv1/weights": rng.normal(0, 0.3, (2 * F, 64)).astype(np.float32),
+         "conv1/BatchNorm/beta": rng.normal(0, 0.3, 64).astype(np.float32)}
+    c = dg.ctx()
+    c.begin_step()
+    c.recording = True
+    want_dx = C % 4 == 0
+    if want_dx:
+        x = c.new_buffer(B * N, C)
+    else:
+        x = torch.empty((B * N, C), dtype=torch.float32, device="cuda")     # raw coordinates: nobody wants d(points)
+    x.copy_(dev(pts.reshape(B * N, C)))
+    for n, v in P.items():
+        c.get_variable(n, v.shape)
+    set_vars(dg, P)
+    outs = dg.ops.edge_conv(x.view(B, N, C), k, F, True)
+    idx = host(dg.ops.edge_conv.last_idx)
+    np.testing.assert_array_equal(idx, O.k_nn(pts, k))
+
+    P64 = [P[n].astype(np.float64) for n in P]
+    ref, cache = O.edge_conv(pts.astype(np.float64), k, *P64, idx=idx, edge_mlp_dtype="bf16")
+    plain, _ = O.edge_conv(pts.astype(np.float64), k, *P64, idx=idx)
+    for name, a, b, p in zip(("max", "mean", "net"), outs, ref, plain):
+        print("%s: max |HIP bf16 - oracle bf16| %.2e;  |oracle bf16 - oracle f32-operands| %.2e (what the mode costs)"
+              % (name, np.abs(host(a) - b).max(), np.abs(b - p).max()))
+        np.testing.assert_allclose(host(a), b, rtol=1e-4, atol=1e-4, err_msg=name)
+    assert np.abs(ref[0] - plain[0]).max() > 1e-4              # the mode IS different arithmetic: the test would notice fp32 operands
+
+    d = [rng.normal(size=r.shape) for r in ref]
+    for t, g in zip(outs, d):
+        v, _, _ = E.as2d(t)
+        c.grad(v).copy_(dev(g.reshape(B * N, -1).astype(np.float32)))
+    c.backward()
+    dx_ref, g_ref = O.edge_conv_bwd(d[0], d[1], d[2], cache)
+    scale = lambda r: 2e-3 * max(1.0, float(np.abs(r).max()))
+    if want_dx:
+        np.testing.assert_allclose(host(c.grad(x)).reshape(B, N, C), dx_ref, rtol=2e-3, atol=scale(dx_ref), err_msg="dx")
+    for n, key in (("conv0/weights", "W0"), ("conv0/BatchNorm/beta", "beta0"), ("conv1/weights", "W1"),
+                   ("conv1/BatchNorm/beta", "beta1")):
+        np.testing.assert_allclose(host(c.var_grads[n]), g_ref[key], rtol=2e-3, atol=scale(g_ref[key]), err_msg=n)
+
+
+def config2_flags(dg, train, emd="bf16"):
+    return dg.DGCNN_FLAGS(MODEL_NAME="residual-dgcnn", EDGE_CONV_LAYERS=6, EDGE_CONV_FILTERS=64, FC_LAYERS=2,
+                          FC_FILTERS=[512, 256], NUM_CLASS=2, KVALUE=40, NUM_CHANNEL=3, TRAIN=train, EDGE_MLP_DTYPE=emd)
+
+
+def test_config2_architecture_logits_n2048_bf16(dg):
+    """configs[2] architecture (residual-dgcnn, 6 x 64, k = 40) at B=2, N=2048 in its named mode: every layer's graph bit-exact
+    against the C oracle on the layer's actual input, logits within 1e-3 of the float64 oracle IN THE SAME MODE fed the same
+    graphs.  Printed: the distance to the fp32-operand twin (the price of bf16 operands through six BatchNorm'ed layers)."""
+    B, N, C, L = 2, 2048, 3, 6
+    flags = config2_flags(dg, train=False)
+    rng = np.random.default_rng(2)
+    pts = rng.random((B, N, C), dtype=np.float32)
+    params = O.init_params(flags, C, seed=3)
+    for n in params:
+        if n.endswith("beta"):
+            params[n] = rng.normal(0, 0.2, params[n].shape).astype(np.float32)
+    dg.trainval(flags).initialize()
+    from dgcnn import _engine as E
+    assert E.EDGE_MLP_DTYPE == "bf16"
+    set_vars(dg, params)
+    dg.ctx().begin_step()
+    with capture_layers() as capl:
+        logits = host(dg.build(dev(pts), flags))
+    idx_list = []
+    for i in range(L):
+        xin, idx = capl.layers["EdgeConv%d" % i]
+        np.testing.assert_array_equal(idx, O.k_nn(xin, 40), err_msg="layer %d" % i)
+        idx_list.append(idx)
+    p64 = {n: v.astype(np.float64) for n, v in params.items()}
+    ref, _ = O.model_forward(pts.astype(np.float64), flags, p64, idx_list=idx_list)
+    f32flags = config2_flags(dg, train=False, emd="f32")
+    plain, _ = O.model_forward(pts.astype(np.float64), f32flags, p64, idx_list=idx_list)
+    e = np.abs(logits - ref)
+    print("configs[2] architecture, bf16 edge-MLP, same graphs: logits max|HIP - fp64 oracle (bf16 mode)| %.3e (mean %.1e); "
+          "bf16-mode oracle vs fp32-operand twin: max %.3e mean %.1e" % (e.max(), e.mean(), np.abs(ref - plain).max(),
+                                                                         np.abs(ref - plain).mean()))
+    np.testing.assert_allclose(logits, ref, rtol=0, atol=1e-3)
+
+
+def test_model_gradients_bf16_small(dg):
+    """A small residual model (3 layers, k = 10, N = 256) trained one micro-step in bf16 mode: loss and every gradient tensor
+    against the float64 oracle in the same mode on the HIP path's graphs."""
+    from dgcnn import _engine as E
+    B, N, C = 2, 256, 4
+    flags = dg.DGCNN_FLAGS(MODEL_NAME="residual-dgcnn", EDGE_CONV_LAYERS=3, EDGE_CONV_FILTERS=64, FC_LAYERS=2, FC_FILTERS=[128, 64],
+                           NUM_CLASS=3, KVALUE=10, NUM_CHANNEL=C, TRAIN=True, EDGE_MLP_DTYPE="bf16")
+    rng = np.random.default_rng(5)
+    pts = rng.random((B, N, C), dtype=np.float32)
+    labels = rng.integers(0, 3, (B, N)).astype(np.int32)
+    params = O.init_params(flags, C, seed=2)
+    keep, E.DROPOUT_KEEP = E.DROPOUT_KEEP, 1.0
+    try:
+        tv, res, cap = run_model(dg, flags, dev(pts), params, train=True, labels=dev(labels))
+    finally:
+        E.DROPOUT_KEEP = keep
+    idx_list = [cap["EdgeConv%d" % i][1] for i in range(3)]
+    p64 = {n: v.astype(np.float64) for n, v in params.items()}
+    G, loss, _, _ = O.train_step_grads(pts.astype(np.float64), labels, flags, p64, idx_list=idx_list)
+    assert abs(float(res[2]) - float(loss)) < 1e-4
+    rel = lambda a, b: np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30)
+    r = {n: rel(host(tv.gradients[n]).astype(np.float64), G[n]) for n in params}
+    print("bf16 edge-MLP, small residual model: worst relative Frobenius gradient error vs the fp64 oracle in the same mode %.2e (%s)"
+          % (max(r.values()), max(r, key=r.get)))
+    assert max(r.values()) < 2e-2, r
+
+
+def test_config2_full_size_property_run_bf16(dg):
+    """configs[2] at FULL size (B=8, N=16384, k=40, residual-dgcnn x 6) in its named mode, one training step: finite loss near
+    ln 2, finite non-zero gradients for every variable, k-NN lists bit-exact on seeded rows, Adam step finite."""
+    from test_gpu_baseline_sizes import _full_size_property_run
+    torch.cuda.reset_peak_memory_stats()
+    loss = _full_size_property_run(dg, config2_flags(dg, train=True), B=8, N=16384, k=40, L=6, nrows=256, seed=43)
+    print("configs[2] full size, bf16 edge-MLP: loss %.5f, peak HBM %.1f GB" % (loss, torch.cuda.max_memory_allocated() / 2 ** 30))
+
+
+def test_bf16_mode_is_refused_with_deterministic_and_bad_values(dg):
+    with pytest.raises(ValueError):
+        dg.trainval(dg.DGCNN_FLAGS(EDGE_MLP_DTYPE="fp8")).initialize()
+    with pytest.raises(ValueError):
+        dg.trainval(dg.DGCNN_FLAGS(EDGE_MLP_DTYPE="bf16", DETERMINISTIC=True)).initialize()
+    from dgcnn import _engine as E
+    E.DETERMINISTIC = E.DETERMINISTIC_ENV_DEFAULT
