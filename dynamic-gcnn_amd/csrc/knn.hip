@@ -13,8 +13,7 @@
 // conflicts); each lane keeps a private sorted (d, j) list of KC entries in registers and inserts
 // with a branch-free v_med3/v_cndmask network, skipped wave-uniformly when no lane improves.
 // The four per-wave lists are merged through LDS at the end.  The (B,N,N) matrix never exists.
-#include "common.h"
-#include <math.h>
+#include "knn_common.h"
 #include <stdlib.h>
 
 namespace {
@@ -51,33 +50,6 @@ __global__ __launch_bounds__(256) void sqnorm_kernel(const float* __restrict__ x
   }
 }
 
-// ---- lane-mask helpers.  hipcc turns nested ?: on register arrays into exec-masked branches (20
-// s_and_saveexec/s_cbranch per insert, measured 10x slower); v_cmp -> SGPR-pair mask -> v_cndmask
-// is forced with the fcmp/icmp builtins and a one-instruction asm select.
-typedef unsigned long long lmask_t;
-__device__ __forceinline__ lmask_t m_flt(float a, float b) { return __builtin_amdgcn_fcmpf(a, b, 4); }   // a <  b (ordered)
-__device__ __forceinline__ lmask_t m_feq(float a, float b) { return __builtin_amdgcn_fcmpf(a, b, 1); }   // a == b
-__device__ __forceinline__ lmask_t m_ilt(int a, int b) { return __builtin_amdgcn_sicmp(a, b, 40); }      // a <  b (signed)
-__device__ __forceinline__ lmask_t m_ine(int a, int b) { return __builtin_amdgcn_sicmp(a, b, 33); }      // a != b
-__device__ __forceinline__ float sel_f(lmask_t m, float t, float f) {
-  float r;
-  asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(f), "v"(t), "s"(m));
-  return r;
-}
-__device__ __forceinline__ int sel_i(lmask_t m, int t, int f) {
-  int r;
-  asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(f), "v"(t), "s"(m));
-  return r;
-}
-
-// smallest float greater than f (f finite or +inf; -0 counts as +0): d <= f  <=>  d < next_up(f)
-__device__ __forceinline__ float next_up(float f) {
-  const float g = f + 0.0f;
-  const unsigned u = __float_as_uint(g);
-  const unsigned v = (g >= 0.0f) ? u + 1u : u - 1u;
-  return (g == INFINITY) ? g : __uint_as_float(v);
-}
-
 #ifndef KNN_SHARE
 #define KNN_SHARE 1      // MFMA kernel; 0: every list filters with its own k-th distance only (A/B switch, profiles/r02/knn_experiments.txt)
 #endif
@@ -95,35 +67,6 @@ __device__ __forceinline__ float next_up(float f) {
 // filter  d < min(own k-th, next_up(tau)).  tau is about the row's GLOBAL k-th distance (the KC/4-th best of a quarter
 // of the candidates), where a list's own k-th is about the global 4k-th: ~2.5x fewer inserts.  The lists publish
 // list_i[KC/4 - 1] in LDS after every drain; a stale (older = larger) value only makes the filter looser.
-// lane mask -> 0 / 1 with inline constants (sel_i would park its two constants in VGPRs)
-__device__ __forceinline__ unsigned sel_01(lmask_t m) {
-  unsigned r;
-  asm("v_cndmask_b32_e64 %0, 0, 1, %1" : "=v"(r) : "s"(m));
-  return r;
-}
-
-template <bool LEX>
-__device__ __forceinline__ lmask_t key_less(float d, int j, float dt, int jt) {
-  return LEX ? (m_flt(d, dt) | (m_feq(d, dt) & m_ilt(j, jt))) : m_flt(d, dt);
-}
-
-// Branch-free sorted insert of (d, j) into an ascending list held in registers: per slot one
-// v_cmp, one v_med3_f32 (new dl[t] = clamp(d, dl[t-1], dl[t])) and two v_cndmask for the index.
-// A lane whose (d, j) is not smaller than its last entry is left unchanged (d = +inf is a no-op).
-template <int KC, bool LEX>
-__device__ __forceinline__ void list_insert(float (&dl)[KC], int (&jl)[KC], float d, int j) {
-  lmask_t ct = key_less<LEX>(d, j, dl[KC - 1], jl[KC - 1]);
-#pragma unroll
-  for (int t = KC - 1; t >= 1; --t) {
-    const lmask_t cp = key_less<LEX>(d, j, dl[t - 1], jl[t - 1]);
-    dl[t] = __builtin_amdgcn_fmed3f(dl[t - 1], d, dl[t]);
-    jl[t] = sel_i(ct, sel_i(cp, jl[t - 1], j), jl[t]);
-    ct = cp;
-  }
-  dl[0] = sel_f(ct, d, dl[0]);
-  jl[0] = sel_i(ct, j, jl[0]);
-}
-
 // Register budget: x_i (CP) + list (2*KC) + ~70 for the candidate stream -> waves/SIMD target.
 template <int CP, int KC>
 constexpr int knn_min_waves() {
@@ -863,20 +806,40 @@ extern "C" int dgcnn_knn_bf16_filter(int mode) {   // A/B switch (tests): 0 neve
   return prev;
 }
 
-extern "C" int dgcnn_knn_workspace_bytes(int B, int N) { return (int)sizeof(float) * B * N; }
+namespace dg {
+size_t knn_grid_workspace_bytes(int B, int N);
+bool knn_grid_applicable(int C, int k);
+int launch_knn_grid(const float* x, const float* sq, int B, int N, int C, int64_t ldx, int k, int32_t* idx, void* ws, hipStream_t st);
+}  // namespace dg
+
+// workspace = [s_i of every row (B*N floats, padded to 256 bytes) | scratch of the cell-grid search (C <= 4, k <= 40)]
+static size_t knn_sq_bytes(int B, int N) { return (((size_t)B * (size_t)N * sizeof(float)) + 255) & ~(size_t)255; }
+
+extern "C" int64_t dgcnn_knn_workspace_bytes(int B, int N, int C, int k) {
+  if (B <= 0 || N <= 0) return 0;
+  size_t n = knn_sq_bytes(B, N);
+  if (dg::knn_grid_applicable(C, k)) n += dg::knn_grid_workspace_bytes(B, N);
+  return (int64_t)n;
+}
 
 extern "C" int dgcnn_knn_f32(const float* x, int B, int N, int C, int64_t ldx, int k, int32_t* idx,
-                             float* sq_ws, void* stream) {
-  DG_REQUIRE(x && idx && sq_ws, DGCNN_EINVAL, "dgcnn_knn_f32: null pointer");
+                             void* ws, size_t ws_bytes, void* stream) {
+  DG_REQUIRE(x && idx && ws, DGCNN_EINVAL, "dgcnn_knn_f32: null pointer");
   DG_REQUIRE(B > 0 && N > 0 && C > 0 && ldx >= C, DGCNN_EINVAL, "dgcnn_knn_f32: bad shape B=%d N=%d C=%d", B, N, C);
   DG_REQUIRE(k > 0 && k <= N, DGCNN_EINVAL,
              "dgcnn_knn_f32: k=%d must be in [1, N=%d] (tf.nn.top_k raises otherwise)", k, N);
   DG_REQUIRE(k <= 64, DGCNN_EUNSUP, "dgcnn_knn_f32: k=%d > 64 unsupported", k);
   DG_REQUIRE(C <= 128, DGCNN_EUNSUP, "dgcnn_knn_f32: C=%d > 128 unsupported", C);
+  DG_REQUIRE((reinterpret_cast<uintptr_t>(ws) & 15) == 0 && ws_bytes >= knn_sq_bytes(B, N), DGCNN_EINVAL,
+             "dgcnn_knn_f32: workspace must be 16-byte aligned and hold dgcnn_knn_workspace_bytes(B, N, C, k) bytes (got %zu)", ws_bytes);
   hipStream_t st = (hipStream_t)stream;
+  float* sq_ws = reinterpret_cast<float*>(ws);
   const int64_t rows = (int64_t)B * N;
   hipLaunchKernelGGL(sqnorm_kernel, dim3((unsigned)dg::cdiv(rows, SQ_ROWS)), dim3(256), sizeof(float) * SQ_ROWS * (C + 1), st, x,
                      ldx, rows, C, sq_ws);
+  // raw coordinates (C <= 4): exact search over a uniform cell grid (knn_grid.hip) when the caller provided its scratch
+  if (dg::knn_grid_applicable(C, k) && !knn_force_valu() && ws_bytes >= knn_sq_bytes(B, N) + dg::knn_grid_workspace_bytes(B, N))
+    return dg::launch_knn_grid(x, sq_ws, B, N, C, ldx, k, idx, reinterpret_cast<char*>(ws) + knn_sq_bytes(B, N), st);
   const int vec_ok = (ldx % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
   if (C <= 4) return dispatch_k<4>(x, sq_ws, B, N, C, ldx, k, vec_ok, idx, st);
   if (C <= 16) return dispatch_k<16>(x, sq_ws, B, N, C, ldx, k, vec_ok, idx, st);

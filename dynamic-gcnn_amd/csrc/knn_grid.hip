@@ -1,0 +1,368 @@
+// knn_grid.hip -- K1 for low-dimensional clouds (C <= 4: the raw-coordinate layer of dgcnn/ops.py:8-19, points (x, y, z[, v])):
+// the SAME k smallest (D_ij, j) as the brute-force kernels (knn.hip) and oracle/knn_oracle.c, bit for bit, without looking at
+// all N candidates of a row.
+//
+//   s_i  = sequential sum of fl(x*x)     p_ij = fmaf chain over c ascending from +0     D_ij = fl( fl(s_i + s_j) - 2 p_ij )
+//
+// (-ffp-contract=off; the arithmetic per PAIR is exactly the brute-force kernel's, so a pair's D has the same bits whichever
+// kernel evaluates it.)  What changes is WHICH pairs are evaluated:
+//
+//   build  (one 1024-thread block per cloud) bounding box of the first min(C, 3) coordinates, a uniform G^3 grid over it
+//          (G^3 <= 4096 bins: histogram, scan and cursors in LDS), counting sort of the points by cell -- z fastest, so the cells
+//          of a z column are one contiguous run of the sorted array.  Sorted records: (x, y, z, s_j) (C <= 3) or (x, y, z, v) + s_j.
+//   query  (one wave per 64 consecutive SORTED points = neighbouring cells) every lane owns one query and walks the shells of
+//          cells around its own cell: ring r = all cells within r of the own cell in every axis.  Candidates that may still enter
+//          the lane's register-resident sorted (d, j) list are parked in LDS and drained by branch-free lexicographic inserts
+//          (knn_common.h), all lanes together.  After ring r a lane is DONE when its k-th distance so far is smaller than
+//          anything an unvisited point can have:
+//              every unvisited point differs from the query by at least `gap` cells in some axis, so its true squared distance is
+//              >= (gap * h)^2;  the computed D_ij is within  (2C + 4) u (s_i + s_j)  of the true value (u = 2^-24: C products and
+//              C + 1 additions in s, C fused steps in p, two additions in D), the computed cell coordinate within 2.1 u * 2 G of
+//              the true one.  With slack for all of that the test is
+//                   kth < (max(0, gap - 1e-5) * h * (1 - 1e-6))^2 * (1 - 1e-6)  -  1e-6 (s_i + max_j s_j)
+//          -- conservative, never tight: a lane that cannot prove it keeps walking (up to the whole grid = brute force: duplicate
+//          points, clouds far from the origin, non-finite coordinates cost time, never correctness; a NaN makes every comparison
+//          of the test false).
+// Work per query at uniform density: the grid is sized for ~0.8 k points per cell, so ring 1 (27 cells, ~22 k candidates) decides
+// almost every query: 432 pair evaluations instead of 2048 at (24, 2048, 3, 20), 864 instead of 16384 / 65536 at k = 40.
+#include "knn_common.h"
+#include <stdlib.h>
+
+namespace {
+
+constexpr int GMAX = 16;                 // cells per axis (G^3 <= 4096 LDS bins)
+constexpr int PARK = 32;                 // parked candidates per lane between two drains
+constexpr int UNR = 4;                   // candidates a lane looks at per wave iteration (loads in flight)
+
+struct GridInfo {                        // one per cloud (64 bytes)
+  float mn[3];                           // lower corner of the bounding box
+  float ih[3];                           // cells per unit length; 0 = the axis has a single cell (flat / non-finite / unused axis)
+  float h[3];                            // (1 / ih) * (1 - 1e-6): a lower bound of the cell size
+  float smax;                            // max_j s_j
+  int G;
+  int pad[5];
+};
+
+__device__ __forceinline__ int cell_axis(float x, float mn, float ih, int G) {
+  const float t = (x - mn) * ih;         // two roundings (contraction is off for the whole library)
+  int c = (int)t;                        // NaN -> 0, out of range saturates
+  c = c < 0 ? 0 : c;
+  return c > G - 1 ? G - 1 : c;
+}
+
+__device__ __forceinline__ float wave_min(float v) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) v = fminf(v, __shfl_xor(v, o));
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+
+__global__ __launch_bounds__(1024) void knn_grid_build_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ sq,
+                                                              int N, int C, int G, float4* __restrict__ ps, float* __restrict__ s4,
+                                                              int32_t* __restrict__ order, int32_t* __restrict__ cell_start,
+                                                              GridInfo* __restrict__ info) {
+  __shared__ int bins[GMAX * GMAX * GMAX];          // histogram, then cursors
+  __shared__ int part[1024];
+  __shared__ float red[7][16];
+  __shared__ GridInfo gi;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int b = blockIdx.x;
+  const float* xb = x + (int64_t)b * N * ldx;
+  const float* sqb = sq + (int64_t)b * N;
+  const int D = C < 3 ? C : 3;
+  const int G3 = G * G * G;
+
+  // ---- bounding box of the grid axes, max s_j (fminf / fmaxf drop NaNs: such points land in cell 0 of their axis) ----
+  float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY}, sm = 0.f;
+  for (int j = tid; j < N; j += 1024) {
+#pragma unroll
+    for (int d = 0; d < 3; ++d)
+      if (d < D) {
+        const float v = xb[(int64_t)j * ldx + d];
+        mn[d] = fminf(mn[d], v);
+        mx[d] = fmaxf(mx[d], v);
+      }
+    sm = fmaxf(sm, sqb[j]);
+  }
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    mn[d] = wave_min(mn[d]);
+    mx[d] = wave_max(mx[d]);
+  }
+  sm = wave_max(sm);
+  if (lane == 0) {
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      red[d][wv] = mn[d];
+      red[3 + d][wv] = mx[d];
+    }
+    red[6][wv] = sm;
+  }
+  for (int i = tid; i < G3; i += 1024) bins[i] = 0;
+  __syncthreads();
+  if (tid == 0) {
+    float a[3] = {INFINITY, INFINITY, INFINITY}, z[3] = {-INFINITY, -INFINITY, -INFINITY}, s = 0.f;
+    for (int w = 0; w < 16; ++w) {
+      for (int d = 0; d < 3; ++d) {
+        a[d] = fminf(a[d], red[d][w]);
+        z[d] = fmaxf(z[d], red[3 + d][w]);
+      }
+      s = fmaxf(s, red[6][w]);
+    }
+    for (int d = 0; d < 3; ++d) {
+      const float range = z[d] - a[d];
+      const bool ok = d < D && G > 1 && range > 0.f && range < INFINITY;
+      const float ih = ok ? (float)G / range : 0.f;
+      gi.mn[d] = ok ? a[d] : 0.f;
+      gi.ih[d] = (ih > 0.f && ih < INFINITY) ? ih : 0.f;
+      gi.h[d] = gi.ih[d] > 0.f ? (1.0f / gi.ih[d]) * (1.0f - 1e-6f) : 0.f;
+    }
+    gi.smax = s;
+    gi.G = G;
+    for (int i = 0; i < 5; ++i) gi.pad[i] = 0;
+    info[b] = gi;
+  }
+  __syncthreads();
+  const GridInfo g = gi;
+  auto cell_of = [&](int j) {
+    int c[3] = {0, 0, 0};
+#pragma unroll
+    for (int d = 0; d < 3; ++d)
+      if (d < D) c[d] = cell_axis(xb[(int64_t)j * ldx + d], g.mn[d], g.ih[d], G);
+    return (c[0] * G + c[1]) * G + c[2];
+  };
+  for (int j = tid; j < N; j += 1024) atomicAdd(&bins[cell_of(j)], 1);
+  __syncthreads();
+  // ---- exclusive scan of the G^3 bins: every thread owns up to 4 consecutive bins ----
+  const int per = (G3 + 1023) / 1024;
+  const int lo = tid * per, hi = (lo + per < G3) ? lo + per : G3;
+  int s = 0;
+  for (int i = lo; i < hi; ++i) s += bins[i];
+  part[tid] = s;
+  __syncthreads();
+  for (int d = 1; d < 1024; d <<= 1) {
+    const int v = (tid >= d) ? part[tid - d] : 0;
+    __syncthreads();
+    part[tid] += v;
+    __syncthreads();
+  }
+  int run = part[tid] - s;
+  int32_t* cs = cell_start + (int64_t)b * (GMAX * GMAX * GMAX + 1);
+  for (int i = lo; i < hi; ++i) {
+    const int n = bins[i];
+    cs[i] = run;
+    bins[i] = run;                       // cursor
+    run += n;
+  }
+  if (tid == 0) cs[G3] = N;
+  __syncthreads();
+  // ---- scatter (the order inside a cell is whatever the cursors hand out: the selection does not depend on it) ----
+  for (int j = tid; j < N; j += 1024) {
+    const int pos = atomicAdd(&bins[cell_of(j)], 1);
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int d = 0; d < 4; ++d)
+      if (d < C) v[d] = xb[(int64_t)j * ldx + d];
+    const float sj = sqb[j];
+    if (C <= 3) v[3] = sj;
+    ps[(int64_t)b * N + pos] = make_float4(v[0], v[1], v[2], v[3]);
+    s4[(int64_t)b * N + pos] = sj;
+    order[(int64_t)b * N + pos] = j;
+  }
+}
+
+template <int KC, bool C4>
+__global__ __launch_bounds__(64) void knn_grid_query_kernel(const float4* __restrict__ ps, const float* __restrict__ s4,
+                                                            const int32_t* __restrict__ order, const int32_t* __restrict__ cell_start,
+                                                            const GridInfo* __restrict__ info, int N, int k, int32_t* __restrict__ idx) {
+  __shared__ float dq[PARK * 64];
+  __shared__ int pj[PARK * 64];
+  const int lane = threadIdx.x;
+  const int b = blockIdx.y;
+  const int q = blockIdx.x * 64 + lane;
+  const bool valid = q < N;
+  const int qc = valid ? q : N - 1;
+  const GridInfo g = info[b];
+  const int G = g.G;
+  const float4* pb = ps + (int64_t)b * N;
+  const float* sb = s4 + (int64_t)b * N;
+  const int32_t* ob = order + (int64_t)b * N;
+  const int32_t* cs = cell_start + (int64_t)b * (GMAX * GMAX * GMAX + 1);
+
+  const float4 P = pb[qc];
+  const float xi0 = P.x, xi1 = P.y, xi2 = P.z, xi3 = C4 ? P.w : 0.f;
+  const float si = C4 ? sb[qc] : P.w;
+  const float tq[3] = {(xi0 - g.mn[0]) * g.ih[0], (xi1 - g.mn[1]) * g.ih[1], (xi2 - g.mn[2]) * g.ih[2]};
+  const int c0 = cell_axis(xi0, g.mn[0], g.ih[0], G), c1 = cell_axis(xi1, g.mn[1], g.ih[1], G), c2 = cell_axis(xi2, g.mn[2], g.ih[2], G);
+  const float dmargin = 1e-6f * (si + g.smax);
+
+  float dl[KC];
+  int jl[KC];
+#pragma unroll
+  for (int t = 0; t < KC; ++t) {
+    dl[t] = INFINITY;
+    jl[t] = 0x7fffffff;
+  }
+  int nb = 0;
+  auto drain = [&]() {
+    int i = 0;
+    while (__any(i < nb)) {
+      const bool live = i < nb;
+      const float d = live ? dq[i * 64 + lane] : INFINITY;
+      const int j = live ? pj[i * 64 + lane] : 0x7fffffff;
+      ++i;
+      list_insert<KC, true>(dl, jl, d, j);
+    }
+    nb = 0;
+  };
+
+  bool done = !valid;
+#pragma unroll 1
+  for (int r = 0; r < GMAX; ++r) {
+    const int W = 2 * r + 1;
+    const int T = 2 * W * W;
+    int tc = 0, p = 0, e = 0;
+#pragma unroll 1
+    while (true) {
+      // ---- lanes whose run is used up step to their next non-empty run of this ring ----
+      while (p >= e && tc < T && !done) {
+        const int col = tc >> 1, sub = tc & 1;
+        ++tc;
+        const int ix = c0 - r + col / W, iy = c1 - r + col % W;
+        if (ix < 0 || ix >= G || iy < 0 || iy >= G) continue;
+        const bool shell = (ix == c0 - r) || (ix == c0 + r) || (iy == c1 - r) || (iy == c1 + r);
+        int zlo, zhi;
+        if (shell) {
+          if (sub) continue;
+          zlo = c2 - r < 0 ? 0 : c2 - r;
+          zhi = c2 + r > G - 1 ? G - 1 : c2 + r;
+        } else {
+          zlo = zhi = sub ? c2 + r : c2 - r;
+          if (zlo < 0 || zlo >= G) continue;
+        }
+        const int base = (ix * G + iy) * G;
+        p = cs[base + zlo];
+        e = cs[base + zhi + 1];
+      }
+      const bool has = (p < e) && !done;
+      if (!__any(has)) break;
+      if (has) {
+        const float thr = dl[KC - 1];
+        float4 v[UNR];
+        float sj[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+          const int pp = (p + u < e) ? p + u : e - 1;
+          v[u] = pb[pp];
+          sj[u] = C4 ? sb[pp] : v[u].w;
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+          float pr = fmaf(xi0, v[u].x, 0.f);
+          pr = fmaf(xi1, v[u].y, pr);
+          pr = fmaf(xi2, v[u].z, pr);
+          pr = fmaf(xi3, C4 ? v[u].w : 0.f, pr);
+          const float t0 = si + sj[u];
+          const float tp = 2.0f * pr;
+          const float d = t0 - tp;
+          if (p + u < e && d <= thr) {
+            dq[nb * 64 + lane] = d;
+            pj[nb * 64 + lane] = ob[p + u];
+            ++nb;
+          }
+        }
+        p += UNR;
+      }
+      if (__any(nb > PARK - UNR)) drain();
+    }
+    drain();
+    // ---- can an unvisited point still enter this lane's list? ----
+    float kth = dl[KC - 1];
+#pragma unroll
+    for (int t = 0; t < KC - 1; ++t)
+      if (t == k - 1) kth = dl[t];
+    const int cc[3] = {c0, c1, c2};
+    float lb = INFINITY;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      if (g.ih[d] > 0.f) {
+        const int lo = cc[d] - r, hi = cc[d] + r;
+        if (lo > 0) lb = fminf(lb, fmaxf(0.f, (tq[d] - (float)lo) - 1e-5f) * g.h[d]);
+        if (hi < G - 1) lb = fminf(lb, fmaxf(0.f, ((float)(hi + 1) - tq[d]) - 1e-5f) * g.h[d]);
+      }
+    }
+    if (lb == INFINITY) done = true;                                  // the ring covered the whole grid
+    else if (kth < lb * lb * (1.0f - 1e-6f) - dmargin) done = true;
+    if (__all(done)) break;
+  }
+
+  if (valid) {
+    int32_t* out = idx + ((int64_t)b * N + ob[q]) * k;
+#pragma unroll
+    for (int t = 0; t < KC; ++t)
+      if (t < k) out[t] = jl[t];
+  }
+}
+
+int g_knn_grid = -1;
+bool knn_grid_on() {
+  if (g_knn_grid < 0) {
+    const char* e = getenv("DGCNN_KNN_GRID");      // A/B switch: 0 = brute-force kernel for C <= 4 as well
+    g_knn_grid = (e && e[0] == '0') ? 0 : 1;
+  }
+  return g_knn_grid == 1;
+}
+
+}  // namespace
+
+namespace dg {
+
+size_t knn_grid_workspace_bytes(int B, int N) {
+  const size_t rows = (size_t)B * (size_t)N;
+  return rows * (sizeof(float4) + sizeof(float) + sizeof(int32_t)) + (size_t)B * ((GMAX * GMAX * GMAX + 1) * sizeof(int32_t) + sizeof(GridInfo)) + 256;
+}
+
+// C <= 4, k <= 40.  sq = the s_j of the cloud (already computed); ws >= knn_grid_workspace_bytes(B, N), 16-byte aligned.
+bool knn_grid_applicable(int C, int k) { return knn_grid_on() && C <= 4 && k <= 40; }
+
+int launch_knn_grid(const float* x, const float* sq, int B, int N, int C, int64_t ldx, int k, int32_t* idx, void* ws, hipStream_t st) {
+  char* w = reinterpret_cast<char*>(ws);
+  const size_t rows = (size_t)B * (size_t)N;
+  float4* ps = reinterpret_cast<float4*>(w);
+  w += rows * sizeof(float4);
+  float* s4 = reinterpret_cast<float*>(w);
+  w += rows * sizeof(float);
+  int32_t* order = reinterpret_cast<int32_t*>(w);
+  w += rows * sizeof(int32_t);
+  w = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(w) + 63) & ~(uintptr_t)63);
+  GridInfo* info = reinterpret_cast<GridInfo*>(w);
+  w += (size_t)B * sizeof(GridInfo);
+  int32_t* cell_start = reinterpret_cast<int32_t*>(w);
+  // ~0.8 k points per cell: the ball of one cell size around a query then holds ~3.4 k points, ring 1 decides
+  int G = (int)floorf(cbrtf((float)N / (0.8f * (float)k)));
+  G = G < 1 ? 1 : (G > GMAX ? GMAX : G);
+  hipLaunchKernelGGL(knn_grid_build_kernel, dim3((unsigned)B), dim3(1024), 0, st, x, ldx, sq, N, C, G, ps, s4, order, cell_start, info);
+  dim3 grid((unsigned)cdiv(N, 64), (unsigned)B);
+#define DG_GRID(KC)                                                                                                              \
+  do {                                                                                                                            \
+    if (C == 4) hipLaunchKernelGGL((knn_grid_query_kernel<KC, true>), grid, dim3(64), 0, st, ps, s4, order, cell_start, info, N, k, idx); \
+    else hipLaunchKernelGGL((knn_grid_query_kernel<KC, false>), grid, dim3(64), 0, st, ps, s4, order, cell_start, info, N, k, idx);      \
+  } while (0)
+  if (k <= 8) DG_GRID(8);
+  else if (k <= 20) DG_GRID(20);
+  else DG_GRID(40);
+#undef DG_GRID
+  return check_launch("dgcnn_knn_f32 (grid)");
+}
+
+}  // namespace dg
+
+extern "C" int dgcnn_knn_grid(int on) {        // A/B switch (tests): returns the previous setting
+  const int prev = knn_grid_on() ? 1 : 0;
+  g_knn_grid = on ? 1 : 0;
+  return prev;
+}

@@ -438,8 +438,9 @@ def rank4(v, B, N):
 def knn(x2d, B, N, k):
     C = x2d.shape[1]
     idx = torch.empty((B, N, k), dtype=torch.int32, device=x2d.device)
-    sq = torch.empty((B * N,), dtype=torch.float32, device=x2d.device)
-    H.call("dgcnn_knn_f32", x2d.data_ptr(), B, N, C, H.ld2(x2d), k, idx.data_ptr(), sq.data_ptr(),
+    nws = int(H.load().dgcnn_knn_workspace_bytes(B, N, C, k))           # s_i (+ the cell grid's scratch for raw coordinates)
+    ws = torch.empty((nws,), dtype=torch.uint8, device=x2d.device)
+    H.call("dgcnn_knn_f32", x2d.data_ptr(), B, N, C, H.ld2(x2d), k, idx.data_ptr(), ws.data_ptr(), nws,
            tag="knn_kernel<C%d,k%d>" % (4 if C <= 4 else 16 if C <= 16 else 64 if C <= 64 else 128,
                                          8 if k <= 8 else 20 if k <= 20 else 40 if k <= 40 else 64),
            work=2.0 * B * N * N * C)

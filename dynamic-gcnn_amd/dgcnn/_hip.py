@@ -23,10 +23,11 @@ c_int, c_i64, c_f32, c_f64, c_vp, c_sz, c_u64 = (ctypes.c_int, ctypes.c_int64, c
 PROTOTYPES = {
     "dgcnn_version": [],
     "dgcnn_last_error": [],
-    "dgcnn_knn_workspace_bytes": [c_int, c_int],
+    "dgcnn_knn_workspace_bytes": [c_int, c_int, c_int, c_int],
+    "dgcnn_knn_grid": [c_int],
     "dgcnn_knn_force_valu": [c_int],
     "dgcnn_knn_bf16_filter": [c_int],
-    "dgcnn_knn_f32": [c_vp, c_int, c_int, c_int, c_i64, c_int, c_vp, c_vp, c_vp],
+    "dgcnn_knn_f32": [c_vp, c_int, c_int, c_int, c_i64, c_int, c_vp, c_vp, c_sz, c_vp],
     "dgcnn_edge_gather_f32": [c_vp, c_i64, c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp],
     "dgcnn_edge_gather_bwd_f32": [c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp, c_i64, c_vp],
     "dgcnn_edge_mlp_f32": [c_vp, c_i64, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp],
@@ -107,6 +108,8 @@ PROTOTYPES = {
     "dgcnn_broadcast_f32": [c_vp, c_i64, c_int, c_vp, c_vp],
 }
 
+INT64_RESULTS = ("dgcnn_knn_workspace_bytes",)      # byte counts; every other entry point returns an int status
+
 _lib = None
 
 
@@ -125,7 +128,8 @@ def load():
         for name, args in PROTOTYPES.items():
             fn = getattr(lib, name)
             fn.argtypes = args
-            fn.restype = ctypes.c_char_p if name == "dgcnn_last_error" else ctypes.c_int
+            fn.restype = (ctypes.c_char_p if name == "dgcnn_last_error" else
+                          ctypes.c_int64 if name in INT64_RESULTS else ctypes.c_int)
         _lib = lib
     return _lib
 

@@ -50,8 +50,14 @@ const char* dgcnn_last_error(void);
  * idx[b][i][0..k) = the k smallest D_ij = (s_i + s_j) - 2 <x_i,x_j> of row i (self included),
  * ascending, ties -> lower j.  Arithmetic order is normative (oracle/knn_oracle.c): bit-exact.
  * x: (B,N,C) with row stride ldx.  No (B,N,N) matrix is ever written to HBM.
- * sq_ws: caller scratch of dgcnn_knn_workspace_bytes(B,N) bytes (the s_i of ops.py:14). */
-int dgcnn_knn_workspace_bytes(int B, int N);
+ * ws: caller scratch (16-byte aligned) of dgcnn_knn_workspace_bytes(B,N,C,k) bytes: the s_i of ops.py:14 and, for raw
+ *   coordinates (C <= 4, k <= 40), the sorted copy / cell table of the exact cell-grid search (csrc/knn_grid.hip: the points of
+ *   a cloud are bucketed into a uniform grid and a row only meets the candidates of the cells around its own until its k-th
+ *   distance provably beats everything further out -- same pairs' arithmetic, same (D, j) order, same indices).  A workspace
+ *   that only holds the s_i (B*N floats rounded up to 256 bytes) selects the all-pairs kernels. */
+int64_t dgcnn_knn_workspace_bytes(int B, int N, int C, int k);
+/* A/B switch (tests): 0 = all-pairs kernel for C <= 4 too; returns the previous setting ($DGCNN_KNN_GRID). */
+int dgcnn_knn_grid(int on);
 /* A/B switch: 1 = distances by VALU fmaf chains for every C (exact by construction), 0 (default) =
  * v_mfma_f32_32x32x2_f32 for C > 4 (bit-identical on gfx950; the tests compare both).  Returns the
  * previous setting. */
@@ -62,7 +68,7 @@ int dgcnn_knn_force_valu(int on);
  * N >= 8192 ($DGCNN_KNN_BF16F = 0 | 1 | auto).  Returns the previous mode. */
 int dgcnn_knn_bf16_filter(int mode);
 int dgcnn_knn_f32(const float* x, int B, int N, int C, int64_t ldx, int k, int32_t* idx,
-                  float* sq_ws, void* stream);
+                  void* ws, size_t ws_bytes, void* stream);
 
 /* ---- K2: dgcnn/ops.py:21-40 edges (gather + tile + sub + concat) ------------------------
  * E[b][i][m][0..C) = x_i ; E[b][i][m][C..2C) = x_{idx[b][i][m]} - x_i.                    */

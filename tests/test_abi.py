@@ -13,7 +13,7 @@ def header_functions():
     text = open(os.path.join(ROOT, "include", "dgcnn_hip.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     out = {}
-    for m in re.finditer(r"\b(?:int|const char\*)\s+(dgcnn_\w+)\s*\(([^;]*?)\)\s*;", text, flags=re.S):
+    for m in re.finditer(r"\b(?:int|int64_t|const char\*)\s+(dgcnn_\w+)\s*\(([^;]*?)\)\s*;", text, flags=re.S):
         args = m.group(2).strip()
         out[m.group(1)] = 0 if args in ("", "void") else len([a for a in args.split(",") if a.strip()])
     return out

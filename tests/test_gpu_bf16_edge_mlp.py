@@ -84,9 +84,15 @@ def config2_flags(dg, train, emd="bf16"):
 
 
 def test_config2_architecture_logits_n2048_bf16(dg):
-    """configs[2] architecture (residual-dgcnn, 6 x 64, k = 40) at B=2, N=2048 in its named mode: every layer's graph bit-exact
-    against the C oracle on the layer's actual input, logits within 1e-3 of the float64 oracle IN THE SAME MODE fed the same
-    graphs.  Printed: the distance to the fp32-operand twin (the price of bf16 operands through six BatchNorm'ed layers)."""
+    """configs[2] architecture (residual-dgcnn, 6 x 64, k = 40) at B=2, N=2048 in its named mode.
+      * every layer's graph bit-exact against the C oracle on the layer's actual input;
+      * LAYER BY LAYER (the oracle in bf16 mode is fed the fp32 input the HIP layer really saw): the layer's output within 1e-4 --
+        the implementation is the mode's arithmetic and nothing else;
+      * END TO END against the float64 oracle in the same mode on the same graphs the bar cannot be the fp32 one: a feature
+        that differs in its last fp32 bit between two evaluations can land on the other side of a bf16 rounding boundary of
+        the NEXT layer's operand (a 2^-9 jump), so any two evaluations of this mode drift apart through six layers.  Measured:
+        max 2.2e-2 / mean 1.1e-3, one tenth of what the mode itself costs against fp32 operands (max 0.21 / mean 1.7e-2).
+        Asserted: max <= 6e-2, mean <= 3e-3 and at least 5x closer to the bf16-mode oracle than that oracle is to the fp32 one."""
     B, N, C, L = 2, 2048, 3, 6
     flags = config2_flags(dg, train=False)
     rng = np.random.default_rng(2)
@@ -102,20 +108,33 @@ def test_config2_architecture_logits_n2048_bf16(dg):
     dg.ctx().begin_step()
     with capture_layers() as capl:
         logits = host(dg.build(dev(pts), flags))
-    idx_list = []
+    idx_list, xin = [], []
     for i in range(L):
-        xin, idx = capl.layers["EdgeConv%d" % i]
-        np.testing.assert_array_equal(idx, O.k_nn(xin, 40), err_msg="layer %d" % i)
+        x_i, idx = capl.layers["EdgeConv%d" % i]
+        np.testing.assert_array_equal(idx, O.k_nn(x_i, 40), err_msg="layer %d" % i)
         idx_list.append(idx)
+        xin.append(x_i)
     p64 = {n: v.astype(np.float64) for n, v in params.items()}
+    worst = 0.0
+    for i in range(L - 1):                  # layer i on ITS OWN fp32 input -> the input layer i + 1 saw (ops.py:116-138)
+        s = "EdgeConv%d/" % i
+        outs, _ = O.edge_conv(xin[i].astype(np.float64), 40, p64[s + "conv0/weights"], p64[s + "conv0/BatchNorm/beta"],
+                              p64[s + "conv1/weights"], p64[s + "conv1/BatchNorm/beta"], relu1=(i == 0), idx=idx_list[i],
+                              edge_mlp_dtype="bf16")
+        nxt = outs[2][:, :, 0, :]
+        if i > 0:
+            nxt = np.maximum(xin[i].astype(np.float64) + nxt, 0)          # relu(shortcut + net), equal widths: ops.py:134
+        err = np.abs(xin[i + 1] - nxt).max()
+        worst = max(worst, err)
+        np.testing.assert_allclose(xin[i + 1], nxt, rtol=0, atol=1e-4, err_msg="layer %d output" % i)
     ref, _ = O.model_forward(pts.astype(np.float64), flags, p64, idx_list=idx_list)
-    f32flags = config2_flags(dg, train=False, emd="f32")
-    plain, _ = O.model_forward(pts.astype(np.float64), f32flags, p64, idx_list=idx_list)
-    e = np.abs(logits - ref)
-    print("configs[2] architecture, bf16 edge-MLP, same graphs: logits max|HIP - fp64 oracle (bf16 mode)| %.3e (mean %.1e); "
-          "bf16-mode oracle vs fp32-operand twin: max %.3e mean %.1e" % (e.max(), e.mean(), np.abs(ref - plain).max(),
-                                                                         np.abs(ref - plain).mean()))
-    np.testing.assert_allclose(logits, ref, rtol=0, atol=1e-3)
+    plain, _ = O.model_forward(pts.astype(np.float64), config2_flags(dg, train=False, emd="f32"), p64, idx_list=idx_list)
+    e, m = np.abs(logits - ref), np.abs(ref - plain)
+    print("configs[2] architecture, bf16 edge-MLP, same graphs: per-layer (same fp32 input) max %.2e | end to end logits "
+          "max|HIP - fp64 oracle (bf16 mode)| %.3e (mean %.1e) | bf16-mode oracle vs fp32-operand twin: max %.3e mean %.1e"
+          % (worst, e.max(), e.mean(), m.max(), m.mean()))
+    assert e.max() <= 6e-2 and e.mean() <= 3e-3, (e.max(), e.mean())
+    assert e.mean() * 5 <= m.mean(), (e.mean(), m.mean())
 
 
 def test_model_gradients_bf16_small(dg):

@@ -1,0 +1,107 @@
+"""The exact cell-grid k-NN of the raw-coordinate layer (csrc/knn_grid.hip; C <= 4, k <= 40) against the all-pairs kernel and the
+C oracle (dgcnn/ops.py:8-19; oracle/knn_oracle.c): the same indices, bit for bit, on inputs chosen to break a spatial search --
+duplicates, exact ties, empty cells, clouds far from the origin, degenerate axes, k == N, ragged N."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import dgcnn_oracle as O
+from gpu_helpers import dev, host
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture()
+def dg():
+    import dgcnn
+    dgcnn.reset()
+    return dgcnn
+
+
+def both(dg, pts, k):
+    """(grid result, all-pairs result) of ops.k_nn on the same cloud."""
+    from dgcnn import _hip as H
+    lib = H.load()
+    x = dev(pts)
+    prev = lib.dgcnn_knn_grid(1)
+    try:
+        a = host(dg.ops.k_nn(x, k))
+        lib.dgcnn_knn_grid(0)
+        b = host(dg.ops.k_nn(x, k))
+    finally:
+        lib.dgcnn_knn_grid(prev)
+    return a, b
+
+
+def clouds(rng):
+    yield "uniform", rng.random((3, 1000, 3), dtype=np.float32), 20
+    yield "uniform, N % 64 != 0, k = 8", rng.random((2, 777, 3), dtype=np.float32), 8
+    yield "k = 40", rng.random((2, 2048, 3), dtype=np.float32), 40
+    yield "integer lattice (exact ties, duplicates)", rng.integers(0, 12, (2, 1500, 3)).astype(np.float32), 20
+    yield "all points identical", np.full((1, 300, 3), 0.25, np.float32), 20
+    yield "two values only", rng.integers(0, 2, (2, 400, 3)).astype(np.float32), 20
+    line = np.zeros((2, 900, 3), np.float32)
+    line[..., 0] = rng.random((2, 900))
+    yield "points on a line (two flat axes)", line, 20
+    plane = rng.random((1, 1200, 3), dtype=np.float32)
+    plane[..., 2] = 0.5
+    yield "points in a plane", plane, 20
+    far = rng.random((2, 1024, 3), dtype=np.float32) + np.float32(1000.0)
+    yield "cloud far from the origin (margins swallow the bound)", far, 20
+    cl = rng.normal(0, 0.01, (2, 1500, 3)).astype(np.float32)
+    cl[:, :20] += 50.0
+    cl[:, 20:40] -= 30.0
+    yield "tight cluster + distant outliers", cl, 20
+    tr = np.cumsum(rng.normal(0, 0.02, (2, 4096, 3)), axis=1).astype(np.float32)
+    yield "random-walk tracks (LArTPC-like, very uneven density)", tr, 20
+    yield "C = 4", rng.random((2, 1100, 4), dtype=np.float32), 20
+    c4 = rng.random((2, 900, 4), dtype=np.float32)
+    c4[..., 3] *= 100.0
+    yield "C = 4, the 4th channel dominates the distance", c4, 20
+    yield "C = 2", rng.random((2, 640, 2), dtype=np.float32), 20
+    yield "C = 1", rng.random((2, 500, 1), dtype=np.float32), 8
+    yield "k == N", rng.random((3, 20, 3), dtype=np.float32), 20
+    yield "N = 5, k = 3", rng.random((4, 5, 3), dtype=np.float32), 3
+    yield "tiny values (denormal squares)", (rng.random((1, 600, 3)) * 1e-20).astype(np.float32), 20
+    yield "huge values", (rng.random((1, 600, 3)) * 1e15).astype(np.float32), 20
+
+
+def test_grid_search_equals_all_pairs_and_the_oracle(dg):
+    rng = np.random.default_rng(2024)
+    for what, pts, k in clouds(rng):
+        a, b = both(dg, pts, k)
+        ref = O.k_nn(pts, k)
+        bad = np.argwhere((a != ref).any(-1))
+        assert len(bad) == 0, "%s: grid differs from the oracle in %d rows, first %s: %s vs %s" % (
+            what, len(bad), bad[0], a[tuple(bad[0])], ref[tuple(bad[0])])
+        np.testing.assert_array_equal(b, ref, err_msg=what + " (all-pairs kernel)")
+
+
+@pytest.mark.parametrize("N,k,C", [(16384, 40, 3), (65536, 20, 3), (65536, 20, 4)])
+def test_grid_search_at_the_large_baseline_sizes(dg, N, k, C):
+    """configs[2] / configs[4] point counts on the raw-coordinate layer: a seeded sample of rows against the C oracle (the grid
+    looks at ~22 k candidates per row instead of N)."""
+    rng = np.random.default_rng(N + C)
+    pts = rng.random((2, N, C), dtype=np.float32)
+    idx = host(dg.ops.k_nn(dev(pts), k))
+    rows = np.sort(rng.permutation(N)[:2048]).astype(np.int32)
+    for b in range(2):
+        np.testing.assert_array_equal(idx[b][rows], O.k_nn_rows(pts[b], k, rows))
+
+
+def test_workspace_too_small_for_the_grid_selects_the_all_pairs_kernel(dg):
+    from dgcnn import _hip as H
+    lib = H.load()
+    B, N, C, k = 2, 300, 3, 10
+    rng = np.random.default_rng(1)
+    pts = rng.random((B, N, C), dtype=np.float32)
+    x = dev(pts)
+    full = int(lib.dgcnn_knn_workspace_bytes(B, N, C, k))
+    small = (B * N * 4 + 255) // 256 * 256
+    assert full > small and int(lib.dgcnn_knn_workspace_bytes(B, N, 64, k)) == small
+    idx = torch.empty((B, N, k), dtype=torch.int32, device="cuda")
+    ws = torch.empty(small, dtype=torch.uint8, device="cuda")
+    H.call("dgcnn_knn_f32", x.data_ptr(), B, N, C, C, k, idx.data_ptr(), ws.data_ptr(), small)
+    np.testing.assert_array_equal(host(idx), O.k_nn(pts, k))
+    with pytest.raises(H.HipError):
+        H.call("dgcnn_knn_f32", x.data_ptr(), B, N, C, C, k, idx.data_ptr(), ws.data_ptr(), small - 256)

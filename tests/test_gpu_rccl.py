@@ -167,7 +167,7 @@ def test_rccl_start_up_prints_nothing_on_stdout():
             "from dgcnn import rccl\n"
             "g = rccl.Group(rank=0, world=1)\n"
             "x = torch.ones(1024, device='cuda'); g.allreduce_sum_(x); g.broadcast_(x); torch.cuda.synchronize()\n"
-            "g.destroy(); print('OK %d' % int(x.sum()))\n") % os.path.join(root, "dynamic-gcnn_amd")
+            "g.destroy(); print('OK', int(x.sum()))\n") % os.path.join(root, "dynamic-gcnn_amd")
     p = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
     assert p.returncode == 0, p.stderr.decode(errors="replace")[-2000:]
     assert p.stdout.decode().strip() == "OK 1024", p.stdout.decode()
