@@ -31,8 +31,10 @@
 namespace {
 
 constexpr int GMAX = 16;                 // cells per axis (G^3 <= 4096 LDS bins)
-constexpr int PARK = 32;                 // parked candidates per lane between two drains
+constexpr int PARK = 16;                 // parked candidates per lane between two drains
 constexpr int UNR = 4;                   // candidates a lane looks at per wave iteration (loads in flight)
+constexpr int QW = 4;                    // waves (of 64 queries) per query block
+constexpr int LDS_CLOUD_MAX = 4096;      // clouds up to this many points are copied into LDS by every query block
 
 struct GridInfo {                        // one per cloud (64 bytes)
   float mn[3];                           // lower corner of the bounding box
@@ -59,6 +61,39 @@ __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
   return v;
+}
+
+// ---- (D, j) as ONE 64-bit key: the lexicographic order of the selection is the unsigned order of
+//      key = ordered(D) << 32 | j,  ordered() = the usual order-preserving map float -> uint32 (after D + 0 so that -0 == +0).
+// One v_cmp_lt_u64 per list slot instead of three compares and two mask operations (knn_common.h's pair form), and the
+// candidate filter can compare keys exactly: a tie in D with a larger index never costs an insert round.
+__device__ __forceinline__ unsigned f32_key(float d) {
+  const unsigned u = __float_as_uint(d + 0.0f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float key_f32(unsigned k) { return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k); }
+__device__ __forceinline__ lmask_t m_ult64(unsigned long long a, unsigned long long b) { return __builtin_amdgcn_uicmpl(a, b, 36); }
+__device__ __forceinline__ unsigned long long sel_u64(lmask_t m, unsigned long long t, unsigned long long f) {
+  const unsigned tl = (unsigned)t, th = (unsigned)(t >> 32), fl = (unsigned)f, fh = (unsigned)(f >> 32);
+  unsigned rl, rh;
+  asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(rl) : "v"(fl), "v"(tl), "s"(m));
+  asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(rh) : "v"(fh), "v"(th), "s"(m));
+  return ((unsigned long long)rh << 32) | rl;
+}
+constexpr unsigned long long KEY_NONE = 0xff8000007fffffffull;      // (+inf, largest index): an empty slot
+
+// Branch-free sorted insert of `key` into an ascending list of 64-bit keys in registers; a lane whose key is not smaller than its
+// last entry is left unchanged (KEY_NONE is a no-op).
+template <int KC>
+__device__ __forceinline__ void list_insert64(unsigned long long (&kl)[KC], unsigned long long key) {
+  lmask_t ct = m_ult64(key, kl[KC - 1]);
+#pragma unroll
+  for (int t = KC - 1; t >= 1; --t) {
+    const lmask_t cp = m_ult64(key, kl[t - 1]);
+    kl[t] = sel_u64(ct, sel_u64(cp, kl[t - 1], key), kl[t]);
+    ct = cp;
+  }
+  kl[0] = sel_u64(ct, key, kl[0]);
 }
 
 __global__ __launch_bounds__(1024) void knn_grid_build_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ sq,
@@ -175,49 +210,71 @@ __global__ __launch_bounds__(1024) void knn_grid_build_kernel(const float* __res
   }
 }
 
-template <int KC, bool C4>
-__global__ __launch_bounds__(64) void knn_grid_query_kernel(const float4* __restrict__ ps, const float* __restrict__ s4,
-                                                            const int32_t* __restrict__ order, const int32_t* __restrict__ cell_start,
-                                                            const GridInfo* __restrict__ info, int N, int k, int32_t* __restrict__ idx) {
-  __shared__ float dq[PARK * 64];
-  __shared__ int pj[PARK * 64];
-  const int lane = threadIdx.x;
+// LDSC: the block first copies the cloud's sorted records, original indices and cell table into LDS (N <= LDS_CLOUD_MAX): a lane's
+// walk is a chain of dependent loads -- cell table -> run bounds -> candidates -- and at (24, 2048) there is less than one wave
+// per SIMD to hide a global round trip behind (262 us with global loads against 155 us for the all-pairs kernel; LDS: see
+// profiles/r04/knn_grid.txt).  Large clouds have thousands of waves and read the records through L1 / L2.
+template <int KC, bool C4, bool LDSC>
+__global__ __launch_bounds__(64 * QW) void knn_grid_query_kernel(const float4* __restrict__ ps, const float* __restrict__ s4,
+                                                                 const int32_t* __restrict__ order, const int32_t* __restrict__ cell_start,
+                                                                 const GridInfo* __restrict__ info, int N, int k, int32_t* __restrict__ idx) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wv = tid >> 6;
+  float* dq = reinterpret_cast<float*>(smem) + wv * (PARK * 64);
+  int* pj = reinterpret_cast<int*>(smem) + QW * (PARK * 64) + wv * (PARK * 64);
   const int b = blockIdx.y;
-  const int q = blockIdx.x * 64 + lane;
+  const int q = blockIdx.x * (64 * QW) + tid;
   const bool valid = q < N;
   const int qc = valid ? q : N - 1;
   const GridInfo g = info[b];
   const int G = g.G;
-  const float4* pb = ps + (int64_t)b * N;
-  const float* sb = s4 + (int64_t)b * N;
-  const int32_t* ob = order + (int64_t)b * N;
-  const int32_t* cs = cell_start + (int64_t)b * (GMAX * GMAX * GMAX + 1);
+  const float4* pbg = ps + (int64_t)b * N;
+  const float* sbg = s4 + (int64_t)b * N;
+  const int32_t* obg = order + (int64_t)b * N;
+  const int32_t* csg = cell_start + (int64_t)b * (GMAX * GMAX * GMAX + 1);
+  // LDS copies (LDSC): [records float4 N][order int N][cells int G^3 + 1][s_j float N (C4)]
+  float4* pl = reinterpret_cast<float4*>(smem + 2 * QW * PARK * 64 * 4);
+  int* ol = reinterpret_cast<int*>(pl + (LDSC ? N : 0));
+  int* cl = ol + (LDSC ? N : 0);
+  float* sl = reinterpret_cast<float*>(cl + (LDSC ? G * G * G + 1 : 0));
+  if (LDSC) {
+    for (int i = tid; i < N; i += 64 * QW) {
+      pl[i] = pbg[i];
+      ol[i] = obg[i];
+      if (C4) sl[i] = sbg[i];
+    }
+    for (int i = tid; i <= G * G * G; i += 64 * QW) cl[i] = csg[i];
+    __syncthreads();
+  }
+  auto rec = [&](int i) -> float4 { return LDSC ? pl[i] : pbg[i]; };
+  auto sqv = [&](int i) -> float { return LDSC ? sl[i] : sbg[i]; };
+  auto org = [&](int i) -> int { return LDSC ? ol[i] : obg[i]; };
+  auto cst = [&](int i) -> int { return LDSC ? cl[i] : csg[i]; };
 
-  const float4 P = pb[qc];
+  const float4 P = rec(qc);
   const float xi0 = P.x, xi1 = P.y, xi2 = P.z, xi3 = C4 ? P.w : 0.f;
-  const float si = C4 ? sb[qc] : P.w;
+  const float si = C4 ? sqv(qc) : P.w;
   const float tq[3] = {(xi0 - g.mn[0]) * g.ih[0], (xi1 - g.mn[1]) * g.ih[1], (xi2 - g.mn[2]) * g.ih[2]};
   const int c0 = cell_axis(xi0, g.mn[0], g.ih[0], G), c1 = cell_axis(xi1, g.mn[1], g.ih[1], G), c2 = cell_axis(xi2, g.mn[2], g.ih[2], G);
   const float dmargin = 1e-6f * (si + g.smax);
 
-  float dl[KC];
-  int jl[KC];
+  unsigned long long kl[KC];
 #pragma unroll
-  for (int t = 0; t < KC; ++t) {
-    dl[t] = INFINITY;
-    jl[t] = 0x7fffffff;
-  }
+  for (int t = 0; t < KC; ++t) kl[t] = KEY_NONE;
+  float thr = INFINITY;                    // D of the list's last entry: candidates with d <= thr are parked
   int nb = 0;
   auto drain = [&]() {
     int i = 0;
     while (__any(i < nb)) {
       const bool live = i < nb;
-      const float d = live ? dq[i * 64 + lane] : INFINITY;
-      const int j = live ? pj[i * 64 + lane] : 0x7fffffff;
+      const unsigned kh = f32_key(live ? dq[i * 64 + lane] : INFINITY);
+      const unsigned kj = (unsigned)(live ? pj[i * 64 + lane] : 0x7fffffff);
       ++i;
-      list_insert<KC, true>(dl, jl, d, j);
+      list_insert64<KC>(kl, ((unsigned long long)kh << 32) | kj);
     }
     nb = 0;
+    thr = key_f32((unsigned)(kl[KC - 1] >> 32));
   };
 
   bool done = !valid;
@@ -245,20 +302,19 @@ __global__ __launch_bounds__(64) void knn_grid_query_kernel(const float4* __rest
           if (zlo < 0 || zlo >= G) continue;
         }
         const int base = (ix * G + iy) * G;
-        p = cs[base + zlo];
-        e = cs[base + zhi + 1];
+        p = cst(base + zlo);
+        e = cst(base + zhi + 1);
       }
       const bool has = (p < e) && !done;
       if (!__any(has)) break;
       if (has) {
-        const float thr = dl[KC - 1];
         float4 v[UNR];
         float sj[UNR];
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
           const int pp = (p + u < e) ? p + u : e - 1;
-          v[u] = pb[pp];
-          sj[u] = C4 ? sb[pp] : v[u].w;
+          v[u] = rec(pp);
+          sj[u] = C4 ? sqv(pp) : v[u].w;
         }
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
@@ -271,7 +327,7 @@ __global__ __launch_bounds__(64) void knn_grid_query_kernel(const float4* __rest
           const float d = t0 - tp;
           if (p + u < e && d <= thr) {
             dq[nb * 64 + lane] = d;
-            pj[nb * 64 + lane] = ob[p + u];
+            pj[nb * 64 + lane] = org(p + u);
             ++nb;
           }
         }
@@ -281,10 +337,11 @@ __global__ __launch_bounds__(64) void knn_grid_query_kernel(const float4* __rest
     }
     drain();
     // ---- can an unvisited point still enter this lane's list? ----
-    float kth = dl[KC - 1];
+    unsigned long long kk = kl[KC - 1];
 #pragma unroll
     for (int t = 0; t < KC - 1; ++t)
-      if (t == k - 1) kth = dl[t];
+      if (t == k - 1) kk = kl[t];
+    const float kth = key_f32((unsigned)(kk >> 32));
     const int cc[3] = {c0, c1, c2};
     float lb = INFINITY;
 #pragma unroll
@@ -301,13 +358,14 @@ __global__ __launch_bounds__(64) void knn_grid_query_kernel(const float4* __rest
   }
 
   if (valid) {
-    int32_t* out = idx + ((int64_t)b * N + ob[q]) * k;
+    int32_t* out = idx + ((int64_t)b * N + org(q)) * k;
 #pragma unroll
     for (int t = 0; t < KC; ++t)
-      if (t < k) out[t] = jl[t];
+      if (t < k) out[t] = (int32_t)(unsigned)kl[t];
   }
 }
 
+bool g_knn_grid_all = false;
 int g_knn_grid = -1;
 bool knn_grid_on() {
   if (g_knn_grid < 0) {
@@ -329,6 +387,16 @@ size_t knn_grid_workspace_bytes(int B, int N) {
 // C <= 4, k <= 40.  sq = the s_j of the cloud (already computed); ws >= knn_grid_workspace_bytes(B, N), 16-byte aligned.
 bool knn_grid_applicable(int C, int k) { return knn_grid_on() && C <= 4 && k <= 40; }
 
+// Where it pays (profiles/r04/knn_grid.txt): the walk costs ~22 k candidates per row whatever N is, the all-pairs kernel N.
+// Measured cross-over between N = 2048 (all pairs 155 us, grid 207 us at B = 24: one 64-query wave per SIMD, bound by its own
+// dependent instruction chain) and N = 4096; at N = 16384 / 65536 the grid is 3.1x / 14x faster.  $DGCNN_KNN_GRID_MIN_N moves it
+// (tests run the grid at every N).
+int knn_grid_min_n() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("DGCNN_KNN_GRID_MIN_N"); v = e ? atoi(e) : 4096; }
+  return g_knn_grid_all ? 0 : v;
+}
+
 int launch_knn_grid(const float* x, const float* sq, int B, int N, int C, int64_t ldx, int k, int32_t* idx, void* ws, hipStream_t st) {
   char* w = reinterpret_cast<char*>(ws);
   const size_t rows = (size_t)B * (size_t)N;
@@ -346,23 +414,41 @@ int launch_knn_grid(const float* x, const float* sq, int B, int N, int C, int64_
   int G = (int)floorf(cbrtf((float)N / (0.8f * (float)k)));
   G = G < 1 ? 1 : (G > GMAX ? GMAX : G);
   hipLaunchKernelGGL(knn_grid_build_kernel, dim3((unsigned)B), dim3(1024), 0, st, x, ldx, sq, N, C, G, ps, s4, order, cell_start, info);
-  dim3 grid((unsigned)cdiv(N, 64), (unsigned)B);
-#define DG_GRID(KC)                                                                                                              \
+  dim3 grid((unsigned)cdiv(N, 64 * QW), (unsigned)B);
+  const size_t park = (size_t)2 * QW * PARK * 64 * 4;
+  const size_t G3 = (size_t)G * G * G;
+  const size_t cloud = (size_t)N * (16 + 4 + (C == 4 ? 4 : 0)) + (G3 + 1) * 4;
+  const bool in_lds = N <= LDS_CLOUD_MAX && park + cloud + 16 <= 160 * 1024;
+#define DG_GRID2(KC, C4)                                                                                                          \
   do {                                                                                                                            \
-    if (C == 4) hipLaunchKernelGGL((knn_grid_query_kernel<KC, true>), grid, dim3(64), 0, st, ps, s4, order, cell_start, info, N, k, idx); \
-    else hipLaunchKernelGGL((knn_grid_query_kernel<KC, false>), grid, dim3(64), 0, st, ps, s4, order, cell_start, info, N, k, idx);      \
+    if (in_lds) {                                                                                                                 \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&knn_grid_query_kernel<KC, C4, true>),                             \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                                          \
+      hipLaunchKernelGGL((knn_grid_query_kernel<KC, C4, true>), grid, dim3(64 * QW), park + cloud + 16, st, ps, s4, order,        \
+                         cell_start, info, N, k, idx);                                                                            \
+    } else {                                                                                                                      \
+      hipLaunchKernelGGL((knn_grid_query_kernel<KC, C4, false>), grid, dim3(64 * QW), park, st, ps, s4, order, cell_start, info,  \
+                         N, k, idx);                                                                                              \
+    }                                                                                                                             \
+  } while (0)
+#define DG_GRID(KC)                    \
+  do {                                 \
+    if (C == 4) DG_GRID2(KC, true);    \
+    else DG_GRID2(KC, false);          \
   } while (0)
   if (k <= 8) DG_GRID(8);
   else if (k <= 20) DG_GRID(20);
   else DG_GRID(40);
 #undef DG_GRID
+#undef DG_GRID2
   return check_launch("dgcnn_knn_f32 (grid)");
 }
 
 }  // namespace dg
 
-extern "C" int dgcnn_knn_grid(int on) {        // A/B switch (tests): returns the previous setting
-  const int prev = knn_grid_on() ? 1 : 0;
-  g_knn_grid = on ? 1 : 0;
+extern "C" int dgcnn_knn_grid(int mode) {      // 0 = never, 1 = where it pays (N >= knn_grid_min_n), 2 = whenever applicable (tests)
+  const int prev = knn_grid_on() ? (g_knn_grid_all ? 2 : 1) : 0;
+  g_knn_grid = mode ? 1 : 0;
+  g_knn_grid_all = mode == 2;
   return prev;
 }

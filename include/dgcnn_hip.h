@@ -56,8 +56,9 @@ const char* dgcnn_last_error(void);
  *   distance provably beats everything further out -- same pairs' arithmetic, same (D, j) order, same indices).  A workspace
  *   that only holds the s_i (B*N floats rounded up to 256 bytes) selects the all-pairs kernels. */
 int64_t dgcnn_knn_workspace_bytes(int B, int N, int C, int k);
-/* A/B switch (tests): 0 = all-pairs kernel for C <= 4 too; returns the previous setting ($DGCNN_KNN_GRID). */
-int dgcnn_knn_grid(int on);
+/* 0 = all-pairs kernel for C <= 4 too, 1 (default) = cell grid where it pays (N >= 4096: $DGCNN_KNN_GRID_MIN_N), 2 = cell grid
+ * whenever applicable (tests); returns the previous setting ($DGCNN_KNN_GRID=0 switches it off). */
+int dgcnn_knn_grid(int mode);
 /* A/B switch: 1 = distances by VALU fmaf chains for every C (exact by construction), 0 (default) =
  * v_mfma_f32_32x32x2_f32 for C > 4 (bit-identical on gfx950; the tests compare both).  Returns the
  * previous setting. */
