@@ -49,6 +49,7 @@ BN1_BWD_TWO_SOURCES = os.environ.get("DGCNN_BN1_BWD_TWO_SOURCES", "1") != "0"   
 COLMAX_IN_EPILOGUE = os.environ.get("DGCNN_COLMAX_EPILOGUE", "1") != "0"   # the global max-pool comes out of MergedEdgeConv's GEMM epilogue
 EDGE_BWD_REDUCE_POINTS = True   # BN backward sums of conv0 from per-point data (False: a pass over the edges)
 SIDE_STREAM_MIN_ROWS = 16384   # below this many points the side stream is not used
+SIDE_STREAM_PRIORITY = int(os.environ.get("DGCNN_SIDE_PRIORITY", "0"))   # HIP stream priority of the side stream (experiment)
 # conv0 of every EdgeConv layer with bf16 OPERANDS (BASELINE.json configs[2] "bf16 edge-MLP MFMA"): E = [x_i, x_j - x_i] is formed
 # in fp32, E and W0 are rounded to bf16 once, the literal (B*N*k) x 2C x F product runs on v_mfma_f32_32x32x16_bf16 with fp32
 # accumulation; the two gradient products round their operands the same way.  "f32" (default): the fp32-class folded form.
@@ -139,7 +140,7 @@ class Context(object):
             return
         main = torch.cuda.current_stream()
         if self.side is None or self.side.device != self.device:
-            self.side = torch.cuda.Stream(device=self.device)
+            self.side = torch.cuda.Stream(device=self.device, priority=SIDE_STREAM_PRIORITY)
         self.side.wait_stream(main)
         for t in temporaries:
             t.record_stream(self.side)

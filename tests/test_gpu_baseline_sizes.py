@@ -101,6 +101,11 @@ def test_config4_knn_n65536_k20_bit_exact(dg, C, kind):
 # ------------------------------------------------------------------------------------------------------
 # configs[1] at full size
 # ------------------------------------------------------------------------------------------------------
+# DETERMINISTIC-mode bars of the end-to-end comparison (measured in round 4, identical in three runs: see DESIGN.md 3)
+DET_LAYER_FACTOR = 1.1
+DET_LOGIT_SHARE_SLACK = 0.02
+
+
 def config1_flags(dg, train):
     return dg.DGCNN_FLAGS(MODEL_NAME="dgcnn", EDGE_CONV_LAYERS=3, EDGE_CONV_FILTERS=[64, 64, 128], FC_LAYERS=2,
                           FC_FILTERS=[512, 256], NUM_CLASS=2, KVALUE=20, NUM_CHANNEL=3, TRAIN=train)
@@ -165,8 +170,10 @@ def _end_to_end_rates(pts, flags, params, idx_list, logits, L):
     return hip, o32, float((err <= 1e-3).mean()), float((err32 <= 1e-3).mean())
 
 
-def test_config1_full_size_logits_and_dynamic_graphs(dg):
-    """(B,N,k,C) = (24,2048,20,3), the headline configuration, inference graph:
+@pytest.mark.parametrize("det", [False, True], ids=["default", "deterministic"])
+def test_config1_full_size_logits_and_dynamic_graphs(dg, det):
+    """(B,N,k,C) = (24,2048,20,3), the headline configuration, inference graph (default kernels, and DETERMINISTIC mode, where the
+    run is ONE set of numbers and the end-to-end bars are relative to the fp32 oracle's own figures instead of fixed floors):
       * every layer's k-NN bit-exact against the C oracle on the layer's actual input (all 24 x 2048 rows);
       * logits within 1e-3 (north_star) of the oracle fed the same neighbour graphs;
       * END TO END (the oracle builds its own graphs from its own features): fraction of rows whose neighbour set
@@ -175,16 +182,28 @@ def test_config1_full_size_logits_and_dynamic_graphs(dg):
         difference of the features into different neighbour lists for near-tie rows)."""
     B, N, C = 24, 2048, 3
     flags = config1_flags(dg, train=False)
+    flags.DETERMINISTIC = det
     rng = np.random.default_rng(0)
     pts = rng.random((B, N, C), dtype=np.float32)
     params = O.init_params(flags, C, seed=1)
     for n in params:
         if n.endswith("beta"):
             params[n] = rng.normal(0, 0.2, params[n].shape).astype(np.float32)
-    logits, idx_list = _forward_with_graphs(dg, flags, pts, params, 3)
+    try:
+        logits, idx_list = _forward_with_graphs(dg, flags, pts, params, 3)
+    finally:
+        from dgcnn import _engine as E
+        E.DETERMINISTIC = E.DETERMINISTIC_ENV_DEFAULT
     assert logits.shape == (B, N, 2)
-    _oracle_three_way(pts, flags, params, idx_list, logits, "configs[1] full size")
+    _oracle_three_way(pts, flags, params, idx_list, logits, "configs[1] full size" + (" [deterministic]" if det else ""))
     hip, o32, w_hip, w_o32 = _end_to_end_rates(pts, flags, params, idx_list, logits, 3)
+    if det:
+        # per layer: rows whose neighbour set differs from the float64 twin's, against the same figure of the fp32 oracle;
+        # end to end: the share of logits within 1e-3 of the twin, against the fp32 oracle's share
+        for i in range(3):
+            assert hip[i] <= DET_LAYER_FACTOR * o32[i] + 1e-3, (i, hip, o32)
+        assert w_hip >= w_o32 - DET_LOGIT_SHARE_SLACK, (w_hip, w_o32)
+        return
     assert max(hip) <= 1.5 * max(o32) + 2e-3, (hip, o32)    # no worse than a reference-grade fp32 evaluation
     # end to end no fp32 evaluation stays within 1e-3 of another everywhere: a row whose neighbour set differs changes its
     # own logits at O(0.1) and, through the global max-pool feature and the BatchNorm statistics, nudges its whole cloud
@@ -254,24 +273,35 @@ def config2_flags(dg, train):
                           FC_FILTERS=[512, 256], NUM_CLASS=2, KVALUE=40, NUM_CHANNEL=3, TRAIN=train)
 
 
-def test_config2_architecture_logits_n2048(dg):
+@pytest.mark.parametrize("det", [False, True], ids=["default", "deterministic"])
+def test_config2_architecture_logits_n2048(dg, det):
     """configs[2] architecture (scripts/lsf/train_dgcnn.sh:8-9: residual-dgcnn, 6 layers x 64, k=40) at B=2, N=2048:
     per-layer bit-exact graphs, logits within 1e-3 of the oracle fed the same graphs; end to end the six stacked dynamic
     graphs diverge layer by layer for ANY fp32 evaluation -- the HIP path's rates are printed next to the fp32 numpy
     restatement's and bounded by them."""
     B, N, C, L = 2, 2048, 3, 6
     flags = config2_flags(dg, train=False)
+    flags.DETERMINISTIC = det
     rng = np.random.default_rng(2)
     pts = rng.random((B, N, C), dtype=np.float32)
     params = O.init_params(flags, C, seed=3)
     for n in params:
         if n.endswith("beta"):
             params[n] = rng.normal(0, 0.2, params[n].shape).astype(np.float32)
-    logits, idx_list = _forward_with_graphs(dg, flags, pts, params, L)
-    _oracle_three_way(pts, flags, params, idx_list, logits, "configs[2] architecture at N=2048")
+    try:
+        logits, idx_list = _forward_with_graphs(dg, flags, pts, params, L)
+    finally:
+        from dgcnn import _engine as E
+        E.DETERMINISTIC = E.DETERMINISTIC_ENV_DEFAULT
+    _oracle_three_way(pts, flags, params, idx_list, logits, "configs[2] architecture at N=2048" + (" [deterministic]" if det else ""))
     hip, o32, w_hip, w_o32 = _end_to_end_rates(pts, flags, params, idx_list, logits, L)
     for i in range(1, L):
-        assert hip[i] <= 1.5 * o32[i] + 5e-3, (i, hip, o32)
+        if det:
+            assert hip[i] <= DET_LAYER_FACTOR * o32[i] + 1e-3, (i, hip, o32)
+        else:
+            assert hip[i] <= 1.5 * o32[i] + 5e-3, (i, hip, o32)
+    if det:
+        assert w_hip >= w_o32 - DET_LOGIT_SHARE_SLACK, (w_hip, w_o32)
 
 
 def _full_size_property_run(dg, flags, B, N, k, L, nrows, seed):

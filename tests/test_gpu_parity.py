@@ -594,11 +594,21 @@ CONFIGS = [
 ]
 
 
+# DETERMINISTIC mode (one writer per statistics slot, fixed-order sums, sorted adjacency): a run is ONE set of numbers, so the
+# gradient bars can sit at ~2x what is measured instead of covering the run-to-run spread of the atomically summed default mode.
+# Measured (round 4, three runs, identical): see DET_GRAD_BAR below.
+DET_GRAD_FRO = 5e-3
+DET_GRAD_ELT = 2e-2
+
+
+@pytest.mark.parametrize("det", [False, True], ids=["default", "deterministic"])
 @pytest.mark.parametrize("cfg", CONFIGS)
-def test_model_logits_and_gradients(dg, cfg):
+def test_model_logits_and_gradients(dg, cfg, det):
     cfg = dict(cfg)
     B, N, C = cfg.pop("B"), cfg.pop("N"), cfg.pop("C")
-    flags = dg.DGCNN_FLAGS(NUM_CLASS=2, FC_LAYERS=2, FC_FILTERS=[512, 256], TRAIN=False, NUM_CHANNEL=C, **cfg)
+    if det and any(f % 4 for f in (cfg["EDGE_CONV_FILTERS"] if isinstance(cfg["EDGE_CONV_FILTERS"], list) else [cfg["EDGE_CONV_FILTERS"]])):
+        pytest.skip("deterministic mode refuses EdgeConv filter counts that are not multiples of 4")
+    flags = dg.DGCNN_FLAGS(NUM_CLASS=2, FC_LAYERS=2, FC_FILTERS=[512, 256], TRAIN=False, NUM_CHANNEL=C, DETERMINISTIC=det, **cfg)
     rng = np.random.default_rng(0)
     pts = rng.random((B, N, C), dtype=np.float32)
     labels = rng.integers(0, 2, (B, N)).astype(np.int32)
@@ -644,7 +654,8 @@ def test_model_logits_and_gradients(dg, cfg):
     # max-over-k / global-max decision flips in fp32 (one point's whole contribution is rerouted): the elementwise
     # bar is 5e-2 of the tensor's scale (observed up to 2.1e-2), the Frobenius bar 2e-2 (observed 1e-6 .. 1.1e-2 over the seven configurations and
     # run to run: the tiny (3,256) clouds feel a single flipped decision most).  A wrong or missing term is O(1).
-    worst = (0.0, "")
+    worst, worst_e = (0.0, ""), (0.0, "")
+    bar_fro, bar_elt = (DET_GRAD_FRO, DET_GRAD_ELT) if det else (2e-2, 5e-2)
     for n in params:
         g = host(tv.gradients[n]).astype(np.float64)
         ref = G[n]
@@ -652,9 +663,13 @@ def test_model_logits_and_gradients(dg, cfg):
         err = np.abs(g - ref)
         fro = np.linalg.norm(g - ref) / max(np.linalg.norm(ref), 1e-6)
         worst = max(worst, (fro, n))
-        assert err.max() <= 5e-2 * scale, (n, err.max() / scale)
-        assert fro <= 2e-2, (n, fro)
-    print("%s: worst relative Frobenius gradient error vs the fp64 twin %.2e (%s)" % (cfg.get("MODEL_NAME"), worst[0], worst[1]))
+        worst_e = max(worst_e, (float(err.max() / scale), n))
+    print("%s [%s]: worst relative Frobenius gradient error vs the fp64 twin %.2e (%s), worst element / scale %.2e (%s)"
+          % (cfg.get("MODEL_NAME"), "deterministic" if det else "default", worst[0], worst[1], worst_e[0], worst_e[1]))
+    from dgcnn import _engine as E2
+    E2.DETERMINISTIC = E2.DETERMINISTIC_ENV_DEFAULT
+    assert worst_e[0] <= bar_elt, worst_e
+    assert worst[0] <= bar_fro, worst
 
 
 @pytest.mark.parametrize("ncls", [3, 4, 5, 8])
