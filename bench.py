@@ -292,8 +292,6 @@ def main():
     if args.same_device:
         local_rank = 0
     torch.cuda.set_device(local_rank)
-    if os.environ.get("DGCNN_MAIN_PRIORITY"):       # experiment: the step's main stream at HIP stream priority -1 (high)
-        torch.cuda.set_stream(torch.cuda.Stream(priority=int(os.environ["DGCNN_MAIN_PRIORITY"])))
     import dgcnn
     from dgcnn import _hip as H
     from dgcnn import parallel

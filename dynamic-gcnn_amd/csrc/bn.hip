@@ -818,8 +818,7 @@ int launch_bwd_reduce(const char* what, Src src, int64_t R, int k, int F, const 
     hipLaunchKernelGGL((bn_bwd_reduce_kernel<4, true>), dim3(grid8(grid_reduce(R * (F / 4)))), dim3(256), sh, st, src, R, k,
                        F, mean, rstd, beta, relu, dmax, lddmax, dmean, lddmean, mx_in, ldmx, cnt_in, red, shift_of(F / 4), dg::stat_slots());
   } else if (vec && k == 1 && !mx_in) {          // k = 1: dz = dmax + dmean / 1 -- `dmean` is the gradient of a second copy of the output
-    static int mb = -1;
-    if (mb < 0) { const char* e = getenv("DGCNN_BN1_RED_BLOCKS"); mb = e ? atoi(e) : 256; }   // experiments
+    const int mb = 256;
     // the kernel ends with 2F double atomics per workgroup, which dominate above ~1 workgroup per CU
     // (F = 256: 19 us at 256 workgroups, 32 us at 2048; 1024-thread workgroups are slower: profiles/bn1_bench.py)
     const K1Grid g = k1_grid(R, F, mb);

@@ -722,9 +722,7 @@ int plan_splits(GemmP& p, void* ws, size_t ws_bytes, const char* what) {
   const int64_t maxs = p.K / 256 > 0 ? p.K / 256 : 1;
   if (s > maxs) s = maxs;
   if (s < 1) s = 1;
-  static int zm_env = -1;
-  if (zm_env < 0) { const char* e = getenv("DGCNN_GEMM_ZMAJOR"); zm_env = e ? atoi(e) : 1; }   // A/B switch
-  if (x3 && zm_env && maxs >= 8) {
+  if (x3 && maxs >= 8) {
     const int64_t cap = big ? 32 : 64;           // workgroups one XCD (32 CUs) runs at a time
     double best_eff = 0.0;
     int64_t best = 0;
@@ -807,14 +805,6 @@ extern "C" int dgcnn_gemm_f32(int transA, int transB, int M, int N, int K,
   DG_REQUIRE(!colmax_keys || (colmax_rows_per_group > 0 && colmax_rows_per_group % 256 == 0 && !transA && N > 4), DGCNN_EUNSUP,
              "dgcnn_gemm_f32: the column-maximum epilogue needs rows_per_group %% 256 == 0 (a tile inside one group), no transA, N > 4");
   p.colmax = reinterpret_cast<unsigned long long*>(colmax_keys); p.colmax_rpg = colmax_rows_per_group;
-  {
-    static int nt = -1;
-    // A/B switch, default off: alone the head GEMMs gain 2-4 % (FC0 dgrad 509 -> 493 us, Merged fwd fetch 76 -> 45 MB), in the step
-    // nothing (4.716 vs 4.725 ms over five alternating pairs): the consumer of C then misses where it used to hit
-    // (profiles/r03/nt_store.txt).  1: outputs of >= 4 M elements, 2: always
-    if (nt < 0) { const char* e = getenv("DGCNN_GEMM_NT_STORE"); nt = e ? atoi(e) : 0; }
-    p.nt_store = (nt == 2 || (nt == 1 && (int64_t)M * N >= (int64_t)(4 << 20))) ? 1 : 0;
-  }
   p.gbvec = gbias && (ldgbias % 4 == 0) && aligned16(gbias);
   p.avec = (lda % 4 == 0) && aligned16(A);
   p.bvec = (ldb % 4 == 0) && aligned16(B);
@@ -864,31 +854,6 @@ extern "C" int dgcnn_gemm_f32(int transA, int transB, int M, int N, int K,
   }
   if (transB) return launch<A_ROW, B_COL, E_STORE>(p, st, "dgcnn_gemm_f32(NT)");
   return launch<A_ROW, B_ROW, E_STORE>(p, st, "dgcnn_gemm_f32(NN)");
-}
-
-// Data gradient dX (+)= dT W^T (W stored [N][K]) that ALSO reduces the BatchNorm-backward sums of the layer whose output occupies
-// columns [c0, c0 + F) of X (GemmP::bnb_*): the separate pass over (dX, T) of that layer is not needed any more.
-extern "C" int dgcnn_gemm_bn_bwd_f32(int M, int N, int K, const float* A, int64_t lda, const float* B, int64_t ldb,
-                                     float* C, int64_t ldc, float beta,
-                                     const float* T, int64_t ldT, const float* mean, const float* rstd, const float* bn_beta,
-                                     int relu, int c0, int F, double* red, void* stream) {
-  DG_REQUIRE(A && B && C && T && mean && rstd && bn_beta && red, DGCNN_EINVAL, "dgcnn_gemm_bn_bwd_f32: null pointer");
-  DG_REQUIRE(M > 0 && N > 0 && K > 0 && F > 0 && c0 >= 0 && c0 + F <= N, DGCNN_EINVAL, "dgcnn_gemm_bn_bwd_f32: bad shape");
-  GemmP p = {};
-  p.stat_slots = dg::stat_slots();
-  p.A = A; p.lda = lda; p.B = B; p.ldb = ldb; p.C = C; p.ldc = ldc;
-  p.M = M; p.N = N; p.K = K; p.beta = beta; p.rpg = 1;
-  p.splits = 1; p.kchunk = K;
-  p.avec = (lda % 4 == 0) && aligned16(A);
-  p.bvec = (ldb % 4 == 0) && aligned16(B);
-  // the sums ride on the float4 store path of the bf16-split kernels' epilogue: quads must not straddle the column range
-  DG_REQUIRE(p.avec && p.bvec && K % 4 == 0 && N % 4 == 0 && ldc % 4 == 0 && aligned16(C) && c0 % 4 == 0 && F % 4 == 0 &&
-                 ldT % 4 == 0 && aligned16(T) && dg::gemm_arith() != 0 && N > 4 && K > 4,
-             DGCNN_EUNSUP, "dgcnn_gemm_bn_bwd_f32: needs float4-loadable operands / column range and the bf16-split arithmetic");
-  p.bnb_T = T; p.bnb_ldT = ldT; p.bnb_mean = mean; p.bnb_rstd = rstd; p.bnb_beta = bn_beta;
-  p.bnb_relu = relu; p.bnb_c0 = c0; p.bnb_F = F; p.bnb_red = red;
-  p.bm = tile_m(M, N, 1);
-  return launch<A_ROW, B_COL, E_STORE>(p, (hipStream_t)stream, "dgcnn_gemm_bn_bwd_f32");
 }
 
 extern "C" int dgcnn_edge_mlp_f32(const float* x, int64_t ldx, const int32_t* idx, const float* W0,

@@ -41,24 +41,8 @@ struct GemmP {
   // that produces the tensor): keys[group][N] <- atomicMax(order-preserving bits of the value << 32 | ~row-in-group), i.e. the
   // largest value and, among ties, the FIRST row.  Needs rows_per_group % tile rows == 0 (checked by the host).
   unsigned long long* colmax; int colmax_rpg;
-  // 1: the output tile is stored with nontemporal (streaming) stores.  A GEMM with many column tiles per row panel (FC0's data
-  // gradient: 14) writes hundreds of MB through the XCD's 4 MB L2 while its workgroups re-read the shared A panel and B tiles from
-  // it: the write stream evicted them (FC0 dgrad fetched 452 MB for 104 MB of operands, profiles/r03_pmc_hbm_bytes.txt)
-  int nt_store;
-  int stat_slots; // slots of p.stats / p.bnb_red (dg::stat_slots() at launch)
-  // BatchNorm-backward sums of the layer BELOW, taken in the epilogue of the data-gradient GEMM that produces that layer's output
-  // gradient (dgcnn_gemm_bn_bwd_f32): for output columns c in [bnb_c0, bnb_c0 + bnb_F), f = c - bnb_c0, the layer's pre-BN tensor
-  // t = bnb_T[row][f]:  xhat = (t - mean) rstd, z = xhat + beta (relu'ed), dz = (relu && z <= 0) ? 0 : C[row][c];
-  // bnb_red[slot][0][f] += dz, bnb_red[slot][1][f] += dz xhat -- the pass that re-read dz and T for these sums is gone.
-  const float* bnb_T; int64_t bnb_ldT; const float* bnb_mean; const float* bnb_rstd; const float* bnb_beta;
-  int bnb_c0, bnb_F, bnb_relu; double* bnb_red;
+  int stat_slots; // slots of p.stats (dg::stat_slots() at launch)
 };
-
-__device__ __forceinline__ void st4_nt(float* p, float a, float b, float c, float d) {
-  typedef float f4v __attribute__((ext_vector_type(4)));
-  f4v v = {a, b, c, d};
-  __builtin_nontemporal_store(v, reinterpret_cast<f4v*>(p));
-}
 
 // order-preserving map float -> uint32 (larger float <=> larger unsigned), and back
 __device__ __forceinline__ unsigned f32_ordered(float v) {
@@ -160,15 +144,6 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[TM][
       if (gcol + q < p.N) gbu[q] = p.gbias[(int64_t)(m0 / p.rpg) * p.ldgbias + gcol + q];
   }
   float cs[4] = {0.f, 0.f, 0.f, 0.f}, cq[4] = {0.f, 0.f, 0.f, 0.f};
-  // BatchNorm-backward mode: this thread's column quad lies inside the layer's column range (quads never straddle: host check)
-  const bool bnb = (p.bnb_T != nullptr) && !split;
-  const int bnf = gcol - p.bnb_c0;
-  const bool bnb_on = bnb && col_ok && bnf >= 0 && bnf + 3 < p.bnb_F;
-  float bmu[4] = {0.f, 0.f, 0.f, 0.f}, brs[4] = {0.f, 0.f, 0.f, 0.f}, bbe[4] = {0.f, 0.f, 0.f, 0.f};
-  if (bnb_on) {
-#pragma unroll
-    for (int q = 0; q < 4; ++q) { bmu[q] = p.bnb_mean[bnf + q]; brs[q] = p.bnb_rstd[bnf + q]; bbe[q] = p.bnb_beta[bnf + q]; }
-  }
   float cmx[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
   int cmr[4] = {0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff};
   const bool want_max = (p.colmax != nullptr) && !split;
@@ -218,29 +193,13 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[TM][
           }
         }
         if (vec_st) {
-          if (p.nt_store) st4_nt(dst, v[0], v[1], v[2], v[3]);
-          else *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
-          if (bnb) {
-            if (bnb_on) {
-              const float4 t4 = *reinterpret_cast<const float4*>(p.bnb_T + (int64_t)grow * p.bnb_ldT + bnf);
-              const float tv4[4] = {t4.x, t4.y, t4.z, t4.w};
+          *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
 #pragma unroll
-              for (int q = 0; q < 4; ++q) {       // same expressions as bn.hip:bn_z (the library is built with -ffp-contract=off)
-                const float xh = (tv4[q] - bmu[q]) * brs[q];
-                float z = xh + bbe[q];
-                if (p.bnb_relu) z = fmaxf(z, 0.f);
-                const float dz = (p.bnb_relu && !(z > 0.f)) ? 0.f : v[q];
-                cs[q] += dz; cq[q] += dz * xh;
-              }
-            }
-          } else {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) { cs[q] += v[q]; cq[q] += v[q] * v[q]; }
-          }
+          for (int q = 0; q < 4; ++q) { cs[q] += v[q]; cq[q] += v[q] * v[q]; }
         } else {
 #pragma unroll
           for (int q = 0; q < 4; ++q)
-            if (gcol + q < p.N) { dst[q] = v[q]; if (!bnb) { cs[q] += v[q]; cq[q] += v[q] * v[q]; } }
+            if (gcol + q < p.N) { dst[q] = v[q]; cs[q] += v[q]; cq[q] += v[q] * v[q]; }
         }
         if (want_max) {
 #pragma unroll
@@ -250,7 +209,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[TM][
       }
     }
   }
-  if ((p.stats || want_max || bnb) && !split) {
+  if ((p.stats || want_max) && !split) {
     // Column reductions of the tile.  The NTH / QV threads that share a column quad park their partial results as float4
     // slots [thread row l][kind][quad] (conflict-free ds_write_b128), one thread per column then walks down the l's (round 2
     // used 8 LDS float atomics per thread, 16 threads deep on every address).
@@ -285,11 +244,6 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[TM][
           const int slot = mt % p.stat_slots;
           atomicAdd(p.stats + ((int64_t)slot * 2 + 0) * p.N + c, (double)s0);
           atomicAdd(p.stats + ((int64_t)slot * 2 + 1) * p.N + c, (double)s1);
-        }
-        if (bnb && c >= p.bnb_c0 && c < p.bnb_c0 + p.bnb_F) {
-          const int slot = mt % p.stat_slots;
-          atomicAdd(p.bnb_red + ((int64_t)slot * 2 + 0) * p.bnb_F + (c - p.bnb_c0), (double)s0);
-          atomicAdd(p.bnb_red + ((int64_t)slot * 2 + 1) * p.bnb_F + (c - p.bnb_c0), (double)s1);
         }
         if (want_max && mr != 0x7fffffff) {
           const int grp = m0 / p.colmax_rpg;                  // the tile lies inside one group (host check)

@@ -19,7 +19,8 @@
 //            consumer reads it with ds_read_b64_tr_b16 (hardware 4x4 transpose), so no second copy of the tensor.
 //   Weights are tiny: dgcnn_split_planes_f32 writes them in whichever orientation the product needs.
 //
-// Formats:  DGCNN_PLANES_BF16X3  a = a1 + a2 + a3 exactly (3 x bf16); 6 partial products (all but a2b3, a3b2, a3b3),
+// Formats:  (round 3 also had DGCNN_PLANES_BF16X3, a = a1 + a2 + a3 exactly, 6 partial products: 1.5x the bytes of the fp32 operands
+//           it replaced and slower than the in-kernel split at kernel and step level -- profiles/r03/gemm_planes.txt -- removed)
 //                                same arithmetic as gemm_x3.hip NP = 6.
 //           DGCNN_PLANES_F16X2   a * 2^e = h1 + h2 (2 x fp16, |a - (h1+h2) 2^-e| <= 2^-22 |a| while h2 is a normal
 //                                fp16 number); 3 partial products (h1h1, h1h2, h2h1) -- see split_f16x2 below.
@@ -47,12 +48,6 @@ using s16x8 = __attribute__((ext_vector_type(8))) short;
 enum { PL_KC = 0, PL_TR = 1 };
 
 template <int FMT> struct Fmt;
-template <> struct Fmt<DGCNN_PLANES_BF16X3> {
-  static constexpr int NPL = 3, NP = 6;
-  static __device__ __forceinline__ f32x16 mfma(s16x8 a, s16x8 b, f32x16 c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
-  }
-};
 template <> struct Fmt<DGCNN_PLANES_F16X2> {
   static constexpr int NPL = 2, NP = 3;
   static __device__ __forceinline__ f32x16 mfma(s16x8 a, s16x8 b, f32x16 c) {
@@ -395,7 +390,7 @@ void launch_reduce_partials(const float* part, int splits, int M, int N, float* 
 extern "C" int dgcnn_split_planes_f32(const float* src, int64_t row_stride, int64_t col_stride, int64_t rows, int cols, int fmt,
                                       const float* scale_dev, void* dst, int64_t plane_stride, int64_t rows_alloc, void* stream) {
   DG_REQUIRE(src && dst && rows > 0 && cols > 0, DGCNN_EINVAL, "dgcnn_split_planes_f32: bad args");
-  DG_REQUIRE(fmt == DGCNN_PLANES_BF16X3 || fmt == DGCNN_PLANES_F16X2, DGCNN_EINVAL, "dgcnn_split_planes_f32: unknown format %d", fmt);
+  DG_REQUIRE(fmt == DGCNN_PLANES_F16X2, DGCNN_EINVAL, "dgcnn_split_planes_f32: unknown format %d (the 3 x bf16 format was removed)", fmt);
   DG_REQUIRE(rows_alloc >= rows && rows_alloc % 64 == 0 && plane_stride % 16 == 0 && aligned16p(dst), DGCNN_EINVAL,
              "dgcnn_split_planes_f32: rows_alloc must be a multiple of 64 >= rows, planes 16-byte aligned");
   const int noct = (cols + 7) / 8;
@@ -406,16 +401,10 @@ extern "C" int dgcnn_split_planes_f32(const float* src, int64_t row_stride, int6
     int64_t gx = rows_alloc / 64;
     if (gx * gy > 8192) gx = dg::cdiv(8192, gy);
     dim3 grid((unsigned)gx, (unsigned)gy);
-    if (fmt == DGCNN_PLANES_BF16X3)
-      hipLaunchKernelGGL((split_rows_kernel<DGCNN_PLANES_BF16X3>), grid, dim3(256), 0, ST, src, row_stride, rows, cols, (char*)dst, plane_stride, rows_alloc, scale_dev);
-    else
-      hipLaunchKernelGGL((split_rows_kernel<DGCNN_PLANES_F16X2>), grid, dim3(256), 0, ST, src, row_stride, rows, cols, (char*)dst, plane_stride, rows_alloc, scale_dev);
+    hipLaunchKernelGGL((split_rows_kernel<DGCNN_PLANES_F16X2>), grid, dim3(256), 0, ST, src, row_stride, rows, cols, (char*)dst, plane_stride, rows_alloc, scale_dev);
   } else {
     const unsigned g = (unsigned)dg::cdiv((int64_t)noct * rows_alloc, 256);
-    if (fmt == DGCNN_PLANES_BF16X3)
-      hipLaunchKernelGGL((split_strided_kernel<DGCNN_PLANES_BF16X3>), dim3(g), dim3(256), 0, ST, src, row_stride, col_stride, rows, cols, (char*)dst, plane_stride, rows_alloc, scale_dev);
-    else
-      hipLaunchKernelGGL((split_strided_kernel<DGCNN_PLANES_F16X2>), dim3(g), dim3(256), 0, ST, src, row_stride, col_stride, rows, cols, (char*)dst, plane_stride, rows_alloc, scale_dev);
+    hipLaunchKernelGGL((split_strided_kernel<DGCNN_PLANES_F16X2>), dim3(g), dim3(256), 0, ST, src, row_stride, col_stride, rows, cols, (char*)dst, plane_stride, rows_alloc, scale_dev);
   }
   return dg::check_launch("dgcnn_split_planes_f32");
 }
@@ -446,7 +435,7 @@ extern "C" int dgcnn_gemm_planes_f32(int form, int fmt, int M, int N, int K,
                                      void* ws, size_t ws_bytes, void* stream) {
   DG_REQUIRE(A && B && C && M > 0 && N > 0 && K > 0, DGCNN_EINVAL, "dgcnn_gemm_planes_f32: bad args");
   DG_REQUIRE(form == DGCNN_PL_KC || form == DGCNN_PL_TR, DGCNN_EINVAL, "dgcnn_gemm_planes_f32: unknown form %d", form);
-  DG_REQUIRE(fmt == DGCNN_PLANES_BF16X3 || fmt == DGCNN_PLANES_F16X2, DGCNN_EINVAL, "dgcnn_gemm_planes_f32: unknown format %d", fmt);
+  DG_REQUIRE(fmt == DGCNN_PLANES_F16X2, DGCNN_EINVAL, "dgcnn_gemm_planes_f32: unknown format %d (the 3 x bf16 format was removed)", fmt);
   DG_REQUIRE(aligned16p(A) && aligned16p(B) && a_plane_stride % 16 == 0 && b_plane_stride % 16 == 0 && a_rows_alloc % 64 == 0 &&
                  b_rows_alloc % 64 == 0, DGCNN_EINVAL, "dgcnn_gemm_planes_f32: planes must be 16-byte aligned, rows_alloc a multiple of 64");
   DG_REQUIRE(!gbias || rows_per_group > 0, DGCNN_EINVAL, "dgcnn_gemm_planes_f32: rows_per_group");
@@ -463,7 +452,7 @@ extern "C" int dgcnn_gemm_planes_f32(int form, int fmt, int M, int N, int K,
   q.Ap = (const char*)A; q.a_ps = a_plane_stride; q.a_rows = a_rows_alloc;
   q.Bp = (const char*)B; q.b_ps = b_plane_stride; q.b_rows = b_rows_alloc;
   q.a_scale = a_scale_dev; q.b_scale = b_scale_dev;
-  { static int ab = -1; if (ab < 0) { const char* e = getenv("DGCNN_PL_ABLATE"); ab = e ? atoi(e) : 0; } q.ablate = ab; }
+  q.ablate = 0;
   p.mtiles = (int)dg::cdiv(M, 256);
   p.ntiles = (int)dg::cdiv(N, 128);
   if (form == DGCNN_PL_KC) {
@@ -501,10 +490,10 @@ extern "C" int dgcnn_gemm_planes_f32(int form, int fmt, int M, int N, int K,
   const unsigned gx = p.xcd_group ? (unsigned)(dg::cdiv(p.mtiles, 8) * 8 * p.ntiles) : (unsigned)(p.mtiles * p.ntiles);
   dim3 grid(gx, 1, 1);
   if (p.zmajor) grid = dim3((unsigned)(dg::cdiv(p.splits, 8) * 8 * p.mtiles * p.ntiles), 1, 1);
-  // bf16x3: 16-k slabs x 4 stages (36 KB each), f16x2: 32-k slabs x 3 stages (48 KB each): up to 108 / 96 KB of DMA in flight per CU
-#define DG_PL(FORM, FMT) hipLaunchKernelGGL((gemm_pl_kernel<FORM, FMT, (FMT == DGCNN_PLANES_BF16X3 ? 16 : 32), (FMT == DGCNN_PLANES_BF16X3 ? 4 : 3)>), grid, dim3(768), 0, ST, q)
-  if (form == DGCNN_PL_KC) { if (fmt == DGCNN_PLANES_BF16X3) DG_PL(PL_KC, DGCNN_PLANES_BF16X3); else DG_PL(PL_KC, DGCNN_PLANES_F16X2); }
-  else { if (fmt == DGCNN_PLANES_BF16X3) DG_PL(PL_TR, DGCNN_PLANES_BF16X3); else DG_PL(PL_TR, DGCNN_PLANES_F16X2); }
+  // 32-k slabs x 3 stages (48 KB each): up to 96 KB of DMA in flight per CU
+#define DG_PL(FORM, FMT) hipLaunchKernelGGL((gemm_pl_kernel<FORM, FMT, 32, 3>), grid, dim3(768), 0, ST, q)
+  if (form == DGCNN_PL_KC) DG_PL(PL_KC, DGCNN_PLANES_F16X2);
+  else DG_PL(PL_TR, DGCNN_PLANES_F16X2);
 #undef DG_PL
   int rc = dg::check_launch("dgcnn_gemm_planes_f32");
   if (rc) return rc;

@@ -644,14 +644,9 @@ void set_gemm_arith(int v) { g_arith = v; }
 // asrc in {A_ROW, A_COL}, bsrc in {B_ROW, B_COL}; operands float4-loadable (checked by the caller).
 // p.mtiles / ntiles / xcd_group / splits / kchunk (multiple of 32 when splits > 1) are set.
 int x3_tile_m(int M, int N, int K) {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("DGCNN_GEMM_X3_BM"); v = e ? atoi(e) : 0; }   // A/B switch: 128 forces the small tile
-  if (v == 128) return 128;
-  static int v64 = -1;
-  if (v64 < 0) { const char* e = getenv("DGCNN_GEMM_X3_BM64"); v64 = e ? atoi(e) : 1; }         // A/B switch
   // short reduction, many rows, one or two column tiles: the kernel is bound by the latency of its few slabs -- 64-row tiles put
   // twice the workgroups (and loads in flight) on a CU
-  if (v64 && dg::gemm_arith() == 6 && K <= 256 && N <= 256 && M >= 8192 && cdiv(M, 128) * cdiv(N, 128) <= 1024) return 64;
+  if (dg::gemm_arith() == 6 && K <= 256 && N <= 256 && M >= 8192 && cdiv(M, 128) * cdiv(N, 128) <= 1024) return 64;
   // small problems (configs[0]: 1024 rows, K ~ 1000): a 256 x 128 tiling, even split over K, leaves most CUs without work
   if (cdiv(M, 256) * cdiv(N, 128) * cdiv(K, 256) < 256) return 128;
   return (M > 128 && N > 64) ? 256 : 128;

@@ -333,42 +333,6 @@ __global__ void global_max_bwd_kernel(const float* __restrict__ dout, const int3
   }
 }
 
-// the same scatter, plus its share of the BatchNorm-backward sums that dgcnn_gemm_bn_bwd_f32 took BEFORE this gradient arrived:
-// the sums are linear in dz, so the (b, f) entries add  m dg  and  m dg xhat  (m = relu mask at the arg-max row) to slot 0
-__global__ void global_max_bwd_bn_kernel(const float* __restrict__ dout, const int32_t* __restrict__ arg, int B, int N, int F,
-                                         float* __restrict__ dx, int64_t lddx, const float* __restrict__ T,
-                                         int64_t ldT, const float* __restrict__ mean, const float* __restrict__ rstd,
-                                         const float* __restrict__ beta, int relu, double* __restrict__ red) {
-  const int f = blockIdx.x * blockDim.x + threadIdx.x;          // one thread per channel, clouds in ascending order: fixed order
-  if (f >= F) return;
-  const float mu = mean[f], rs = rstd[f], be = beta[f];
-  double s0 = 0.0, s1 = 0.0;
-  for (int b0 = 0; b0 < B; b0 += 8) {                  // 8 clouds' loads in flight, sums still in ascending b
-    int64_t row[8];
-    float g[8], t[8], old[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int b = (b0 + u < B) ? (b0 + u) : (B - 1);
-      row[u] = (int64_t)b * N + arg[(int64_t)b * F + f];
-      g[u] = dout[(int64_t)b * F + f];
-    }
-#pragma unroll
-    for (int u = 0; u < 8; ++u) { t[u] = T[row[u] * ldT + f]; old[u] = dx[row[u] * lddx + f]; }
-#pragma unroll
-    for (int u = 0; u < 8; ++u)
-      if (b0 + u < B) {
-        dx[row[u] * lddx + f] = old[u] + g[u];
-        const float xh = (t[u] - mu) * rs;
-        float z = xh + be;
-        if (relu) z = fmaxf(z, 0.f);
-        const float dz = (relu && !(z > 0.f)) ? 0.f : g[u];
-        s0 += (double)dz;
-        s1 += (double)(dz * xh);
-      }
-  }
-  atomicAdd(red + f, s0);              // slot 0 has one other writer at most (the GEMM's first row tile), and that kernel is complete
-  atomicAdd(red + F + f, s1);
-}
 
 __global__ __launch_bounds__(64 * RG) void group_colsum_kernel(const float* __restrict__ x, int64_t ldx, int rows,
                                                                int F, float* __restrict__ out) {
@@ -536,9 +500,7 @@ extern "C" int dgcnn_edge_csr_build(const int32_t* idx, int B, int N, int k, int
     int G = 1;
     while (G < 64 && ((int64_t)B * G < 256 || dg::cdiv(N, G) > 12288) && dg::cdiv(N, G * 2) >= 64) G *= 2;
     const int T = (int)dg::cdiv(N, G);
-    static int use_lds = -1;
-    if (use_lds < 0) { const char* e = getenv("DGCNN_CSR_GLOBAL"); use_lds = (e && e[0] == '1') ? 0 : 1; }   // A/B switch
-    if (use_lds && T <= 12288) {     // <= 52 KB of dynamic LDS
+    if (T <= 12288) {     // <= 52 KB of dynamic LDS
       const size_t sh = sizeof(int) * ((size_t)T + 1024 + 1);
       hipLaunchKernelGGL(csr_cloud_kernel, dim3((unsigned)dg::cdiv(N, T), (unsigned)B), dim3(1024), sh, ST, idx, N, k, T, off, rev);
       return dg::check_launch("dgcnn_edge_csr_build");
@@ -610,16 +572,6 @@ extern "C" int dgcnn_global_max_bwd_f32(const float* dout, const int32_t* arg, i
   const int64_t total = (int64_t)B * F;
   hipLaunchKernelGGL(global_max_bwd_kernel, dim3(grid1d(total)), dim3(256), 0, ST, dout, arg, N, F, total, dx, lddx);
   return dg::check_launch("dgcnn_global_max_bwd_f32");
-}
-
-extern "C" int dgcnn_global_max_bwd_bn_f32(const float* dout, const int32_t* arg, int B, int N, int F, float* dx, int64_t lddx,
-                                           const float* T, int64_t ldT, const float* mean, const float* rstd, const float* beta,
-                                           int relu, double* red, void* stream) {
-  DG_REQUIRE(dout && arg && dx && T && mean && rstd && beta && red && B > 0 && N > 0 && F > 0, DGCNN_EINVAL,
-             "dgcnn_global_max_bwd_bn_f32: bad args");
-  hipLaunchKernelGGL(global_max_bwd_bn_kernel, dim3((unsigned)dg::cdiv(F, 64)), dim3(64), 0, ST, dout, arg, B, N, F, dx, lddx, T, ldT,
-                     mean, rstd, beta, relu, red);
-  return dg::check_launch("dgcnn_global_max_bwd_bn_f32");
 }
 
 extern "C" int dgcnn_group_colsum_f32(const float* x, int64_t ldx, int G, int rows_per_group, int F, float* out,

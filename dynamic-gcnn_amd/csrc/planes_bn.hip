@@ -309,16 +309,12 @@ extern "C" int dgcnn_bn_act_planes_f32(const float* T, int64_t ldt, int64_t R, i
                                        int64_t plane_stride, int64_t rows_alloc, float* out, int64_t ldo, float* out2,
                                        int64_t ldo2, void* stream) {
   DG_REQUIRE(T && mean && rstd && beta && planes && R > 0 && F > 0, DGCNN_EINVAL, "dgcnn_bn_act_planes_f32: bad args");
-  DG_REQUIRE(fmt == DGCNN_PLANES_BF16X3 || fmt == DGCNN_PLANES_F16X2, DGCNN_EINVAL, "dgcnn_bn_act_planes_f32: unknown format %d", fmt);
+  DG_REQUIRE(fmt == DGCNN_PLANES_F16X2, DGCNN_EINVAL, "dgcnn_bn_act_planes_f32: unknown format %d", fmt);
   DG_REQUIRE(F % 8 == 0 && ldt % 4 == 0 && a16(T) && a16(mean) && a16(rstd) && a16(beta) && a16(planes) && plane_stride % 16 == 0 &&
                  rows_alloc % 64 == 0 && rows_alloc >= R && (!out || (a16(out) && ldo % 4 == 0)) && (!out2 || (a16(out2) && ldo2 % 4 == 0)),
              DGCNN_EINVAL, "dgcnn_bn_act_planes_f32: F %% 8, 16-byte aligned operands, rows_alloc %% 64 required");
   dim3 grid = plane_grid(rows_alloc, F);
-  if (fmt == DGCNN_PLANES_F16X2)
-    hipLaunchKernelGGL((bn_act_planes_kernel<DGCNN_PLANES_F16X2>), grid, dim3(256), 0, ST, T, ldt, R, F, mean, rstd, beta, relu,
-                       scale_dev, (char*)planes, plane_stride, rows_alloc, out, ldo, out2, ldo2);
-  else
-    hipLaunchKernelGGL((bn_act_planes_kernel<DGCNN_PLANES_BF16X3>), grid, dim3(256), 0, ST, T, ldt, R, F, mean, rstd, beta, relu,
+  hipLaunchKernelGGL((bn_act_planes_kernel<DGCNN_PLANES_F16X2>), grid, dim3(256), 0, ST, T, ldt, R, F, mean, rstd, beta, relu,
                        scale_dev, (char*)planes, plane_stride, rows_alloc, out, ldo, out2, ldo2);
   return dg::check_launch("dgcnn_bn_act_planes_f32");
 }
@@ -348,7 +344,7 @@ extern "C" int dgcnn_bn1_bwd_apply_planes_f32(const float* T, int64_t R, int F, 
                                               float* dbeta, float dbeta_beta, void* stream) {
   DG_REQUIRE(T && mean && rstd && beta && dout && red && maxbits && planes && scale_dev && R > 0 && F > 0, DGCNN_EINVAL,
              "dgcnn_bn1_bwd_apply_planes_f32: bad args");
-  DG_REQUIRE(fmt == DGCNN_PLANES_BF16X3 || fmt == DGCNN_PLANES_F16X2, DGCNN_EINVAL, "dgcnn_bn1_bwd_apply_planes_f32: unknown format %d", fmt);
+  DG_REQUIRE(fmt == DGCNN_PLANES_F16X2, DGCNN_EINVAL, "dgcnn_bn1_bwd_apply_planes_f32: unknown format %d", fmt);
   DG_REQUIRE(F % 8 == 0 && lddo % 4 == 0 && a16(T) && a16(dout) && a16(planes) && plane_stride % 16 == 0 && rows_alloc % 64 == 0 &&
                  rows_alloc >= R && (!dT || a16(dT)), DGCNN_EINVAL, "dgcnn_bn1_bwd_apply_planes_f32: F %% 8, aligned operands required");
   DG_REQUIRE(!gsum || (rows_per_group > 0 && rows_per_group % 64 == 0), DGCNN_EUNSUP,
@@ -364,11 +360,7 @@ extern "C" int dgcnn_bn1_bwd_apply_planes_f32(const float* T, int64_t R, int F, 
       if (rows_per_group % cnd == 0) { chunk = cnd; break; }
   }
   dim3 grid((unsigned)dg::cdiv(rows_alloc, chunk), (unsigned)dg::cdiv(F / 8, 4 * OPT));
-  if (fmt == DGCNN_PLANES_F16X2)
-    hipLaunchKernelGGL((bn1_bwd_apply_planes_kernel<DGCNN_PLANES_F16X2>), grid, dim3(256), 0, ST, T, R, F, mean, rstd, beta, relu, dout,
-                       lddo, cf, scale_dev, (char*)planes, plane_stride, rows_alloc, dT, gsum, ldgsum, rows_per_group, chunk);
-  else
-    hipLaunchKernelGGL((bn1_bwd_apply_planes_kernel<DGCNN_PLANES_BF16X3>), grid, dim3(256), 0, ST, T, R, F, mean, rstd, beta, relu, dout,
+  hipLaunchKernelGGL((bn1_bwd_apply_planes_kernel<DGCNN_PLANES_F16X2>), grid, dim3(256), 0, ST, T, R, F, mean, rstd, beta, relu, dout,
                        lddo, cf, scale_dev, (char*)planes, plane_stride, rows_alloc, dT, gsum, ldgsum, rows_per_group, chunk);
   return dg::check_launch("dgcnn_bn1_bwd_apply_planes_f32");
 }

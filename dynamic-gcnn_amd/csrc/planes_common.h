@@ -6,7 +6,6 @@
 namespace {
 
 template <int FMT> struct PlaneFmt;
-template <> struct PlaneFmt<DGCNN_PLANES_BF16X3> { static constexpr int NPL = 3; };
 template <> struct PlaneFmt<DGCNN_PLANES_F16X2> { static constexpr int NPL = 2; };
 
 __device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {
@@ -16,16 +15,6 @@ __device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {
 }
 
 // (x0, x1) -> packed pairs of the split terms (x0 in the low half)
-__device__ __forceinline__ void split_bf16x3(float x0, float x1, unsigned (&o)[3]) {
-  o[0] = cvt_pk_bf16(x0, x1);
-  const float r0 = x0 - __uint_as_float(o[0] << 16);
-  const float r1 = x1 - __uint_as_float(o[0] & 0xffff0000u);
-  o[1] = cvt_pk_bf16(r0, r1);
-  const float s0 = r0 - __uint_as_float(o[1] << 16);
-  const float s1 = r1 - __uint_as_float(o[1] & 0xffff0000u);
-  o[2] = cvt_pk_bf16(s0, s1);
-}
-
 // fp16 pair: h1 = rn16(x), h2 = rn16(x - h1) (x already scaled by the tensor's power of two; |x| <= 65504 or it saturates)
 __device__ __forceinline__ void split_f16x2(float x0, float x1, unsigned (&o)[3]) {
   const float lim = 65504.f;
@@ -43,8 +32,7 @@ __device__ __forceinline__ void split8(const float (&v)[8], float scale, uint4 (
   unsigned w[4][3];
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
-    if (FMT == DGCNN_PLANES_BF16X3) split_bf16x3(v[2 * e], v[2 * e + 1], w[e]);
-    else split_f16x2(v[2 * e] * scale, v[2 * e + 1] * scale, w[e]);
+    split_f16x2(v[2 * e] * scale, v[2 * e + 1] * scale, w[e]);
   }
 #pragma unroll
   for (int pl = 0; pl < 3; ++pl) o[pl] = make_uint4(w[0][pl], w[1][pl], w[2][pl], w[3][pl]);

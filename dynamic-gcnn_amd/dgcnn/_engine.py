@@ -37,19 +37,11 @@ EDGE_MLP_LITERAL = False  # True: conv0 as the literal (B*N*k) x 2C GEMM over E 
 EDGE_MATERIALIZE_Y = False  # True: gather-add writes the (B*N*k, F) conv0 output and BatchNorm streams it (A/B switch);
                             # False: the BatchNorm passes recompute y = V[neighbour] + U[point] (no edge tensor in the forward)
 WGRAD_SIDE_STREAM = os.environ.get("DGCNN_SIDE_STREAM", "1") != "0"   # weight-gradient GEMMs on a second HIP stream
-WGRAD_AFTER_DGRAD = os.environ.get("DGCNN_WGRAD_AFTER_DGRAD", "1") != "0"   # side-stream weight gradients start behind the data gradient
-WEIGHT_PREP_AHEAD = os.environ.get("DGCNN_WPREP", "1") != "0"   # parameter-only kernels of the step go first, on the side stream
-EDGE_BWD_FUSED_L0 = os.environ.get("DGCNN_EDGE_BWD_FUSED_L0", "1") != "0"   # input layer (C <= 4, no input gradient): one backward pass
-FUSE_DROPOUT = os.environ.get("DGCNN_FUSE_DROPOUT", "1") != "0"   # tf.nn.dropout inside the last FC layer's BatchNorm passes
-# BatchNorm-backward sums of MergedEdgeConv / FC0 from the epilogue of the data-gradient GEMM above them (dgcnn_gemm_bn_bwd_f32).
-# Off by default: -350 MB and two launches per step, but no step time (profiles/r03/bnb_epilogue.txt: those passes ran under the
-# side stream's weight-gradient GEMMs anyway) -- and the data-gradient GEMMs, the step's dominant kernel, get 4-19 us longer.
-BN_BWD_IN_DGRAD = os.environ.get("DGCNN_BN_BWD_IN_DGRAD", "0") != "0"
-BN1_BWD_TWO_SOURCES = os.environ.get("DGCNN_BN1_BWD_TWO_SOURCES", "1") != "0"   # conv1's backward reads both output gradients (no add pass)
-COLMAX_IN_EPILOGUE = os.environ.get("DGCNN_COLMAX_EPILOGUE", "1") != "0"   # the global max-pool comes out of MergedEdgeConv's GEMM epilogue
+# Fusions with a separate-pass twin that the tests compare them against (module constants, not run-time switches):
+EDGE_BWD_FUSED_L0 = True   # input layer (C <= 4, no input gradient): conv0's whole backward in one pass
+FUSE_DROPOUT = True        # tf.nn.dropout inside the last FC layer's BatchNorm passes
 EDGE_BWD_REDUCE_POINTS = True   # BN backward sums of conv0 from per-point data (False: a pass over the edges)
 SIDE_STREAM_MIN_ROWS = 16384   # below this many points the side stream is not used
-SIDE_STREAM_PRIORITY = int(os.environ.get("DGCNN_SIDE_PRIORITY", "0"))   # HIP stream priority of the side stream (experiment)
 # conv0 of every EdgeConv layer with bf16 OPERANDS (BASELINE.json configs[2] "bf16 edge-MLP MFMA"): E = [x_i, x_j - x_i] is formed
 # in fp32, E and W0 are rounded to bf16 once, the literal (B*N*k) x 2C x F product runs on v_mfma_f32_32x32x16_bf16 with fp32
 # accumulation; the two gradient products round their operands the same way.  "f32" (default): the fp32-class folded form.
@@ -68,8 +60,8 @@ DETERMINISTIC = DETERMINISTIC_ENV_DEFAULT      # trainval.initialize() sets it p
 
 
 # Head GEMMs (MergedEdgeConv, FC0, FC1: 98 % of the step's GEMM flops) from pre-split operand planes (csrc/gemm_pl.hip):
-#   "f16"  two fp16 planes per operand, 3 partial products   "bf16"  three bf16 planes, 6 partial products   "0"  off
-HEAD_PLANES_ENV_DEFAULT = {"f16": PL.F16X2, "bf16": PL.BF16X3}.get(os.environ.get("DGCNN_HEAD_PLANES", "0").lower())
+#   "f16"  two fp16 planes per operand, 3 partial products   "0"  off
+HEAD_PLANES_ENV_DEFAULT = {"f16": PL.F16X2}.get(os.environ.get("DGCNN_HEAD_PLANES", "0").lower())
 HEAD_PLANES = HEAD_PLANES_ENV_DEFAULT          # trainval.initialize() sets it per instance (flag HEAD_PLANES, else this default)
 PLANES_MIN_ROWS = 8192
 
@@ -104,7 +96,6 @@ class Context(object):
         self.capturing = False           # inside a HIP-graph capture: no host-side per-step state may be baked in
         self.debug = False
         self.planes = {}                 # (data_ptr, rows, cols) of an fp32 2-D view -> PlaneSet holding it as GEMM operand planes (this step)
-        self.bn_hooks = {}               # data_ptr of a BatchNorm layer's output view -> BnBwdHook (this step)
         self.pl_scales = None            # device float[2]: power-of-two scales of the step's activation / weight plane sets (fp16 planes)
         self.pl_scales_ready = False
         self.pl_ws = None
@@ -140,7 +131,7 @@ class Context(object):
             return
         main = torch.cuda.current_stream()
         if self.side is None or self.side.device != self.device:
-            self.side = torch.cuda.Stream(device=self.device, priority=SIDE_STREAM_PRIORITY)
+            self.side = torch.cuda.Stream(device=self.device)
         self.side.wait_stream(main)
         for t in temporaries:
             t.record_stream(self.side)
@@ -247,7 +238,6 @@ class Context(object):
         self.tape = []
         self.roots = []
         self.planes = {}
-        self.bn_hooks = {}
         self.pl_scales_ready = False
         self.wprep = {}
         self.wprep_event = None
@@ -518,58 +508,6 @@ def bn_bwd_reduce(Y, R, k, F, mean, rstd, beta, relu, dmx, dmn, mx, cnt, red, ta
                H._p(cnt), red.data_ptr(), tag=tag, work=work)
 
 
-class BnBwdHook(object):
-    """A BatchNorm layer offers the two sums of its backward (sum dz, sum dz*xhat) to whoever produces d(its output): the data-
-    gradient GEMM of the layer ABOVE takes them in its epilogue (dgcnn_gemm_bn_bwd_f32) while the tile of dz is still in registers,
-    and the layer's own pass over (dz, T) is dropped.  served: `red` holds the sums (slots), not finalised."""
-    __slots__ = ("out", "T", "mean", "rstd", "beta", "relu", "F", "red", "served")
-
-    def __init__(self, out, T, mean, rstd, beta, relu):
-        self.out, self.T, self.mean, self.rstd, self.beta, self.relu = out, T, mean, rstd, beta, bool(relu)
-        self.F = out.shape[1]
-        self.red = None
-        self.served = False
-
-
-def bn_hook_inside(x):
-    """The widest unserved hook whose output view is a column range of the 2-D view x (same rows, same leading dimension):
-    (hook, first column) or (None, 0)."""
-    c = ctx()
-    best, best_c0 = None, 0
-    px, ld = x.data_ptr(), H.ld2(x)
-    for h in c.bn_hooks.values():
-        if h.served or h.out.shape[0] != x.shape[0] or H.ld2(h.out) != ld:
-            continue
-        off = (h.out.data_ptr() - px) // 4
-        if off < 0 or off >= x.shape[1] or off + h.F > x.shape[1]:
-            continue
-        if best is None or h.F > best.F:
-            best, best_c0 = h, int(off)
-    return best, best_c0
-
-
-def dgrad_gemm(dT, W, x, dx, beta, arith=None):
-    """dx (+)= dT W^T for the layer input x; when a BatchNorm layer's output is a column range of x and offered a hook, the GEMM's
-    epilogue also reduces that layer's backward sums (BN_BWD_IN_DGRAD)."""
-    h, c0 = (None, 0)
-    if BN_BWD_IN_DGRAD and arith is None and H.gemm_arith() != 0:
-        h, c0 = bn_hook_inside(x)
-    if h is not None:
-        M, K = dT.shape
-        N = W.shape[0]
-        al = lambda t: t.data_ptr() % 16 == 0 and H.ld2(t) % 4 == 0
-        if (c0 % 4 == 0 and h.F % 4 == 0 and N % 4 == 0 and K % 4 == 0 and N > 4 and K > 4 and al(dT) and al(W) and al(dx) and
-                al(h.T) and tuple(dx.shape) == (M, N) and W.shape[1] == K):
-            h.red = ctx().stats(h.F)
-            H.call("dgcnn_gemm_bn_bwd_f32", M, N, K, dT.data_ptr(), H.ld2(dT), W.data_ptr(), H.ld2(W), dx.data_ptr(), H.ld2(dx),
-                   float(beta), h.T.data_ptr(), H.ld2(h.T), h.mean.data_ptr(), h.rstd.data_ptr(), h.beta.data_ptr(), int(h.relu),
-                   c0, h.F, h.red.data_ptr(), tag=_gemm_tag(M, N, K, False, True, dT, W), work=2.0 * M * N * K,
-                   nbytes=4.0 * (M * K + K * N + (2 if beta != 0.0 else 1) * M * N + M * h.F))
-            h.served = True
-            return
-    gemm(dT, W, dx, transB=True, beta=beta, arith=arith)
-
-
 def bn_finalize(stats, F, count):
     dev = stats.device
     mr = torch.empty((2, F), dtype=torch.float32, device=dev)
@@ -582,7 +520,7 @@ def bn_finalize(stats, F, count):
 # dgcnn/ops.py:62-70,125-133,153-160 ; dgcnn/model.py:46-53,65-72,94-101
 # ----------------------------------------------------------------------------------------------
 def conv_bn_act(x, leaf_scope, num_outputs, relu=True, out=None, out2=None, gbias=None, rpg=0, w_rows=None, arith=None,
-                plane_out=None, f32_out=True, gmax=None, drop_keep=None, offer_bwd_sums=False):
+                plane_out=None, f32_out=True, gmax=None, drop_keep=None):
     """x: (R,Cin) view.  Variables `<scope>/weights` [Cin(+extra), Cout], `<scope>/BatchNorm/beta`.
     w_rows: (lo, hi) row range of the weight that multiplies x (FC0 with the folded global feature).
     Returns the (R,Cout) output (a fresh tracked buffer unless `out` is given).
@@ -590,9 +528,6 @@ def conv_bn_act(x, leaf_scope, num_outputs, relu=True, out=None, out2=None, gbia
     activated output as operand planes of the NEXT product (f32_out = False: the fp32 `out` is then never written -- it only
     names the tensor and carries its gradient); gmax = (B, N): also return the per-cloud max over the points of the output
     (model.py:76-77), taken on the GEMM output and normalised afterwards (BN + ReLU are monotone).
-    offer_bwd_sums: the caller guarantees that d(out) is COMPLETE once the data-gradient GEMM of the one layer that consumes `out`
-    has run (apart from the gmax gradient, which adds its own share): that GEMM then takes this layer's BatchNorm-backward sums in
-    its epilogue (BnBwdHook) and the pass over (d(out), T) is skipped.
     drop_keep: tf.nn.dropout(out, drop_keep) behind the layer (model.py:90-91), fused into the BatchNorm passes where the
     kernels allow it (the returned tensor is the DROPPED output either way)."""
     c = ctx()
@@ -613,7 +548,7 @@ def conv_bn_act(x, leaf_scope, num_outputs, relu=True, out=None, out2=None, gbia
     # the per-cloud column maximum (model.py:76-77), when asked for, comes out of the GEMM's epilogue as packed (value, first row)
     # keys -- a tile of 256 rows must lie inside one cloud; otherwise a separate pass over T below
     keys = None
-    if gmax is not None and COLMAX_IN_EPILOGUE and gmax[1] % 256 == 0 and gmax[0] * gmax[1] == R and F > 4:
+    if gmax is not None and gmax[1] % 256 == 0 and gmax[0] * gmax[1] == R and F > 4:
         keys = c.stats_raw(gmax[0] * F)                                    # zeroed uint64[B][F]
     if use_pl:
         c.ensure_plane_scales(R)
@@ -647,12 +582,6 @@ def conv_bn_act(x, leaf_scope, num_outputs, relu=True, out=None, out2=None, gbia
                int(relu), out.data_ptr(), H.ld2(out), 0, 0, H._p(out2), 0 if out2 is None else H.ld2(out2), 0,
                tag="bn_act_kreduce_kernel<k=1>", work=4.0 * R * F * (2 if out2 is None else 3))
 
-    hook = None
-    if (offer_bwd_sums and c.recording and BN_BWD_IN_DGRAD and not use_pl and not fuse_drop and out2 is None and
-            F % 4 == 0 and drop_keep is None):
-        # whoever computes d(out) with a data-gradient GEMM may take this layer's backward sums along (dgrad_gemm)
-        hook = c.bn_hooks[out.data_ptr()] = BnBwdHook(out, T, mean, rstd, beta, relu)
-
     if c.recording:
         def bwd():
             dout = c.grad(out)
@@ -660,7 +589,7 @@ def conv_bn_act(x, leaf_scope, num_outputs, relu=True, out=None, out2=None, gbia
                 return
             d2 = c.grad(out2) if out2 is not None else None
             # (DETERMINISTIC: unaligned parameter slices send the reduce to the fixed-order twin, which takes one gradient)
-            if d2 is not None and (fuse_drop or use_pl or DETERMINISTIC or F % 4 != 0 or not BN1_BWD_TWO_SOURCES):
+            if d2 is not None and (fuse_drop or use_pl or DETERMINISTIC or F % 4 != 0):
                 # the second copy's gradient joins the first (the default passes below read both instead)
                 H.call("dgcnn_copy2d_f32", d2.data_ptr(), H.ld2(d2), dout.data_ptr(), H.ld2(dout), R, F, 1)
                 d2 = None
@@ -674,12 +603,10 @@ def conv_bn_act(x, leaf_scope, num_outputs, relu=True, out=None, out2=None, gbia
                        c.var_grads[bname].data_ptr(), 1.0, tag="bn_bwd_apply_kernel<k=1>", work=4.0 * R * F * 5)
                 dT = T
                 dx, bx = c.grad_w(x)
-                if WGRAD_AFTER_DGRAD and dx is not None:
-                    dgrad_gemm(dT, Wx, x, dx, bx, arith)
+                if dx is not None:
+                    gemm(dT, Wx, dx, transB=True, beta=bx, arith=arith)       # data gradient first, on the critical path
                 with c.off_critical_path(rows=R):
-                    gemm(x, dT, dWx, transA=True, beta=1.0, arith=arith)
-                if not WGRAD_AFTER_DGRAD and dx is not None:
-                    dgrad_gemm(dT, Wx, x, dx, bx, arith)
+                    gemm(x, dT, dWx, transA=True, beta=1.0, arith=arith)      # weight gradient behind it, on the side stream
                 if dgb is not None:
                     tmp = torch.empty_like(gbias)
                     H.call("dgcnn_group_colsum_f32", dT.data_ptr(), H.ld2(dT), gbias.shape[0], rpg, F, tmp.data_ptr())
@@ -721,22 +648,20 @@ def conv_bn_act(x, leaf_scope, num_outputs, relu=True, out=None, out2=None, gbia
                     H.call("dgcnn_axpby_f32", tmp.data_ptr(), 1.0, dgb.data_ptr(), 1.0, tmp.numel())
                 return
             nsrc = 1 if d2 is None else 2                                  # k = 1: dz = dout + d2 (the kernels' dmax + dmean / k)
-            if hook is not None and hook.served:
-                red = hook.red                                             # taken by the GEMM that wrote dout (dgrad_gemm)
-            else:
-                bn_bwd_reduce(T, R, 1, F, mean, rstd, beta, relu, dout, d2, None, None, red,
-                              tag="bn_bwd_reduce_kernel<k=1>", work=4.0 * R * F * (1 + nsrc))
+            bn_bwd_reduce(T, R, 1, F, mean, rstd, beta, relu, dout, d2, None, None, red,
+                          tag="bn_bwd_reduce_kernel<k=1>", work=4.0 * R * F * (1 + nsrc))
             H.call("dgcnn_bn_bwd_apply_f32", T.data_ptr(), R, 1, F, mean.data_ptr(), rstd.data_ptr(), beta.data_ptr(),
                    int(relu), dout.data_ptr(), H.ld2(dout), H._p(d2), 0 if d2 is None else H.ld2(d2), 0, 0, 0, red.data_ptr(),
                    T.data_ptr(), 0, 0, c.var_grads[bname].data_ptr(), 1.0, tag="bn_bwd_apply_kernel<k=1>", work=4.0 * R * F * (2 + nsrc))
             dT = T
+            # data gradient FIRST, on the critical path; the weight gradient is issued behind it on the side stream, so that it
+            # runs under the bandwidth-bound BatchNorm / gather passes that follow on the main stream -- not next to the data
+            # gradient, another matrix-pipe kernel at the package power cap (both then run at half speed: profiles/r03/wgrad_order.txt)
             dx, bx = c.grad_w(x)
-            if WGRAD_AFTER_DGRAD and dx is not None:
-                dgrad_gemm(dT, Wx, x, dx, bx, arith)                   # dx (+)= dT W^T (+ the BatchNorm-backward sums of the layer below)
+            if dx is not None:
+                gemm(dT, Wx, dx, transB=True, beta=bx, arith=arith)    # dx (+)= dT W^T
             with c.off_critical_path(rows=R):
                 gemm(x, dT, dWx, transA=True, beta=1.0, arith=arith)   # dW += x^T dT
-            if not WGRAD_AFTER_DGRAD and dx is not None:
-                dgrad_gemm(dT, Wx, x, dx, bx, arith)
             if dgb is not None:                                         # tf.tile^T: sum over the cloud
                 tmp = torch.empty_like(gbias)
                 H.call("dgcnn_group_colsum_f32", dT.data_ptr(), H.ld2(dT), gbias.shape[0], rpg, F, tmp.data_ptr())
@@ -763,11 +688,7 @@ def conv_bn_act(x, leaf_scope, num_outputs, relu=True, out=None, out2=None, gbia
             dg_, dout = c.grad(g), c.grad(out)
             if dg_ is None or dout is None:
                 return
-            if hook is not None and hook.served:      # the sums of this layer's BatchNorm backward were taken before dg arrives: add its share
-                H.call("dgcnn_global_max_bwd_bn_f32", dg_.data_ptr(), arg.data_ptr(), Bc, Nc, F, dout.data_ptr(), H.ld2(dout),
-                       T.data_ptr(), H.ld2(T), mean.data_ptr(), rstd.data_ptr(), beta.data_ptr(), int(relu), hook.red.data_ptr())
-            else:
-                H.call("dgcnn_global_max_bwd_f32", dg_.data_ptr(), arg.data_ptr(), Bc, Nc, F, dout.data_ptr(), H.ld2(dout))
+            H.call("dgcnn_global_max_bwd_f32", dg_.data_ptr(), arg.data_ptr(), Bc, Nc, F, dout.data_ptr(), H.ld2(dout))
         c.tape.append(bwd_g)
     return out, g
 
@@ -775,17 +696,13 @@ def conv_bn_act(x, leaf_scope, num_outputs, relu=True, out=None, out2=None, gbia
 # ----------------------------------------------------------------------------------------------
 # dgcnn/ops.py:42-73 edge_conv as one block
 # ----------------------------------------------------------------------------------------------
-UV_UNDER_KNN = os.environ.get("DGCNN_UV_UNDER_KNN", "0") != "0"     # A/B switch, off: measured SLOWER (5.34-5.87 vs 5.05 ms/step at
-#                                                                    configs[1]: the GEMM's 157 KB workgroups displace k-NN blocks)
-
-
 def prepare_step_weights(edge_w0, head_w):
     """Everything that depends on the PARAMETERS only -- conv0's folded weights [Wa - Wb | Wb] of every EdgeConv layer and, in
     plane mode, the head weights as operand planes in both orientations -- issued at the start of the step on the side stream,
     where it runs under the first k-NN instead of as ~10 six-microsecond kernels on the critical path.
     edge_w0: [(W0 (2C, F), C, F)]; head_w: [Wx views] (plane mode, else empty)."""
     c = ctx()
-    if not (WGRAD_SIDE_STREAM and WEIGHT_PREP_AHEAD and c.flat_param is not None) or c.wprep:
+    if not (WGRAD_SIDE_STREAM and c.flat_param is not None) or c.wprep:
         return
     dev = c.device
     items, temps = [], []
@@ -821,7 +738,7 @@ def prepared(key):
     return v
 
 
-def _point_gemm(c, x, W0, R, C, F, side):
+def _point_gemm(c, x, W0, R, C, F):
     """Wcat = [Wa - Wb | Wb] and [U | V] = X Wcat (conv0 folded to the points).  C = 3 (raw coordinates): the reduction
     dimension is padded to 4 with a zero column / zero weight row so that the GEMM takes the float4 path."""
     Cp = (C + 3) // 4 * 4
@@ -834,17 +751,11 @@ def _point_gemm(c, x, W0, R, C, F, side):
         wcat = ready if ready is not None else torch.empty((C, 2 * F), dtype=torch.float32, device=x.device)
     UV = torch.empty((R, 2 * F), dtype=torch.float32, device=x.device)
 
-    def issue():
-        if Cp != C:
-            H.call("dgcnn_copy2d_f32", x.data_ptr(), H.ld2(x), xg.data_ptr(), Cp, R, C, 0)
-        if ready is None:
-            H.call("dgcnn_edge_weight_split_f32", W0.data_ptr(), C, F, wcat.data_ptr())
-        gemm(xg, wcat, UV, arith=None)
-    if side:
-        with c.off_critical_path(xg, wcat, UV, rows=R):
-            issue()
-    else:
-        issue()
+    if Cp != C:
+        H.call("dgcnn_copy2d_f32", x.data_ptr(), H.ld2(x), xg.data_ptr(), Cp, R, C, 0)
+    if ready is None:
+        H.call("dgcnn_edge_weight_split_f32", W0.data_ptr(), C, F, wcat.data_ptr())
+    gemm(xg, wcat, UV, arith=None)
     return Cp, xg, wcat, UV
 
 
@@ -863,12 +774,7 @@ def edge_conv_block(x, B, N, k, num_filters, relu1=True, outs=None, net2=None):
     bf16 = EDGE_MLP_DTYPE == "bf16"
     literal = EDGE_MLP_LITERAL or bf16
     gather = (not literal) and (not EDGE_MLP_NBR_GEMM) and F % 4 == 0 and F <= 1024
-    # the point-level GEMM [U|V] = X Wcat needs only x: it CAN be issued on the side stream under the k-NN kernel (switch)
-    uv_early = gather and UV_UNDER_KNN and WGRAD_SIDE_STREAM and R >= SIDE_STREAM_MIN_ROWS
-    pre = _point_gemm(c, x, W0, R, C, F, side=True) if uv_early else None
     idx = knn(x, B, N, k)                                               # ops.py:8-19
-    if uv_early:
-        c.join_side()
     virtual = gather and not EDGE_MATERIALIZE_Y and k < 256   # conv0 output never written: recomputed from (V, U, idx)
     #                                                           (the edge BN passes pack tie / positive counts: k < 256)
     Y = None if virtual else torch.empty((R * k, F), dtype=torch.float32, device=x.device)
@@ -908,7 +814,7 @@ def edge_conv_block(x, B, N, k, num_filters, relu1=True, outs=None, net2=None):
         # bound by the HBM write of Y, which also takes the BatchNorm column sums.
         # C = 3 (raw coordinates): pad the reduction dimension to 4 with a zero column / zero weight row so that
         # the point-level GEMMs take the float4 path (the generic scalar kernel costs ~10x more on them)
-        Cp, xg, wcat, UV = pre if pre is not None else _point_gemm(c, x, W0, R, C, F, side=False)
+        Cp, xg, wcat, UV = _point_gemm(c, x, W0, R, C, F)
         H.call("dgcnn_edge_gather_add_f32", UV[:, F:].data_ptr(), 2 * F, UV.data_ptr(), 2 * F, idx.data_ptr(),
                B, N, k, F, H._p(Y), st.data_ptr(),
                tag="edge_gather_add_kernel", work=4.0 * ((0 if virtual else R * k * F) + 2 * R * F) + 4.0 * R * k)   # ops.py:21-52
@@ -1036,13 +942,11 @@ def edge_conv_block(x, B, N, k, num_filters, relu1=True, outs=None, net2=None):
                 dwcat = torch.empty((Cp, 2 * F), dtype=torch.float32, device=x.device)
                 # dUV / dwcat are locals of this closure allocated on the main stream: record them on the side stream,
                 # or the caching allocator may hand dUV's block to the next main-stream allocation while the side GEMM reads it
-                if WGRAD_AFTER_DGRAD and dx is not None:
+                if dx is not None:
                     gemm(dUV, wcat[:C], dx, transB=True, beta=1.0, arith=None)
                 with c.off_critical_path(dwcat, dUV, rows=R):
                     gemm(xg, dUV, dwcat, transA=True, arith=None)
                     H.call("dgcnn_edge_wgrad_combine_f32", dwcat.data_ptr(), C, F, dW0.data_ptr())
-                if not WGRAD_AFTER_DGRAD and dx is not None:
-                    gemm(dUV, wcat[:C], dx, transB=True, beta=1.0, arith=None)
                 return
             if bf16:
                 # dW0 = E^T dY and dE = dY W0^T with bf16 operands (the same rounding of E and W0 as the forward, dY rounded once)

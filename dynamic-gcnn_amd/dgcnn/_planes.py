@@ -10,9 +10,9 @@ import torch
 
 from . import _hip as H
 
-BF16X3, F16X2 = 0, 1          # include/dgcnn_hip.h: DGCNN_PLANES_*
+F16X2 = 1                     # include/dgcnn_hip.h: DGCNN_PLANES_F16X2 (the only plane format)
 KC, TR = 0, 1                 # DGCNN_PL_KC / DGCNN_PL_TR
-NPLANES = {BF16X3: 3, F16X2: 2}
+NPLANES = {F16X2: 2}
 
 
 def rows_alloc(rows):
@@ -22,7 +22,7 @@ def rows_alloc(rows):
 class PlaneSet(object):
     """rows x cols (cols % 8 == 0) in `fmt`; `buf` = uint8 storage of NPL x (cols/8) x rows_alloc x 16 bytes."""
 
-    def __init__(self, rows, cols, fmt=BF16X3, device=None, zero=False):
+    def __init__(self, rows, cols, fmt=F16X2, device=None, zero=False):
         if cols % 8:
             raise ValueError("PlaneSet: cols must be a multiple of 8, got %d" % cols)
         self.rows, self.cols, self.fmt = int(rows), int(cols), int(fmt)
@@ -79,7 +79,7 @@ class PlaneSet(object):
         return self
 
 
-def from_f32(src, fmt=BF16X3, transpose=False):
+def from_f32(src, fmt=F16X2, transpose=False):
     r, c = (src.shape[1], src.shape[0]) if transpose else (src.shape[0], src.shape[1])
     return PlaneSet(r, c, fmt, device=src.device).fill_from(src, transpose)
 
@@ -101,5 +101,5 @@ def gemm(form, A, B, C, beta=0.0, gbias=None, rpg=0, stats=None, ws=None, colmax
     H.call("dgcnn_gemm_planes_f32", form, A.fmt, M, N, K, A.ptr(), A.plane_stride, A.ra, B.ptr(), B.plane_stride, B.ra,
            H._p(A.scale), H._p(B.scale), C.data_ptr(), H.ld2(C), float(beta), H._p(gbias), 0 if gbias is None else H.ld2(gbias), int(rpg),
            H._p(stats), H._p(colmax), int(colmax_rpg), H._p(ws), 0 if ws is None else ws.numel(),
-           tag="gemm_pl_kernel<%s,%s>" % ("KC" if form == KC else "TR", "bf16x3" if A.fmt == BF16X3 else "f16x2"),
+           tag="gemm_pl_kernel<%s,%s>" % ("KC" if form == KC else "TR", "f16x2"),
            work=2.0 * M * N * K)

@@ -54,7 +54,7 @@ _OPTIONS = [
     ("EDGE_MLP_DTYPE", "-emd", str, "f32", "ti", "operands of the edge MLP (conv0 of every EdgeConv layer): f32 | bf16 (literal edge-level "
                                                  "product on the bf16 MFMA pipe, fp32 accumulate: BASELINE configs[2])"),
     ("HEAD_PLANES", "-hp", str, None, "ti", "head GEMMs (MergedEdgeConv, FC*) from operand planes written by the BatchNorm passes: "
-                                             "0 | f16 (2 fp16 planes, 3 products) | bf16 (3 bf16 planes, 6 products); default $DGCNN_HEAD_PLANES"),
+                                             "0 | f16 (2 fp16 planes, 3 products); default $DGCNN_HEAD_PLANES"),
 ]
 
 

@@ -114,9 +114,7 @@ def build(point_cloud, flags):
     else:
         # model.py:65-77: MergedEdgeConv, then the max-pool over the points of each cloud -- taken on the GEMM output (in its
         # epilogue where the tile shape allows) and normalised afterwards: BN + ReLU are non-decreasing
-        # (d(merged) = FC0's data gradient + the max-pool gradient and nothing else: FC0's GEMM takes this layer's BatchNorm-backward sums)
-        merged, g = E.conv_bn_act(merged_in, "MergedEdgeConv", 1024, relu=True, out=big[:, ctot - 1024:], gmax=(B, N),
-                                  offer_bwd_sums=True)
+        merged, g = E.conv_bn_act(merged_in, "MergedEdgeConv", 1024, relu=True, out=big[:, ctot - 1024:], gmax=(B, N))
     tensors.append(E.rank4(merged, B, N))                          # model.py:74
 
     # model.py:80-88: concat([tile(g)] + tensors) -> fc.  FC0 is split as described in the docstring.
@@ -130,9 +128,8 @@ def build(point_cloud, flags):
                             plane_out=c.new_planes(R, fcf[0], "act"), f32_out=False)
     else:
         net = E.conv_bn_act(big, "FC0", fcf[0], relu=True, gbias=gb, rpg=N, w_rows=(1024, 1024 + ctot, 1024 + ctot),
-                            drop_keep=keep if num_fc == 1 else None, offer_bwd_sums=num_fc >= 2)    # (one consumer: FC1)
+                            drop_keep=keep if num_fc == 1 else None)
     for i in range(1, num_fc):                                     # ops.py:151-160
-        net = E.conv_bn_act(net, "FC%d" % i, fcf[i], relu=True, drop_keep=keep if i == num_fc - 1 else None,
-                            offer_bwd_sums=i < num_fc - 1)
+        net = E.conv_bn_act(net, "FC%d" % i, fcf[i], relu=True, drop_keep=keep if i == num_fc - 1 else None)
     fin = E.conv_bn_act(net, "Final", num_class, relu=True)        # model.py:94-101 (BN + ReLU on the logits)
     return fin.view(B, N, num_class)                                # model.py:104 squeeze

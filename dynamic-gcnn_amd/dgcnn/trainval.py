@@ -113,9 +113,9 @@ class trainval(object):
         if hp is None:
             E.HEAD_PLANES = E.HEAD_PLANES_ENV_DEFAULT
         else:
-            if str(hp).lower() not in ("0", "", "none", "off", "f16", "bf16"):
-                raise ValueError("HEAD_PLANES must be 0, f16 or bf16, got %r" % (hp,))
-            E.HEAD_PLANES = {"f16": E.PL.F16X2, "bf16": E.PL.BF16X3}.get(str(hp).lower())
+            if str(hp).lower() not in ("0", "", "none", "off", "f16"):
+                raise ValueError("HEAD_PLANES must be 0 or f16, got %r" % (hp,))
+            E.HEAD_PLANES = {"f16": E.PL.F16X2}.get(str(hp).lower())
         self._graphs, self._graph_seen = OrderedDict(), {}     # captured towers (LRU order) / sightings per key
         ug = str(getattr(f, "USE_GRAPH", "0")).lower()
         self._use_graph = "auto" if ug == "auto" else ug in ("1", "true", "yes", "on")

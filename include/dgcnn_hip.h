@@ -196,17 +196,6 @@ int dgcnn_edge_bn_bwd_apply_wgrad_f32(const float* V, int64_t ldv, const float* 
  * gemm_x3.hip).  1 = only the leading bf16 term of each operand: plain bf16 operands with fp32 accumulation (NOT fp32
  * class: the bf16 edge-MLP mode of BASELINE configs[2]; the host selects it around the EdgeConv conv0 / conv1 products).
  * Default 6, or $DGCNN_GEMM_ARITH = f32 | bf16x6 | bf16x9 | bf16x1.  Process-wide.                     */
-/* Backward of slim.conv2d 1x1 w.r.t. its input (ops.py:153-160, model.py:65-72):  dX[M][N] = beta dX + dT[M][K] W^T  (W stored
- * [N][K] = the layer's [Cin][Cout] weight) -- which ALSO takes the two sums of the BatchNorm backward of the layer BELOW, whose
- * output occupies columns [c0, c0 + F) of X: with that layer's pre-BN tensor T (M x F, leading dimension ldT), batch statistics and
- * beta,  xhat = (T - mean) rstd,  z = relu?(xhat + beta),  dz = (relu && z <= 0) ? 0 : dX[.][c0 + f]:
- *   red[slot][0][f] += sum_rows dz,  red[slot][1][f] += sum_rows dz xhat      (red: double[DGCNN_STAT_SLOTS][2][F], zeroed)
- * i.e. what dgcnn_bn_bwd_reduce_f32(k = 1) computes in a pass of its own over (dX, T).  Operands float4-loadable, c0 % 4 == 0,
- * F % 4 == 0, bf16-split arithmetic (DGCNN_EUNSUP otherwise: call dgcnn_gemm_f32 + dgcnn_bn_bwd_reduce_f32).               */
-int dgcnn_gemm_bn_bwd_f32(int M, int N, int K, const float* A, int64_t lda, const float* B, int64_t ldb,
-                          float* C, int64_t ldc, float beta,
-                          const float* T, int64_t ldT, const float* mean, const float* rstd, const float* bn_beta,
-                          int relu, int c0, int F, double* red, void* stream);
 int dgcnn_gemm_set_arith(int mode);
 int dgcnn_gemm_get_arith(void);
 /* Rows of the output tile the bf16-split GEMM picks for an (M,N,K) product: 64 | 128 | 256 (256 = the wave-specialised
@@ -229,7 +218,6 @@ int dgcnn_colmax_decode_f32(const void* keys, int64_t n, float* vals, int32_t* a
  * Plane set of a tensor X (rows x cols):  element (row, c) of plane p at
  *     base + p * plane_stride + ((c / 8) * rows_alloc + row) * 16 + (c % 8) * 2        [bytes]
  * rows_alloc = rows rounded up to 64, pad rows are zero.
- *   DGCNN_PLANES_BF16X3: x = x1 + x2 + x3 exactly (3 bf16 planes), 6 partial products (== dgcnn_gemm_f32 arithmetic 6)
  *   DGCNN_PLANES_F16X2 : x * scale = h1 + h2 (2 fp16 planes; scale = a power of two read from scale_dev, chosen so that
  *                        max |x| * scale < 2^15: dgcnn_planes_scale_f32 or a producer's analytic bound), 3 partial products;
  *                        the GEMM divides its result by scale_A * scale_B (device scalars, exact).
@@ -239,7 +227,7 @@ int dgcnn_colmax_decode_f32(const void* keys, int64_t n, float* vals, int32_t* a
  *   DGCNN_PL_KC: A has M rows, B has N rows, the reduction runs over the K channels of both (K % 32 == 0); A / B point at the
  *                first octet of the channel range;   DGCNN_PL_TR: A has M channels, B has N channels (M, N % 16 == 0), the
  *                reduction runs over the K rows of both (X^T dY; split over K into ws).  gbias / stats as dgcnn_gemm_f32 (KC only). */
-#define DGCNN_PLANES_BF16X3 0
+/* (format 0, three bf16 planes / 6 partial products, existed in round 3: slower than the in-kernel split, removed) */
 #define DGCNN_PLANES_F16X2 1
 #define DGCNN_PL_KC 0
 #define DGCNN_PL_TR 1
@@ -335,11 +323,6 @@ int dgcnn_global_max_f32(const float* x, int64_t ldx, int B, int N, int F, float
 /* its gradient: dx[b][arg[b][f]][f] += dout[b][f] */
 int dgcnn_global_max_bwd_f32(const float* dout, const int32_t* arg, int B, int N, int F,
                              float* dx, int64_t lddx, void* stream);
-/* the same, for a tensor whose BatchNorm-backward sums were already taken by dgcnn_gemm_bn_bwd_f32 (before this gradient
- * arrived): also adds this gradient's share  m dg, m dg xhat  (m = relu mask at the arg-max row) to slot 0 of `red` */
-int dgcnn_global_max_bwd_bn_f32(const float* dout, const int32_t* arg, int B, int N, int F, float* dx, int64_t lddx,
-                                const float* T, int64_t ldT, const float* mean, const float* rstd, const float* beta,
-                                int relu, double* red, void* stream);
 /* out[g][f] = sum over the rows_per_group rows of group g (tf.tile^T, model.py:81) */
 int dgcnn_group_colsum_f32(const float* x, int64_t ldx, int G, int rows_per_group, int F,
                            float* out, void* stream);

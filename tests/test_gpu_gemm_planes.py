@@ -1,5 +1,5 @@
-"""The plane GEMM (csrc/gemm_pl.hip): fp32 products from operands pre-split into 16-bit planes, against float64 numpy and
-against the in-kernel-split GEMM (dgcnn_gemm_f32, arithmetic 6) it replaces."""
+"""The plane GEMM (csrc/gemm_pl.hip): fp32-class products from operands pre-split into two fp16 planes (DGCNN_PLANES_F16X2, the
+opt-in HEAD_PLANES='f16' mode), against float64 numpy and against the in-kernel-split GEMM (dgcnn_gemm_f32, arithmetic 6)."""
 import numpy as np
 import pytest
 import torch
@@ -21,10 +21,7 @@ def _planes_to_host(ps):
     out = np.zeros((ps.rows, ps.cols), np.float64)
     for p in range(npl):
         a = raw[p].view(np.uint16).reshape(-1, ps.ra, 8)
-        if ps.fmt == P.BF16X3:
-            v = (a.astype(np.uint32) << 16).view(np.float32)
-        else:
-            v = a.view(np.float16).astype(np.float32)
+        v = a.view(np.float16).astype(np.float32)
         o0 = ps.c0 // 8
         blk = v[o0:o0 + ps.cols // 8]                         # (noct, ra, 8)
         out += blk.transpose(1, 0, 2).reshape(ps.ra, -1)[:ps.rows].astype(np.float64)
@@ -32,23 +29,22 @@ def _planes_to_host(ps):
 
 
 @pytest.mark.parametrize("rows,cols", [(64, 8), (100, 64), (1000, 200), (513, 1728)])
-def test_bf16x3_split_is_exact_and_pads_with_zeros(rows, cols):
-    x = _rand((rows, cols), 1) * np.exp(_rand((rows, cols), 2) * 4)        # wide dynamic range
+def test_split_pads_with_zeros_and_takes_strided_views(rows, cols):
+    x = _rand((rows, cols), 1)
     ps = P.from_f32(torch.from_numpy(x).cuda())
-    np.testing.assert_array_equal(_planes_to_host(ps), x.astype(np.float64))            # three bf16 terms hold all 24 bits
-    raw = ps.buf.cpu().numpy().reshape(3, cols // 8, ps.ra, 16)
+    np.testing.assert_allclose(_planes_to_host(ps), x.astype(np.float64), rtol=2.0 ** -21, atol=2.0 ** -24)    # 22 bits per element
+    raw = ps.buf.cpu().numpy().reshape(2, cols // 8, ps.ra, 16)
     assert not raw[:, :, rows:, :].any()                                                 # pad rows are zero
-    # a strided source view
-    wide = torch.from_numpy(_rand((rows, cols + 24), 3)).cuda()
+    wide = torch.from_numpy(_rand((rows, cols + 24), 3)).cuda()                          # a strided source view
     ps2 = P.from_f32(wide[:, 8:8 + cols])
-    np.testing.assert_array_equal(_planes_to_host(ps2), wide[:, 8:8 + cols].cpu().numpy().astype(np.float64))
+    np.testing.assert_allclose(_planes_to_host(ps2), wide[:, 8:8 + cols].cpu().numpy().astype(np.float64), rtol=2.0 ** -21, atol=2.0 ** -24)
 
 
 def test_split_of_the_transposed_orientation():
     w = _rand((192, 1024), 5, 0.05)
     pt = P.from_f32(torch.from_numpy(w).cuda(), transpose=True)                          # rows = 1024 outputs, cols = 192 inputs
     assert (pt.rows, pt.cols) == (1024, 192)
-    np.testing.assert_array_equal(_planes_to_host(pt), w.T.astype(np.float64))
+    np.testing.assert_allclose(_planes_to_host(pt), w.T.astype(np.float64), rtol=2.0 ** -21, atol=2.0 ** -26)
 
 
 def _err(C, ref, A, B):
@@ -66,11 +62,11 @@ def test_kc_product_matches_float64(M, N, K):
     P.gemm(P.KC, Xp, Wp, C)
     ref = X.astype(np.float64) @ W.astype(np.float64)
     e = _err(C.cpu().numpy().astype(np.float64), ref, X.astype(np.float64), W.astype(np.float64))
-    assert e < 4e-7, e                                        # fp32 class (a plain fp32 chain: ~sqrt(K) 6e-8)
-    # against the in-kernel-split GEMM: same six partial products, same accumulator -> equal up to the summation order
+    assert e < 6e-7, e                                        # fp32 class (2^-22 per operand: worst case 2 x 2.4e-7 + the dropped h2 h2 term)
+    # against the in-kernel-split GEMM (exact 3-way bf16 split, 6 partial products)
     C2 = torch.empty((M, N), device="cuda")
     E.gemm(torch.from_numpy(X).cuda(), torch.from_numpy(W).cuda(), C2)
-    assert _err(C.cpu().numpy().astype(np.float64), C2.cpu().numpy().astype(np.float64), X.astype(np.float64), W.astype(np.float64)) < 4e-7
+    assert _err(C.cpu().numpy().astype(np.float64), C2.cpu().numpy().astype(np.float64), X.astype(np.float64), W.astype(np.float64)) < 6e-7
 
 
 def test_kc_epilogue_options_beta_bias_stats_and_channel_views():
@@ -107,7 +103,7 @@ def test_tr_product_matches_float64(M, N, K):
     Xd, Yd = X.astype(np.float64), dY.astype(np.float64)
     ref = C0 + Xd.T @ Yd
     e = float((np.abs(C.cpu().numpy() - ref) / np.maximum(np.abs(Xd).T @ np.abs(Yd), 1e-30)).max())
-    assert e < 4e-7, e
+    assert e < 6e-7, e
 
 
 # ------------------------------------------------------------------------------------------------------

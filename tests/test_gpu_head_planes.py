@@ -16,7 +16,7 @@ B, N, C = 4, 2048, 3
 
 
 def _flags(train, mode=None):
-    hp = {None: None, P.F16X2: "f16", P.BF16X3: "bf16"}[mode]
+    hp = {None: None, P.F16X2: "f16"}[mode]
     return dgcnn.DGCNN_FLAGS(MODEL_NAME="dgcnn", EDGE_CONV_LAYERS=2, EDGE_CONV_FILTERS=[64, 64], FC_LAYERS=2, FC_FILTERS=[512, 256],
                              NUM_CLASS=3, KVALUE=12, NUM_CHANNEL=C, TRAIN=train, SEED=3, HEAD_PLANES=hp)
 
@@ -55,7 +55,7 @@ def _run(mode, case, train):
     return out, grads, [layers["EdgeConv%d" % i][1] for i in range(2)], used
 
 
-@pytest.mark.parametrize("mode", [P.F16X2, P.BF16X3])
+@pytest.mark.parametrize("mode", [P.F16X2])
 def test_plane_mode_training_step_matches_the_float64_twin(case, mode):
     pts, labels, params = case
     res, grads, idx_list, used = _run(mode, case, train=True)
@@ -71,7 +71,7 @@ def test_plane_mode_training_step_matches_the_float64_twin(case, mode):
     assert rel[worst] < 1e-2, rel
 
 
-@pytest.mark.parametrize("mode", [P.F16X2, P.BF16X3])
+@pytest.mark.parametrize("mode", [P.F16X2])
 def test_plane_mode_inference_logits(case, mode):
     pts, labels, params = case
     res, _, idx_list, used = _run(mode, case, train=False)

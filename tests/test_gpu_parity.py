@@ -1068,93 +1068,6 @@ def test_column_maximum_from_the_gemm_epilogue(dg, B, N, Cin, F):
     np.testing.assert_allclose(s[1], (Th.reshape(-1, F).astype(np.float64) ** 2).sum(0), rtol=1e-5, atol=1e-2)
 
 
-@pytest.mark.parametrize("M,N,K,c0,F,relu", [(512, 192, 64, 64, 128, 1), (3000, 1728, 512, 704, 1024, 1), (777, 256, 128, 0, 256, 0),
-                                              (8300, 64, 128, 0, 64, 1)])
-def test_dgrad_gemm_takes_the_batchnorm_backward_sums_of_the_layer_below(dg, M, N, K, c0, F, relu):
-    """ops.py:153-160 / model.py:65-72 backward: dX = dT W^T, and in the same launch the two sums of the BatchNorm backward of the
-    layer whose output is columns [c0, c0+F) of X (sum dz, sum dz*xhat with the ReLU mask recomputed from that layer's pre-BN
-    tensor) -- against numpy on the GEMM's own output, and against the stand-alone reduce pass."""
-    from dgcnn import _engine as E
-    rng = np.random.default_rng(M + N + K + c0)
-    dT = rng.normal(size=(M, K)).astype(np.float32)
-    W = rng.normal(0, 0.2, size=(N, K)).astype(np.float32)
-    T = rng.normal(size=(M, F)).astype(np.float32)
-    mean = T.mean(0).astype(np.float32)
-    rstd = (1.0 / np.sqrt(T.var(0) + 1e-3)).astype(np.float32)
-    beta = rng.normal(0, 0.3, size=F).astype(np.float32)
-    old = rng.normal(size=(M, N)).astype(np.float32)
-    dX = dev(old)
-    red = torch.zeros(E.H.STAT_SLOTS * 2 * F, dtype=torch.float64, device="cuda")
-    Td, md, rd, bd, dTd, Wd = dev(T), dev(mean), dev(rstd), dev(beta), dev(dT), dev(W)
-    E.H.call("dgcnn_gemm_bn_bwd_f32", M, N, K, dTd.data_ptr(), K, Wd.data_ptr(), K, dX.data_ptr(), N, 1.0,
-             Td.data_ptr(), F, md.data_ptr(), rd.data_ptr(), bd.data_ptr(), relu, c0, F, red.data_ptr())
-    got = host(dX)
-    ref = old.astype(np.float64) + dT.astype(np.float64) @ W.astype(np.float64).T
-    np.testing.assert_allclose(got, ref, rtol=1e-5, atol=2e-6 * K ** 0.5 * 4 + 1e-5)
-    xh = ((T - mean) * rstd).astype(np.float32)                      # the kernels' expressions, in float32
-    z = xh + beta
-    dz = got[:, c0:c0 + F].astype(np.float64)
-    if relu:
-        dz = np.where(z > 0, dz, 0.0)
-    s = host(red).reshape(E.H.STAT_SLOTS, 2, F).sum(0)
-    np.testing.assert_allclose(s[0], dz.sum(0), rtol=1e-5, atol=1e-3)
-    np.testing.assert_allclose(s[1], (dz * xh).sum(0), rtol=1e-5, atol=1e-3)
-    # the pass it replaces, on the same dX
-    red2 = torch.zeros_like(red)
-    sl = dX[:, c0:c0 + F]
-    E.H.call("dgcnn_bn_bwd_reduce_f32", Td.data_ptr(), M, 1, F, md.data_ptr(), rd.data_ptr(), bd.data_ptr(), relu,
-             sl.data_ptr(), N, 0, 0, 0, 0, 0, red2.data_ptr())
-    s2 = host(red2).reshape(E.H.STAT_SLOTS, 2, F).sum(0)
-    np.testing.assert_allclose(s, s2, rtol=1e-5, atol=1e-3)
-
-
-def test_bn_backward_sums_in_the_dgrad_epilogue_leave_the_gradients_unchanged(dg):
-    """The whole model with and without BN_BWD_IN_DGRAD: MergedEdgeConv's sums come from FC0's data-gradient GEMM (+ the max-pool
-    gradient's share from dgcnn_global_max_bwd_bn_f32), FC0's from FC1's; the stand-alone reduce launches of those layers are gone.
-    Same loss, gradients within the run-to-run noise of the atomically accumulated statistics."""
-    from dgcnn import _engine as E
-    rng = np.random.default_rng(78)
-    B, N = 4, 1024
-    pts = rng.random((B, N, 3), dtype=np.float32)
-    lab = rng.integers(0, 2, (B, N)).astype(np.int32)
-    flags = dg.DGCNN_FLAGS(MODEL_NAME="dgcnn", EDGE_CONV_LAYERS=2, EDGE_CONV_FILTERS=[32, 64], FC_LAYERS=2, FC_FILTERS=[128, 64],
-                           NUM_CLASS=2, KVALUE=8, NUM_CHANNEL=3, TRAIN=True, SEED=9)
-    old = E.BN_BWD_IN_DGRAD
-    flags.DETERMINISTIC = True          # bit-identical forward passes: only the place where the sums are taken differs
-    out = {}
-    calls = []
-    orig = E.H.call
-
-    def spy(name, *a, **kw):
-        calls.append(name)
-        return orig(name, *a, **kw)
-    try:
-        for fused in (True, False):
-            E.BN_BWD_IN_DGRAD = fused
-            tv = dg.trainval(flags).initialize()
-            del calls[:]
-            E.H.call = spy
-            try:
-                tv.zero_gradients(None)
-                res = tv.accum_gradient(None, [pts], [lab])
-            finally:
-                E.H.call = orig
-            assert (calls.count("dgcnn_gemm_bn_bwd_f32") == 2) == fused, calls.count("dgcnn_gemm_bn_bwd_f32")
-            assert ("dgcnn_global_max_bwd_bn_f32" in calls) == fused and ("dgcnn_global_max_bwd_f32" in calls) == (not fused)
-            # reduce launches: conv1 x 2 + Final always; MergedEdgeConv and FC0 only when not fused (FC1: inside its dropout-fused pass)
-            # (deterministic mode: the class dimension's reduce is the fixed-order twin)
-            nred = calls.count("dgcnn_bn_bwd_reduce_f32") + calls.count("dgcnn_bn_bwd_reduce_det_f32")
-            assert nred == (3 if fused else 5), nred
-            out[fused] = (float(res[2]), host(dg.ctx().flat_grad).copy())
-    finally:
-        E.BN_BWD_IN_DGRAD = old
-        E.DETERMINISTIC = False
-        dg.reset()
-    assert abs(out[True][0] - out[False][0]) < 2e-6, (out[True][0], out[False][0])
-    ga, gb = out[True][1].astype(np.float64), out[False][1].astype(np.float64)
-    assert np.linalg.norm(ga - gb) <= 2e-5 * np.linalg.norm(gb), np.linalg.norm(ga - gb) / np.linalg.norm(gb)
-
-
 @pytest.mark.parametrize("M,N,K,transB", [(8200, 64, 128, False), (8200, 64, 256, True), (12345, 128, 64, False), (9000, 256, 64, True),
                                           (4100, 64, 64, False), (49152, 256, 64, False)])
 def test_short_reduction_gemms_of_the_edgeconv_blocks(dg, M, N, K, transB):
