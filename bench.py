@@ -33,6 +33,7 @@ B, N, K_NN, C = 24, 2048, 20, 3
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_bf16 dense peak
 PEAK_HBM_GBS = 8000.0             # HBM3E spec
+PEAK_L2_GBS = 34500.0             # MI355X_MICROARCH.md: aggregate L2 -> CU bandwidth (8 XCDs x 4 MB)
 
 
 def make_flags(dgcnn, train=True):
@@ -510,6 +511,14 @@ def main():
                     extra.append({"kernel": t, "bound": "mfma", "achieved": round(work / sec / 1e12, 2), "peak": round(pk, 1),
                                   "unit": "TFLOP/s", "frac": round(work / sec / 1e12 / pk, 4), "launches": n,
                                   "avg_us": round(sec / n * 1e6, 1)})
+            elif nbytes > 0:
+                # passes that re-form y = V[neighbour] + U[point] per edge instead of streaming a materialised (B N k, F) tensor: the
+                # bytes that move are rows GATHERED from the point-level [U | V] buffer (25-50 MB: resident in the XCDs' L2s), so the
+                # roof is the L2 -> CU bandwidth, not HBM; `hbm_GBs` is what the pass moves through HBM (outputs, indices)
+                extra.append({"kernel": t, "bound": "l2-gather", "achieved": round(nbytes / sec / 1e9, 1), "peak": PEAK_L2_GBS,
+                              "unit": "GB/s", "frac": round(nbytes / sec / 1e9 / PEAK_L2_GBS, 4), "launches": n,
+                              "avg_us": round(sec / n * 1e6, 1), "hbm_GBs": round(work / sec / 1e9, 1),
+                              "note": "gathered bytes = 4 (R k F + R F) per launch (one F-float row of V per edge + U once per point)"})
             elif work > 0:
                 extra.append({"kernel": t, "bound": "hbm", "achieved": round(work / sec / 1e9, 1), "peak": PEAK_HBM_GBS,
                               "unit": "GB/s", "frac": round(work / sec / 1e9 / PEAK_HBM_GBS, 4), "launches": n,

@@ -817,7 +817,8 @@ def edge_conv_block(x, B, N, k, num_filters, relu1=True, outs=None, net2=None):
         Cp, xg, wcat, UV = _point_gemm(c, x, W0, R, C, F)
         H.call("dgcnn_edge_gather_add_f32", UV[:, F:].data_ptr(), 2 * F, UV.data_ptr(), 2 * F, idx.data_ptr(),
                B, N, k, F, H._p(Y), st.data_ptr(),
-               tag="edge_gather_add_kernel", work=4.0 * ((0 if virtual else R * k * F) + 2 * R * F) + 4.0 * R * k)   # ops.py:21-52
+               tag="edge_gather_add_kernel", work=4.0 * ((0 if virtual else R * k * F) + 2 * R * F) + 4.0 * R * k,
+               nbytes=4.0 * (R * k * F + R * F))   # ops.py:21-52   (nbytes: rows gathered from L2 -- bench.py's l2-gather roof)
         if not virtual:
             UV = None
     else:
@@ -846,7 +847,7 @@ def edge_conv_block(x, B, N, k, num_filters, relu1=True, outs=None, net2=None):
         esrc = (UV[:, F:].data_ptr(), 2 * F, UV.data_ptr(), 2 * F, idx.data_ptr(), B, N, k, F)
         H.call("dgcnn_edge_bn_act_kreduce_f32", *esrc, mean.data_ptr(), rstd.data_ptr(), beta0.data_ptr(), 1,
                mx.data_ptr(), H.ld2(mx), mn.data_ptr(), H.ld2(mn), H._p(cnt),
-               tag="bn_act_kreduce_kernel<edge>", work=4.0 * (4 * R * F) + 4.0 * R * k)   # ops.py:54-58
+               tag="bn_act_kreduce_kernel<edge>", work=4.0 * (4 * R * F) + 4.0 * R * k, nbytes=4.0 * (R * k * F + R * F))   # ops.py:54-58
     else:
         H.call("dgcnn_bn_act_kreduce_f32", Y.data_ptr(), R, k, F, mean.data_ptr(), rstd.data_ptr(), beta0.data_ptr(), 1,
                mx.data_ptr(), H.ld2(mx), mn.data_ptr(), H.ld2(mn), 0, 0, H._p(cnt),
@@ -895,7 +896,8 @@ def edge_conv_block(x, B, N, k, num_filters, relu1=True, outs=None, net2=None):
                 H.call("dgcnn_edge_bn_bwd_apply_wgrad_f32", *esrc, mean.data_ptr(), rstd.data_ptr(), beta0.data_ptr(),
                        dmx.data_ptr(), H.ld2(dmx), dmn.data_ptr(), H.ld2(dmn), mx.data_ptr(), H.ld2(mx), cnt.data_ptr(),
                        red.data_ptr(), x.data_ptr(), H.ld2(x), C, c.var_grads[w0name].data_ptr(), c.var_grads[b0name].data_ptr(), 1.0,
-                       ws.data_ptr(), ws.numel(), tag="edge_bwd_apply_wgrad_kernel", work=4.0 * (4 * R * F) + 4.0 * R * k)
+                       ws.data_ptr(), ws.numel(), tag="edge_bwd_apply_wgrad_kernel", work=4.0 * (4 * R * F) + 4.0 * R * k,
+                       nbytes=4.0 * (R * k * F + R * F))
                 return
             need_sum = (dx is not None) or not literal
             dUV = dysum = None
@@ -911,7 +913,7 @@ def edge_conv_block(x, B, N, k, num_filters, relu1=True, outs=None, net2=None):
                        1, dmx.data_ptr(), H.ld2(dmx), dmn.data_ptr(), H.ld2(dmn), mx.data_ptr(), H.ld2(mx), cnt.data_ptr(),
                        red.data_ptr(), dY.data_ptr(),
                        H._p(dysum), 0 if dysum is None else H.ld2(dysum), c.var_grads[b0name].data_ptr(), 1.0,
-                       tag="bn_bwd_apply_kernel<edge>", work=4.0 * (R * k * F + 7 * R * F) + 4.0 * R * k)
+                       tag="bn_bwd_apply_kernel<edge>", work=4.0 * (R * k * F + 7 * R * F) + 4.0 * R * k, nbytes=4.0 * (R * k * F + R * F))
             else:
                 H.call("dgcnn_bn_bwd_apply_f32", Y.data_ptr(), R, k, F, mean.data_ptr(), rstd.data_ptr(), beta0.data_ptr(),
                        1, dmx.data_ptr(), H.ld2(dmx), dmn.data_ptr(), H.ld2(dmn), mx.data_ptr(), H.ld2(mx), cnt.data_ptr(),
