@@ -1,0 +1,303 @@
+// edge_mlp_bf16.hip -- conv0 of an EdgeConv layer (dgcnn/ops.py:21-52) as the LITERAL edge-level product with bf16 operands:
+// BASELINE.json configs[2] "bf16 edge-MLP MFMA" (the reference's production shape scripts/lsf/train_dgcnn.sh:8-9 with the operand
+// precision BASELINE names; the reference itself computes conv0 in float32 -- the mode is defined by oracle.edge_conv(...,
+// edge_mlp_dtype="bf16")):
+//
+//     E[e] = [x_i, x_j - x_i]   formed in fp32 (the difference BEFORE any rounding), rounded to bf16 once (RNE)
+//     y[e] = E[e] W0            W0 rounded to bf16 once; v_mfma_f32_32x32x16_bf16, fp32 accumulation over the 2C channels in order
+//
+// The (B N k, 2C) edge tensor and the (B N k, F) product are never written in the forward -- the tile is recomputed by every pass:
+//     PASS 0  BatchNorm statistics: column sums of y and y^2 over all edges -> double[slots][2][F]
+//     PASS 1  z = relu((y - mean) rstd + beta), max / mean / #ties over the k edges of every point -> (B N, F) each
+//     PASS 2  y written out (B N k, F): the backward's input (bit-identical to what passes 0 / 1 saw: same instruction sequence)
+// One workgroup = 4 waves = 128 edge rows; wave w gathers and rounds ITS 32 rows into LDS (row stride 2K + 16 bytes: conflict-free
+// ds_read_b128 of the MFMA A fragments) and multiplies them with all F columns; the bf16 weight fragments of the whole layer stay
+// in registers for the kernel's lifetime (K x F <= 128 x 128: 128 VGPRs); workgroups are persistent over the tiles.
+// PASS 1 tiles hold floor(128 / k) whole points (the max / mean over k must see all edges of a point); the others are dense.
+#include "common.h"
+#include <math.h>
+
+namespace {
+
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+
+constexpr int RT = 128;                  // edge rows per tile
+
+struct EdgeP {
+  const float* x; int64_t ldx; const int32_t* idx; const float* W0;
+  int B, N, C, k, F;
+  float* Y;                              // PASS 2
+  double* stats; int nslots;             // PASS 0
+  const float* mean; const float* rstd; const float* beta;      // PASS 1
+  float* mx; int64_t ldmx; float* mn; int64_t ldmn; float* cnt;
+};
+
+__device__ __forceinline__ unsigned pk_bf16(float lo, float hi) {
+  unsigned r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+  return r;
+}
+
+// same expressions as bn.hip:bn_z (the library is built with -ffp-contract=off): the backward recomputes z from the materialised
+// y and compares it with the maximum taken here
+__device__ __forceinline__ float bn_z1(float y, float mu, float rs, float be) { return fmaxf((y - mu) * rs + be, 0.f); }
+
+// CK = K / 16: 1 (raw coordinates, C <= 4: E = [x_i, 0.. | x_j - x_i, 0..], 8 + 8 channels) or 8 (C = 64).  FB = F / 32.
+template <int PASS, int CK, int FB>
+__global__ __launch_bounds__(256) void edge_mlp_bf16_kernel(EdgeP p) {
+  constexpr int K = 16 * CK;
+  constexpr int S = 2 * K + 16;          // bytes per LDS row of E
+  constexpr int FP = 32 * FB + 1;        // floats per LDS row of y (PASS 1)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* Es = smem;
+  float* Yt = reinterpret_cast<float*>(smem + RT * S);
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6, l31 = lane & 31, lh = lane >> 5;
+  const int C = p.C, k = p.k, F = 32 * FB;
+  const int64_t R = (int64_t)p.B * p.N;
+  const int64_t Me = R * k;
+  const int P = RT / k;                  // whole points per PASS-1 tile
+  const int64_t ntiles = (PASS == 1) ? (R + P - 1) / P : (Me + RT - 1) / RT;
+
+  // ---- the layer's weights as bf16 MFMA B fragments: wf[s][j] = W0[16 s + 8 lh .. + 7][32 j + l31] ----
+  bf16x8 wf[CK][FB];
+#pragma unroll
+  for (int s = 0; s < CK; ++s)
+#pragma unroll
+    for (int j = 0; j < FB; ++j) {
+      float v[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int kk = 16 * s + 8 * lh + q;
+        int row;                            // row of W0 (2C x F) this channel of E multiplies, or -1 (pad channel)
+        if (CK == 1) row = (kk < 8) ? (kk < C ? kk : -1) : (kk - 8 < C ? C + kk - 8 : -1);
+        else row = kk;
+        v[q] = row >= 0 ? p.W0[(int64_t)row * F + 32 * j + l31] : 0.f;
+      }
+      const u32x4 pk = {pk_bf16(v[0], v[1]), pk_bf16(v[2], v[3]), pk_bf16(v[4], v[5]), pk_bf16(v[6], v[7])};
+      wf[s][j] = __builtin_bit_cast(bf16x8, pk);
+    }
+
+  float cs[FB], cq[FB];
+#pragma unroll
+  for (int j = 0; j < FB; ++j) cs[j] = cq[j] = 0.f;
+
+#pragma unroll 1
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    // ---- gather + round: wave w stages rows 32 w .. 32 w + 31 of the tile ----
+    {
+      const int r = (CK == 1) ? (32 * w + l31) : (t >> 1);            // (t >> 1 lies in [32 w, 32 w + 32))
+      int64_t e, gp;
+      bool valid;
+      if (PASS == 1) {
+        const int pi = r / k;
+        gp = tile * P + pi;
+        valid = pi < P && gp < R;
+        e = gp * k + (r - pi * k);
+      } else {
+        e = tile * RT + r;
+        valid = e < Me;
+        gp = e / k;
+      }
+      char* dst = Es + r * S;
+      if (CK == 1) {
+        if (lh == 0) {
+          float xi[4] = {0.f, 0.f, 0.f, 0.f}, d[4] = {0.f, 0.f, 0.f, 0.f};
+          if (valid) {
+            const int64_t nb = (gp / p.N) * p.N + p.idx[e];
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+              if (c < C) {
+                xi[c] = p.x[gp * p.ldx + c];
+                d[c] = p.x[nb * p.ldx + c] - xi[c];
+              }
+          }
+          const u32x4 a = {pk_bf16(xi[0], xi[1]), pk_bf16(xi[2], xi[3]), 0u, 0u};
+          const u32x4 b = {pk_bf16(d[0], d[1]), pk_bf16(d[2], d[3]), 0u, 0u};
+          *reinterpret_cast<u32x4*>(dst) = a;
+          *reinterpret_cast<u32x4*>(dst + 16) = b;
+        }
+      } else {
+        const int h = t & 1;                                            // channels 32 h .. 32 h + 31 of x_i and of x_j - x_i
+        float4 xi[8], xj[8];
+        if (valid) {
+          const int64_t nb = (gp / p.N) * p.N + p.idx[e];
+          const float4* pi4 = reinterpret_cast<const float4*>(p.x + gp * p.ldx + 32 * h);
+          const float4* pj4 = reinterpret_cast<const float4*>(p.x + nb * p.ldx + 32 * h);
+#pragma unroll
+          for (int q = 0; q < 8; ++q) { xi[q] = pi4[q]; xj[q] = pj4[q]; }
+        } else {
+#pragma unroll
+          for (int q = 0; q < 8; ++q) xi[q] = xj[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {                                   // 8 channels per 16-byte store
+          const float4 a0 = xi[2 * q], a1 = xi[2 * q + 1], b0 = xj[2 * q], b1 = xj[2 * q + 1];
+          const u32x4 ci = {pk_bf16(a0.x, a0.y), pk_bf16(a0.z, a0.w), pk_bf16(a1.x, a1.y), pk_bf16(a1.z, a1.w)};
+          const u32x4 di = {pk_bf16(b0.x - a0.x, b0.y - a0.y), pk_bf16(b0.z - a0.z, b0.w - a0.w),
+                            pk_bf16(b1.x - a1.x, b1.y - a1.y), pk_bf16(b1.z - a1.z, b1.w - a1.w)};
+          *reinterpret_cast<u32x4*>(dst + 64 * h + 16 * q) = ci;
+          *reinterpret_cast<u32x4*>(dst + 128 + 64 * h + 16 * q) = di;
+        }
+      }
+    }
+    __syncthreads();
+    // ---- y tile of this wave: 32 rows x F ----
+    f32x16 acc[FB];
+#pragma unroll
+    for (int j = 0; j < FB; ++j)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[j][q] = 0.f;
+#pragma unroll
+    for (int s = 0; s < CK; ++s) {
+      const bf16x8 a = *reinterpret_cast<const bf16x8*>(Es + (32 * w + l31) * S + 32 * s + 16 * lh);
+#pragma unroll
+      for (int j = 0; j < FB; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, wf[s][j], acc[j], 0, 0, 0);
+    }
+    // C/D layout: acc[j][q] = y[row 32 w + (q & 3) + 8 (q >> 2) + 4 lh][col 32 j + l31]
+    if (PASS == 0) {
+      // rows past the end of the edge list are zero rows of E: y = 0 exactly, they add nothing
+#pragma unroll
+      for (int j = 0; j < FB; ++j)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          cs[j] += acc[j][q];
+          cq[j] += acc[j][q] * acc[j][q];
+        }
+      __syncthreads();                                                  // (E rows are rewritten by the next tile)
+    } else if (PASS == 2) {
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int64_t e = tile * RT + 32 * w + (q & 3) + 8 * (q >> 2) + 4 * lh;
+        if (e < Me) {
+#pragma unroll
+          for (int j = 0; j < FB; ++j) p.Y[e * F + 32 * j + l31] = acc[j][q];
+        }
+      }
+      __syncthreads();
+    } else {
+#pragma unroll
+      for (int j = 0; j < FB; ++j)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) Yt[(32 * w + (q & 3) + 8 * (q >> 2) + 4 * lh) * FP + 32 * j + l31] = acc[j][q];
+      __syncthreads();
+      const float invk = 1.0f / (float)k;
+      for (int it = t; it < P * F; it += 256) {
+        const int pi = it / F, c = it - pi * F;
+        const int64_t gp = tile * P + pi;
+        if (gp < R) {
+          const float mu = p.mean[c], rs = p.rstd[c], be = p.beta[c];
+          float mx = -INFINITY, sm = 0.f, cn = 0.f;
+          for (int m = 0; m < k; ++m) {
+            const float z = bn_z1(Yt[(pi * k + m) * FP + c], mu, rs, be);
+            const bool gt = z > mx;
+            cn = gt ? 1.f : ((z == mx) ? cn + 1.f : cn);                // ties share the max gradient
+            mx = gt ? z : mx;
+            sm += z;
+          }
+          p.mx[gp * p.ldmx + c] = mx;
+          p.mn[gp * p.ldmn + c] = sm * invk;
+          if (p.cnt) p.cnt[gp * F + c] = cn;
+        }
+      }
+      __syncthreads();
+    }
+  }
+
+  if (PASS == 0) {
+    // column sums: lanes l and l + 32 hold the same columns (other rows); then the four waves through LDS, one writer per column
+    float* red = reinterpret_cast<float*>(smem);                        // [4 waves][2][F]
+#pragma unroll
+    for (int j = 0; j < FB; ++j) {
+      cs[j] += __shfl_xor(cs[j], 32);
+      cq[j] += __shfl_xor(cq[j], 32);
+    }
+    __syncthreads();
+    if (lh == 0) {
+#pragma unroll
+      for (int j = 0; j < FB; ++j) {
+        red[(w * 2 + 0) * F + 32 * j + l31] = cs[j];
+        red[(w * 2 + 1) * F + 32 * j + l31] = cq[j];
+      }
+    }
+    __syncthreads();
+    const int slot = blockIdx.x % p.nslots;
+    for (int i = t; i < 2 * F; i += 256) {
+      const double v = (double)red[i] + (double)red[2 * F + i] + (double)red[4 * F + i] + (double)red[6 * F + i];
+      atomicAdd(p.stats + (int64_t)slot * 2 * F + i, v);
+    }
+  }
+}
+
+template <int PASS>
+int launch_pass(const EdgeP& p, hipStream_t st, const char* what) {
+  const int CK = p.C <= 4 ? 1 : 8;
+  const int FB = p.F / 32;
+  const int K = 16 * CK;
+  const int64_t R = (int64_t)p.B * p.N;
+  const int64_t ntiles = (PASS == 1) ? dg::cdiv(R, (int64_t)(RT / p.k)) : dg::cdiv(R * p.k, (int64_t)RT);
+  size_t sh = (size_t)RT * (2 * K + 16);
+  if (PASS == 1) sh += (size_t)RT * (p.F + 1) * sizeof(float);
+  if (PASS == 0 && sh < (size_t)8 * p.F * sizeof(float)) sh = (size_t)8 * p.F * sizeof(float);
+  int64_t g = ntiles < 1024 ? ntiles : 1024;
+  if (PASS == 0) g = dg::cap_writers(g);                               // (reproducible configuration: one writer per slot)
+  if (g < 1) g = 1;
+#define DG_E(CKV, FBV)                                                                                                        \
+  do {                                                                                                                        \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&edge_mlp_bf16_kernel<PASS, CKV, FBV>),                           \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                                        \
+    hipLaunchKernelGGL((edge_mlp_bf16_kernel<PASS, CKV, FBV>), dim3((unsigned)g), dim3(256), sh, st, p);                      \
+  } while (0)
+  if (CK == 1) {
+    if (FB == 1) DG_E(1, 1); else if (FB == 2) DG_E(1, 2); else DG_E(1, 4);
+  } else {
+    if (FB == 1) DG_E(8, 1); else if (FB == 2) DG_E(8, 2); else DG_E(8, 4);
+  }
+#undef DG_E
+  return dg::check_launch(what);
+}
+
+bool shape_ok(int C, int k, int F) { return (C <= 4 || C == 64) && (F == 32 || F == 64 || F == 128) && k <= RT; }
+
+}  // namespace
+
+// 1 when the fused kernels take this layer shape (C <= 4 or C == 64; F in {32, 64, 128}; k <= 128), else 0
+extern "C" int dgcnn_edge_mlp_bf16_supported(int C, int k, int F) { return shape_ok(C, k, F) ? 1 : 0; }
+
+#define DG_EDGE_COMMON(name)                                                                                                  \
+  DG_REQUIRE(x && idx && W0 && B > 0 && N > 0 && C > 0 && k > 0 && F > 0, DGCNN_EINVAL, name ": bad args");                    \
+  DG_REQUIRE(shape_ok(C, k, F), DGCNN_EUNSUP, name ": needs C <= 4 or C == 64, F in {32, 64, 128}, k <= 128 (C=%d k=%d F=%d)", C, k, F); \
+  DG_REQUIRE((int64_t)B * N * k < (1ll << 31), DGCNN_EUNSUP, name ": B*N*k >= 2^31");                                          \
+  DG_REQUIRE(C <= 4 || (ldx % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0), DGCNN_EINVAL, name ": x must be float4-loadable"); \
+  EdgeP p = {};                                                                                                                \
+  p.x = x; p.ldx = ldx; p.idx = idx; p.W0 = W0; p.B = B; p.N = N; p.C = C; p.k = k; p.F = F
+
+// y = E W0 written out (B N k, F): the literal bf16 edge MLP (dgcnn_edge_mlp_f32 | bf16)
+extern "C" int dgcnn_edge_mlp_bf16(const float* x, int64_t ldx, const int32_t* idx, const float* W0, int B, int N, int C, int k,
+                                   int F, float* Y, void* stream) {
+  DG_EDGE_COMMON("dgcnn_edge_mlp_bf16");
+  DG_REQUIRE(Y, DGCNN_EINVAL, "dgcnn_edge_mlp_bf16: null output");
+  p.Y = Y;
+  return launch_pass<2>(p, (hipStream_t)stream, "dgcnn_edge_mlp_bf16");
+}
+
+// BatchNorm statistics of y without writing it: stats[slot][0][f] += sum_e y, stats[slot][1][f] += sum_e y^2
+extern "C" int dgcnn_edge_mlp_bf16_stats(const float* x, int64_t ldx, const int32_t* idx, const float* W0, int B, int N, int C,
+                                         int k, int F, double* stats, void* stream) {
+  DG_EDGE_COMMON("dgcnn_edge_mlp_bf16_stats");
+  DG_REQUIRE(stats, DGCNN_EINVAL, "dgcnn_edge_mlp_bf16_stats: null output");
+  p.stats = stats;
+  p.nslots = dg::stat_slots();
+  return launch_pass<0>(p, (hipStream_t)stream, "dgcnn_edge_mlp_bf16_stats");
+}
+
+// relu(BatchNorm(y)) reduced over the k edges of every point, y recomputed: max -> mx, mean -> mn, #ties of the max -> cnt
+extern "C" int dgcnn_edge_mlp_bf16_bn_kreduce(const float* x, int64_t ldx, const int32_t* idx, const float* W0, int B, int N,
+                                              int C, int k, int F, const float* mean, const float* rstd, const float* beta,
+                                              float* mx, int64_t ldmx, float* mn, int64_t ldmn, float* cnt, void* stream) {
+  DG_EDGE_COMMON("dgcnn_edge_mlp_bf16_bn_kreduce");
+  DG_REQUIRE(mean && rstd && beta && mx && mn && ldmx >= F && ldmn >= F, DGCNN_EINVAL, "dgcnn_edge_mlp_bf16_bn_kreduce: bad args");
+  p.mean = mean; p.rstd = rstd; p.beta = beta; p.mx = mx; p.ldmx = ldmx; p.mn = mn; p.ldmn = ldmn; p.cnt = cnt;
+  return launch_pass<1>(p, (hipStream_t)stream, "dgcnn_edge_mlp_bf16_bn_kreduce");
+}

@@ -777,30 +777,45 @@ def edge_conv_block(x, B, N, k, num_filters, relu1=True, outs=None, net2=None):
     idx = knn(x, B, N, k)                                               # ops.py:8-19
     virtual = gather and not EDGE_MATERIALIZE_Y and k < 256   # conv0 output never written: recomputed from (V, U, idx)
     #                                                           (the edge BN passes pack tie / positive counts: k < 256)
-    Y = None if virtual else torch.empty((R * k, F), dtype=torch.float32, device=x.device)
+    Y = None if virtual else torch.empty((R * k, F), dtype=torch.float32, device=x.device)   # (the fused bf16 path frees it below)
     wd = wcat = UV = None
     Ee = W0p = None
-    if bf16:
-        # the literal edge tensor, formed in fp32 (the difference x_j - x_i BEFORE any rounding), then ONE product whose operands
-        # the GEMM rounds to bf16 (arith = 1: v_cvt_pk_bf16_f32, round to nearest even) with fp32 accumulation on the bf16 MFMA pipe.
-        # Raw coordinates (C = 3): channels padded to 4 so that the product takes the float4 path (zero columns / zero weight rows)
-        Cp = (C + 3) // 4 * 4
-        xg = x
+    fused_bf16 = False
+    Cp = (C + 3) // 4 * 4
+
+    def bf16_operands():
+        """The literal edge tensor in fp32 (the difference x_j - x_i BEFORE any rounding; channels padded to a multiple of 4 so
+        that the products take the float4 path) and the matching weight rows -- the operands the bf16 products round."""
+        xg, Wp = x, W0
         if Cp != C:
             xg = torch.zeros((R, Cp), dtype=torch.float32, device=x.device)
             H.call("dgcnn_copy2d_f32", x.data_ptr(), H.ld2(x), xg.data_ptr(), Cp, R, C, 0)
-            W0p = torch.zeros((2 * Cp, F), dtype=torch.float32, device=x.device)
-            H.call("dgcnn_copy2d_f32", W0[:C].data_ptr(), F, W0p[:C].data_ptr(), F, C, F, 0)
-            H.call("dgcnn_copy2d_f32", W0[C:].data_ptr(), F, W0p[Cp:Cp + C].data_ptr(), F, C, F, 0)
+            Wp = torch.zeros((2 * Cp, F), dtype=torch.float32, device=x.device)
+            H.call("dgcnn_copy2d_f32", W0[:C].data_ptr(), F, Wp[:C].data_ptr(), F, C, F, 0)
+            H.call("dgcnn_copy2d_f32", W0[C:].data_ptr(), F, Wp[Cp:Cp + C].data_ptr(), F, C, F, 0)
+        E_ = torch.empty((R * k, 2 * Cp), dtype=torch.float32, device=x.device)
+        H.call("dgcnn_edge_gather_f32", xg.data_ptr(), H.ld2(xg), idx.data_ptr(), B, N, Cp, k, E_.data_ptr())   # ops.py:21-40
+        return E_, Wp
+
+    if bf16:
+        fused_bf16 = (bool(H.load().dgcnn_edge_mlp_bf16_supported(C, k, F)) and W0.is_contiguous() and
+                      (C <= 4 or (H.ld2(x) % 4 == 0 and x.data_ptr() % 16 == 0)))
+        bsrc = (x.data_ptr(), H.ld2(x), idx.data_ptr(), W0.data_ptr(), B, N, C, k, F)
+        if fused_bf16:
+            # csrc/edge_mlp_bf16.hip: E = [x_i, x_j - x_i] gathered, rounded and multiplied tile by tile on the bf16 MFMA pipe;
+            # neither E nor y is written: this pass takes the BatchNorm sums, the next one recomputes y for BN + ReLU + max / mean
+            Y = None
+            H.call("dgcnn_edge_mlp_bf16_stats", *bsrc, st.data_ptr(), tag="edge_mlp_bf16_kernel<stats>",
+                   work=2.0 * R * k * 2 * C * F, nbytes=4.0 * (R * k * C + R * C))
         else:
-            W0p = W0
-        Ee = torch.empty((R * k, 2 * Cp), dtype=torch.float32, device=x.device)
-        H.call("dgcnn_edge_gather_f32", xg.data_ptr(), H.ld2(xg), idx.data_ptr(), B, N, Cp, k, Ee.data_ptr())   # ops.py:21-40
-        gemm(Ee, W0p, Y, stats=None if DETERMINISTIC else st, arith=1)                                          # ops.py:47-52
-        if DETERMINISTIC:
-            colstats_det(Y, st)
-        if not c.recording:
-            Ee = None
+            # shapes the fused kernels do not take: the edge tensor in fp32, then ONE product whose operands the GEMM rounds to
+            # bf16 (arith = 1: v_cvt_pk_bf16_f32, round to nearest even) with fp32 accumulation on the bf16 MFMA pipe
+            Ee, W0p = bf16_operands()
+            gemm(Ee, W0p, Y, stats=None if DETERMINISTIC else st, arith=1)                                      # ops.py:47-52
+            if DETERMINISTIC:
+                colstats_det(Y, st)
+            if not c.recording:
+                Ee = None
     elif literal:
         H.call("dgcnn_edge_mlp_f32", x.data_ptr(), H.ld2(x), idx.data_ptr(), W0.data_ptr(), B, N, C, k, F,
                Y.data_ptr(), 0 if DETERMINISTIC else st.data_ptr(),
@@ -843,7 +858,11 @@ def edge_conv_block(x, B, N, k, num_filters, relu1=True, outs=None, net2=None):
         mm, net_out = outs
     mx, mn = mm[:, :F], mm[:, F:]
     cnt = torch.empty((R, F), dtype=torch.float32, device=x.device) if c.recording else None   # ties of the max
-    if virtual:
+    if fused_bf16:
+        H.call("dgcnn_edge_mlp_bf16_bn_kreduce", *bsrc, mean.data_ptr(), rstd.data_ptr(), beta0.data_ptr(),
+               mx.data_ptr(), H.ld2(mx), mn.data_ptr(), H.ld2(mn), H._p(cnt),
+               tag="edge_mlp_bf16_kernel<bn_kreduce>", work=2.0 * R * k * 2 * C * F, nbytes=4.0 * (R * k * C + R * C))   # ops.py:53-58
+    elif virtual:
         esrc = (UV[:, F:].data_ptr(), 2 * F, UV.data_ptr(), 2 * F, idx.data_ptr(), B, N, k, F)
         H.call("dgcnn_edge_bn_act_kreduce_f32", *esrc, mean.data_ptr(), rstd.data_ptr(), beta0.data_ptr(), 1,
                mx.data_ptr(), H.ld2(mx), mn.data_ptr(), H.ld2(mn), H._p(cnt),
@@ -870,11 +889,19 @@ def edge_conv_block(x, B, N, k, num_filters, relu1=True, outs=None, net2=None):
 
     if c.recording:
         def bwd():
+            nonlocal Y, Ee, W0p
             dmm = c.grad(mm)
             if dmm is None:
                 return
             dmx, dmn = dmm[:, :F], dmm[:, F:]
             red = c.stats(F)
+            if fused_bf16:
+                # the forward wrote neither E nor y: both are formed again for the backward (y by the SAME instruction sequence,
+                # so the recomputed z compares equal to the maxima the forward took), used by the passes below and dropped
+                Y = torch.empty((R * k, F), dtype=torch.float32, device=x.device)
+                H.call("dgcnn_edge_mlp_bf16", *bsrc, Y.data_ptr(), tag="edge_mlp_bf16_kernel<write>",
+                       work=2.0 * R * k * 2 * C * F, nbytes=4.0 * (R * k * C + R * C))
+                Ee, W0p = bf16_operands()
             if virtual and EDGE_BWD_REDUCE_POINTS:
                 # sum dz, sum dz*xhat from the forward's per-point outputs alone (bn.hip): no pass over the edges
                 H.call("dgcnn_edge_bn_bwd_reduce_points_f32", mx.data_ptr(), H.ld2(mx), mn.data_ptr(), H.ld2(mn),
@@ -966,6 +993,8 @@ def edge_conv_block(x, B, N, k, num_filters, relu1=True, outs=None, net2=None):
                         raise H.HipError("bf16 edge-MLP: an input gradient for a channel count that is not a multiple of 4 "
                                          "is not implemented (C = %d)" % C)
                     H.call("dgcnn_edge_gather_bwd_f32", dE.data_ptr(), idx.data_ptr(), B, N, C, k, dx.data_ptr(), H.ld2(dx))
+                if fused_bf16:
+                    Y = Ee = None                   # (recomputed for this backward only)
                 return
             if literal:
                 H.call("dgcnn_edge_mlp_wgrad_f32", x.data_ptr(), H.ld2(x), idx.data_ptr(), dY.data_ptr(), B, N, C, k, F,

@@ -97,6 +97,11 @@ PROTOTYPES = {
     "dgcnn_softmax_xent_f32": [c_vp, c_vp, c_vp, c_i64, c_int, c_vp, c_vp, c_vp, c_vp],
     "dgcnn_axpby_f32": [c_vp, c_f32, c_vp, c_f32, c_i64, c_vp],
     "dgcnn_adam_f32": [c_vp, c_vp, c_vp, c_vp, c_i64, c_f32, c_f32, c_f32, c_f32, c_vp],
+    "dgcnn_edge_mlp_bf16_supported": [c_int, c_int, c_int],
+    "dgcnn_edge_mlp_bf16": [c_vp, c_i64, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp],
+    "dgcnn_edge_mlp_bf16_stats": [c_vp, c_i64, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp],
+    "dgcnn_edge_mlp_bf16_bn_kreduce": [c_vp, c_i64, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_i64,
+                                       c_vp, c_i64, c_vp, c_vp],
     "dgcnn_comm_unique_id": [c_vp],
     "dgcnn_comm_init": [c_int, c_int, c_vp, c_vp],
     "dgcnn_comm_destroy": [c_vp],

@@ -71,6 +71,23 @@ int dgcnn_knn_bf16_filter(int mode);
 int dgcnn_knn_f32(const float* x, int B, int N, int C, int64_t ldx, int k, int32_t* idx,
                   void* ws, size_t ws_bytes, void* stream);
 
+/* ---- K3 in its bf16-operand form (BASELINE configs[2] "bf16 edge-MLP MFMA"): conv0 of an EdgeConv layer, ops.py:21-52 ------
+ * E[e] = [x_i, x_j - x_i] formed in fp32 and rounded to bf16 once (RNE), W0 (2C x F, row-major) rounded to bf16 once,
+ * y = E W0 on v_mfma_f32_32x32x16_bf16 with fp32 accumulation; neither E nor y is written by the two forward passes:
+ *   dgcnn_edge_mlp_bf16_stats      stats[slot][0][f] += sum_e y[e][f], stats[slot][1][f] += sum_e y[e][f]^2  (double[slots][2][F], zeroed)
+ *   dgcnn_edge_mlp_bf16_bn_kreduce z = relu((y - mean) rstd + beta) recomputed; max / mean over the k edges of each point and the
+ *                                  number of edges attaining the max (cnt, (B N, F) dense; may be null)
+ *   dgcnn_edge_mlp_bf16            y written out, (B N k, F) dense -- bit-identical to what the two passes saw (backward input)
+ * Shapes: C <= 4 or C == 64 (x float4-loadable), F in {32, 64, 128}, k <= 128 (dgcnn_edge_mlp_bf16_supported; DGCNN_EUNSUP else). */
+int dgcnn_edge_mlp_bf16_supported(int C, int k, int F);
+int dgcnn_edge_mlp_bf16(const float* x, int64_t ldx, const int32_t* idx, const float* W0, int B, int N, int C, int k, int F,
+                        float* Y, void* stream);
+int dgcnn_edge_mlp_bf16_stats(const float* x, int64_t ldx, const int32_t* idx, const float* W0, int B, int N, int C, int k, int F,
+                              double* stats, void* stream);
+int dgcnn_edge_mlp_bf16_bn_kreduce(const float* x, int64_t ldx, const int32_t* idx, const float* W0, int B, int N, int C, int k,
+                                   int F, const float* mean, const float* rstd, const float* beta, float* mx, int64_t ldmx,
+                                   float* mn, int64_t ldmn, float* cnt, void* stream);
+
 /* ---- K2: dgcnn/ops.py:21-40 edges (gather + tile + sub + concat) ------------------------
  * E[b][i][m][0..C) = x_i ; E[b][i][m][C..2C) = x_{idx[b][i][m]} - x_i.                    */
 int dgcnn_edge_gather_f32(const float* x, int64_t ldx, const int32_t* idx, int B, int N, int C, int k,

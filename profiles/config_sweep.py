@@ -16,8 +16,11 @@ CONFIGS = [
     ("configs[0] B=2 N=512 k=10, 1 EdgeConv", dict(MODEL_NAME="dgcnn", EDGE_CONV_LAYERS=1, EDGE_CONV_FILTERS=64, KVALUE=10), 2, 512, 3),
     ("configs[1] B=24 N=2048 k=20, 3 EdgeConv (64,64,128)", dict(MODEL_NAME="dgcnn", EDGE_CONV_LAYERS=3, EDGE_CONV_FILTERS=[64, 64, 128], KVALUE=20), 24, 2048, 3),
     ("configs[2] B=8 N=16384 k=40 residual x6 (fp32 path)", dict(MODEL_NAME="residual-dgcnn", EDGE_CONV_LAYERS=6, EDGE_CONV_FILTERS=64, KVALUE=40), 8, 16384, 3),
+    ("configs[2] B=8 N=16384 k=40 residual x6, bf16 edge-MLP (named mode)", dict(MODEL_NAME="residual-dgcnn", EDGE_CONV_LAYERS=6, EDGE_CONV_FILTERS=64, KVALUE=40, EDGE_MLP_DTYPE="bf16"), 8, 16384, 3),
     ("configs[4] per-GPU B=8 N=65536 k=20, 3 EdgeConv", dict(MODEL_NAME="dgcnn", EDGE_CONV_LAYERS=3, EDGE_CONV_FILTERS=[64, 64, 128], KVALUE=20), 8, 65536, 3),
 ]
+if "--only" in sys.argv:
+    CONFIGS = [c for c in CONFIGS if sys.argv[sys.argv.index("--only") + 1] in c[0]]
 
 
 def main():
