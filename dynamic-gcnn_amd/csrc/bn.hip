@@ -358,6 +358,10 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
     const float* __restrict__ dmax, int64_t lddmax, const float* __restrict__ dmean, int64_t lddmean,
     const float* __restrict__ mx_in, int64_t ldmx, const float* __restrict__ cnt_in,
     const double* __restrict__ red, float* dY, float* __restrict__ dYsum, int64_t lddysum, int fv_shift) {
+  // relu: bit 0 = the layer has a ReLU; bit 1 = dY is written as bf16 VALUES (round to nearest even, stored as fp32) and dYsum adds
+  // those -- the operand rounding of the bf16 edge-MLP's gradient products (oracle.conv_bn_act_bwd(operand_round)), done once here
+  const bool round_dy = (relu & 2) != 0;
+  relu &= 1;
   const int FV = F / V;
   const Items its = items_of<G>(R, FV);
   const float invk = 1.0f / (float)k;
@@ -409,6 +413,10 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
             else dz = dmx[v];
             if (relu && !(z > 0.f)) dz = 0.f;
             o[v] = rs[v] * (dz - c1[v] - xh * c2[v]);
+            if (round_dy) {
+              const unsigned u = __float_as_uint(o[v]);
+              o[v] = __uint_as_float((u + 0x7fffu + ((u >> 16) & 1u)) & 0xffff0000u);
+            }
             acc[v] += o[v];
           }
           Vec<V>::st(dy + (int64_t)(m + b) * F, o);

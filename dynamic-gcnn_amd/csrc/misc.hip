@@ -546,6 +546,20 @@ extern "C" int dgcnn_edge_gather_add_f32(const float* V, int64_t ldv, const floa
   return dg::check_launch("dgcnn_edge_gather_add_f32");
 }
 
+// dst = src rounded to bf16 values (nearest even), kept as fp32: the weight operand of the bf16 edge-MLP's point-level gradient products
+__global__ void round_bf16_kernel(const float* __restrict__ src, float* __restrict__ dst, int64_t n) {
+  GRID_STRIDE(i, n) {
+    const unsigned u = __float_as_uint(src[i]);
+    dst[i] = __uint_as_float((u + 0x7fffu + ((u >> 16) & 1u)) & 0xffff0000u);
+  }
+}
+
+extern "C" int dgcnn_round_bf16_f32(const float* src, float* dst, int64_t n, void* stream) {
+  DG_REQUIRE(src && dst && n > 0, DGCNN_EINVAL, "dgcnn_round_bf16_f32: bad args");
+  hipLaunchKernelGGL(round_bf16_kernel, dim3(grid1d(n)), dim3(256), 0, ST, src, dst, n);
+  return dg::check_launch("dgcnn_round_bf16_f32");
+}
+
 extern "C" int dgcnn_edge_weight_split_f32(const float* W0, int C, int F, float* Wcat, void* stream) {
   DG_REQUIRE(W0 && Wcat && C > 0 && F > 0, DGCNN_EINVAL, "dgcnn_edge_weight_split_f32: bad args");
   hipLaunchKernelGGL(edge_weight_split_kernel, dim3(grid1d((int64_t)C * F)), dim3(256), 0, ST, W0, C, F, Wcat);

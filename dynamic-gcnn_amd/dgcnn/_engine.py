@@ -943,7 +943,7 @@ def edge_conv_block(x, B, N, k, num_filters, relu1=True, outs=None, net2=None):
                        tag="bn_bwd_apply_kernel<edge>", work=4.0 * (R * k * F + 7 * R * F) + 4.0 * R * k, nbytes=4.0 * (R * k * F + R * F))
             else:
                 H.call("dgcnn_bn_bwd_apply_f32", Y.data_ptr(), R, k, F, mean.data_ptr(), rstd.data_ptr(), beta0.data_ptr(),
-                       1, dmx.data_ptr(), H.ld2(dmx), dmn.data_ptr(), H.ld2(dmn), mx.data_ptr(), H.ld2(mx), cnt.data_ptr(),
+                       3 if bf16 else 1, dmx.data_ptr(), H.ld2(dmx), dmn.data_ptr(), H.ld2(dmn), mx.data_ptr(), H.ld2(mx), cnt.data_ptr(),
                        red.data_ptr(), Y.data_ptr(),
                        H._p(dysum), 0 if dysum is None else H.ld2(dysum), c.var_grads[b0name].data_ptr(), 1.0,
                        tag="bn_bwd_apply_kernel", work=4.0 * (2 * R * k * F + 3 * R * F))
@@ -978,7 +978,8 @@ def edge_conv_block(x, B, N, k, num_filters, relu1=True, outs=None, net2=None):
                     H.call("dgcnn_edge_wgrad_combine_f32", dwcat.data_ptr(), C, F, dW0.data_ptr())
                 return
             if bf16:
-                # dW0 = E^T dY and dE = dY W0^T with bf16 operands (the same rounding of E and W0 as the forward, dY rounded once)
+                # dW0 = E^T dY with bf16 operands: E and W0 rounded as in the forward; dY was written on the bf16 grid by the
+                # apply pass (relu flag 3), so the product's own rounding (arith = 1) leaves it unchanged
                 if W0p is W0:
                     gemm(Ee, dY, dW0, transA=True, beta=1.0, arith=1)
                 else:
@@ -987,12 +988,21 @@ def edge_conv_block(x, B, N, k, num_filters, relu1=True, outs=None, net2=None):
                     H.call("dgcnn_copy2d_f32", dWp[:C].data_ptr(), F, dW0[:C].data_ptr(), F, C, F, 1)
                     H.call("dgcnn_copy2d_f32", dWp[Cp:Cp + C].data_ptr(), F, dW0[C:].data_ptr(), F, C, F, 1)
                 if dx is not None:
-                    dE = torch.empty((R * k, 2 * Cp), dtype=torch.float32, device=x.device)
-                    gemm(dY, W0p, dE, transB=True, arith=1)
-                    if Cp != C:
-                        raise H.HipError("bf16 edge-MLP: an input gradient for a channel count that is not a multiple of 4 "
-                                         "is not implemented (C = %d)" % C)
-                    H.call("dgcnn_edge_gather_bwd_f32", dE.data_ptr(), idx.data_ptr(), B, N, C, k, dx.data_ptr(), H.ld2(dx))
+                    # dE = dY W0'^T (W0' = bf16(W0)) never exists: the transpose of `edges` is linear, so
+                    #   dx_i += (sum_m dY) (W0'[:C] - W0'[C:])^T        dx_j += (sum of the dY rows of the edges that point at j) W0'[C:]^T
+                    # -- the same sums of the same bf16 x bf16 products as the literal edge-level product + scatter-add, taken at
+                    # the points (k times fewer MACs, no atomics); the point-level products run in the exact arithmetic
+                    W0r = torch.empty_like(W0)
+                    H.call("dgcnn_round_bf16_f32", W0.data_ptr(), W0r.data_ptr(), W0.numel())
+                    wdb = torch.empty((C, F), dtype=torch.float32, device=x.device)
+                    H.call("dgcnn_copy2d_f32", W0r[:C].data_ptr(), F, wdb.data_ptr(), F, C, F, 0)
+                    H.call("dgcnn_axpby_f32", W0r[C:].data_ptr(), -1.0, wdb.data_ptr(), 1.0, C * F)
+                    gemm(dysum, wdb, dx, transB=True, beta=1.0)
+                    if F % 4 != 0:
+                        raise H.HipError("bf16 edge-MLP: the input gradient needs filter counts that are multiples of 4 (F = %d)" % F)
+                    S = torch.empty((R, F), dtype=torch.float32, device=x.device)
+                    incoming_sum(S)
+                    gemm(S, W0r[C:], dx, transB=True, beta=1.0)
                 if fused_bf16:
                     Y = Ee = None                   # (recomputed for this backward only)
                 return

@@ -98,6 +98,7 @@ PROTOTYPES = {
     "dgcnn_axpby_f32": [c_vp, c_f32, c_vp, c_f32, c_i64, c_vp],
     "dgcnn_adam_f32": [c_vp, c_vp, c_vp, c_vp, c_i64, c_f32, c_f32, c_f32, c_f32, c_vp],
     "dgcnn_edge_mlp_bf16_supported": [c_int, c_int, c_int],
+    "dgcnn_round_bf16_f32": [c_vp, c_vp, c_i64, c_vp],
     "dgcnn_edge_mlp_bf16": [c_vp, c_i64, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp],
     "dgcnn_edge_mlp_bf16_stats": [c_vp, c_i64, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp],
     "dgcnn_edge_mlp_bf16_bn_kreduce": [c_vp, c_i64, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_i64,

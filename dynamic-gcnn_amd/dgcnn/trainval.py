@@ -106,8 +106,6 @@ class trainval(object):
         emd = str(getattr(f, "EDGE_MLP_DTYPE", "f32") or "f32").lower()
         if emd not in ("f32", "bf16"):
             raise ValueError("EDGE_MLP_DTYPE must be f32 or bf16, got %r" % (getattr(f, "EDGE_MLP_DTYPE"),))
-        if emd == "bf16" and E.DETERMINISTIC:
-            raise ValueError("EDGE_MLP_DTYPE=bf16 with DETERMINISTIC: the neighbour gradient of the bf16 edge-MLP is an atomic scatter")
         E.EDGE_MLP_DTYPE = emd                           # per instance, like DETERMINISTIC
         hp = getattr(f, "HEAD_PLANES", None)             # per instance, like DETERMINISTIC: flag, else the environment default
         if hp is None:

@@ -80,6 +80,8 @@ int dgcnn_knn_f32(const float* x, int B, int N, int C, int64_t ldx, int k, int32
  *   dgcnn_edge_mlp_bf16            y written out, (B N k, F) dense -- bit-identical to what the two passes saw (backward input)
  * Shapes: C <= 4 or C == 64 (x float4-loadable), F in {32, 64, 128}, k <= 128 (dgcnn_edge_mlp_bf16_supported; DGCNN_EUNSUP else). */
 int dgcnn_edge_mlp_bf16_supported(int C, int k, int F);
+/* dst[i] = src[i] rounded to the nearest bf16 value (ties to even), kept as fp32 (weights of the mode's point-level gradient products) */
+int dgcnn_round_bf16_f32(const float* src, float* dst, int64_t n, void* stream);
 int dgcnn_edge_mlp_bf16(const float* x, int64_t ldx, const int32_t* idx, const float* W0, int B, int N, int C, int k, int F,
                         float* Y, void* stream);
 int dgcnn_edge_mlp_bf16_stats(const float* x, int64_t ldx, const int32_t* idx, const float* W0, int B, int N, int C, int k, int F,
@@ -308,7 +310,9 @@ int dgcnn_bn_bwd_reduce_f32(const float* Y, int64_t R, int k, int F,
                             double* red, void* stream);
 /* backward, pass 2: dY = rstd*(dZ - red0/cnt - xhat*red1/cnt) written to dY (may alias Y);
  * dbeta[f] (+)= red0 ; dYsum[r][f] = sum_m dY (optional, feeds the centre dgrad).
- * `red` is reduced over its slots in place (slot 0 then holds the totals).                  */
+ * `red` is reduced over its slots in place (slot 0 then holds the totals).
+ * relu: bit 0 = the layer has a ReLU; bit 1 (value 2, k > 1 only) = dY is written as bf16 VALUES (nearest even, stored as fp32)
+ * and dYsum adds those: the operand rounding of the bf16 edge-MLP's gradient products, done once where dY is formed. */
 int dgcnn_bn_bwd_apply_f32(const float* Y, int64_t R, int k, int F,
                            const float* mean, const float* rstd, const float* beta, int relu,
                            const float* dmax, int64_t lddmax, const float* dmean, int64_t lddmean,

@@ -175,13 +175,34 @@ def test_config2_full_size_property_run_bf16(dg):
     print("configs[2] full size, bf16 edge-MLP: loss %.5f, peak HBM %.1f GB" % (loss, torch.cuda.max_memory_allocated() / 2 ** 30))
 
 
-def test_bf16_mode_is_refused_with_deterministic_and_bad_values(dg):
+def test_bf16_mode_rejects_unknown_values_and_runs_deterministically(dg):
+    """An unknown EDGE_MLP_DTYPE is refused at initialize(); with DETERMINISTIC the mode is bit-reproducible run to run (its
+    neighbour gradient is a sum over sorted incoming edges at the points, not an atomic scatter)."""
+    from dgcnn import _engine as E
     with pytest.raises(ValueError):
         dg.trainval(dg.DGCNN_FLAGS(EDGE_MLP_DTYPE="fp8")).initialize()
-    with pytest.raises(ValueError):
-        dg.trainval(dg.DGCNN_FLAGS(EDGE_MLP_DTYPE="bf16", DETERMINISTIC=True)).initialize()
-    from dgcnn import _engine as E
-    E.DETERMINISTIC = E.DETERMINISTIC_ENV_DEFAULT
+    B, N, C = 2, 256, 3
+    rng = np.random.default_rng(9)
+    pts = dev(rng.random((B, N, C), dtype=np.float32))
+    labels = dev(rng.integers(0, 2, (B, N)).astype(np.int32))
+    runs = []
+    try:
+        for _ in range(2):
+            dg.reset()
+            f = dg.DGCNN_FLAGS(MODEL_NAME="residual-dgcnn", EDGE_CONV_LAYERS=3, EDGE_CONV_FILTERS=64, FC_LAYERS=1, FC_FILTERS=[64], NUM_CLASS=2,
+                               KVALUE=8, NUM_CHANNEL=C, TRAIN=True, SEED=4, EDGE_MLP_DTYPE="bf16", DETERMINISTIC=True)
+            tv = dg.trainval(f).initialize()
+            for _ in range(2):
+                tv.zero_gradients(None)
+                tv.accum_gradient(None, [pts], [labels])
+                g = host(dg.ctx().flat_grad).copy()
+                tv.apply_gradient(None)
+            runs.append((g, host(dg.ctx().flat_param).copy()))
+    finally:
+        E.DETERMINISTIC = E.DETERMINISTIC_ENV_DEFAULT
+    np.testing.assert_array_equal(runs[0][0], runs[1][0])
+    np.testing.assert_array_equal(runs[0][1], runs[1][1])
+    assert np.abs(runs[0][0]).sum() > 0
 
 
 @pytest.mark.parametrize("B,N,C,k,F", [(2, 100, 64, 20, 64), (1, 333, 64, 40, 128), (3, 77, 3, 7, 32), (2, 64, 4, 10, 128), (1, 130, 64, 128, 32)])
