@@ -752,14 +752,8 @@ int knn_bf16f_mode() {
   return g_knn_bf16f;
 }
 
-int g_knn_valu = -1;
-bool knn_force_valu() {
-  if (g_knn_valu < 0) {
-    const char* e = getenv("DGCNN_KNN_VALU");   // A/B switch: VALU fmaf distance for every C
-    g_knn_valu = (e && e[0] == '1') ? 1 : 0;
-  }
-  return g_knn_valu == 1;
-}
+int g_knn_valu = 0;            // dgcnn_knn_force_valu (tests): VALU fmaf distances for every C
+bool knn_force_valu() { return g_knn_valu == 1; }
 
 template <int CP, int KC>
 void launch_knn(const float* x, const float* sq, int B, int N, int C, int64_t ldx, int k, int vec_ok,
