@@ -643,7 +643,11 @@ void set_gemm_arith(int v) { g_arith = v; }
 
 // asrc in {A_ROW, A_COL}, bsrc in {B_ROW, B_COL}; operands float4-loadable (checked by the caller).
 // p.mtiles / ntiles / xcd_group / splits / kchunk (multiple of 32 when splits > 1) are set.
+int g_x3_tile_override = 0;      // dgcnn_gemm_x3_tile_override (tools): 0 = the rule below, 128 / 256 = that row tile where legal
+
 int x3_tile_m(int M, int N, int K) {
+  if (g_x3_tile_override == 128) return 128;
+  if (g_x3_tile_override == 256 && M > 128 && N > 64) return 256;
   // short reduction, many rows, one or two column tiles: the kernel is bound by the latency of its few slabs -- 64-row tiles put
   // twice the workgroups (and loads in flight) on a CU
   if (dg::gemm_arith() == 6 && K <= 256 && N <= 256 && M >= 8192 && cdiv(M, 128) * cdiv(N, 128) <= 1024) return 64;
@@ -673,3 +677,9 @@ extern "C" int dgcnn_gemm_set_arith(int mode) {
 extern "C" int dgcnn_gemm_get_arith(void) { return dg::gemm_arith(); }
 
 extern "C" int dgcnn_gemm_x3_tile_rows(int M, int N, int K) { return dg::x3_tile_m(M, N, K); }
+
+extern "C" int dgcnn_gemm_x3_tile_override(int bm) {      // tools: force the 128- or 256-row tile (0 = automatic); returns the previous value
+  const int prev = dg::g_x3_tile_override;
+  dg::g_x3_tile_override = (bm == 128 || bm == 256) ? bm : 0;
+  return prev;
+}

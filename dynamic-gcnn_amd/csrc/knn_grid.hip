@@ -280,28 +280,37 @@ __global__ __launch_bounds__(64 * QW) void knn_grid_query_kernel(const float4* _
   bool done = !valid;
 #pragma unroll 1
   for (int r = 0; r < GMAX; ++r) {
-    const int W = 2 * r + 1;
-    const int T = 2 * W * W;
-    int tc = 0, p = 0, e = 0;
+    // columns (dx, dy) of the ring, clipped to the grid; a column on the ring's rim (|dx| == r or |dy| == r) is one run of up to
+    // 2 r + 1 cells along z, an inner column contributes its two end cells.  Stepped incrementally (no divisions: this loop runs
+    // once per run and lane, and at N = 2048 it used to cost as much as the candidates themselves).
+    const int dx0 = -r < -c0 ? -c0 : -r, dx1 = r > G - 1 - c0 ? G - 1 - c0 : r;
+    const int dy0 = -r < -c1 ? -c1 : -r, dy1 = r > G - 1 - c1 ? G - 1 - c1 : r;
+    int dx = dx0, dy = dy0, sub = 0, p = 0, e = 0;
+    bool more = true;
 #pragma unroll 1
     while (true) {
       // ---- lanes whose run is used up step to their next non-empty run of this ring ----
-      while (p >= e && tc < T && !done) {
-        const int col = tc >> 1, sub = tc & 1;
-        ++tc;
-        const int ix = c0 - r + col / W, iy = c1 - r + col % W;
-        if (ix < 0 || ix >= G || iy < 0 || iy >= G) continue;
-        const bool shell = (ix == c0 - r) || (ix == c0 + r) || (iy == c1 - r) || (iy == c1 + r);
+      while (p >= e && more && !done) {
+        const bool rim = (dx == -r) || (dx == r) || (dy == -r) || (dy == r);
+        const int base = ((c0 + dx) * G + (c1 + dy)) * G;
         int zlo, zhi;
-        if (shell) {
-          if (sub) continue;
+        if (rim) {
           zlo = c2 - r < 0 ? 0 : c2 - r;
           zhi = c2 + r > G - 1 ? G - 1 : c2 + r;
         } else {
           zlo = zhi = sub ? c2 + r : c2 - r;
-          if (zlo < 0 || zlo >= G) continue;
         }
-        const int base = (ix * G + iy) * G;
+        // next column / end cell
+        if (!rim && sub == 0) {
+          sub = 1;
+        } else {
+          sub = 0;
+          if (++dy > dy1) {
+            dy = dy0;
+            if (++dx > dx1) more = false;
+          }
+        }
+        if (zlo < 0 || zhi >= G) continue;
         p = cst(base + zlo);
         e = cst(base + zhi + 1);
       }
@@ -411,7 +420,9 @@ int launch_knn_grid(const float* x, const float* sq, int B, int N, int C, int64_
   w += (size_t)B * sizeof(GridInfo);
   int32_t* cell_start = reinterpret_cast<int32_t*>(w);
   // ~0.8 k points per cell: the ball of one cell size around a query then holds ~3.4 k points, ring 1 decides
-  int G = (int)floorf(cbrtf((float)N / (0.8f * (float)k)));
+  static float dens = -1.f;
+  if (dens < 0.f) { const char* e = getenv("DGCNN_KNN_GRID_DENS"); dens = e ? (float)atof(e) : 0.2f; }     // experiment: points per cell / k
+  int G = (int)floorf(cbrtf((float)N / (dens * (float)k)));
   G = G < 1 ? 1 : (G > GMAX ? GMAX : G);
   hipLaunchKernelGGL(knn_grid_build_kernel, dim3((unsigned)B), dim3(1024), 0, st, x, ldx, sq, N, C, G, ps, s4, order, cell_start, info);
   dim3 grid((unsigned)cdiv(N, 64 * QW), (unsigned)B);
