@@ -830,11 +830,12 @@ extern "C" int dgcnn_knn_f32(const float* x, int B, int N, int C, int64_t ldx, i
   hipStream_t st = (hipStream_t)stream;
   float* sq_ws = reinterpret_cast<float*>(ws);
   const int64_t rows = (int64_t)B * N;
+  // raw coordinates (C <= 4) when the caller provided the scratch: exact search over a uniform cell grid (knn_grid.hip)
+  const bool grid_ws = dg::knn_grid_applicable(C, k) && !knn_force_valu() &&
+                       ws_bytes >= knn_sq_bytes(B, N) + dg::knn_grid_workspace_bytes(B, N);
   hipLaunchKernelGGL(sqnorm_kernel, dim3((unsigned)dg::cdiv(rows, SQ_ROWS)), dim3(256), sizeof(float) * SQ_ROWS * (C + 1), st, x,
                      ldx, rows, C, sq_ws);
-  // raw coordinates (C <= 4): exact search over a uniform cell grid (knn_grid.hip) when the caller provided its scratch
-  if (dg::knn_grid_applicable(C, k) && N >= dg::knn_grid_min_n() && !knn_force_valu() &&
-      ws_bytes >= knn_sq_bytes(B, N) + dg::knn_grid_workspace_bytes(B, N))
+  if (grid_ws && N >= dg::knn_grid_min_n())
     return dg::launch_knn_grid(x, sq_ws, B, N, C, ldx, k, idx, reinterpret_cast<char*>(ws) + knn_sq_bytes(B, N), st);
   const int vec_ok = (ldx % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
   if (C <= 4) return dispatch_k<4>(x, sq_ws, B, N, C, ldx, k, vec_ok, idx, st);

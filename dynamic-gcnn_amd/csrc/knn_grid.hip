@@ -419,10 +419,11 @@ int launch_knn_grid(const float* x, const float* sq, int B, int N, int C, int64_
   GridInfo* info = reinterpret_cast<GridInfo*>(w);
   w += (size_t)B * sizeof(GridInfo);
   int32_t* cell_start = reinterpret_cast<int32_t*>(w);
-  // ~0.8 k points per cell: the ball of one cell size around a query then holds ~3.4 k points, ring 1 decides
-  static float dens = -1.f;
-  if (dens < 0.f) { const char* e = getenv("DGCNN_KNN_GRID_DENS"); dens = e ? (float)atof(e) : 0.2f; }     // experiment: points per cell / k
-  int G = (int)floorf(cbrtf((float)N / (dens * (float)k)));
+  // ~0.1 k points per cell (cell edge ~ 0.75 of the radius of a ball holding k points): rings are thin shells, a lane stops within
+  // a fraction of a cell of its k-th distance.  Measured against 0.8 k / 0.2 k points per cell (profiles/r04/knn_grid.txt):
+  // (8, 16384, 3, 40) 648 / 544 / 386 us, (24, 2048, 3, 20) 191 / 160 / 151 us; finer than that the empty runs cost more than the
+  // pairs they save.  G <= GMAX = 16: clouds of 65536 points stay at 16 points per cell.
+  int G = (int)floorf(cbrtf((float)N / (0.1f * (float)k)));
   G = G < 1 ? 1 : (G > GMAX ? GMAX : G);
   hipLaunchKernelGGL(knn_grid_build_kernel, dim3((unsigned)B), dim3(1024), 0, st, x, ldx, sq, N, C, G, ps, s4, order, cell_start, info);
   dim3 grid((unsigned)cdiv(N, 64 * QW), (unsigned)B);
@@ -457,7 +458,8 @@ int launch_knn_grid(const float* x, const float* sq, int B, int N, int C, int64_
 
 }  // namespace dg
 
-extern "C" int dgcnn_knn_grid(int mode) {      // 0 = never, 1 = where it pays (N >= knn_grid_min_n), 2 = whenever applicable (tests)
+// 0 = never, 1 = where it pays (N >= knn_grid_min_n), 2 = whenever applicable (tests)
+extern "C" int dgcnn_knn_grid(int mode) {
   const int prev = knn_grid_on() ? (g_knn_grid_all ? 2 : 1) : 0;
   g_knn_grid = mode ? 1 : 0;
   g_knn_grid_all = mode == 2;

@@ -18,12 +18,12 @@ def dg():
     return dgcnn
 
 
-def both(dg, pts, k):
+def both(dg, pts, k, mode=2):
     """(grid result, all-pairs result) of ops.k_nn on the same cloud."""
     from dgcnn import _hip as H
     lib = H.load()
     x = dev(pts)
-    prev = lib.dgcnn_knn_grid(2)
+    prev = lib.dgcnn_knn_grid(mode)
     try:
         a = host(dg.ops.k_nn(x, k))
         lib.dgcnn_knn_grid(0)
@@ -75,6 +75,21 @@ def test_grid_search_equals_all_pairs_and_the_oracle(dg):
         assert len(bad) == 0, "%s: grid differs from the oracle in %d rows, first %s: %s vs %s" % (
             what, len(bad), bad[0], a[tuple(bad[0])], ref[tuple(bad[0])])
         np.testing.assert_array_equal(b, ref, err_msg=what + " (all-pairs kernel)")
+
+
+def test_grid_search_at_the_headline_shape(dg):
+    """(24, 2048, 3, 20) with the grid forced on against the C oracle, every row of four clouds; skewed clouds too."""
+    from dgcnn import _hip as H
+    prev = H.load().dgcnn_knn_grid(2)
+    rng = np.random.default_rng(11)
+    pts = rng.random((4, 2048, 3), dtype=np.float32)
+    pts[1] = np.cumsum(rng.normal(0, 0.02, (2048, 3)), axis=0).astype(np.float32)
+    pts[2, :, 0] *= 100.0                                       # one long axis
+    pts[3] = rng.integers(0, 16, (2048, 3)).astype(np.float32)
+    try:
+        np.testing.assert_array_equal(host(dg.ops.k_nn(dev(pts), 20)), O.k_nn(pts, 20))
+    finally:
+        H.load().dgcnn_knn_grid(prev)
 
 
 @pytest.mark.parametrize("N,k,C", [(16384, 40, 3), (65536, 20, 3), (65536, 20, 4)])
