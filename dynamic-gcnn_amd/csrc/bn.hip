@@ -1021,6 +1021,10 @@ extern "C" int dgcnn_bn1_bwd_dropout_f32(const float* T, int64_t R, int F, const
 
 namespace dg {
 void launch_reduce_partials(const float* part, int splits, int M, int N, float* C, int64_t ldc, float beta, hipStream_t st);
+// slots of a backward reduction -> slot 0 (+ d(beta)); edge_mlp_bf16.hip
+void launch_bn_bwd_finalize(double* red, int F, float* dbeta, float dbeta_beta, hipStream_t st) {
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)cdiv(F, FIN_COLS)), dim3(FIN_COLS * FIN_LANES), 0, st, red, F, stat_slots(), dbeta, dbeta_beta);
+}
 }
 
 extern "C" int dgcnn_edge_bn_bwd_apply_wgrad_f32(const float* V, int64_t ldv, const float* U, int64_t ldu,

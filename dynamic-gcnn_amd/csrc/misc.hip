@@ -186,6 +186,38 @@ __global__ __launch_bounds__(256) void csr_gather_sum_kernel(const float* __rest
   }
 }
 
+// the same sum over dY stored as bf16 (edge_mlp_bf16.hip's backward): same values, same order of additions, half the bytes
+__global__ __launch_bounds__(256) void csr_gather_sum_bf16_kernel(const uint16_t* __restrict__ dY, const int32_t* __restrict__ off,
+                                                                  const int32_t* __restrict__ rev, int64_t R, int F,
+                                                                  float* __restrict__ S, int64_t lds) {
+  const int FV = F / 4;
+  auto ld = [&](int64_t row, int f) {
+    typedef unsigned u2v __attribute__((ext_vector_type(2)));
+    const u2v v = __builtin_nontemporal_load(reinterpret_cast<const u2v*>(dY + row * F + f));
+    return make_float4(__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u), __uint_as_float(v.y << 16),
+                       __uint_as_float(v.y & 0xffff0000u));
+  };
+  GRID_STRIDE(it, R * FV) {
+    const int64_t j = it / FV;
+    const int f = (int)(it % FV) * 4;
+    const int p0 = off[j], p1 = off[j + 1];
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    int p = p0;
+    for (; p + 3 < p1; p += 4) {
+      const float4 v0 = ld(rev[p], f), v1 = ld(rev[p + 1], f), v2 = ld(rev[p + 2], f), v3 = ld(rev[p + 3], f);
+      a.x += (v0.x + v1.x) + (v2.x + v3.x);
+      a.y += (v0.y + v1.y) + (v2.y + v3.y);
+      a.z += (v0.z + v1.z) + (v2.z + v3.z);
+      a.w += (v0.w + v1.w) + (v2.w + v3.w);
+    }
+    for (; p < p1; ++p) {
+      const float4 v = ld(rev[p], f);
+      a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    }
+    *reinterpret_cast<float4*>(S + j * lds + f) = a;
+  }
+}
+
 // ---- conv0 of an EdgeConv layer without an edge-level GEMM.  The 1x1 convolution is linear, so for the
 // edge (i, j):  [x_i, x_j - x_i] W0 = x_i (Wa - Wb) + x_j Wb = U[i] + V[j]  with  [U | V] = X [Wa-Wb | Wb]
 // ONE point-level GEMM (k times fewer MACs than the edge-level product of dgcnn/ops.py:47-52).  What is
@@ -521,6 +553,17 @@ extern "C" int dgcnn_edge_gather_sum_f32(const float* dY, const int32_t* off, co
   unsigned g = grid1d(R * (F / 4));
   hipLaunchKernelGGL(csr_gather_sum_kernel, dim3(g), dim3(256), 0, ST, dY, off, rev, R, F, S, lds);
   return dg::check_launch("dgcnn_edge_gather_sum_f32");
+}
+
+extern "C" int dgcnn_edge_gather_sum_bf16(const void* dY, const int32_t* off, const int32_t* rev, int64_t R, int F, float* S,
+                                          int64_t lds, void* stream) {
+  DG_REQUIRE(dY && off && rev && S && R > 0 && F > 0, DGCNN_EINVAL, "dgcnn_edge_gather_sum_bf16: bad args");
+  DG_REQUIRE(F % 4 == 0 && (reinterpret_cast<uintptr_t>(dY) & 7) == 0, DGCNN_EUNSUP, "dgcnn_edge_gather_sum_bf16: F %% 4 == 0, dY 8-byte aligned");
+  DG_REQUIRE(lds >= F && lds % 4 == 0 && (reinterpret_cast<uintptr_t>(S) & 15) == 0, DGCNN_EINVAL,
+             "dgcnn_edge_gather_sum_bf16: S must be 16-byte aligned with lds %% 4 == 0");
+  hipLaunchKernelGGL(csr_gather_sum_bf16_kernel, dim3(grid1d(R * (F / 4))), dim3(256), 0, ST, reinterpret_cast<const uint16_t*>(dY), off,
+                     rev, R, F, S, lds);
+  return dg::check_launch("dgcnn_edge_gather_sum_bf16");
 }
 
 extern "C" int dgcnn_edge_gather_add_f32(const float* V, int64_t ldv, const float* U, int64_t ldu, const int32_t* idx,

@@ -40,6 +40,7 @@ WGRAD_SIDE_STREAM = os.environ.get("DGCNN_SIDE_STREAM", "1") != "0"   # weight-g
 # Fusions with a separate-pass twin that the tests compare them against (module constants, not run-time switches):
 EDGE_BWD_FUSED_L0 = True   # input layer (C <= 4, no input gradient): conv0's whole backward in one pass
 FUSE_DROPOUT = True        # tf.nn.dropout inside the last FC layer's BatchNorm passes
+BF16_FUSED_BWD = True      # bf16 edge-MLP: the layer's backward in one pass over the edges (tests switch it off to compare)
 EDGE_BWD_REDUCE_POINTS = True   # BN backward sums of conv0 from per-point data (False: a pass over the edges)
 SIDE_STREAM_MIN_ROWS = 16384   # below this many points the side stream is not used
 # conv0 of every EdgeConv layer with bf16 OPERANDS (BASELINE.json configs[2] "bf16 edge-MLP MFMA"): E = [x_i, x_j - x_i] is formed
@@ -780,7 +781,7 @@ def edge_conv_block(x, B, N, k, num_filters, relu1=True, outs=None, net2=None):
     Y = None if virtual else torch.empty((R * k, F), dtype=torch.float32, device=x.device)   # (the fused bf16 path frees it below)
     wd = wcat = UV = None
     Ee = W0p = None
-    fused_bf16 = False
+    fused_bf16 = fused_bwd = False
     Cp = (C + 3) // 4 * 4
 
     def bf16_operands():
@@ -801,6 +802,8 @@ def edge_conv_block(x, B, N, k, num_filters, relu1=True, outs=None, net2=None):
         fused_bf16 = (bool(H.load().dgcnn_edge_mlp_bf16_supported(C, k, F)) and W0.is_contiguous() and
                       (C <= 4 or (H.ld2(x) % 4 == 0 and x.data_ptr() % 16 == 0)))
         bsrc = (x.data_ptr(), H.ld2(x), idx.data_ptr(), W0.data_ptr(), B, N, C, k, F)
+        # the backward in one pass over the edges (8 <= k < 256): the forward then packs (#ties, #positives) as the fp32 edge kernels do
+        fused_bwd = fused_bf16 and c.recording and BF16_FUSED_BWD and bool(H.load().dgcnn_edge_mlp_bf16_bwd_supported(C, k, F))
         if fused_bf16:
             # csrc/edge_mlp_bf16.hip: E = [x_i, x_j - x_i] gathered, rounded and multiplied tile by tile on the bf16 MFMA pipe;
             # neither E nor y is written: this pass takes the BatchNorm sums, the next one recomputes y for BN + ReLU + max / mean
@@ -860,7 +863,7 @@ def edge_conv_block(x, B, N, k, num_filters, relu1=True, outs=None, net2=None):
     cnt = torch.empty((R, F), dtype=torch.float32, device=x.device) if c.recording else None   # ties of the max
     if fused_bf16:
         H.call("dgcnn_edge_mlp_bf16_bn_kreduce", *bsrc, mean.data_ptr(), rstd.data_ptr(), beta0.data_ptr(),
-               mx.data_ptr(), H.ld2(mx), mn.data_ptr(), H.ld2(mn), H._p(cnt),
+               mx.data_ptr(), H.ld2(mx), mn.data_ptr(), H.ld2(mn), H._p(cnt), 1 if fused_bwd else 0,
                tag="edge_mlp_bf16_kernel<bn_kreduce>", work=2.0 * R * k * 2 * C * F, nbytes=4.0 * (R * k * C + R * C))   # ops.py:53-58
     elif virtual:
         esrc = (UV[:, F:].data_ptr(), 2 * F, UV.data_ptr(), 2 * F, idx.data_ptr(), B, N, k, F)
@@ -895,6 +898,45 @@ def edge_conv_block(x, B, N, k, num_filters, relu1=True, outs=None, net2=None):
                 return
             dmx, dmn = dmm[:, :F], dmm[:, F:]
             red = c.stats(F)
+            if fused_bf16 and fused_bwd:
+                # csrc/edge_mlp_bf16.hip: sums of the BatchNorm backward from the forward's per-point outputs, then ONE pass over the
+                # edges that recomputes y, forms dY (rounded to bf16), takes dW0 = E^T dY on the matrix pipe and leaves dY as bf16
+                # for the transposed-adjacency sum -- E, y and an fp32 dY are never written
+                H.call("dgcnn_edge_bn_bwd_reduce_points_f32", mx.data_ptr(), H.ld2(mx), mn.data_ptr(), H.ld2(mn),
+                       cnt.data_ptr(), dmx.data_ptr(), H.ld2(dmx), dmn.data_ptr(), H.ld2(dmn), beta0.data_ptr(), R, k, F,
+                       red.data_ptr(), tag="edge_bwd_reduce_points_kernel", work=4.0 * 5 * R * F)
+                dx = c.grad(x)
+                dYb = dysum = None
+                if dx is not None:
+                    dYb = torch.empty((R * k, F), dtype=torch.bfloat16, device=x.device)
+                    dysum = torch.empty((R, F), dtype=torch.float32, device=x.device)
+                ws = c.workspace()
+                H.call("dgcnn_edge_mlp_bf16_bwd", *bsrc, mean.data_ptr(), rstd.data_ptr(), beta0.data_ptr(), mx.data_ptr(), H.ld2(mx),
+                       cnt.data_ptr(), dmx.data_ptr(), H.ld2(dmx), dmn.data_ptr(), H.ld2(dmn), red.data_ptr(), H._p(dYb), H._p(dysum),
+                       F, c.var_grads[w0name].data_ptr(), c.var_grads[b0name].data_ptr(), 1.0, ws.data_ptr(), ws.numel(),
+                       tag="edge_mlp_bf16_kernel<bwd>", work=2.0 * R * k * 2 * C * F * 2, nbytes=4.0 * (R * k * C + R * C))
+                if dx is not None:
+                    # dx_i += (sum_m dY) (W0'[:C] - W0'[C:])^T,  dx_j += (sum of the incoming dY rows) W0'[C:]^T,  W0' = bf16(W0)
+                    W0r = torch.empty_like(W0)
+                    H.call("dgcnn_round_bf16_f32", W0.data_ptr(), W0r.data_ptr(), W0.numel())
+                    wdb = torch.empty((C, F), dtype=torch.float32, device=x.device)
+                    H.call("dgcnn_copy2d_f32", W0r[:C].data_ptr(), F, wdb.data_ptr(), F, C, F, 0)
+                    H.call("dgcnn_axpby_f32", W0r[C:].data_ptr(), -1.0, wdb.data_ptr(), 1.0, C * F)
+                    gemm(dysum, wdb, dx, transB=True, beta=1.0)
+                    if csr is not None:
+                        off, rev = csr
+                    else:
+                        cws = torch.empty(2 * R, dtype=torch.int32, device=x.device)
+                        off = torch.empty(R + 1, dtype=torch.int32, device=x.device)
+                        rev = torch.empty(R * k, dtype=torch.int32, device=x.device)
+                        H.call("dgcnn_edge_csr_build", idx.data_ptr(), B, N, k, cws.data_ptr(), off.data_ptr(), rev.data_ptr())
+                        if DETERMINISTIC:
+                            H.call("dgcnn_edge_csr_sort", off.data_ptr(), rev.data_ptr(), R)
+                    S = torch.empty((R, F), dtype=torch.float32, device=x.device)
+                    H.call("dgcnn_edge_gather_sum_bf16", dYb.data_ptr(), off.data_ptr(), rev.data_ptr(), R, F, S.data_ptr(), F,
+                           tag="csr_gather_sum_kernel<bf16>", work=2.0 * R * k * F + 4.0 * R * F)
+                    gemm(S, W0r[C:], dx, transB=True, beta=1.0)
+                return
             if fused_bf16:
                 # the forward wrote neither E nor y: both are formed again for the backward (y by the SAME instruction sequence,
                 # so the recomputed z compares equal to the maxima the forward took), used by the passes below and dropped

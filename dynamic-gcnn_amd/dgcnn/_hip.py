@@ -103,7 +103,12 @@ PROTOTYPES = {
     "dgcnn_edge_mlp_bf16": [c_vp, c_i64, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp],
     "dgcnn_edge_mlp_bf16_stats": [c_vp, c_i64, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp],
     "dgcnn_edge_mlp_bf16_bn_kreduce": [c_vp, c_i64, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_i64,
-                                       c_vp, c_i64, c_vp, c_vp],
+                                       c_vp, c_i64, c_vp, c_int, c_vp],
+    "dgcnn_edge_mlp_bf16_bwd_supported": [c_int, c_int, c_int],
+    "dgcnn_edge_mlp_bf16_bwd_workspace_bytes": [c_int, c_int, c_int, c_int, c_int],
+    "dgcnn_edge_mlp_bf16_bwd": [c_vp, c_i64, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp,
+                                c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_f32, c_vp, ctypes.c_size_t, c_vp],
+    "dgcnn_edge_gather_sum_bf16": [c_vp, c_vp, c_vp, c_i64, c_int, c_vp, c_i64, c_vp],
     "dgcnn_comm_unique_id": [c_vp],
     "dgcnn_comm_init": [c_int, c_int, c_vp, c_vp],
     "dgcnn_comm_destroy": [c_vp],
@@ -112,7 +117,7 @@ PROTOTYPES = {
     "dgcnn_broadcast_f32": [c_vp, c_i64, c_int, c_vp, c_vp],
 }
 
-INT64_RESULTS = ("dgcnn_knn_workspace_bytes",)      # byte counts; every other entry point returns an int status
+INT64_RESULTS = ("dgcnn_knn_workspace_bytes", "dgcnn_edge_mlp_bf16_bwd_workspace_bytes")      # byte counts; every other entry point returns an int status
 
 _lib = None
 

@@ -76,10 +76,27 @@ int dgcnn_knn_f32(const float* x, int B, int N, int C, int64_t ldx, int k, int32
  * y = E W0 on v_mfma_f32_32x32x16_bf16 with fp32 accumulation; neither E nor y is written by the two forward passes:
  *   dgcnn_edge_mlp_bf16_stats      stats[slot][0][f] += sum_e y[e][f], stats[slot][1][f] += sum_e y[e][f]^2  (double[slots][2][F], zeroed)
  *   dgcnn_edge_mlp_bf16_bn_kreduce z = relu((y - mean) rstd + beta) recomputed; max / mean over the k edges of each point and the
- *                                  number of edges attaining the max (cnt, (B N, F) dense; may be null)
- *   dgcnn_edge_mlp_bf16            y written out, (B N k, F) dense -- bit-identical to what the two passes saw (backward input)
+ *                                  number of edges attaining the max (cnt, (B N, F) dense; may be null); pack_cnt = 1: cnt =
+ *                                  #ties + 256 #(z > 0), the packing of the fp32 edge kernels (dgcnn_edge_bn_act_kreduce_f32), which
+ *                                  dgcnn_edge_bn_bwd_reduce_points_f32 and dgcnn_edge_mlp_bf16_bwd read (k < 256)
+ *   dgcnn_edge_mlp_bf16            y written out, (B N k, F) dense -- bit-identical to what the two passes saw
+ *   dgcnn_edge_mlp_bf16_bwd        the layer's backward in ONE pass over the edges, y recomputed: red = the slots written by
+ *                                  dgcnn_edge_bn_bwd_reduce_points_f32 (reduced here; dbeta = dbeta_beta * dbeta + sum dz);
+ *                                  dY = rstd (dz - c1 - xhat c2) rounded to bf16 -> dYb (B N k, F) bf16 and dysum = sum_m dY (B N, F)
+ *                                  (either may be null); dW0 (2C, F) += E^T dY on the matrix pipe.  Neither E nor y nor an fp32 dY
+ *                                  is written.  ws >= dgcnn_edge_mlp_bf16_bwd_workspace_bytes.  8 <= k < 256.
+ *   dgcnn_edge_gather_sum_bf16     dgcnn_edge_gather_sum_f32 over that bf16 dY (same additions in the same order)
  * Shapes: C <= 4 or C == 64 (x float4-loadable), F in {32, 64, 128}, k <= 128 (dgcnn_edge_mlp_bf16_supported; DGCNN_EUNSUP else). */
 int dgcnn_edge_mlp_bf16_supported(int C, int k, int F);
+int dgcnn_edge_mlp_bf16_bwd_supported(int C, int k, int F);
+int64_t dgcnn_edge_mlp_bf16_bwd_workspace_bytes(int B, int N, int C, int k, int F);
+int dgcnn_edge_mlp_bf16_bwd(const float* x, int64_t ldx, const int32_t* idx, const float* W0, int B, int N, int C, int k, int F,
+                            const float* mean, const float* rstd, const float* beta, const float* mx, int64_t ldmx,
+                            const float* cnt, const float* dmx, int64_t lddmx, const float* dmn, int64_t lddmn, double* red,
+                            void* dYb, float* dysum, int64_t lddysum, float* dW0, float* dbeta, float dbeta_beta, void* ws,
+                            size_t ws_bytes, void* stream);
+int dgcnn_edge_gather_sum_bf16(const void* dY, const int32_t* off, const int32_t* rev, int64_t R, int F, float* S, int64_t lds,
+                               void* stream);
 /* dst[i] = src[i] rounded to the nearest bf16 value (ties to even), kept as fp32 (weights of the mode's point-level gradient products) */
 int dgcnn_round_bf16_f32(const float* src, float* dst, int64_t n, void* stream);
 int dgcnn_edge_mlp_bf16(const float* x, int64_t ldx, const int32_t* idx, const float* W0, int B, int N, int C, int k, int F,
@@ -88,7 +105,7 @@ int dgcnn_edge_mlp_bf16_stats(const float* x, int64_t ldx, const int32_t* idx, c
                               double* stats, void* stream);
 int dgcnn_edge_mlp_bf16_bn_kreduce(const float* x, int64_t ldx, const int32_t* idx, const float* W0, int B, int N, int C, int k,
                                    int F, const float* mean, const float* rstd, const float* beta, float* mx, int64_t ldmx,
-                                   float* mn, int64_t ldmn, float* cnt, void* stream);
+                                   float* mn, int64_t ldmn, float* cnt, int pack_cnt, void* stream);
 
 /* ---- K2: dgcnn/ops.py:21-40 edges (gather + tile + sub + concat) ------------------------
  * E[b][i][m][0..C) = x_i ; E[b][i][m][C..2C) = x_{idx[b][i][m]} - x_i.                    */

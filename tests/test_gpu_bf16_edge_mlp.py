@@ -26,7 +26,8 @@ def dg():
     dgcnn.reset()
 
 
-@pytest.mark.parametrize("B,N,C,k,F", [(2, 64, 3, 5, 8), (2, 128, 64, 20, 64), (1, 96, 4, 7, 128), (2, 64, 64, 10, 32)])
+@pytest.mark.parametrize("B,N,C,k,F", [(2, 64, 3, 5, 8), (2, 128, 64, 20, 64), (1, 96, 4, 7, 128), (2, 64, 64, 10, 32),
+                                       (1, 96, 4, 10, 128), (2, 64, 3, 8, 64), (1, 50, 64, 40, 128)])
 def test_edge_conv_bf16_forward_backward(dg, B, N, C, k, F):
     """One edge_conv block in bf16 mode against the oracle in bf16 mode (same graph): [max, mean, net] within 1e-4 and the
     gradients w.r.t. X (C % 4 == 0), W0, beta0, W1, beta1 within 2e-3 -- the bars of the fp32 block test
@@ -242,7 +243,7 @@ def test_fused_passes_agree_with_each_other_and_with_the_rounded_product(dg, B, 
         cnt = torch.zeros((R, F), device="cuda")
         if fused:
             H.call("dgcnn_edge_mlp_bf16_bn_kreduce", *src, mean.data_ptr(), rstd.data_ptr(), beta.data_ptr(),
-                   mx.data_ptr(), H.ld2(mx), mn.data_ptr(), H.ld2(mn), cnt.data_ptr())
+                   mx.data_ptr(), H.ld2(mx), mn.data_ptr(), H.ld2(mn), cnt.data_ptr(), 0)
         else:
             H.call("dgcnn_bn_act_kreduce_f32", Y.data_ptr(), R, k, F, mean.data_ptr(), rstd.data_ptr(), beta.data_ptr(), 1,
                    mx.data_ptr(), H.ld2(mx), mn.data_ptr(), H.ld2(mn), 0, 0, cnt.data_ptr())
@@ -250,3 +251,129 @@ def test_fused_passes_agree_with_each_other_and_with_the_rounded_product(dg, B, 
     np.testing.assert_array_equal(outs[0][0][:, :F], outs[1][0][:, :F])            # max
     np.testing.assert_array_equal(outs[0][1], outs[1][1])                          # ties
     np.testing.assert_allclose(outs[0][0][:, F:2 * F], outs[1][0][:, F:2 * F], rtol=0, atol=2e-6)   # mean: the order of the k additions differs
+
+
+@pytest.mark.parametrize("B,N,C,k,F", [(2, 100, 64, 20, 64), (1, 333, 64, 40, 128), (3, 77, 3, 8, 32), (2, 64, 4, 10, 128), (1, 130, 64, 128, 32),
+                                       (2, 50, 64, 9, 64)])
+def test_fused_backward_pass_against_the_dense_kernels(dg, B, N, C, k, F):
+    """dgcnn_edge_mlp_bf16_bwd (one pass over the edges, y recomputed) against the dense route it replaces -- y written out,
+    dgcnn_bn_bwd_apply_f32 with the bf16 rounding flag, E gathered, a separate weight-gradient product: dY bit for bit (as bf16),
+    its per-point sums and d(beta) bit for bit, dW0 = round(E)^T dY against float64 (only the fp32 accumulation differs), and the
+    transposed-adjacency sum over the bf16 dY equal to the fp32 kernel's over the same values."""
+    from dgcnn import _hip as H
+    lib = H.load()
+    rng = np.random.default_rng(B * 100 + k)
+    R = B * N
+    pts = rng.normal(size=(B, N, C)).astype(np.float32)
+    W0 = rng.normal(0, 0.3, (2 * C, F)).astype(np.float32)
+    x, W = dev(pts.reshape(R, C)), dev(W0)
+    idx_h = rng.integers(0, N, (B, N, k)).astype(np.int32)
+    idx = dev(idx_h)
+    assert lib.dgcnn_edge_mlp_bf16_bwd_supported(C, k, F) == 1
+    src = (x.data_ptr(), C, idx.data_ptr(), W.data_ptr(), B, N, C, k, F)
+    Y = torch.empty((R * k, F), device="cuda")
+    H.call("dgcnn_edge_mlp_bf16", *src, Y.data_ptr())
+    mean, rstd, beta = dev(rng.normal(0, 0.3, F).astype(np.float32)), dev((0.5 + rng.random(F)).astype(np.float32)), dev(rng.normal(0, 0.3, F).astype(np.float32))
+    mx, mn, cntp = (torch.empty((R, F), device="cuda") for _ in range(3))
+    H.call("dgcnn_edge_mlp_bf16_bn_kreduce", *src, mean.data_ptr(), rstd.data_ptr(), beta.data_ptr(), mx.data_ptr(), F, mn.data_ptr(), F,
+           cntp.data_ptr(), 1)
+    ties = cntp - 256.0 * torch.floor(cntp / 256.0)
+    npos = host(torch.floor(cntp / 256.0))
+    z = np.maximum((host(Y).reshape(R, k, F) - host(mean)) * host(rstd) + host(beta), 0)
+    np.testing.assert_array_equal(npos, (z > 0).sum(1))                                   # the packed half the forward adds
+    dmx, dmn = dev(rng.normal(size=(R, F)).astype(np.float32)), dev(rng.normal(size=(R, F)).astype(np.float32))
+    red = torch.zeros((H.STAT_SLOTS, 2, F), dtype=torch.float64, device="cuda")
+    H.call("dgcnn_edge_bn_bwd_reduce_points_f32", mx.data_ptr(), F, mn.data_ptr(), F, cntp.data_ptr(), dmx.data_ptr(), F, dmn.data_ptr(), F,
+           beta.data_ptr(), R, k, F, red.data_ptr())
+    redA, redB = red.clone(), red.clone()
+    # dense route
+    dYd, dysA, dbA = torch.empty_like(Y), torch.empty((R, F), device="cuda"), torch.zeros(F, device="cuda")
+    H.call("dgcnn_bn_bwd_apply_f32", Y.data_ptr(), R, k, F, mean.data_ptr(), rstd.data_ptr(), beta.data_ptr(), 3, dmx.data_ptr(), F,
+           dmn.data_ptr(), F, mx.data_ptr(), F, ties.data_ptr(), redA.data_ptr(), dYd.data_ptr(), dysA.data_ptr(), F, dbA.data_ptr(), 0.0)
+    # fused pass
+    need = int(lib.dgcnn_edge_mlp_bf16_bwd_workspace_bytes(B, N, C, k, F))
+    ws = torch.empty(need, dtype=torch.uint8, device="cuda")
+    dYb = torch.full((R * k, F), float("nan"), dtype=torch.bfloat16, device="cuda")
+    dysB, dbB = torch.full((R, F), float("nan"), device="cuda"), torch.zeros(F, device="cuda")
+    dW0 = torch.ones((2 * C, F), device="cuda")                                           # accumulated into
+    H.call("dgcnn_edge_mlp_bf16_bwd", *src, mean.data_ptr(), rstd.data_ptr(), beta.data_ptr(), mx.data_ptr(), F, cntp.data_ptr(),
+           dmx.data_ptr(), F, dmn.data_ptr(), F, redB.data_ptr(), dYb.data_ptr(), dysB.data_ptr(), F, dW0.data_ptr(), dbB.data_ptr(), 0.0,
+           ws.data_ptr(), need)
+    dY_h = host(dYd)
+    np.testing.assert_array_equal(host(dYb.float()), dY_h)
+    np.testing.assert_array_equal(host(dysB), host(dysA))
+    np.testing.assert_array_equal(host(dbB), host(dbA))
+    Eb = O.bf16_round(O.edges(pts, k, idx_h).reshape(R * k, 2 * C)).astype(np.float64)
+    ref = Eb.T @ dY_h.astype(np.float64)
+    scale = np.abs(Eb).T @ np.abs(dY_h.astype(np.float64))
+    got = host(dW0).astype(np.float64) - 1.0
+    assert (np.abs(got - ref) <= 3e-6 * scale + 1e-5).all(), float((np.abs(got - ref) / (scale + 1e-30)).max())
+    # without an input gradient nothing but dW0 / d(beta) is written
+    dW0n, dbN = torch.zeros((2 * C, F), device="cuda"), torch.zeros(F, device="cuda")
+    redC = red.clone()
+    H.call("dgcnn_edge_mlp_bf16_bwd", *src, mean.data_ptr(), rstd.data_ptr(), beta.data_ptr(), mx.data_ptr(), F, cntp.data_ptr(),
+           dmx.data_ptr(), F, dmn.data_ptr(), F, redC.data_ptr(), 0, 0, 0, dW0n.data_ptr(), dbN.data_ptr(), 0.0, ws.data_ptr(), need)
+    np.testing.assert_allclose(host(dW0n), host(dW0) - 1.0, rtol=0, atol=1e-5 * float(np.abs(ref).max() + 1))
+    # transposed-adjacency sum over the bf16 rows == over the same values stored as fp32
+    cws = torch.empty(2 * R, dtype=torch.int32, device="cuda")
+    off, rev = torch.empty(R + 1, dtype=torch.int32, device="cuda"), torch.empty(R * k, dtype=torch.int32, device="cuda")
+    H.call("dgcnn_edge_csr_build", idx.data_ptr(), B, N, k, cws.data_ptr(), off.data_ptr(), rev.data_ptr())
+    H.call("dgcnn_edge_csr_sort", off.data_ptr(), rev.data_ptr(), R)
+    S1, S2 = torch.empty((R, F), device="cuda"), torch.empty((R, F), device="cuda")
+    H.call("dgcnn_edge_gather_sum_f32", dYd.data_ptr(), off.data_ptr(), rev.data_ptr(), R, F, S1.data_ptr(), F)
+    H.call("dgcnn_edge_gather_sum_bf16", dYb.data_ptr(), off.data_ptr(), rev.data_ptr(), R, F, S2.data_ptr(), F)
+    np.testing.assert_array_equal(host(S1), host(S2))
+    with pytest.raises(H.HipError):
+        H.call("dgcnn_edge_mlp_bf16_bwd", *src[:7], 4, F, mean.data_ptr(), rstd.data_ptr(), beta.data_ptr(), mx.data_ptr(), F, cntp.data_ptr(),
+               dmx.data_ptr(), F, dmn.data_ptr(), F, redC.data_ptr(), 0, 0, 0, dW0n.data_ptr(), dbN.data_ptr(), 0.0, ws.data_ptr(), need)
+
+
+def test_fused_and_unfused_backward_of_a_block_agree(dg):
+    """The same block, gradients with the one-pass backward and with the dense route (E.BF16_FUSED_BWD off): equal up to the one
+    place where they differ by construction -- the two column sums of the BatchNorm backward come from the per-point outputs in the
+    fused route (xhat = z - beta where z > 0) and from the edges in the dense one -- i.e. a few 1e-7 of c1 / c2, which can move a
+    dY across a bf16 rounding boundary now and then (2^-9 of that element)."""
+    from dgcnn import _engine as E
+    B, N, C, k, F = 2, 128, 64, 20, 64
+    rng = np.random.default_rng(5)
+    pts = rng.random((B, N, C), dtype=np.float32)
+    P = {"conv0/weights": rng.normal(0, 0.5, (2 * C, F)).astype(np.float32),
+         "conv0/BatchNorm/beta": rng.normal(0, 0.3, F).astype(np.float32),
+         "conv1/weights": rng.normal(0, 0.3, (2 * F, 64)).astype(np.float32),
+         "conv1/BatchNorm/beta": rng.normal(0, 0.3, 64).astype(np.float32)}
+    d = None
+    res = []
+    try:
+        for fused in (True, False):
+            dg.reset()
+            E.EDGE_MLP_DTYPE = "bf16"
+            E.BF16_FUSED_BWD = fused
+            c = dg.ctx()
+            c.begin_step()
+            c.recording = True
+            x = c.new_buffer(B * N, C)
+            x.copy_(dev(pts.reshape(B * N, C)))
+            for n, v in P.items():
+                c.get_variable(n, v.shape)
+            set_vars(dg, P)
+            calls = []
+            orig = E.H.call
+            E.H.call = lambda name, *a, **kw: (calls.append(name), orig(name, *a, **kw))[1]
+            try:
+                outs = dg.ops.edge_conv(x.view(B, N, C), k, F, True)
+                if d is None:
+                    d = [rng.normal(size=tuple(o.shape)).astype(np.float32) for o in outs]
+                for t, g in zip(outs, d):
+                    v, _, _ = E.as2d(t)
+                    c.grad(v).copy_(dev(g.reshape(B * N, -1)))
+                c.backward()
+            finally:
+                E.H.call = orig
+            assert ("dgcnn_edge_mlp_bf16_bwd" in calls) == fused and ("dgcnn_edge_gather_f32" in calls) == (not fused)
+            res.append({n: host(c.var_grads[n]).copy() for n in P} | {"dx": host(c.grad(x)).copy()})
+    finally:
+        E.BF16_FUSED_BWD = True
+    for n in res[0]:
+        a, b = res[0][n], res[1][n]
+        assert np.abs(a - b).max() <= 2e-3 * max(1.0, np.abs(b).max()), (n, np.abs(a - b).max())
+        assert np.median(np.abs(a - b)) <= 1e-5 * max(1.0, np.abs(b).max()), n
