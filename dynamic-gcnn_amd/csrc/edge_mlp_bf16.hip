@@ -297,7 +297,7 @@ __global__ __launch_bounds__(512) void edge_mlp_bf16_bwd_kernel(EdgeBwdP bp) {
   // LDS: [E buffer 0][E buffer 1][dY tile][vectors 0: pm | pg1 | pg2][vectors 1]
   char* Ds = smem + 2 * RT * S;
   auto Eb = [&](int b) { return smem + b * (RT * S); };
-  auto vb = [&](int b) { return reinterpret_cast<float*>(Ds + RT * SD) + b * (3 * P * F); };
+  auto vb = [&](int b) { return reinterpret_cast<float4*>(Ds + RT * SD) + b * (P * F); };    // (max, dmax / ties, dmean / k, -) per (point, column)
 
   if (w >= 4) {
     // ------------------------------------------------------------------------------------------------ loaders
@@ -373,7 +373,7 @@ __global__ __launch_bounds__(512) void edge_mlp_bf16_bwd_kernel(EdgeBwdP bp) {
         }
       }
     };
-    auto commit_vec = [&](int64_t tile, float* v) {
+    auto commit_vec = [&](int64_t tile, float4* v) {
 #pragma unroll
       for (int i = 0; i < VMAX; ++i) {
         const int it = u + 256 * i;
@@ -382,9 +382,7 @@ __global__ __launch_bounds__(512) void edge_mlp_bf16_bwd_kernel(EdgeBwdP bp) {
           const bool ok = tile * P + pi < R;
           float cn = vc[i];
           cn -= (float)CNT_POS * floorf(cn * (1.0f / CNT_POS));               // #ties of the max
-          v[it] = ok ? vm[i] : 0.f;
-          v[P * F + it] = ok ? vdx[i] / cn : 0.f;
-          v[2 * P * F + it] = ok ? vdn[i] * invk : 0.f;
+          v[it] = ok ? make_float4(vm[i], vdx[i] / cn, vdn[i] * invk, 0.f) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
       }
     };
@@ -409,6 +407,30 @@ __global__ __launch_bounds__(512) void edge_mlp_bf16_bwd_kernel(EdgeBwdP bp) {
       if (more) {
         commit_row(Eb((it + 1) & 1));
         commit_vec(next, vb((it + 1) & 1));
+      }
+      // ---- dYsum of the tile's points (m ascending, as bn_bwd_apply_kernel adds them) ----
+      if (bp.dysum) {
+        for (int i2 = u; i2 < P * F; i2 += 256) {
+          const int pi = i2 / F, c = i2 - pi * F;
+          const int64_t gp = tile * P + pi;
+          if (gp < R) {
+            float a = 0.f;
+            for (int m = 0; m < k; ++m)
+              a += __uint_as_float((unsigned)*reinterpret_cast<const unsigned short*>(Ds + (pi * k + m) * SD + 2 * c) << 16);
+            bp.dysum[gp * bp.lddysum + c] = a;
+          }
+        }
+      }
+      // ---- dY rows of the tile: P k consecutive edges, 16 bytes per store ----
+      if (bp.dYb) {
+        const int64_t e0 = tile * P * k;
+        const int64_t left = Me - e0;
+        const int nr = left < (int64_t)P * k ? (int)left : P * k;
+        constexpr int CH = F / 8;
+        for (int ch = u; ch < nr * CH; ch += 256) {
+          const int row = ch / CH, cc = ch - row * CH;
+          *reinterpret_cast<u32x4*>(bp.dYb + (e0 + row) * F + 8 * cc) = *reinterpret_cast<const u32x4*>(Ds + row * SD + 16 * cc);
+        }
       }
       __syncthreads();                                                    // (compute: done with buffer it & 1)
     }
@@ -463,9 +485,7 @@ __global__ __launch_bounds__(512) void edge_mlp_bf16_bwd_kernel(EdgeBwdP bp) {
 #pragma unroll 1
   for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x, ++it) {
     const char* Es = Eb(it & 1);
-    const float* pm = vb(it & 1);
-    const float* pg1 = pm + P * F;
-    const float* pg2 = pg1 + P * F;
+    const float4* pv = vb(it & 1);
     // ---- y tile of this wave (the forward's instruction sequence) ----
     f32x16 acc[FB];
 #pragma unroll
@@ -478,27 +498,32 @@ __global__ __launch_bounds__(512) void edge_mlp_bf16_bwd_kernel(EdgeBwdP bp) {
 #pragma unroll
       for (int j = 0; j < FB; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, wf[s][j], acc[j], 0, 0, 0);
     }
-    // ---- dY of the wave's 32 rows -> LDS as bf16 ----
+    // ---- dY of the wave's 32 rows -> LDS as bf16 (v_cvt_pk_bf16_f32: round to nearest even, the dense kernels' integer form) ----
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
       const int row = 32 * w + (q & 3) + 8 * (q >> 2) + 4 * lh;
       const int pi = prow[q];
       const bool valid = pi < P && tile * P + pi < R;
+      float o[FB];
 #pragma unroll
       for (int j = 0; j < FB; ++j) {
         const int c = 32 * j + l31;
-        unsigned short ob = 0;
+        o[j] = 0.f;
         if (valid) {
           const float y = acc[j][q];
           const float xh = (y - mu[j]) * rs[j];
           const float z = fmaxf(xh + be[j], 0.f);
-          float dz = ((z == pm[pi * F + c]) ? pg1[pi * F + c] : 0.f) + pg2[pi * F + c];
+          const float4 v4 = pv[pi * F + c];
+          float dz = ((z == v4.x) ? v4.y : 0.f) + v4.z;
           if (!(z > 0.f)) dz = 0.f;
-          const float o = rs[j] * (dz - c1[j] - xh * c2[j]);
-          const unsigned u = __float_as_uint(o);
-          ob = (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+          o[j] = rs[j] * (dz - c1[j] - xh * c2[j]);
         }
-        *reinterpret_cast<unsigned short*>(Ds + row * SD + 2 * c) = ob;
+      }
+#pragma unroll
+      for (int j = 0; j < FB; j += 2) {
+        const unsigned pk = pk_bf16(o[j], j + 1 < FB ? o[j + 1] : 0.f);
+        *reinterpret_cast<unsigned short*>(Ds + row * SD + 2 * (32 * j + l31)) = (unsigned short)(pk & 0xffffu);
+        if (j + 1 < FB) *reinterpret_cast<unsigned short*>(Ds + row * SD + 2 * (32 * (j + 1) + l31)) = (unsigned short)(pk >> 16);
       }
     }
     __syncthreads();
@@ -516,30 +541,7 @@ __global__ __launch_bounds__(512) void edge_mlp_bf16_bwd_kernel(EdgeBwdP bp) {
         }
       }
     }
-    // ---- dYsum of the tile's points (m ascending, as bn_bwd_apply_kernel adds them) ----
-    if (bp.dysum) {
-      for (int i2 = t; i2 < P * F; i2 += 256) {
-        const int pi = i2 / F, c = i2 - pi * F;
-        const int64_t gp = tile * P + pi;
-        if (gp < R) {
-          float a = 0.f;
-          for (int m = 0; m < k; ++m)
-            a += __uint_as_float((unsigned)*reinterpret_cast<const unsigned short*>(Ds + (pi * k + m) * SD + 2 * c) << 16);
-          bp.dysum[gp * bp.lddysum + c] = a;
-        }
-      }
-    }
-    // ---- dY rows of the tile: P k consecutive edges, 16 bytes per store ----
-    if (bp.dYb) {
-      const int64_t e0 = tile * P * k;
-      const int64_t left = Me - e0;
-      const int nr = left < (int64_t)P * k ? (int)left : P * k;
-      constexpr int CH = F / 8;
-      for (int ch = t; ch < nr * CH; ch += 256) {
-        const int row = ch / CH, cc = ch - row * CH;
-        *reinterpret_cast<u32x4*>(bp.dYb + (e0 + row) * F + 8 * cc) = *reinterpret_cast<const u32x4*>(Ds + row * SD + 16 * cc);
-      }
-    }
+    // (the per-point sums of dY and the dY rows themselves leave through the loader waves, which idle here)
     __syncthreads();
   }
 
@@ -589,8 +591,13 @@ int launch_pass(const EdgeP& p, hipStream_t st, const char* what) {
 }
 
 bool shape_ok(int C, int k, int F) { return (C <= 4 || C == 64) && (F == 32 || F == 64 || F == 128) && k <= RT; }
-// the backward keeps three (P, F) vectors of the tile's P = floor(128 / k) points in LDS: k >= 8 bounds P at 16
-bool bwd_shape_ok(int C, int k, int F) { return shape_ok(C, k, F) && k >= 8 && k < CNT_POS; }
+// LDS of the backward: two E buffers, the dY tile, two buffers of (P, F) float4 vectors for the tile's P = floor(128 / k) points
+size_t bwd_lds_bytes(int C, int k, int F) {
+  const int K = 16 * (C <= 4 ? 1 : 8), P = RT / k;
+  return (size_t)2 * RT * (2 * K + 16) + (size_t)RT * (2 * F + 16) + (size_t)2 * 4 * P * F * sizeof(float);
+}
+// k >= 8 bounds P at 16; the widest layers (C = 64, F = 128) need k >= 10 to fit 160 KB
+bool bwd_shape_ok(int C, int k, int F) { return shape_ok(C, k, F) && k >= 8 && k < CNT_POS && bwd_lds_bytes(C, k, F) <= 160 * 1024; }
 
 }  // namespace
 
@@ -660,7 +667,7 @@ extern "C" int dgcnn_edge_mlp_bf16_bwd(const float* x, int64_t ldx, const int32_
                                        int64_t lddmn, double* red, void* dYb, float* dysum, int64_t lddysum, float* dW0,
                                        float* dbeta, float dbeta_beta, void* ws, size_t ws_bytes, void* stream) {
   DG_EDGE_COMMON("dgcnn_edge_mlp_bf16_bwd");
-  DG_REQUIRE(bwd_shape_ok(C, k, F), DGCNN_EUNSUP, "dgcnn_edge_mlp_bf16_bwd: needs 8 <= k < %d (k=%d)", CNT_POS, k);
+  DG_REQUIRE(bwd_shape_ok(C, k, F), DGCNN_EUNSUP, "dgcnn_edge_mlp_bf16_bwd: needs 8 <= k < %d and %zu bytes of LDS <= 160 KB (k=%d)", CNT_POS, bwd_lds_bytes(C, k, F), k);
   DG_REQUIRE(mean && rstd && beta && mx && cnt && dmx && dmn && red && dW0 && ws && ldmx >= F && lddmx >= F && lddmn >= F, DGCNN_EINVAL,
              "dgcnn_edge_mlp_bf16_bwd: bad args");
   DG_REQUIRE(!dysum || lddysum >= F, DGCNN_EINVAL, "dgcnn_edge_mlp_bf16_bwd: lddysum < F");
@@ -674,10 +681,10 @@ extern "C" int dgcnn_edge_mlp_bf16_bwd(const float* x, int64_t ldx, const int32_
   bp.e.mean = mean; bp.e.rstd = rstd; bp.e.beta = beta; bp.e.mx = const_cast<float*>(mx); bp.e.ldmx = ldmx; bp.e.cnt = const_cast<float*>(cnt);
   bp.dmx = dmx; bp.lddmx = lddmx; bp.dmn = dmn; bp.lddmn = lddmn; bp.red = red;
   bp.dYb = reinterpret_cast<uint16_t*>(dYb); bp.dysum = dysum; bp.lddysum = lddysum; bp.partial = reinterpret_cast<float*>(ws);
-  const int CK = C <= 4 ? 1 : 8, FB = F / 32, K = 16 * CK, P = RT / k;
+  const int CK = C <= 4 ? 1 : 8, FB = F / 32, P = RT / k;
   const int64_t ntiles = dg::cdiv((int64_t)B * N, (int64_t)P);
   const int64_t g = ntiles < 512 ? ntiles : 512;
-  const size_t sh = (size_t)2 * RT * (2 * K + 16) + (size_t)RT * (2 * F + 16) + (size_t)2 * 3 * P * F * sizeof(float);
+  const size_t sh = bwd_lds_bytes(C, k, F);
 #define DG_B(CKV, FBV)                                                                                                        \
   do {                                                                                                                        \
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&edge_mlp_bf16_bwd_kernel<CKV, FBV>),                             \

@@ -84,7 +84,8 @@ int dgcnn_knn_f32(const float* x, int B, int N, int C, int64_t ldx, int k, int32
  *                                  dgcnn_edge_bn_bwd_reduce_points_f32 (reduced here; dbeta = dbeta_beta * dbeta + sum dz);
  *                                  dY = rstd (dz - c1 - xhat c2) rounded to bf16 -> dYb (B N k, F) bf16 and dysum = sum_m dY (B N, F)
  *                                  (either may be null); dW0 (2C, F) += E^T dY on the matrix pipe.  Neither E nor y nor an fp32 dY
- *                                  is written.  ws >= dgcnn_edge_mlp_bf16_bwd_workspace_bytes.  8 <= k < 256.
+ *                                  is written.  ws >= dgcnn_edge_mlp_bf16_bwd_workspace_bytes.  8 <= k < 256 (C = 64 with F = 128: k >= 10, LDS);
+ *                                  dgcnn_edge_mlp_bf16_bwd_supported tells.
  *   dgcnn_edge_gather_sum_bf16     dgcnn_edge_gather_sum_f32 over that bf16 dY (same additions in the same order)
  * Shapes: C <= 4 or C == 64 (x float4-loadable), F in {32, 64, 128}, k <= 128 (dgcnn_edge_mlp_bf16_supported; DGCNN_EUNSUP else). */
 int dgcnn_edge_mlp_bf16_supported(int C, int k, int F);

@@ -27,7 +27,7 @@ def dg():
 
 
 @pytest.mark.parametrize("B,N,C,k,F", [(2, 64, 3, 5, 8), (2, 128, 64, 20, 64), (1, 96, 4, 7, 128), (2, 64, 64, 10, 32),
-                                       (1, 96, 4, 10, 128), (2, 64, 3, 8, 64), (1, 50, 64, 40, 128)])
+                                       (1, 96, 4, 10, 128), (2, 64, 3, 8, 64), (1, 50, 64, 40, 128), (1, 70, 64, 10, 128), (1, 60, 64, 8, 128)])
 def test_edge_conv_bf16_forward_backward(dg, B, N, C, k, F):
     """One edge_conv block in bf16 mode against the oracle in bf16 mode (same graph): [max, mean, net] within 1e-4 and the
     gradients w.r.t. X (C % 4 == 0), W0, beta0, W1, beta1 within 2e-3 -- the bars of the fp32 block test
@@ -270,6 +270,8 @@ def test_fused_backward_pass_against_the_dense_kernels(dg, B, N, C, k, F):
     idx_h = rng.integers(0, N, (B, N, k)).astype(np.int32)
     idx = dev(idx_h)
     assert lib.dgcnn_edge_mlp_bf16_bwd_supported(C, k, F) == 1
+    assert lib.dgcnn_edge_mlp_bf16_bwd_supported(64, 7, 64) == 0 and lib.dgcnn_edge_mlp_bf16_bwd_supported(64, 8, 64) == 1
+    assert lib.dgcnn_edge_mlp_bf16_bwd_supported(64, 8, 128) == 0 and lib.dgcnn_edge_mlp_bf16_bwd_supported(64, 10, 128) == 1   # LDS
     src = (x.data_ptr(), C, idx.data_ptr(), W.data_ptr(), B, N, C, k, F)
     Y = torch.empty((R * k, F), device="cuda")
     H.call("dgcnn_edge_mlp_bf16", *src, Y.data_ptr())
