@@ -52,10 +52,10 @@ def cpu_model():
     return "unknown CPU"
 
 
-def cpu_baseline(clouds=24, iters=3):
+def cpu_baseline(clouds=24, iters=5):
     """The reference graph restated op-for-op on torch-CPU (oracle/torch_twin.py), fwd+bwd, timed on
     this host's cores on the SAME batch size as the GPU step (all 24 clouds: BatchNorm statistics over the whole batch, as in
-    the reference; MEDIAN of 3 iterations, ~25-30 s).
+    the reference; MEDIAN of 5 iterations, ~40 s).
     torch's intra-op pool collapses when oversubscribed (256 threads: 0.14 clouds/s, 16 threads: 2.9 clouds/s on the
     2x EPYC 9575F GPU-box host, profiles/r01_cpu_threads.txt), so a short sweep picks the thread count first and
     `cores` reports the count actually used."""
@@ -171,8 +171,8 @@ def comm_fields(group, dist, world, per_rank_elapsed, steps, exposed_ms, bucket_
     ar = {"bucket_MB": round(bucket_elems * 4 / 1e6, 2),
           "exposed_ms_per_step": {"median": round(exposed_ms[len(exposed_ms) // 2], 4), "max": round(exposed_ms[-1], 4),
                                   "steps": len(exposed_ms)} if exposed_ms else None,
-          "note": "event pair on the step's stream around the all-reduce section of apply_gradient in eager steps right after the "
-                  "timed region: with the own communicator the head bucket (97 % of the bytes) is already travelling when that "
+          "note": "event pair on the step's stream around the all-reduce section of apply_gradient in steps right after the "
+                  "timed regions, launched the way the timed steps were: with the own communicator the head bucket (97 % of the bytes) is already travelling when that "
                   "section starts, so this is the EXPOSED part of the collective (+ the 1/world scale); at N = 1 there is no "
                   "collective in the step and it reads ~0"}
     return {"collective_backend": backend, "rccl_ranks": ranks, "rccl_rank": myrank, "rccl_ranks_source": src,
@@ -263,15 +263,19 @@ def main():
                          "torch.distributed); nccl = RCCL through torch.distributed; gloo = only for the single-GPU-box sanity run "
                          "of the N > 1 logic, with --same-device")
     ap.add_argument("--same-device", action="store_true", help="all ranks on cuda:0 (sanity runs only)")
-    ap.add_argument("--deterministic", action="store_true", help="deterministic mode (one writer per statistics slot, fixed-order "
-                    "finalize, sorted adjacency): bit-reproducible steps, ~6 %% slower (DESIGN 2)")
+    ap.add_argument("--deterministic", action="store_true", help="(the default since round 5; kept so that old command lines run)")
+    ap.add_argument("--atomics", action="store_true", help="the atomics mode instead of the deterministic kernels (32 statistics slots, "
+                    "several writers each, unsorted adjacency): 3-4 %% faster, reproducible to ~1e-7 per step only (DESIGN 2)")
+    ap.add_argument("--repeats", type=int, default=0, help="the K-step timed region is run this many times back to back and the MEDIAN "
+                    "region is reported (all of them in config.per_repeat_ms_per_step); 0 = as many as fill ~2 s, at least 5")
     ap.add_argument("--no-edgeconv-stack", action="store_true", help="skip the EdgeConv-stack-only passes after the timed region "
                     "(profiling runs)")
-    ap.add_argument("--graph", default="auto", choices=["0", "1", "auto"],
-                    help="1: replay the forward+backward tower as a captured HIP graph (the reference replays a static TF graph "
-                         "with sess.run); 0: eager launches; auto (default): a few untimed steps of each during warm-up, then the "
-                         "faster mode for the timed region (eager wins on a fast host, replay when the host cannot enqueue "
-                         "~150 launches per step as fast as the GPU retires them)")
+    ap.add_argument("--graph", default="auto", choices=["0", "1", "plan", "auto"],
+                    help="how the forward+backward tower is launched (the reference replays a static TF graph with sess.run): "
+                         "plan = recorded launch plan re-issued from one C loop (csrc/plan.cc); 1 = captured HIP graph; 0 = eager "
+                         "launches from Python; auto (default) = a few untimed steps of eager and plan during warm-up, then the plan "
+                         "unless eager is more than 3 %% faster AND its host enqueue takes less than half a step (an eager step is "
+                         "~140 launches from Python: it is the mode a busy host slows down, BENCH_r04)")
     ap.add_argument("--dry-run", action="store_true",
                     help="plumbing check WITHOUT a GPU (tests/test_bench_launch.py): the launch / rendezvous / fence / timing / "
                          "gather / JSON path of an N-rank run with a stand-in step and the communicator class named by "
@@ -317,10 +321,9 @@ def main():
                 else:
                     dist.init_process_group(backend=backend, rank=rank, world_size=world)
     flags = make_flags(dgcnn)
-    if args.deterministic:
-        flags.DETERMINISTIC = True
+    flags.DETERMINISTIC = not args.atomics
     tv = dgcnn.trainval(flags).initialize()
-    tv.use_graph(args.graph == "1")
+    tv.use_graph({"1": True, "plan": "plan"}.get(args.graph, False))
 
     rng = np.random.default_rng(rank)                     # per-rank synthetic shard
     pts = torch.from_numpy(rng.random((B, N, C), dtype=np.float32)).cuda()
@@ -367,38 +370,60 @@ def main():
             t = time.perf_counter()
             for _ in range(n):
                 step()
+            t_host = time.perf_counter() - t
             torch.cuda.synchronize()
-            return (time.perf_counter() - t) / n
+            return (time.perf_counter() - t) / n, t_host / n
         tv.use_graph(False)
-        t_eager = rate()
-        tv.use_graph(True)
+        t_eager, h_eager = rate()
+        tv.use_graph("plan")
         step()
-        step()                                  # sighting + capture
-        t_graph = rate()
-        use = t_graph < t_eager
+        step()                                  # sighting + recording
+        t_plan, h_plan = rate()
+        # the plan unless eager wins clearly AND has host headroom: an eager step is ~140 launches from Python, the mode that a
+        # busy host stretches (BENCH_r04: calibration 4.75 ms, timed region 6.69 ms with 5.4 ms of host enqueue)
+        v = [t_eager, t_plan, h_eager]
         if group is not None:                   # every rank must make the same choice
-            v = group.gather_scalars([t_eager, t_graph]).max(0).values
-            use = bool(v[1] < v[0])
+            v = [float(x) for x in group.gather_scalars(v).max(0).values]
         elif dist is not None:
-            v = torch.tensor([t_eager, t_graph], dtype=torch.float64, device="cuda")
-            dist.all_reduce(v, op=dist.ReduceOp.MAX)
-            use = bool(v[1] < v[0])
-        tv.use_graph(use)
-        calib = {"eager_ms": round(t_eager * 1e3, 3), "graph_ms": round(t_graph * 1e3, 3)}
-    use_graph = bool(tv._use_graph)
+            vt = torch.tensor(v, dtype=torch.float64, device="cuda")
+            dist.all_reduce(vt, op=dist.ReduceOp.MAX)
+            v = [float(x) for x in vt]
+        eager_wins = v[0] < 0.97 * v[1] and v[2] < 0.5 * v[0]
+        tv.use_graph(False if eager_wins else "plan")
+        calib = {"eager_ms": round(t_eager * 1e3, 3), "plan_ms": round(t_plan * 1e3, 3),
+                 "eager_host_enqueue_ms": round(h_eager * 1e3, 3), "plan_host_enqueue_ms": round(h_plan * 1e3, 3),
+                 "rule": "plan unless eager_ms < 0.97 plan_ms and eager_host_enqueue_ms < 0.5 eager_ms (max over ranks)"}
+    launch_mode = tv._use_graph
+    mode_name = {"plan": "launch-plan replay", True: "hip-graph replay", False: "eager"}[launch_mode]
 
-    # ---- timed region: exactly K steps, no instrumentation (an event pair around every launch of the dominant kernel
-    # perturbs what it measures: with the plane GEMMs +0.1 .. +1.9 ms per step, profiles/r03/bench_events.txt) ----
+    # ---- timed regions: R times EXACTLY K steps, each bracketed by fence() on both sides, no instrumentation (an event pair
+    # around every launch of the dominant kernel perturbs what it measures: with the plane GEMMs +0.1 .. +1.9 ms per step,
+    # profiles/r03/bench_events.txt).  The MEDIAN region is the reported one; all R are in the line. ----
     H.TIMER = None
+    step()
     fence()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        res = step()
-    t_issue = time.perf_counter() - t0          # host time to enqueue K steps (launch-bound check)
+    step()
     fence()
-    elapsed = time.perf_counter() - t0
+    t_probe = time.perf_counter() - t0
+    R = args.repeats if args.repeats > 0 else max(5, min(25, int(2.0 / max(args.steps * t_probe, 1e-4)) + 1))
+    if group is not None:                       # (one R for every rank)
+        R = int(group.gather_scalars([float(R)]).max(0).values[0])
+    elif dist is not None:
+        vt = torch.tensor([float(R)], dtype=torch.float64, device="cuda")
+        dist.all_reduce(vt, op=dist.ReduceOp.MAX)
+        R = int(vt[0])
+    regions, issues = [], []
+    for _ in range(R):
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            res = step()
+        issues.append(time.perf_counter() - t0)  # host time to enqueue K steps (launch-bound check)
+        fence()
+        regions.append(time.perf_counter() - t0)
     # ---- the dominant kernel, live: HIP events (on the launch stream) around its launches in eager steps that follow the
-    # timed region immediately (same process, same buffers, same two-stream schedule) ----
+    # timed regions immediately (same process, same buffers, same two-stream schedule) ----
     tv.use_graph(False)
     H.TIMER = H.Timer(watch={dominant})
     for _ in range(max(args.steps // 4, 3)):
@@ -406,35 +431,40 @@ def main():
     dom = H.TIMER.summary()[dominant]
     H.TIMER = None
     # ---- the collective, live: event pairs around the part of the all-reduce the step's stream has to WAIT for (the head bucket
-    # travels under the EdgeConv backward; what is left is the exposed cost), same eager steps, after the timed region ----
+    # travels under the EdgeConv backward; what is left is the exposed cost) -- in the launch mode of the timed regions ----
+    tv.use_graph(launch_mode)
     tv._ar_events = []
     for _ in range(max(args.steps // 4, 3)):
         step()
     torch.cuda.synchronize()
     exposed_ms = sorted(a.elapsed_time(b) for a, b in tv._ar_events)
     tv._ar_events = None
-    tv.use_graph(use_graph)
     loss = float(res[2])
+    plan_info = tv.launch_plan_info()
 
     # replicas must hold identical parameters after identical Adam steps on the all-reduced gradient
     chk = torch.stack([dgcnn.ctx().flat_param.double().sum(), dgcnn.ctx().flat_param.double().abs().sum()])
-    per_rank = [elapsed]
+    per_rank_regions = [regions]
     if group is not None:
-        allv = group.gather_scalars([elapsed] + [float(x) for x in chk.float()])      # (world, 3)
-        per_rank = [float(x) for x in allv[:, 0]]
-        elapsed = float(allv[:, 0].max())
-        if not bool((allv[:, 1:] == allv[0, 1:]).all()):
+        allv = group.gather_scalars(regions + [float(x) for x in chk.float()])      # (world, R + 2)
+        per_rank_regions = [[float(x) for x in row[:R]] for row in allv]
+        if not bool((allv[:, R:] == allv[0, R:]).all()):
             raise SystemExit("replicas diverged: parameter checksums differ across ranks")
     elif dist is not None:
-        box = [torch.zeros(1, dtype=torch.float64, device="cuda") for _ in range(world)]
-        dist.all_gather(box, torch.tensor([elapsed], dtype=torch.float64, device="cuda"))
-        per_rank = [float(x.item()) for x in box]
-        elapsed = max(per_rank)
+        box = [torch.zeros(R, dtype=torch.float64, device="cuda") for _ in range(world)]
+        dist.all_gather(box, torch.tensor(regions, dtype=torch.float64, device="cuda"))
+        per_rank_regions = [[float(v) for v in x] for x in box]
         lo, hi = chk.clone(), chk.clone()
         dist.all_reduce(lo, op=dist.ReduceOp.MIN)
         dist.all_reduce(hi, op=dist.ReduceOp.MAX)
         if not torch.equal(lo, hi):
             raise SystemExit("replicas diverged: parameter checksums differ across ranks")
+    region_max = [max(r[i] for r in per_rank_regions) for i in range(R)]          # per region: the slowest rank
+    order = sorted(range(R), key=lambda i: region_max[i])
+    mid = order[R // 2]                                                            # the median region
+    elapsed = region_max[mid]
+    per_rank = [r[mid] for r in per_rank_regions]
+    t_issue = issues[mid]
 
     # the group the gradient all-reduce ran in: backend "nccl" IS RCCL on ROCm (gloo only in the one-device sanity run)
     comm = comm_fields(group, dist, world, per_rank, args.steps, exposed_ms, dgcnn.ctx().flat_grad.numel())
@@ -548,12 +578,18 @@ def main():
                        "rccl_rank": comm["rccl_rank"], "rccl_ranks_source": comm["rccl_ranks_source"],
                        "per_rank_ms_per_step": comm["per_rank_ms_per_step"], "allreduce": comm["allreduce"],
                        "final_loss": round(loss, 5), "host_enqueue_ms_per_step": round(t_issue / args.steps * 1e3, 3),
-                       "launch_mode": "hip-graph replay" if use_graph else "eager", "launch_mode_calibration": calib},
+                       "launch_mode": mode_name, "launch_mode_calibration": calib,
+                       "deterministic": not args.atomics,
+                       "repeats": R, "per_repeat_ms_per_step": [round(t / args.steps * 1e3, 3) for t in region_max],
+                       "repeat_spread": round((max(region_max) - min(region_max)) / elapsed, 4),
+                       "timing": "the K-step region (fence = device synchronize + barrier on both sides) is run `repeats` times "
+                                 "back to back; ms_per_step / value are those of the MEDIAN region (max over ranks per region)",
+                       "launches_per_step": (dict(plan_info[0], outside_plan="zero-gradient memset, dropout-seed fill, softmax / "
+                                                  "[loss, accuracy] copies, (all-reduce rest piece + scale), Adam")
+                                             if plan_info else None)},
             "roofline": roof,
             "roofline_extra": extra[:14],
         }
-        if args.deterministic:
-            out["config"]["deterministic"] = True
         if world == 1:
             probe = one_rank_rccl_probe(dgcnn.ctx().flat_grad.numel())
             out["config"]["rccl_probe"] = probe

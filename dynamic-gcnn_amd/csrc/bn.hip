@@ -794,17 +794,17 @@ int launch_act_kreduce(const char* what, Src src, int64_t R, int k, int F, const
                    (!out2 || ((ldout2 % 4 == 0) && a16(out2))) && (!cnt_out || a16(cnt_out));
   if (G) {
     DG_REQUIRE(vec, DGCNN_EINVAL, "%s: outputs must be 16-byte aligned with leading dimensions %% 4 == 0", what);
-    hipLaunchKernelGGL((bn_act_kreduce_kernel<4, true>), dim3(grid8(grid_for(R * (F / 4)))), dim3(256), 0, st, src, R, k, F,
+    dg::launch((bn_act_kreduce_kernel<4, true>), dim3(grid8(grid_for(R * (F / 4)))), dim3(256), 0, st, src, R, k, F,
                        mean, rstd, beta, relu, max_out, ldmax, mean_out, ldmean, out2, ldout2, cnt_out, shift_of(F / 4));
   } else if (vec && k == 1 && !mean_out) {
     const K1Grid g = k1_grid(R, F, 4096);
-    hipLaunchKernelGGL(bn1_act_kernel, g.grid, dim3(256), 0, st, src.Y, R, F, g.FVB, g.RP, mean, rstd, beta, relu, max_out,
+    dg::launch(bn1_act_kernel, g.grid, dim3(256), 0, st, src.Y, R, F, g.FVB, g.RP, mean, rstd, beta, relu, max_out,
                        ldmax, out2, ldout2, cnt_out, (const uint64_t*)nullptr, 1.0f);
   } else if (vec) {
-    hipLaunchKernelGGL((bn_act_kreduce_kernel<4, false>), dim3(grid_for(R * (F / 4))), dim3(256), 0, st, src, R, k, F, mean,
+    dg::launch((bn_act_kreduce_kernel<4, false>), dim3(grid_for(R * (F / 4))), dim3(256), 0, st, src, R, k, F, mean,
                        rstd, beta, relu, max_out, ldmax, mean_out, ldmean, out2, ldout2, cnt_out, shift_of(F / 4));
   } else {
-    hipLaunchKernelGGL((bn_act_kreduce_kernel<1, false>), dim3(grid_for(R * F)), dim3(256), 0, st, src, R, k, F, mean, rstd,
+    dg::launch((bn_act_kreduce_kernel<1, false>), dim3(grid_for(R * F)), dim3(256), 0, st, src, R, k, F, mean, rstd,
                        beta, relu, max_out, ldmax, mean_out, ldmean, out2, ldout2, cnt_out, shift_of(F));
   }
   return dg::check_launch(what);
@@ -824,7 +824,7 @@ int launch_bwd_reduce(const char* what, Src src, int64_t R, int k, int F, const 
   const size_t sh = (size_t)2 * F * sizeof(float);
   if (G) {
     DG_REQUIRE(vec, DGCNN_EINVAL, "%s: operands must be 16-byte aligned with leading dimensions %% 4 == 0", what);
-    hipLaunchKernelGGL((bn_bwd_reduce_kernel<4, true>), dim3(grid8(grid_reduce(R * (F / 4)))), dim3(256), sh, st, src, R, k,
+    dg::launch((bn_bwd_reduce_kernel<4, true>), dim3(grid8(grid_reduce(R * (F / 4)))), dim3(256), sh, st, src, R, k,
                        F, mean, rstd, beta, relu, dmax, lddmax, dmean, lddmean, mx_in, ldmx, cnt_in, red, shift_of(F / 4), dg::stat_slots());
   } else if (vec && k == 1 && !mx_in) {          // k = 1: dz = dmax + dmean / 1 -- `dmean` is the gradient of a second copy of the output
     const int mb = 256;
@@ -832,14 +832,14 @@ int launch_bwd_reduce(const char* what, Src src, int64_t R, int k, int F, const 
     // (F = 256: 19 us at 256 workgroups, 32 us at 2048; 1024-thread workgroups are slower: profiles/bn1_bench.py)
     const K1Grid g = k1_grid(R, F, mb);
     const size_t sh1 = sizeof(float) * K1_PARK_FLOATS;
-    hipLaunchKernelGGL((bn1_bwd_kernel<false>), g.grid, dim3(256), sh1, st, src.Y, R, F, g.FVB, g.RP, mean, rstd, beta, relu,
+    dg::launch((bn1_bwd_kernel<false>), g.grid, dim3(256), sh1, st, src.Y, R, F, g.FVB, g.RP, mean, rstd, beta, relu,
                        dmax, lddmax, dmean, lddmean, red, (float*)nullptr, (float*)nullptr, (int64_t)0, (const uint64_t*)nullptr, 1.0f,
                        dg::stat_slots());
   } else if (vec) {
-    hipLaunchKernelGGL((bn_bwd_reduce_kernel<4, false>), dim3(grid_reduce(R * (F / 4))), dim3(256), sh, st, src, R, k, F,
+    dg::launch((bn_bwd_reduce_kernel<4, false>), dim3(grid_reduce(R * (F / 4))), dim3(256), sh, st, src, R, k, F,
                        mean, rstd, beta, relu, dmax, lddmax, dmean, lddmean, mx_in, ldmx, cnt_in, red, shift_of(F / 4), dg::stat_slots());
   } else {
-    hipLaunchKernelGGL((bn_bwd_reduce_kernel<1, false>), dim3(grid_reduce(R * F)), dim3(256), sh, st, src, R, k, F, mean,
+    dg::launch((bn_bwd_reduce_kernel<1, false>), dim3(grid_reduce(R * F)), dim3(256), sh, st, src, R, k, F, mean,
                        rstd, beta, relu, dmax, lddmax, dmean, lddmean, mx_in, ldmx, cnt_in, red, shift_of(F), dg::stat_slots());
   }
   return dg::check_launch(what);
@@ -852,7 +852,7 @@ int launch_bwd_apply(const char* what, Src src, int64_t R, int k, int F, const f
                      float* dYsum, int64_t lddysum, float* dbeta, float dbeta_beta, hipStream_t st) {
   DG_REQUIRE(mean && rstd && beta && dmax && red && dY, DGCNN_EINVAL, "%s: null pointer", what);
   DG_REQUIRE(!dYsum || lddysum >= F, DGCNN_EINVAL, "%s: lddysum < F", what);
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)dg::cdiv(F, FIN_COLS)), dim3(FIN_COLS * FIN_LANES), 0, st, red, F, dg::stat_slots(), dbeta,
+  dg::launch(bn_bwd_finalize_kernel, dim3((unsigned)dg::cdiv(F, FIN_COLS)), dim3(FIN_COLS * FIN_LANES), 0, st, red, F, dg::stat_slots(), dbeta,
                      dbeta_beta);
   const bool vec = (F % 4 == 0) && (lddmax % 4 == 0) && (G || a16(src.Y)) && a16(dY) && a16(dmax) && a16(mean) &&
                    a16(rstd) && a16(beta) && (!dmean || ((lddmean % 4 == 0) && a16(dmean))) &&
@@ -860,19 +860,19 @@ int launch_bwd_apply(const char* what, Src src, int64_t R, int k, int F, const f
                    (!mx_in || ((ldmx % 4 == 0) && a16(mx_in) && a16(cnt_in)));
   if (G) {
     DG_REQUIRE(vec, DGCNN_EINVAL, "%s: operands must be 16-byte aligned with leading dimensions %% 4 == 0", what);
-    hipLaunchKernelGGL((bn_bwd_apply_kernel<4, true>), dim3(grid8(grid_for(R * (F / 4)))), dim3(256), 0, st, src, R, k, F,
+    dg::launch((bn_bwd_apply_kernel<4, true>), dim3(grid8(grid_for(R * (F / 4)))), dim3(256), 0, st, src, R, k, F,
                        mean, rstd, beta, relu, dmax, lddmax, dmean, lddmean, mx_in, ldmx, cnt_in, red, dY, dYsum, lddysum,
                        shift_of(F / 4));
   } else if (vec && k == 1 && !mx_in) {
     const K1Grid g = k1_grid(R, F, 4096);
-    hipLaunchKernelGGL((bn1_bwd_kernel<true>), g.grid, dim3(256), 0, st, src.Y, R, F, g.FVB, g.RP, mean, rstd, beta, relu,
+    dg::launch((bn1_bwd_kernel<true>), g.grid, dim3(256), 0, st, src.Y, R, F, g.FVB, g.RP, mean, rstd, beta, relu,
                        dmax, lddmax, dmean, lddmean, red, dY, dYsum, lddysum, (const uint64_t*)nullptr, 1.0f, dg::stat_slots());
   } else if (vec) {
-    hipLaunchKernelGGL((bn_bwd_apply_kernel<4, false>), dim3(grid_for(R * (F / 4))), dim3(256), 0, st, src, R, k, F, mean,
+    dg::launch((bn_bwd_apply_kernel<4, false>), dim3(grid_for(R * (F / 4))), dim3(256), 0, st, src, R, k, F, mean,
                        rstd, beta, relu, dmax, lddmax, dmean, lddmean, mx_in, ldmx, cnt_in, red, dY, dYsum, lddysum,
                        shift_of(F / 4));
   } else {
-    hipLaunchKernelGGL((bn_bwd_apply_kernel<1, false>), dim3(grid_for(R * F)), dim3(256), 0, st, src, R, k, F, mean, rstd,
+    dg::launch((bn_bwd_apply_kernel<1, false>), dim3(grid_for(R * F)), dim3(256), 0, st, src, R, k, F, mean, rstd,
                        beta, relu, dmax, lddmax, dmean, lddmean, mx_in, ldmx, cnt_in, red, dY, dYsum, lddysum, shift_of(F));
   }
   return dg::check_launch(what);
@@ -883,7 +883,7 @@ int launch_bwd_apply(const char* what, Src src, int64_t R, int k, int F, const f
 extern "C" int dgcnn_bn_finalize_f32(const double* stats, int F, double count, float eps,
                                      float* mean, float* rstd, void* stream) {
   DG_REQUIRE(stats && mean && rstd && F > 0 && count > 0, DGCNN_EINVAL, "dgcnn_bn_finalize_f32: bad args");
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)dg::cdiv(F, FIN_COLS)), dim3(FIN_COLS * FIN_LANES), 0, (hipStream_t)stream,
+  dg::launch(bn_finalize_kernel, dim3((unsigned)dg::cdiv(F, FIN_COLS)), dim3(FIN_COLS * FIN_LANES), 0, (hipStream_t)stream,
                      stats, F, dg::stat_slots(), count, eps, mean, rstd);
   return dg::check_launch("dgcnn_bn_finalize_f32");
 }
@@ -960,7 +960,7 @@ extern "C" int dgcnn_edge_bn_bwd_reduce_points_f32(const float* mx, int64_t ldmx
              "dgcnn_edge_bn_bwd_reduce_points_f32: operands must be 16-byte aligned with leading dimensions %% 4 == 0");
   const K1Grid g = k1_grid(R, F, 256);
   const size_t sh = sizeof(float) * K1_PARK_FLOATS;
-  hipLaunchKernelGGL(edge_bwd_reduce_points_kernel, g.grid, dim3(256), sh, (hipStream_t)stream, mx, ldmx, mn, ldmn, cntpos,
+  dg::launch(edge_bwd_reduce_points_kernel, g.grid, dim3(256), sh, (hipStream_t)stream, mx, ldmx, mn, ldmn, cntpos,
                      dmax, lddmax, dmean, lddmean, beta, R, k, F, g.FVB, g.RP, red, dg::stat_slots());
   return dg::check_launch("dgcnn_edge_bn_bwd_reduce_points_f32");
 }
@@ -995,7 +995,7 @@ extern "C" int dgcnn_bn1_act_dropout_f32(const float* T, int64_t R, int F, const
   if (rc) return rc;
   DG_REQUIRE(out && ldo % 4 == 0 && a16(out), DGCNN_EINVAL, "dgcnn_bn1_act_dropout_f32: out must be 16-byte aligned, ld %% 4 == 0");
   const K1Grid g = k1_grid(R, F, 4096);
-  hipLaunchKernelGGL(bn1_act_kernel, g.grid, dim3(256), 0, (hipStream_t)stream, T, R, F, g.FVB, g.RP, mean, rstd, beta, relu, out,
+  dg::launch(bn1_act_kernel, g.grid, dim3(256), 0, (hipStream_t)stream, T, R, F, g.FVB, g.RP, mean, rstd, beta, relu, out,
                      ldo, (float*)nullptr, (int64_t)0, (float*)nullptr, seed_dev, keep);
   return dg::check_launch("dgcnn_bn1_act_dropout_f32");
 }
@@ -1010,11 +1010,11 @@ extern "C" int dgcnn_bn1_bwd_dropout_f32(const float* T, int64_t R, int F, const
   hipStream_t st = (hipStream_t)stream;
   const K1Grid gr = k1_grid(R, F, 256);
   const size_t sh1 = sizeof(float) * K1_PARK_FLOATS;
-  hipLaunchKernelGGL((bn1_bwd_kernel<false>), gr.grid, dim3(256), sh1, st, T, R, F, gr.FVB, gr.RP, mean, rstd, beta, relu, dout, lddo,
+  dg::launch((bn1_bwd_kernel<false>), gr.grid, dim3(256), sh1, st, T, R, F, gr.FVB, gr.RP, mean, rstd, beta, relu, dout, lddo,
                      (const float*)nullptr, (int64_t)0, red, (float*)nullptr, (float*)nullptr, (int64_t)0, seed_dev, keep, dg::stat_slots());
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)dg::cdiv(F, FIN_COLS)), dim3(FIN_COLS * FIN_LANES), 0, st, red, F, dg::stat_slots(), dbeta, dbeta_beta);
+  dg::launch(bn_bwd_finalize_kernel, dim3((unsigned)dg::cdiv(F, FIN_COLS)), dim3(FIN_COLS * FIN_LANES), 0, st, red, F, dg::stat_slots(), dbeta, dbeta_beta);
   const K1Grid ga = k1_grid(R, F, 4096);
-  hipLaunchKernelGGL((bn1_bwd_kernel<true>), ga.grid, dim3(256), 0, st, T, R, F, ga.FVB, ga.RP, mean, rstd, beta, relu, dout, lddo,
+  dg::launch((bn1_bwd_kernel<true>), ga.grid, dim3(256), 0, st, T, R, F, ga.FVB, ga.RP, mean, rstd, beta, relu, dout, lddo,
                      (const float*)nullptr, (int64_t)0, red, dT, (float*)nullptr, (int64_t)0, seed_dev, keep, dg::stat_slots());
   return dg::check_launch("dgcnn_bn1_bwd_dropout_f32");
 }
@@ -1023,7 +1023,7 @@ namespace dg {
 void launch_reduce_partials(const float* part, int splits, int M, int N, float* C, int64_t ldc, float beta, hipStream_t st);
 // slots of a backward reduction -> slot 0 (+ d(beta)); edge_mlp_bf16.hip
 void launch_bn_bwd_finalize(double* red, int F, float* dbeta, float dbeta_beta, hipStream_t st) {
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)cdiv(F, FIN_COLS)), dim3(FIN_COLS * FIN_LANES), 0, st, red, F, stat_slots(), dbeta, dbeta_beta);
+  dg::launch(bn_bwd_finalize_kernel, dim3((unsigned)cdiv(F, FIN_COLS)), dim3(FIN_COLS * FIN_LANES), 0, st, red, F, stat_slots(), dbeta, dbeta_beta);
 }
 }
 
@@ -1045,12 +1045,12 @@ extern "C" int dgcnn_edge_bn_bwd_apply_wgrad_f32(const float* V, int64_t ldv, co
              "dgcnn_edge_bn_bwd_apply_wgrad_f32: F / 4 must be a power of two <= 256, operands 16-byte aligned");
   hipStream_t st = (hipStream_t)stream;
   const int64_t R = (int64_t)B * N;
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)dg::cdiv(F, FIN_COLS)), dim3(FIN_COLS * FIN_LANES), 0, st, red, F, dg::stat_slots(), dbeta, dbeta_beta);
+  dg::launch(bn_bwd_finalize_kernel, dim3((unsigned)dg::cdiv(F, FIN_COLS)), dim3(FIN_COLS * FIN_LANES), 0, st, red, F, dg::stat_slots(), dbeta, dbeta_beta);
   const unsigned grid = grid8(grid_reduce(R * FV));                 // <= 1024 blocks: one partial tile each
   const size_t need = (size_t)grid * 2 * C * F * sizeof(float);
   DG_REQUIRE(ws_bytes >= need, DGCNN_ENOSPC, "dgcnn_edge_bn_bwd_apply_wgrad_f32: workspace too small (%zu < %zu)", ws_bytes, need);
   const size_t shb = (size_t)(256 / FV) * 2 * 4 * F * sizeof(float);
-  hipLaunchKernelGGL((edge_bwd_apply_wgrad_kernel<4>), dim3(grid), dim3(256), shb, st, edge_src(V, ldv, U, ldu, idx, N), R, k, F,
+  dg::launch((edge_bwd_apply_wgrad_kernel<4>), dim3(grid), dim3(256), shb, st, edge_src(V, ldv, U, ldu, idx, N), R, k, F,
                      mean, rstd, beta, dmax, lddmax, dmean, lddmean, mx_in, ldmx, cnt_in, red, x, ldx, C,
                      reinterpret_cast<float*>(ws), shift_of(FV));
   rc = dg::check_launch("dgcnn_edge_bn_bwd_apply_wgrad_f32");

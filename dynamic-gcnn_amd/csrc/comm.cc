@@ -77,7 +77,22 @@ struct StdoutToStderr {
   }
 };
 
-bool g_first_collective = true;      // (lazy initialisation inside RCCL may print as well: the first collective is quiet too)
+// Lazy initialisation inside RCCL may print as well: the FIRST collective of every communicator is quiet too.  (fd 1 is process
+// wide: a thread of the host that writes to stdout during those few calls lands on stderr -- the host of this library is the
+// single-threaded Python driver; NCCL_DEBUG / RCCL_LOG do not silence the banner of this build.)
+int64_t g_ar_calls = 0, g_ar_elems = 0;      // every all-reduce issued through this library (direct calls and plan replays)
+void* g_warm[16];
+int g_warm_n = 0;
+bool quiet_first(void* comm) {
+  for (int i = 0; i < g_warm_n; ++i)
+    if (g_warm[i] == comm) return false;
+  if (g_warm_n < 16) g_warm[g_warm_n++] = comm;
+  return true;
+}
+void forget_comm(void* comm) {
+  for (int i = 0; i < g_warm_n; ++i)
+    if (g_warm[i] == comm) { g_warm[i] = g_warm[--g_warm_n]; return; }
+}
 
 int check(int rc, const char* what) {
   if (rc == 0) return DGCNN_OK;
@@ -117,24 +132,36 @@ extern "C" int dgcnn_comm_init(int world, int rank, const void* id128, void** co
 
 extern "C" int dgcnn_comm_destroy(void* comm) {
   if (!comm || !g.lib) return DGCNN_OK;
+  forget_comm(comm);
   StdoutToStderr quiet;
   return check(g.CommDestroy((Comm)comm), "ncclCommDestroy");
 }
 
+namespace dg {
+void plan_add_allreduce(float* buf, int64_t count, void* comm, hipStream_t st);      // plan.cc
+
+// the collective itself (also what a replayed launch plan calls)
+int comm_allreduce(float* buf, int64_t count, void* comm, hipStream_t st) {
+  g_ar_calls += 1;
+  g_ar_elems += count;
+  if (quiet_first(comm)) {
+    StdoutToStderr quiet;
+    return check(g.AllReduce(buf, buf, (size_t)count, kFloat32, kSum, (Comm)comm, st), "ncclAllReduce");
+  }
+  return check(g.AllReduce(buf, buf, (size_t)count, kFloat32, kSum, (Comm)comm, st), "ncclAllReduce");
+}
+}  // namespace dg
+
 extern "C" int dgcnn_allreduce_f32(float* buf, int64_t count, void* comm, void* stream) {
   DG_REQUIRE(buf && comm && count > 0 && g.lib, DGCNN_EINVAL, "dgcnn_allreduce_f32: bad args (communicator from dgcnn_comm_init)");
-  if (g_first_collective) {
-    g_first_collective = false;
-    StdoutToStderr quiet;
-    return check(g.AllReduce(buf, buf, (size_t)count, kFloat32, kSum, (Comm)comm, (hipStream_t)stream), "ncclAllReduce");
-  }
-  return check(g.AllReduce(buf, buf, (size_t)count, kFloat32, kSum, (Comm)comm, (hipStream_t)stream), "ncclAllReduce");
+  const int rc = dg::comm_allreduce(buf, count, comm, (hipStream_t)stream);
+  if (rc == DGCNN_OK) dg::plan_add_allreduce(buf, count, comm, (hipStream_t)stream);
+  return rc;
 }
 
 extern "C" int dgcnn_broadcast_f32(float* buf, int64_t count, int root, void* comm, void* stream) {
   DG_REQUIRE(buf && comm && count > 0 && root >= 0 && g.lib, DGCNN_EINVAL, "dgcnn_broadcast_f32: bad args");
-  if (g_first_collective) {
-    g_first_collective = false;
+  if (quiet_first(comm)) {
     StdoutToStderr quiet;
     return check(g.Broadcast(buf, buf, (size_t)count, kFloat32, root, (Comm)comm, (hipStream_t)stream), "ncclBroadcast");
   }
@@ -150,4 +177,12 @@ extern "C" int dgcnn_comm_info(void* comm, int* nranks, int* rank, int* device) 
   rc = check(g.CommUserRank((Comm)comm, rank), "ncclCommUserRank");
   if (rc) return rc;
   return check(g.CommCuDevice((Comm)comm, device), "ncclCommCuDevice");
+}
+
+// All-reduce calls / elements issued through this library so far, replayed launch plans included (a replay issues its recorded
+// collectives from C: the host-side wrappers never see them) -- tests and bench.py count the collectives of a step with it.
+extern "C" int dgcnn_comm_counters(int64_t* allreduce_calls, int64_t* allreduce_elems) {
+  if (allreduce_calls) *allreduce_calls = g_ar_calls;
+  if (allreduce_elems) *allreduce_elems = g_ar_elems;
+  return DGCNN_OK;
 }

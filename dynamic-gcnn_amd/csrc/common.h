@@ -4,6 +4,8 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdarg.h>
+#include <tuple>
+#include <utility>
 #include "../../include/dgcnn_hip.h"
 
 namespace dg {
@@ -28,6 +30,36 @@ inline int check_launch(const char* what) {
   } while (0)
 
 static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// ---- launch plans (plan.cc) --------------------------------------------------------------------------------------------
+// Every kernel launch, memset, cross-stream wait and collective of the library goes through the four functions below.  While a
+// plan is being recorded (dgcnn_plan_begin .. dgcnn_plan_end) each of them ALSO appends itself -- kernel address, launch
+// geometry, a private copy of the argument values, the stream -- to the plan; dgcnn_plan_replay then re-issues the whole list
+// from one C loop.  The reference replays a static TF graph with sess.run (dgcnn/trainval.py:103-129); this is that, with plain
+// stream semantics (same two-stream schedule as the eager step, RCCL calls included) and ~2 us of host time per launch.
+bool plan_recording();
+void plan_add_kernel(const void* fn, dim3 g, dim3 b, size_t sh, hipStream_t st, void** argv, const size_t* sizes, int n);
+int memset_async(void* p, int value, size_t bytes, hipStream_t st);
+int stream_wait(hipStream_t waiter, hipStream_t signaller);
+
+template <class Tuple, size_t... I>
+inline void launch_tuple(const void* fn, dim3 g, dim3 b, size_t sh, hipStream_t st, Tuple& args, std::index_sequence<I...>) {
+  void* argv[] = {(void*)&std::get<I>(args)..., nullptr};
+  (void)hipLaunchKernel(fn, g, b, argv, sh, st);
+  if (plan_recording()) {
+    const size_t sizes[] = {sizeof(std::get<I>(args))..., 0};
+    plan_add_kernel(fn, g, b, sh, st, argv, sizes, (int)sizeof...(I));
+  }
+}
+
+// launch(kernel, grid, block, dynamic LDS bytes, stream, kernel arguments...): arguments are converted to the kernel's
+// parameter types exactly as a call would convert them
+template <class... KA, class... A>
+inline void launch(void (*k)(KA...), dim3 g, dim3 b, size_t sh, hipStream_t st, A&&... a) {
+  static_assert(sizeof...(KA) == sizeof...(A), "dg::launch: argument count differs from the kernel's parameter list");
+  std::tuple<KA...> args{static_cast<KA>(std::forward<A>(a))...};
+  launch_tuple(reinterpret_cast<const void*>(k), g, b, sh, st, args, std::index_sequence_for<KA...>{});
+}
 
 // Accumulation slots of every `stats` / `red` buffer (double[slots][2][F]): a producer workgroup adds its partial sums to slot
 // (writer index % slots).  Default DGCNN_STAT_SLOTS; dgcnn_set_stat_slots(n) with n >= the number of writers gives every slot a

@@ -162,8 +162,8 @@ extern "C" int dgcnn_colstats_det_f32(const float* Y, int64_t rows, int F, int64
   DG_REQUIRE(Y && stats && ws && rows > 0 && F > 0 && F <= 256 * DET_C, DGCNN_EINVAL, "dgcnn_colstats_det_f32: bad args (F <= %d)", 256 * DET_C);
   DG_REQUIRE(ws_bytes >= sizeof(double) * DET_G * 2 * (size_t)F, DGCNN_ENOSPC, "dgcnn_colstats_det_f32: workspace too small");
   double* part = reinterpret_cast<double*>(ws);
-  hipLaunchKernelGGL(colstats_det_kernel, dim3(DET_G), dim3(256), 0, ST, Y, rows, F, ld, part);
-  hipLaunchKernelGGL(det_stage2_kernel, dim3((unsigned)dg::cdiv(2 * F, 256)), dim3(256), 0, ST, part, F, stats);
+  dg::launch(colstats_det_kernel, dim3(DET_G), dim3(256), 0, ST, Y, rows, F, ld, part);
+  dg::launch(det_stage2_kernel, dim3((unsigned)dg::cdiv(2 * F, 256)), dim3(256), 0, ST, part, F, stats);
   return dg::check_launch("dgcnn_colstats_det_f32");
 }
 
@@ -176,14 +176,14 @@ extern "C" int dgcnn_bn_bwd_reduce_det_f32(const float* Y, int64_t R, int k, int
   DG_REQUIRE(!dmean || (mx_in && cnt_in), DGCNN_EINVAL, "dgcnn_bn_bwd_reduce_det_f32: the k > 1 form needs the forward's max / tie counts");
   DG_REQUIRE(ws_bytes >= sizeof(double) * DET_G * 2 * (size_t)F, DGCNN_ENOSPC, "dgcnn_bn_bwd_reduce_det_f32: workspace too small");
   double* part = reinterpret_cast<double*>(ws);
-  hipLaunchKernelGGL(bn_bwd_reduce_det_kernel, dim3(DET_G), dim3(256), 0, ST, Y, R, k, F, mean, rstd, beta, relu, dmax, lddmax,
+  dg::launch(bn_bwd_reduce_det_kernel, dim3(DET_G), dim3(256), 0, ST, Y, R, k, F, mean, rstd, beta, relu, dmax, lddmax,
                      dmean, lddmean, mx_in, ldmx, cnt_in, part);
-  hipLaunchKernelGGL(det_stage2_kernel, dim3((unsigned)dg::cdiv(2 * F, 256)), dim3(256), 0, ST, part, F, red);
+  dg::launch(det_stage2_kernel, dim3((unsigned)dg::cdiv(2 * F, 256)), dim3(256), 0, ST, part, F, red);
   return dg::check_launch("dgcnn_bn_bwd_reduce_det_f32");
 }
 
 extern "C" int dgcnn_edge_csr_sort(const int32_t* off, int32_t* rev, int64_t R, void* stream) {
   DG_REQUIRE(off && rev && R > 0, DGCNN_EINVAL, "dgcnn_edge_csr_sort: bad args");
-  hipLaunchKernelGGL(csr_sort_kernel, dim3((unsigned)dg::cdiv(R, 256)), dim3(256), 0, ST, off, rev, R);
+  dg::launch(csr_sort_kernel, dim3((unsigned)dg::cdiv(R, 256)), dim3(256), 0, ST, off, rev, R);
   return dg::check_launch("dgcnn_edge_csr_sort");
 }

@@ -579,7 +579,7 @@ int launch_pass(const EdgeP& p, hipStream_t st, const char* what) {
   do {                                                                                                                        \
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&edge_mlp_bf16_kernel<PASS, CKV, FBV>),                           \
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                                        \
-    hipLaunchKernelGGL((edge_mlp_bf16_kernel<PASS, CKV, FBV>), dim3((unsigned)g), dim3(256), sh, st, p);                      \
+    dg::launch((edge_mlp_bf16_kernel<PASS, CKV, FBV>), dim3((unsigned)g), dim3(256), sh, st, p);                      \
   } while (0)
   if (CK == 1) {
     if (FB == 1) DG_E(1, 1); else if (FB == 2) DG_E(1, 2); else DG_E(1, 4);
@@ -689,7 +689,7 @@ extern "C" int dgcnn_edge_mlp_bf16_bwd(const float* x, int64_t ldx, const int32_
   do {                                                                                                                        \
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&edge_mlp_bf16_bwd_kernel<CKV, FBV>),                             \
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                                        \
-    hipLaunchKernelGGL((edge_mlp_bf16_bwd_kernel<CKV, FBV>), dim3((unsigned)g), dim3(512), sh, st, bp);                       \
+    dg::launch((edge_mlp_bf16_bwd_kernel<CKV, FBV>), dim3((unsigned)g), dim3(512), sh, st, bp);                       \
   } while (0)
   if (CK == 1) {
     if (FB == 1) DG_B(1, 1); else if (FB == 2) DG_B(1, 2); else DG_B(1, 4);

@@ -650,11 +650,11 @@ void launch_bm(GemmP& p, hipStream_t st, bool vec, int bn) {
   const unsigned gx = p.xcd_group ? (unsigned)(dg::cdiv(p.mtiles, 8) * 8 * p.ntiles) : (unsigned)(p.mtiles * p.ntiles);
   dim3 grid(gx, 1, (unsigned)p.splits);
   if (bn == 64) {
-    if (vec) hipLaunchKernelGGL((gemm_kernel<ASRC, BSRC, EPI, BM, 64, true>), grid, dim3(NT), 0, st, p);
-    else hipLaunchKernelGGL((gemm_kernel<ASRC, BSRC, EPI, BM, 64, false>), grid, dim3(NT), 0, st, p);
+    if (vec) dg::launch((gemm_kernel<ASRC, BSRC, EPI, BM, 64, true>), grid, dim3(NT), 0, st, p);
+    else dg::launch((gemm_kernel<ASRC, BSRC, EPI, BM, 64, false>), grid, dim3(NT), 0, st, p);
   } else {
-    if (vec) hipLaunchKernelGGL((gemm_kernel<ASRC, BSRC, EPI, BM, 128, true>), grid, dim3(NT), 0, st, p);
-    else hipLaunchKernelGGL((gemm_kernel<ASRC, BSRC, EPI, BM, 128, false>), grid, dim3(NT), 0, st, p);
+    if (vec) dg::launch((gemm_kernel<ASRC, BSRC, EPI, BM, 128, true>), grid, dim3(NT), 0, st, p);
+    else dg::launch((gemm_kernel<ASRC, BSRC, EPI, BM, 128, false>), grid, dim3(NT), 0, st, p);
   }
 }
 
@@ -697,7 +697,7 @@ int launch(GemmP& p, hipStream_t st, const char* what) {
   if (rc) return rc;
   if (p.splits > 1) {
     const int64_t n = (int64_t)p.M * p.N;
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)dg::cdiv(n, 64)), dim3(64 * RL), 0, st,
+    dg::launch(reduce_partials_kernel, dim3((unsigned)dg::cdiv(n, 64)), dim3(64 * RL), 0, st,
                        p.partial, p.splits, p.M, p.N, p.C, p.ldc, p.beta);
     rc = dg::check_launch(what);
   }
@@ -757,7 +757,7 @@ int plan_splits(GemmP& p, void* ws, size_t ws_bytes, const char* what) {
 
 namespace dg {
 void launch_reduce_partials(const float* part, int splits, int M, int N, float* C, int64_t ldc, float beta, hipStream_t st) {
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)dg::cdiv((int64_t)M * N, 64)), dim3(64 * RL), 0, st, part, splits, M, N,
+  dg::launch(reduce_partials_kernel, dim3((unsigned)dg::cdiv((int64_t)M * N, 64)), dim3(64 * RL), 0, st, part, splits, M, N,
                      C, ldc, beta);
 }
 }  // namespace dg
@@ -780,7 +780,7 @@ __global__ void colmax_decode_kernel(const unsigned long long* __restrict__ keys
 
 extern "C" int dgcnn_colmax_decode_f32(const void* keys, int64_t n, float* vals, int32_t* arg, void* stream) {
   DG_REQUIRE(keys && vals && arg && n > 0, DGCNN_EINVAL, "dgcnn_colmax_decode_f32: bad args");
-  hipLaunchKernelGGL(colmax_decode_kernel, dim3((unsigned)dg::cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream,
+  dg::launch(colmax_decode_kernel, dim3((unsigned)dg::cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream,
                      (const unsigned long long*)keys, n, vals, arg);
   return dg::check_launch("dgcnn_colmax_decode_f32");
 }
@@ -813,7 +813,7 @@ extern "C" int dgcnn_gemm_f32(int transA, int transB, int M, int N, int K,
   if (!gbias && !transA && !transB && N <= 4 && K % 4 == 0 && K <= 4096 && p.avec) {
     const size_t sh = sizeof(float) * ((size_t)K * N + 8 * N);
     const unsigned g = (unsigned)dg::cap_writers(dg::cdiv(M, 4) < 2048 ? dg::cdiv(M, 4) : 2048);
-#define DG_SK_NN(NN) hipLaunchKernelGGL((skinny_nn_kernel<NN>), dim3(g), dim3(256), sh, st, A, lda, B, ldb, C, ldc, M, K, beta, stats, dg::stat_slots())
+#define DG_SK_NN(NN) dg::launch((skinny_nn_kernel<NN>), dim3(g), dim3(256), sh, st, A, lda, B, ldb, C, ldc, M, K, beta, stats, dg::stat_slots())
     if (N == 1) DG_SK_NN(1); else if (N == 2) DG_SK_NN(2); else if (N == 3) DG_SK_NN(3); else DG_SK_NN(4);
 #undef DG_SK_NN
     return dg::check_launch("dgcnn_gemm_f32(NN skinny)");
@@ -823,10 +823,10 @@ extern "C" int dgcnn_gemm_f32(int transA, int transB, int M, int N, int K,
     if (nb > 512) nb = 512;
     if (ws_bytes >= (size_t)nb * M * N * sizeof(float)) {
       float* part = reinterpret_cast<float*>(ws);
-#define DG_SK_TN(NN) hipLaunchKernelGGL((skinny_tn_kernel<NN>), dim3((unsigned)nb), dim3(256), 0, st, A, lda, B, ldb, M, K, part)
+#define DG_SK_TN(NN) dg::launch((skinny_tn_kernel<NN>), dim3((unsigned)nb), dim3(256), 0, st, A, lda, B, ldb, M, K, part)
       if (N == 1) DG_SK_TN(1); else if (N == 2) DG_SK_TN(2); else if (N == 3) DG_SK_TN(3); else DG_SK_TN(4);
 #undef DG_SK_TN
-      hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)dg::cdiv((int64_t)M * N, 64)), dim3(64 * RL), 0, st, part,
+      dg::launch(reduce_partials_kernel, dim3((unsigned)dg::cdiv((int64_t)M * N, 64)), dim3(64 * RL), 0, st, part,
                          (int)nb, M, N, C, ldc, beta);
       return dg::check_launch("dgcnn_gemm_f32(TN skinny)");
     }
@@ -834,7 +834,7 @@ extern "C" int dgcnn_gemm_f32(int transA, int transB, int M, int N, int K,
   if (!gbias && !stats && transB && K <= 4 && N % 4 == 0 && ldc % 4 == 0 && aligned16(C)) {
     const int64_t items = (int64_t)M * (N / 4);
     const unsigned g = (unsigned)(dg::cdiv(items, 256) < 8192 ? dg::cdiv(items, 256) : 8192);
-#define DG_SK_NT(KK) hipLaunchKernelGGL((skinny_nt_kernel<KK>), dim3(g), dim3(256), 0, st, A, lda, B, ldb, C, ldc, M, N, beta)
+#define DG_SK_NT(KK) dg::launch((skinny_nt_kernel<KK>), dim3(g), dim3(256), 0, st, A, lda, B, ldb, C, ldc, M, N, beta)
     if (K == 1) DG_SK_NT(1); else if (K == 2) DG_SK_NT(2); else if (K == 3) DG_SK_NT(3); else DG_SK_NT(4);
 #undef DG_SK_NT
     return dg::check_launch("dgcnn_gemm_f32(NT skinny)");
@@ -894,12 +894,12 @@ extern "C" int dgcnn_edge_mlp_wgrad_f32(const float* x, int64_t ldx, const int32
     const size_t need = (size_t)nblk * 2 * C * F * sizeof(float);
     DG_REQUIRE(ws && ws_bytes >= need, DGCNN_ENOSPC, "dgcnn_edge_mlp_wgrad_f32: workspace too small (%zu < %zu)", ws_bytes, need);
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL((edge_wgrad_smallc_kernel<4>), dim3((unsigned)nblk), dim3(256), 0, st, x, ldx, idx, dY, Me, N, k,
+    dg::launch((edge_wgrad_smallc_kernel<4>), dim3((unsigned)nblk), dim3(256), 0, st, x, ldx, idx, dY, Me, N, k,
                        C, F, chunk, 0, reinterpret_cast<float*>(ws));
     int rc0 = dg::check_launch("dgcnn_edge_mlp_wgrad_f32(small C)");
     if (rc0) return rc0;
     const int64_t n = (int64_t)2 * C * F;
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)dg::cdiv(n, 64)), dim3(64 * RL), 0, st,
+    dg::launch(reduce_partials_kernel, dim3((unsigned)dg::cdiv(n, 64)), dim3(64 * RL), 0, st,
                        reinterpret_cast<const float*>(ws), nblk, 2 * C, F, dW0, (int64_t)F, beta);
     return dg::check_launch("dgcnn_edge_mlp_wgrad_f32(small C reduce)");
   }
@@ -964,12 +964,12 @@ extern "C" int dgcnn_edge_nbr_wgrad_f32(const float* x, int64_t ldx, const int32
     const size_t need = (size_t)nblk * C * F * sizeof(float);
     DG_REQUIRE(ws && ws_bytes >= need, DGCNN_ENOSPC, "dgcnn_edge_nbr_wgrad_f32: workspace too small (%zu < %zu)", ws_bytes, need);
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL((edge_wgrad_smallc_kernel<4>), dim3((unsigned)nblk), dim3(256), 0, st, x, ldx, idx, dY, Me, N, k,
+    dg::launch((edge_wgrad_smallc_kernel<4>), dim3((unsigned)nblk), dim3(256), 0, st, x, ldx, idx, dY, Me, N, k,
                        C, F, chunk, 1, reinterpret_cast<float*>(ws));
     int rc0 = dg::check_launch("dgcnn_edge_nbr_wgrad_f32(small C)");
     if (rc0) return rc0;
     const int64_t n = (int64_t)C * F;
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)dg::cdiv(n, 64)), dim3(64 * RL), 0, st,
+    dg::launch(reduce_partials_kernel, dim3((unsigned)dg::cdiv(n, 64)), dim3(64 * RL), 0, st,
                        reinterpret_cast<const float*>(ws), nblk, C, F, dWb, (int64_t)F, beta);
     return dg::check_launch("dgcnn_edge_nbr_wgrad_f32(small C reduce)");
   }

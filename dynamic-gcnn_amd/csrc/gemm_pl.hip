@@ -401,10 +401,10 @@ extern "C" int dgcnn_split_planes_f32(const float* src, int64_t row_stride, int6
     int64_t gx = rows_alloc / 64;
     if (gx * gy > 8192) gx = dg::cdiv(8192, gy);
     dim3 grid((unsigned)gx, (unsigned)gy);
-    hipLaunchKernelGGL((split_rows_kernel<DGCNN_PLANES_F16X2>), grid, dim3(256), 0, ST, src, row_stride, rows, cols, (char*)dst, plane_stride, rows_alloc, scale_dev);
+    dg::launch((split_rows_kernel<DGCNN_PLANES_F16X2>), grid, dim3(256), 0, ST, src, row_stride, rows, cols, (char*)dst, plane_stride, rows_alloc, scale_dev);
   } else {
     const unsigned g = (unsigned)dg::cdiv((int64_t)noct * rows_alloc, 256);
-    hipLaunchKernelGGL((split_strided_kernel<DGCNN_PLANES_F16X2>), dim3(g), dim3(256), 0, ST, src, row_stride, col_stride, rows, cols, (char*)dst, plane_stride, rows_alloc, scale_dev);
+    dg::launch((split_strided_kernel<DGCNN_PLANES_F16X2>), dim3(g), dim3(256), 0, ST, src, row_stride, col_stride, rows, cols, (char*)dst, plane_stride, rows_alloc, scale_dev);
   }
   return dg::check_launch("dgcnn_split_planes_f32");
 }
@@ -414,11 +414,11 @@ extern "C" int dgcnn_planes_scale_f32(const float* src, int64_t ld, int64_t rows
                                       void* ws, void* stream) {
   DG_REQUIRE(src && scale_dev && ws && rows > 0 && cols > 0 && cols % 4 == 0 && ld % 4 == 0 && aligned16p(src), DGCNN_EINVAL,
              "dgcnn_planes_scale_f32: bad args (float4-loadable view needed)");
-  (void)hipMemsetAsync(ws, 0, 4, ST);
+  (void)dg::memset_async(ws, 0, 4, ST);
   const int64_t n4 = rows * (cols / 4);
   const unsigned g = (unsigned)(dg::cdiv(n4, 256 * 8) < 2048 ? dg::cdiv(n4, 256 * 8) : 2048);
-  hipLaunchKernelGGL(absmax_kernel, dim3(g ? g : 1), dim3(256), 0, ST, src, ld, rows, cols, (unsigned*)ws);
-  hipLaunchKernelGGL(scale_from_max_kernel, dim3(1), dim3(1), 0, ST, (const unsigned*)ws, bound_mul, scale_dev);
+  dg::launch(absmax_kernel, dim3(g ? g : 1), dim3(256), 0, ST, src, ld, rows, cols, (unsigned*)ws);
+  dg::launch(scale_from_max_kernel, dim3(1), dim3(1), 0, ST, (const unsigned*)ws, bound_mul, scale_dev);
   return dg::check_launch("dgcnn_planes_scale_f32");
 }
 
@@ -491,7 +491,7 @@ extern "C" int dgcnn_gemm_planes_f32(int form, int fmt, int M, int N, int K,
   dim3 grid(gx, 1, 1);
   if (p.zmajor) grid = dim3((unsigned)(dg::cdiv(p.splits, 8) * 8 * p.mtiles * p.ntiles), 1, 1);
   // 32-k slabs x 3 stages (48 KB each): up to 96 KB of DMA in flight per CU
-#define DG_PL(FORM, FMT) hipLaunchKernelGGL((gemm_pl_kernel<FORM, FMT, 32, 3>), grid, dim3(768), 0, ST, q)
+#define DG_PL(FORM, FMT) dg::launch((gemm_pl_kernel<FORM, FMT, 32, 3>), grid, dim3(768), 0, ST, q)
   if (form == DGCNN_PL_KC) DG_PL(PL_KC, DGCNN_PLANES_F16X2);
   else DG_PL(PL_TR, DGCNN_PLANES_F16X2);
 #undef DG_PL

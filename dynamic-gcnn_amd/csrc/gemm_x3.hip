@@ -604,24 +604,24 @@ int g_arith = -1;      // -1: not resolved yet; 0 native fp32 MFMA; 6 / 9 partia
 template <int AKIND, int BKIND>
 void launch_kind(GemmP& p, hipStream_t st, int bn, int np, dim3 grid) {
   if (p.bm == 256) {
-    if (np == 9) hipLaunchKernelGGL((gemm_x3w2_kernel<AKIND, BKIND, 9>), grid, dim3(768), 0, st, p);
-    else if (np == 1) hipLaunchKernelGGL((gemm_x3w2_kernel<AKIND, BKIND, 1>), grid, dim3(768), 0, st, p);
-    else hipLaunchKernelGGL((gemm_x3w2_kernel<AKIND, BKIND, 6>), grid, dim3(768), 0, st, p);
+    if (np == 9) dg::launch((gemm_x3w2_kernel<AKIND, BKIND, 9>), grid, dim3(768), 0, st, p);
+    else if (np == 1) dg::launch((gemm_x3w2_kernel<AKIND, BKIND, 1>), grid, dim3(768), 0, st, p);
+    else dg::launch((gemm_x3w2_kernel<AKIND, BKIND, 6>), grid, dim3(768), 0, st, p);
     return;
   }
   if (p.bm == 64) {          // short reductions over many rows (conv1, the point-level [U|V] product and their data gradients)
-    if (bn == 64) hipLaunchKernelGGL((gemm_x3_kernel<AKIND, BKIND, 64, 6, 64>), grid, dim3(NT), 0, st, p);
-    else hipLaunchKernelGGL((gemm_x3_kernel<AKIND, BKIND, 128, 6, 64>), grid, dim3(NT), 0, st, p);
+    if (bn == 64) dg::launch((gemm_x3_kernel<AKIND, BKIND, 64, 6, 64>), grid, dim3(NT), 0, st, p);
+    else dg::launch((gemm_x3_kernel<AKIND, BKIND, 128, 6, 64>), grid, dim3(NT), 0, st, p);
     return;
   }
   if (bn == 64) {
-    if (np == 9) hipLaunchKernelGGL((gemm_x3_kernel<AKIND, BKIND, 64, 9>), grid, dim3(NT), 0, st, p);
-    else if (np == 1) hipLaunchKernelGGL((gemm_x3_kernel<AKIND, BKIND, 64, 1>), grid, dim3(NT), 0, st, p);
-    else hipLaunchKernelGGL((gemm_x3_kernel<AKIND, BKIND, 64, 6>), grid, dim3(NT), 0, st, p);
+    if (np == 9) dg::launch((gemm_x3_kernel<AKIND, BKIND, 64, 9>), grid, dim3(NT), 0, st, p);
+    else if (np == 1) dg::launch((gemm_x3_kernel<AKIND, BKIND, 64, 1>), grid, dim3(NT), 0, st, p);
+    else dg::launch((gemm_x3_kernel<AKIND, BKIND, 64, 6>), grid, dim3(NT), 0, st, p);
   } else {
-    if (np == 9) hipLaunchKernelGGL((gemm_x3_kernel<AKIND, BKIND, 128, 9>), grid, dim3(NT), 0, st, p);
-    else if (np == 1) hipLaunchKernelGGL((gemm_x3_kernel<AKIND, BKIND, 128, 1>), grid, dim3(NT), 0, st, p);
-    else hipLaunchKernelGGL((gemm_x3_kernel<AKIND, BKIND, 128, 6>), grid, dim3(NT), 0, st, p);
+    if (np == 9) dg::launch((gemm_x3_kernel<AKIND, BKIND, 128, 9>), grid, dim3(NT), 0, st, p);
+    else if (np == 1) dg::launch((gemm_x3_kernel<AKIND, BKIND, 128, 1>), grid, dim3(NT), 0, st, p);
+    else dg::launch((gemm_x3_kernel<AKIND, BKIND, 128, 6>), grid, dim3(NT), 0, st, p);
   }
 }
 

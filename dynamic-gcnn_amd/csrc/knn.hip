@@ -762,18 +762,18 @@ void launch_knn(const float* x, const float* sq, int B, int N, int C, int64_t ld
   if constexpr (CP == 64) {                      // large feature-space graphs: bf16 matrix pipe + exact re-check of the survivors
     const int m = knn_bf16f_mode();
     if (!knn_force_valu() && vec_ok && C % 4 == 0 && C > 16 && (m == 1 || (m == 2 && N >= 8192))) {
-      hipLaunchKernelGGL((knn_bf16f_kernel<KC>), grid, dim3(256), 0, st, x, sq, N, C, ldx, k, idx);
+      dg::launch((knn_bf16f_kernel<KC>), grid, dim3(256), 0, st, x, sq, N, C, ldx, k, idx);
       return;
     }
   }
   if constexpr (CP >= 16 && CP <= 64) {
     if (!knn_force_valu()) {
-      if (vec_ok && C % 4 == 0) hipLaunchKernelGGL((knn_mfma_kernel<CP, KC, true>), grid, dim3(256), 0, st, x, sq, N, C, ldx, k, idx);
-      else hipLaunchKernelGGL((knn_mfma_kernel<CP, KC, false>), grid, dim3(256), 0, st, x, sq, N, C, ldx, k, idx);
+      if (vec_ok && C % 4 == 0) dg::launch((knn_mfma_kernel<CP, KC, true>), grid, dim3(256), 0, st, x, sq, N, C, ldx, k, idx);
+      else dg::launch((knn_mfma_kernel<CP, KC, false>), grid, dim3(256), 0, st, x, sq, N, C, ldx, k, idx);
       return;
     }
   }
-  hipLaunchKernelGGL((knn_kernel<CP, KC>), grid, dim3(256), 0, st, x, sq, N, C, ldx, k, vec_ok, idx);
+  dg::launch((knn_kernel<CP, KC>), grid, dim3(256), 0, st, x, sq, N, C, ldx, k, vec_ok, idx);
 }
 
 template <int CP>
@@ -833,7 +833,7 @@ extern "C" int dgcnn_knn_f32(const float* x, int B, int N, int C, int64_t ldx, i
   // raw coordinates (C <= 4) when the caller provided the scratch: exact search over a uniform cell grid (knn_grid.hip)
   const bool grid_ws = dg::knn_grid_applicable(C, k) && !knn_force_valu() &&
                        ws_bytes >= knn_sq_bytes(B, N) + dg::knn_grid_workspace_bytes(B, N);
-  hipLaunchKernelGGL(sqnorm_kernel, dim3((unsigned)dg::cdiv(rows, SQ_ROWS)), dim3(256), sizeof(float) * SQ_ROWS * (C + 1), st, x,
+  dg::launch(sqnorm_kernel, dim3((unsigned)dg::cdiv(rows, SQ_ROWS)), dim3(256), sizeof(float) * SQ_ROWS * (C + 1), st, x,
                      ldx, rows, C, sq_ws);
   if (grid_ws && N >= dg::knn_grid_min_n())
     return dg::launch_knn_grid(x, sq_ws, B, N, C, ldx, k, idx, reinterpret_cast<char*>(ws) + knn_sq_bytes(B, N), st);

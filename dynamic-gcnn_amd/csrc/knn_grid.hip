@@ -425,7 +425,7 @@ int launch_knn_grid(const float* x, const float* sq, int B, int N, int C, int64_
   // pairs they save.  G <= GMAX = 16: clouds of 65536 points stay at 16 points per cell.
   int G = (int)floorf(cbrtf((float)N / (0.1f * (float)k)));
   G = G < 1 ? 1 : (G > GMAX ? GMAX : G);
-  hipLaunchKernelGGL(knn_grid_build_kernel, dim3((unsigned)B), dim3(1024), 0, st, x, ldx, sq, N, C, G, ps, s4, order, cell_start, info);
+  dg::launch(knn_grid_build_kernel, dim3((unsigned)B), dim3(1024), 0, st, x, ldx, sq, N, C, G, ps, s4, order, cell_start, info);
   dim3 grid((unsigned)cdiv(N, 64 * QW), (unsigned)B);
   const size_t park = (size_t)2 * QW * PARK * 64 * 4;
   const size_t G3 = (size_t)G * G * G;
@@ -436,10 +436,10 @@ int launch_knn_grid(const float* x, const float* sq, int B, int N, int C, int64_
     if (in_lds) {                                                                                                                 \
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&knn_grid_query_kernel<KC, C4, true>),                             \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                                          \
-      hipLaunchKernelGGL((knn_grid_query_kernel<KC, C4, true>), grid, dim3(64 * QW), park + cloud + 16, st, ps, s4, order,        \
+      dg::launch((knn_grid_query_kernel<KC, C4, true>), grid, dim3(64 * QW), park + cloud + 16, st, ps, s4, order,        \
                          cell_start, info, N, k, idx);                                                                            \
     } else {                                                                                                                      \
-      hipLaunchKernelGGL((knn_grid_query_kernel<KC, C4, false>), grid, dim3(64 * QW), park, st, ps, s4, order, cell_start, info,  \
+      dg::launch((knn_grid_query_kernel<KC, C4, false>), grid, dim3(64 * QW), park, st, ps, s4, order, cell_start, info,  \
                          N, k, idx);                                                                                              \
     }                                                                                                                             \
   } while (0)

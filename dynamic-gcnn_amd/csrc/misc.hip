@@ -443,6 +443,16 @@ __global__ void copy2d_kernel(const float* __restrict__ src, int64_t lds, float*
   }
 }
 
+// tf.tile of the per-cloud global feature over the points of its cloud (model.py:80-81): dst[g * rows + i][f] = src[g][f]
+__global__ void tile_rows_kernel(const float* __restrict__ src, int64_t lds, float* __restrict__ dst, int64_t ldd,
+                                 int64_t R, int rows, int F) {
+  GRID_STRIDE(i, R * F) {
+    const int64_t r = i / F;
+    const int f = (int)(i % F);
+    dst[r * ldd + f] = src[(r / rows) * lds + f];
+  }
+}
+
 __global__ __launch_bounds__(256) void softmax_xent_kernel(const float* __restrict__ logits,
                                                            const int32_t* __restrict__ labels,
                                                            const float* __restrict__ weight, int64_t rows, int ncls,
@@ -510,7 +520,7 @@ extern "C" int dgcnn_edge_gather_f32(const float* x, int64_t ldx, const int32_t*
                                      float* E, void* stream) {
   DG_REQUIRE(x && idx && E && B > 0 && N > 0 && C > 0 && k > 0, DGCNN_EINVAL, "dgcnn_edge_gather_f32: bad args");
   const int64_t total = (int64_t)B * N * k * 2 * C;
-  hipLaunchKernelGGL(edge_gather_kernel, dim3(grid1d(total)), dim3(256), 0, ST, x, ldx, idx, N, C, k, total, E);
+  dg::launch(edge_gather_kernel, dim3(grid1d(total)), dim3(256), 0, ST, x, ldx, idx, N, C, k, total, E);
   return dg::check_launch("dgcnn_edge_gather_f32");
 }
 
@@ -518,7 +528,7 @@ extern "C" int dgcnn_edge_gather_bwd_f32(const float* dE, const int32_t* idx, in
                                          float* dx, int64_t lddx, void* stream) {
   DG_REQUIRE(dE && idx && dx && B > 0 && N > 0 && C > 0 && k > 0, DGCNN_EINVAL, "dgcnn_edge_gather_bwd_f32: bad args");
   const int64_t total = (int64_t)B * N * k * C;
-  hipLaunchKernelGGL(edge_gather_bwd_kernel, dim3(grid1d(total)), dim3(256), 0, ST, dE, idx, N, C, k, total, dx, lddx);
+  dg::launch(edge_gather_bwd_kernel, dim3(grid1d(total)), dim3(256), 0, ST, dE, idx, N, C, k, total, dx, lddx);
   return dg::check_launch("dgcnn_edge_gather_bwd_f32");
 }
 
@@ -534,14 +544,14 @@ extern "C" int dgcnn_edge_csr_build(const int32_t* idx, int B, int N, int k, int
     const int T = (int)dg::cdiv(N, G);
     if (T <= 12288) {     // <= 52 KB of dynamic LDS
       const size_t sh = sizeof(int) * ((size_t)T + 1024 + 1);
-      hipLaunchKernelGGL(csr_cloud_kernel, dim3((unsigned)dg::cdiv(N, T), (unsigned)B), dim3(1024), sh, ST, idx, N, k, T, off, rev);
+      dg::launch(csr_cloud_kernel, dim3((unsigned)dg::cdiv(N, T), (unsigned)B), dim3(1024), sh, ST, idx, N, k, T, off, rev);
       return dg::check_launch("dgcnn_edge_csr_build");
     }
   }
-  (void)hipMemsetAsync(cnt_ws, 0, sizeof(int32_t) * 2 * (size_t)B * N, ST);      // [counts | cursors]
-  hipLaunchKernelGGL(csr_count_kernel, dim3(grid1d(Me)), dim3(256), 0, ST, idx, N, k, Me, cnt_ws);
-  hipLaunchKernelGGL(csr_scan_kernel, dim3((unsigned)B), dim3(1024), 0, ST, cnt_ws, N, k, off);
-  hipLaunchKernelGGL(csr_fill_kernel, dim3(grid1d(Me)), dim3(256), 0, ST, idx, N, k, Me, off, cnt_ws + (size_t)B * N, rev);
+  (void)dg::memset_async(cnt_ws, 0, sizeof(int32_t) * 2 * (size_t)B * N, ST);      // [counts | cursors]
+  dg::launch(csr_count_kernel, dim3(grid1d(Me)), dim3(256), 0, ST, idx, N, k, Me, cnt_ws);
+  dg::launch(csr_scan_kernel, dim3((unsigned)B), dim3(1024), 0, ST, cnt_ws, N, k, off);
+  dg::launch(csr_fill_kernel, dim3(grid1d(Me)), dim3(256), 0, ST, idx, N, k, Me, off, cnt_ws + (size_t)B * N, rev);
   return dg::check_launch("dgcnn_edge_csr_build");
 }
 
@@ -551,7 +561,7 @@ extern "C" int dgcnn_edge_gather_sum_f32(const float* dY, const int32_t* off, co
   DG_REQUIRE(lds >= F && lds % 4 == 0 && (reinterpret_cast<uintptr_t>(S) & 15) == 0, DGCNN_EINVAL,
              "dgcnn_edge_gather_sum_f32: S must be 16-byte aligned with lds %% 4 == 0");
   unsigned g = grid1d(R * (F / 4));
-  hipLaunchKernelGGL(csr_gather_sum_kernel, dim3(g), dim3(256), 0, ST, dY, off, rev, R, F, S, lds);
+  dg::launch(csr_gather_sum_kernel, dim3(g), dim3(256), 0, ST, dY, off, rev, R, F, S, lds);
   return dg::check_launch("dgcnn_edge_gather_sum_f32");
 }
 
@@ -561,7 +571,7 @@ extern "C" int dgcnn_edge_gather_sum_bf16(const void* dY, const int32_t* off, co
   DG_REQUIRE(F % 4 == 0 && (reinterpret_cast<uintptr_t>(dY) & 7) == 0, DGCNN_EUNSUP, "dgcnn_edge_gather_sum_bf16: F %% 4 == 0, dY 8-byte aligned");
   DG_REQUIRE(lds >= F && lds % 4 == 0 && (reinterpret_cast<uintptr_t>(S) & 15) == 0, DGCNN_EINVAL,
              "dgcnn_edge_gather_sum_bf16: S must be 16-byte aligned with lds %% 4 == 0");
-  hipLaunchKernelGGL(csr_gather_sum_bf16_kernel, dim3(grid1d(R * (F / 4))), dim3(256), 0, ST, reinterpret_cast<const uint16_t*>(dY), off,
+  dg::launch(csr_gather_sum_bf16_kernel, dim3(grid1d(R * (F / 4))), dim3(256), 0, ST, reinterpret_cast<const uint16_t*>(dY), off,
                      rev, R, F, S, lds);
   return dg::check_launch("dgcnn_edge_gather_sum_bf16");
 }
@@ -584,7 +594,7 @@ extern "C" int dgcnn_edge_gather_add_f32(const float* V, int64_t ldv, const floa
   int64_t g = dg::cdiv(passes_x, trips);
   g = dg::cap_writers(g * 8) / 8;                                         // (reproducible configuration: one writer per slot)
   if (g < 1) g = 1;
-  hipLaunchKernelGGL(edge_gather_add_kernel, dim3((unsigned)g * 8), dim3(256), 0, ST, V, ldv, U, ldu, idx, (unsigned)pts,
+  dg::launch(edge_gather_add_kernel, dim3((unsigned)g * 8), dim3(256), 0, ST, V, ldv, U, ldu, idx, (unsigned)pts,
                      (unsigned)N, (unsigned)k, F, Y, stats, dg::stat_slots());
   return dg::check_launch("dgcnn_edge_gather_add_f32");
 }
@@ -599,26 +609,26 @@ __global__ void round_bf16_kernel(const float* __restrict__ src, float* __restri
 
 extern "C" int dgcnn_round_bf16_f32(const float* src, float* dst, int64_t n, void* stream) {
   DG_REQUIRE(src && dst && n > 0, DGCNN_EINVAL, "dgcnn_round_bf16_f32: bad args");
-  hipLaunchKernelGGL(round_bf16_kernel, dim3(grid1d(n)), dim3(256), 0, ST, src, dst, n);
+  dg::launch(round_bf16_kernel, dim3(grid1d(n)), dim3(256), 0, ST, src, dst, n);
   return dg::check_launch("dgcnn_round_bf16_f32");
 }
 
 extern "C" int dgcnn_edge_weight_split_f32(const float* W0, int C, int F, float* Wcat, void* stream) {
   DG_REQUIRE(W0 && Wcat && C > 0 && F > 0, DGCNN_EINVAL, "dgcnn_edge_weight_split_f32: bad args");
-  hipLaunchKernelGGL(edge_weight_split_kernel, dim3(grid1d((int64_t)C * F)), dim3(256), 0, ST, W0, C, F, Wcat);
+  dg::launch(edge_weight_split_kernel, dim3(grid1d((int64_t)C * F)), dim3(256), 0, ST, W0, C, F, Wcat);
   return dg::check_launch("dgcnn_edge_weight_split_f32");
 }
 
 extern "C" int dgcnn_edge_wgrad_combine_f32(const float* dWcat, int C, int F, float* dW0, void* stream) {
   DG_REQUIRE(dWcat && dW0 && C > 0 && F > 0, DGCNN_EINVAL, "dgcnn_edge_wgrad_combine_f32: bad args");
-  hipLaunchKernelGGL(edge_wgrad_combine_kernel, dim3(grid1d((int64_t)C * F)), dim3(256), 0, ST, dWcat, C, F, dW0);
+  dg::launch(edge_wgrad_combine_kernel, dim3(grid1d((int64_t)C * F)), dim3(256), 0, ST, dWcat, C, F, dW0);
   return dg::check_launch("dgcnn_edge_wgrad_combine_f32");
 }
 
 extern "C" int dgcnn_global_max_f32(const float* x, int64_t ldx, int B, int N, int F, float* out, int32_t* arg,
                                     void* stream) {
   DG_REQUIRE(x && out && B > 0 && N > 0 && F > 0, DGCNN_EINVAL, "dgcnn_global_max_f32: bad args");
-  hipLaunchKernelGGL(global_max_kernel, dim3((unsigned)dg::cdiv(F, 64), (unsigned)B), dim3(64 * RG), 0, ST, x, ldx, N, F,
+  dg::launch(global_max_kernel, dim3((unsigned)dg::cdiv(F, 64), (unsigned)B), dim3(64 * RG), 0, ST, x, ldx, N, F,
                      out, arg);
   return dg::check_launch("dgcnn_global_max_f32");
 }
@@ -627,49 +637,57 @@ extern "C" int dgcnn_global_max_bwd_f32(const float* dout, const int32_t* arg, i
                                         int64_t lddx, void* stream) {
   DG_REQUIRE(dout && arg && dx && B > 0 && N > 0 && F > 0, DGCNN_EINVAL, "dgcnn_global_max_bwd_f32: bad args");
   const int64_t total = (int64_t)B * F;
-  hipLaunchKernelGGL(global_max_bwd_kernel, dim3(grid1d(total)), dim3(256), 0, ST, dout, arg, N, F, total, dx, lddx);
+  dg::launch(global_max_bwd_kernel, dim3(grid1d(total)), dim3(256), 0, ST, dout, arg, N, F, total, dx, lddx);
   return dg::check_launch("dgcnn_global_max_bwd_f32");
 }
 
 extern "C" int dgcnn_group_colsum_f32(const float* x, int64_t ldx, int G, int rows_per_group, int F, float* out,
                                       void* stream) {
   DG_REQUIRE(x && out && G > 0 && rows_per_group > 0 && F > 0, DGCNN_EINVAL, "dgcnn_group_colsum_f32: bad args");
-  hipLaunchKernelGGL(group_colsum_kernel, dim3((unsigned)dg::cdiv(F, 64), (unsigned)G), dim3(64 * RG), 0, ST, x, ldx,
+  dg::launch(group_colsum_kernel, dim3((unsigned)dg::cdiv(F, 64), (unsigned)G), dim3(64 * RG), 0, ST, x, ldx,
                      rows_per_group, F, out);
   return dg::check_launch("dgcnn_group_colsum_f32");
 }
 
+extern "C" int dgcnn_tile_rows_f32(const float* src, int64_t lds, int G, int rows_per_group, int F, float* dst, int64_t ldd,
+                                   void* stream) {
+  DG_REQUIRE(src && dst && G > 0 && rows_per_group > 0 && F > 0, DGCNN_EINVAL, "dgcnn_tile_rows_f32: bad args");
+  const int64_t R = (int64_t)G * rows_per_group;
+  dg::launch(tile_rows_kernel, dim3(grid1d(R * F)), dim3(256), 0, ST, src, lds, dst, ldd, R, rows_per_group, F);
+  return dg::check_launch("dgcnn_tile_rows_f32");
+}
+
 extern "C" int dgcnn_dropout_f32(const float* x, float* y, int64_t n, float keep, uint64_t seed, void* stream) {
   DG_REQUIRE(x && y && n > 0 && keep > 0.f && keep <= 1.f, DGCNN_EINVAL, "dgcnn_dropout_f32: bad args");
-  hipLaunchKernelGGL(dropout_kernel, dim3(grid1d(n)), dim3(256), 0, ST, x, y, n, keep, seed);
+  dg::launch(dropout_kernel, dim3(grid1d(n)), dim3(256), 0, ST, x, y, n, keep, seed);
   return dg::check_launch("dgcnn_dropout_f32");
 }
 
 extern "C" int dgcnn_dropout_dev_f32(const float* x, float* y, int64_t n, float keep, const uint64_t* seed_dev,
                                      void* stream) {
   DG_REQUIRE(x && y && seed_dev && n > 0 && keep > 0.f && keep <= 1.f, DGCNN_EINVAL, "dgcnn_dropout_dev_f32: bad args");
-  hipLaunchKernelGGL(dropout_dev_kernel, dim3(grid1d(n)), dim3(256), 0, ST, x, y, n, keep, seed_dev);
+  dg::launch(dropout_dev_kernel, dim3(grid1d(n)), dim3(256), 0, ST, x, y, n, keep, seed_dev);
   return dg::check_launch("dgcnn_dropout_dev_f32");
 }
 
 extern "C" int dgcnn_add_relu_f32(const float* a, int64_t lda, const float* b, int64_t ldb, int64_t R, int F,
                                   float* out, int64_t ldo, void* stream) {
   DG_REQUIRE(a && b && out && R > 0 && F > 0, DGCNN_EINVAL, "dgcnn_add_relu_f32: bad args");
-  hipLaunchKernelGGL(add_relu_kernel, dim3(grid1d(R * F)), dim3(256), 0, ST, a, lda, b, ldb, R, F, out, ldo);
+  dg::launch(add_relu_kernel, dim3(grid1d(R * F)), dim3(256), 0, ST, a, lda, b, ldb, R, F, out, ldo);
   return dg::check_launch("dgcnn_add_relu_f32");
 }
 
 extern "C" int dgcnn_relu_bwd_f32(const float* dout, int64_t lddo, const float* out, int64_t ldo, int64_t R, int F,
                                   float* d, int64_t ldd, void* stream) {
   DG_REQUIRE(dout && out && d && R > 0 && F > 0, DGCNN_EINVAL, "dgcnn_relu_bwd_f32: bad args");
-  hipLaunchKernelGGL(relu_bwd_kernel, dim3(grid1d(R * F)), dim3(256), 0, ST, dout, lddo, out, ldo, R, F, d, ldd);
+  dg::launch(relu_bwd_kernel, dim3(grid1d(R * F)), dim3(256), 0, ST, dout, lddo, out, ldo, R, F, d, ldd);
   return dg::check_launch("dgcnn_relu_bwd_f32");
 }
 
 extern "C" int dgcnn_copy2d_f32(const float* src, int64_t lds, float* dst, int64_t ldd, int64_t R, int F,
                                 int accumulate, void* stream) {
   DG_REQUIRE(src && dst && R > 0 && F > 0, DGCNN_EINVAL, "dgcnn_copy2d_f32: bad args");
-  hipLaunchKernelGGL(copy2d_kernel, dim3(grid1d(R * F)), dim3(256), 0, ST, src, lds, dst, ldd, R, F, accumulate);
+  dg::launch(copy2d_kernel, dim3(grid1d(R * F)), dim3(256), 0, ST, src, lds, dst, ldd, R, F, accumulate);
   return dg::check_launch("dgcnn_copy2d_f32");
 }
 
@@ -680,20 +698,20 @@ extern "C" int dgcnn_softmax_xent_f32(const float* logits, const int32_t* labels
   DG_REQUIRE(!dlogits || labels, DGCNN_EINVAL, "dgcnn_softmax_xent_f32: dlogits needs labels");
   unsigned g = grid1d(rows);
   if (g > 1024) g = 1024;
-  hipLaunchKernelGGL(softmax_xent_kernel, dim3(g), dim3(256), 0, ST, logits, labels, weight, rows, ncls, softmax,
+  dg::launch(softmax_xent_kernel, dim3(g), dim3(256), 0, ST, logits, labels, weight, rows, ncls, softmax,
                      dlogits, scal);
   return dg::check_launch("dgcnn_softmax_xent_f32");
 }
 
 extern "C" int dgcnn_axpby_f32(const float* x, float a, float* y, float b, int64_t n, void* stream) {
   DG_REQUIRE(x && y && n > 0, DGCNN_EINVAL, "dgcnn_axpby_f32: bad args");
-  hipLaunchKernelGGL(axpby_kernel, dim3(grid1d(n)), dim3(256), 0, ST, x, a, y, b, n);
+  dg::launch(axpby_kernel, dim3(grid1d(n)), dim3(256), 0, ST, x, a, y, b, n);
   return dg::check_launch("dgcnn_axpby_f32");
 }
 
 extern "C" int dgcnn_adam_f32(float* param, const float* grad, float* m, float* v, int64_t n, float lr_t, float b1,
                               float b2, float eps, void* stream) {
   DG_REQUIRE(param && grad && m && v && n > 0, DGCNN_EINVAL, "dgcnn_adam_f32: bad args");
-  hipLaunchKernelGGL(adam_kernel, dim3(grid1d(n)), dim3(256), 0, ST, param, grad, m, v, n, lr_t, b1, b2, eps);
+  dg::launch(adam_kernel, dim3(grid1d(n)), dim3(256), 0, ST, param, grad, m, v, n, lr_t, b1, b2, eps);
   return dg::check_launch("dgcnn_adam_f32");
 }

@@ -297,10 +297,10 @@ inline dim3 plane_grid(int64_t rows_alloc, int F) {
 extern "C" int dgcnn_param_scales_f32(const float* params, int64_t n, double rows_max, float act_mul, float* scales,
                                       void* ws, void* stream) {
   DG_REQUIRE(params && scales && ws && n > 0 && rows_max >= 1.0 && act_mul > 0.f, DGCNN_EINVAL, "dgcnn_param_scales_f32: bad args");
-  (void)hipMemsetAsync(ws, 0, 4, ST);
+  (void)dg::memset_async(ws, 0, 4, ST);
   const unsigned g = (unsigned)(dg::cdiv(n, 256 * 16) < 1024 ? dg::cdiv(n, 256 * 16) : 1024);
-  hipLaunchKernelGGL(absmax_flat_kernel, dim3(g ? g : 1), dim3(256), 0, ST, params, n, (unsigned*)ws);
-  hipLaunchKernelGGL(param_scales_kernel, dim3(1), dim3(1), 0, ST, (const unsigned*)ws, rows_max, act_mul, scales);
+  dg::launch(absmax_flat_kernel, dim3(g ? g : 1), dim3(256), 0, ST, params, n, (unsigned*)ws);
+  dg::launch(param_scales_kernel, dim3(1), dim3(1), 0, ST, (const unsigned*)ws, rows_max, act_mul, scales);
   return dg::check_launch("dgcnn_param_scales_f32");
 }
 
@@ -314,7 +314,7 @@ extern "C" int dgcnn_bn_act_planes_f32(const float* T, int64_t ldt, int64_t R, i
                  rows_alloc % 64 == 0 && rows_alloc >= R && (!out || (a16(out) && ldo % 4 == 0)) && (!out2 || (a16(out2) && ldo2 % 4 == 0)),
              DGCNN_EINVAL, "dgcnn_bn_act_planes_f32: F %% 8, 16-byte aligned operands, rows_alloc %% 64 required");
   dim3 grid = plane_grid(rows_alloc, F);
-  hipLaunchKernelGGL((bn_act_planes_kernel<DGCNN_PLANES_F16X2>), grid, dim3(256), 0, ST, T, ldt, R, F, mean, rstd, beta, relu,
+  dg::launch((bn_act_planes_kernel<DGCNN_PLANES_F16X2>), grid, dim3(256), 0, ST, T, ldt, R, F, mean, rstd, beta, relu,
                        scale_dev, (char*)planes, plane_stride, rows_alloc, out, ldo, out2, ldo2);
   return dg::check_launch("dgcnn_bn_act_planes_f32");
 }
@@ -332,7 +332,7 @@ extern "C" int dgcnn_bn1_bwd_reduce_max_f32(const float* T, int64_t R, int F, co
   int64_t gx = dg::cdiv(R, (int64_t)RP * 4);
   if (gx > 256) gx = 256;
   const size_t shb = sizeof(float) * 4 * (size_t)(F < 1024 ? F : 1024);
-  hipLaunchKernelGGL(bn1_bwd_reduce_max_kernel, dim3((unsigned)gx, (unsigned)dg::cdiv(FV, 256)), dim3(256), shb, ST, T, R, F, FVB, RP,
+  dg::launch(bn1_bwd_reduce_max_kernel, dim3((unsigned)gx, (unsigned)dg::cdiv(FV, 256)), dim3(256), shb, ST, T, R, F, FVB, RP,
                      mean, rstd, beta, relu, dout, lddo, red, (unsigned*)maxbits);
   return dg::check_launch("dgcnn_bn1_bwd_reduce_max_f32");
 }
@@ -349,7 +349,7 @@ extern "C" int dgcnn_bn1_bwd_apply_planes_f32(const float* T, int64_t R, int F, 
                  rows_alloc >= R && (!dT || a16(dT)), DGCNN_EINVAL, "dgcnn_bn1_bwd_apply_planes_f32: F %% 8, aligned operands required");
   DG_REQUIRE(!gsum || (rows_per_group > 0 && rows_per_group % 64 == 0), DGCNN_EUNSUP,
              "dgcnn_bn1_bwd_apply_planes_f32: per-group sums need rows_per_group %% 64 == 0 (got %d)", rows_per_group);
-  hipLaunchKernelGGL(bn1_bwd_finalize_bound_kernel, dim3((unsigned)dg::cdiv(F, 128)), dim3(128), 0, ST, red, (unsigned*)maxbits, F,
+  dg::launch(bn1_bwd_finalize_bound_kernel, dim3((unsigned)dg::cdiv(F, 128)), dim3(128), 0, ST, red, (unsigned*)maxbits, F,
                      (double)R, rstd, dbeta, dbeta_beta);
   const float* cf = reinterpret_cast<const float*>(maxbits);
   // rows per block: a multiple of 64, <= 512, dividing rows_per_group when group sums are wanted
@@ -360,7 +360,7 @@ extern "C" int dgcnn_bn1_bwd_apply_planes_f32(const float* T, int64_t R, int F, 
       if (rows_per_group % cnd == 0) { chunk = cnd; break; }
   }
   dim3 grid((unsigned)dg::cdiv(rows_alloc, chunk), (unsigned)dg::cdiv(F / 8, 4 * OPT));
-  hipLaunchKernelGGL((bn1_bwd_apply_planes_kernel<DGCNN_PLANES_F16X2>), grid, dim3(256), 0, ST, T, R, F, mean, rstd, beta, relu, dout,
+  dg::launch((bn1_bwd_apply_planes_kernel<DGCNN_PLANES_F16X2>), grid, dim3(256), 0, ST, T, R, F, mean, rstd, beta, relu, dout,
                        lddo, cf, scale_dev, (char*)planes, plane_stride, rows_alloc, dT, gsum, ldgsum, rows_per_group, chunk);
   return dg::check_launch("dgcnn_bn1_bwd_apply_planes_f32");
 }

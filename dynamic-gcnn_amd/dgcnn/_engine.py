@@ -50,13 +50,13 @@ SIDE_STREAM_MIN_ROWS = 16384   # below this many points the side stream is not u
 EDGE_MLP_DTYPE = "f32"
 EDGE_MLP_NBR_GEMM = False  # True: factored conv0 with an edge-level neighbour GEMM instead of point-level GEMM + gather-add
 SCATTER_ATOMICS = False  # True: dx_j += dY W^T by fp32 atomics in the GEMM epilogue (A/B switch)
-# Deterministic mode: run-to-run bit-reproducible results.  The default kernels sum the BatchNorm statistics (forward and the
-# two backward sums) with LDS / fp64 atomics and fill the transposed adjacency through LDS cursors -- reproducible to ~1e-7
-# only, which the dynamic graphs amplify into a few different neighbour lists per step.  With this switch the statistics come
-# from fixed-order two-stage sums over MATERIALISED tensors (csrc/det.hip: conv0's output is written out for it) and the
-# adjacency buckets are sorted: slower (~2x at configs[1]), same math.  The reported loss / accuracy scalars are still summed
-# with atomics (they feed nothing back).
-DETERMINISTIC_ENV_DEFAULT = os.environ.get("DGCNN_DETERMINISTIC", "0") not in ("0", "")
+# Deterministic mode (the DEFAULT since round 5): run-to-run bit-reproducible results.  Every statistics / reduction slot has ONE
+# writer (dgcnn_set_stat_slots raises the slot count to the widest producer's workgroup count), the finalize kernels add the slots
+# in a fixed order, the transposed adjacency's buckets are sorted.  Same kernels as the atomics mode otherwise: +3-4 % at
+# configs[1].  The atomics mode (DETERMINISTIC=False / DGCNN_DETERMINISTIC=0: 32 slots, fp64 atomics from several
+# workgroups per slot, unsorted buckets) is reproducible to ~1e-7 per step only, which the dynamic graphs amplify into a few
+# different neighbour lists per step.  The reported loss / accuracy scalars are summed with atomics in both (they feed nothing back).
+DETERMINISTIC_ENV_DEFAULT = os.environ.get("DGCNN_DETERMINISTIC", "1") not in ("0", "")
 DETERMINISTIC = DETERMINISTIC_ENV_DEFAULT      # trainval.initialize() sets it per instance (flag, else this default)
 
 
@@ -87,6 +87,7 @@ class Context(object):
         self.ws_side = None
         self.side = None                 # second HIP stream: weight-gradient GEMMs (nothing on the critical path needs them)
         self.side_busy = False
+        self.side_hold = []              # recording a launch plan: tensors the side stream touches, kept until the join
         self.seed = 1
         self._rng = None
         self.stat_arena = None
@@ -101,7 +102,7 @@ class Context(object):
         self.pl_scales_ready = False
         self.pl_ws = None
         self.wprep = {}                  # weight-only work of the step, issued ahead on the side stream: key -> tensor / PlaneSet
-        self.wprep_event = None          # recorded behind it; the first consumer makes the main stream wait for it
+        self.wprep_event = None          # True while the main stream has not yet been made to wait for it (prepared())
         self.head_grads_hook = None      # called by the backward when every head gradient is final (trainval: bucketed all-reduce)
 
     # ---- device / scratch -------------------------------------------------------------
@@ -133,17 +134,23 @@ class Context(object):
         main = torch.cuda.current_stream()
         if self.side is None or self.side.device != self.device:
             self.side = torch.cuda.Stream(device=self.device)
-        self.side.wait_stream(main)
+        H.stream_wait(self.side, main)
         for t in temporaries:
             t.record_stream(self.side)
+        if self.capturing:
+            # a recorded step is replayed with the addresses of THIS run: a block the allocator handed out again because it SAW the
+            # side stream finish (an event query, not stream order) would be a race on replay -- side-stream temporaries stay
+            # alive until the streams have joined
+            self.side_hold.extend(temporaries)
         self.side_busy = True
         with torch.cuda.stream(self.side):
             yield
 
     def join_side(self):
         if self.side_busy:
-            torch.cuda.current_stream().wait_stream(self.side)
+            H.stream_wait(torch.cuda.current_stream(), self.side)
             self.side_busy = False
+        self.side_hold = []
 
     def stats(self, F):
         """Zeroed double[SLOTS][2][F] carved from one arena that is memset once per step."""
@@ -152,11 +159,11 @@ class Context(object):
         if self.stat_arena is None or self.stat_arena.device != self.device or self.stat_arena.numel() < want:
             # a captured HIP graph has the arena's address (and the slot count) baked into its launches: trainval keys its
             # graphs on arena_key() and drops those recorded against an arena that no longer exists
-            self.stat_arena = torch.zeros(want, dtype=torch.float64, device=self.device)
+            self.stat_arena = H.zeros(want, torch.float64, self.device)
             self.stat_off = 0
             self.arena_gen += 1
         if self.stat_off + n > self.stat_arena.numel():
-            return torch.zeros(n, dtype=torch.float64, device=self.device)
+            return H.zeros(n, torch.float64, self.device)
         s = self.stat_arena[self.stat_off:self.stat_off + n]
         self.stat_off += n
         return s
@@ -229,7 +236,7 @@ class Context(object):
             self.stats(1)
             self.stat_off = 0
         if self.stat_off + n > self.stat_arena.numel():
-            return torch.zeros(n, dtype=torch.float64, device=self.device)
+            return H.zeros(n, torch.float64, self.device)
         s = self.stat_arena[self.stat_off:self.stat_off + n]
         self.stat_off += n
         return s
@@ -248,9 +255,9 @@ class Context(object):
             self.configure_slots(0)
         if self.stat_arena is not None:
             if self.capturing:
-                self.stat_arena.zero_()          # a captured step cannot know what ran before it: whole arena (8 MB memset)
+                H.memset(self.stat_arena)        # a captured step cannot know what ran before it: whole arena (8 MB memset)
             elif self.stat_off > 0:
-                self.stat_arena[:self.stat_off].zero_()
+                H.memset(self.stat_arena[:self.stat_off])
         self.stat_off = 0
         if not self.capturing:                   # (a replayed graph gets its seed from advance_seed(), called by the replayer)
             self.advance_seed()
@@ -332,7 +339,7 @@ class Context(object):
             base = root.data_ptr()
             if base <= ptr < base + root.numel() * 4:
                 if slot[0] is None:
-                    slot[0] = torch.zeros_like(root)
+                    slot[0] = H.memset(torch.empty_like(root))
                 off = (ptr - base) // 4
                 ld = root.shape[1]
                 r0, c0 = off // ld, off % ld
@@ -624,7 +631,7 @@ def conv_bn_act(x, leaf_scope, num_outputs, relu=True, out=None, out2=None, gbia
                 if HEAD_PLANES == PL.F16X2:
                     dTp.scale = sc
                 fused_gsum = dgb is not None and rpg % 64 == 0
-                tmp = torch.zeros_like(gbias) if fused_gsum else None
+                tmp = H.memset(torch.empty_like(gbias)) if fused_gsum else None
                 dT32 = T if (dgb is not None and not fused_gsum) else None        # (in place: every element is read before it is written)
                 H.call("dgcnn_bn1_bwd_apply_planes_f32", T.data_ptr(), R, F, mean.data_ptr(), rstd.data_ptr(), beta.data_ptr(),
                        int(relu), dout.data_ptr(), H.ld2(dout), red.data_ptr(), maxbits.data_ptr(), HEAD_PLANES, sc.data_ptr(),
@@ -709,7 +716,9 @@ def prepare_step_weights(edge_w0, head_w):
     items, temps = [], []
     for W0, C, F in edge_w0:
         Cp = (C + 3) // 4 * 4
-        wcat = (torch.zeros if Cp != C else torch.empty)((Cp, 2 * F), dtype=torch.float32, device=dev)
+        wcat = torch.empty((Cp, 2 * F), dtype=torch.float32, device=dev)
+        if Cp != C:
+            H.memset(wcat)
         items.append((("wcat", W0.data_ptr()), wcat, W0, C, F))
         temps.append(wcat)
     planes = []
@@ -726,15 +735,17 @@ def prepare_step_weights(edge_w0, head_w):
             c.wprep[("wT", Wx.data_ptr())] = wt.fill_from(Wx, transpose=True)
             c.wprep[("w", Wx.data_ptr())] = wd.fill_from(Wx)
         if c.side is not None and torch.cuda.current_stream() == c.side:
-            c.wprep_event = c.side.record_event()
+            c.wprep_event = True          # the first consumer makes the main stream wait for the side stream (prepared())
 
 
 def prepared(key):
     """A tensor prepared by prepare_step_weights (the main stream is made to wait for the preparation once), or None."""
     c = ctx()
     v = c.wprep.get(key)
-    if v is not None and c.wprep_event is not None:
-        torch.cuda.current_stream().wait_event(c.wprep_event)
+    if v is not None and c.wprep_event:
+        # (waits for everything on the side stream so far: between the preparation and its first consumer -- conv0 of the first
+        # EdgeConv layer, right behind the first k-NN -- nothing else is issued there)
+        H.stream_wait(torch.cuda.current_stream(), c.side)
         c.wprep_event = None
     return v
 
@@ -746,8 +757,8 @@ def _point_gemm(c, x, W0, R, C, F):
     xg = x
     ready = prepared(("wcat", W0.data_ptr()))
     if Cp != C:
-        xg = torch.zeros((R, Cp), dtype=torch.float32, device=x.device)
-        wcat = ready if ready is not None else torch.zeros((Cp, 2 * F), dtype=torch.float32, device=x.device)
+        xg = H.zeros((R, Cp), torch.float32, x.device)
+        wcat = ready if ready is not None else H.zeros((Cp, 2 * F), torch.float32, x.device)
     else:
         wcat = ready if ready is not None else torch.empty((C, 2 * F), dtype=torch.float32, device=x.device)
     UV = torch.empty((R, 2 * F), dtype=torch.float32, device=x.device)
@@ -789,9 +800,9 @@ def edge_conv_block(x, B, N, k, num_filters, relu1=True, outs=None, net2=None):
         that the products take the float4 path) and the matching weight rows -- the operands the bf16 products round."""
         xg, Wp = x, W0
         if Cp != C:
-            xg = torch.zeros((R, Cp), dtype=torch.float32, device=x.device)
+            xg = H.zeros((R, Cp), torch.float32, x.device)
             H.call("dgcnn_copy2d_f32", x.data_ptr(), H.ld2(x), xg.data_ptr(), Cp, R, C, 0)
-            Wp = torch.zeros((2 * Cp, F), dtype=torch.float32, device=x.device)
+            Wp = H.zeros((2 * Cp, F), torch.float32, x.device)
             H.call("dgcnn_copy2d_f32", W0[:C].data_ptr(), F, Wp[:C].data_ptr(), F, C, F, 0)
             H.call("dgcnn_copy2d_f32", W0[C:].data_ptr(), F, Wp[Cp:Cp + C].data_ptr(), F, C, F, 0)
         E_ = torch.empty((R * k, 2 * Cp), dtype=torch.float32, device=x.device)
@@ -1140,6 +1151,24 @@ def dropout(x, keep=DROPOUT_KEEP):
     return out
 
 
+def tile_rows(g, out, rows):
+    """tf.tile of a per-cloud (B,F) tensor over the `rows` points of its cloud into the (B*rows, F) view `out` (model.py:80-81);
+    backward: tf.tile^T = the sum over the cloud."""
+    c = ctx()
+    G, F = g.shape
+    H.call("dgcnn_tile_rows_f32", g.data_ptr(), H.ld2(g), G, int(rows), F, out.data_ptr(), H.ld2(out))
+    if c.recording:
+        def bwd():
+            dout, dg_ = c.grad(out), c.grad(g)
+            if dout is None or dg_ is None:
+                return
+            tmp = torch.empty((G, F), dtype=torch.float32, device=g.device)
+            H.call("dgcnn_group_colsum_f32", dout.data_ptr(), H.ld2(dout), G, int(rows), F, tmp.data_ptr())
+            H.call("dgcnn_copy2d_f32", tmp.data_ptr(), F, dg_.data_ptr(), H.ld2(dg_), G, F, 1)
+        c.tape.append(bwd)
+    return out
+
+
 def global_max(x, B, N):
     """(B*N,F) -> (B,F) max over the points of each cloud, first arg-max remembered for the backward."""
     c = ctx()
@@ -1201,7 +1230,7 @@ def softmax_loss(logits2d, labels, weight, want_grad):
     R, ncls = logits2d.shape
     assert logits2d.is_contiguous()
     sm = torch.empty((R, ncls), dtype=torch.float32, device=logits2d.device)
-    scal = torch.zeros(2, dtype=torch.float32, device=logits2d.device)
+    scal = H.zeros(2, torch.float32, logits2d.device)
     dl = None
     if want_grad:
         dl = c.grad(logits2d)

@@ -90,6 +90,7 @@ PROTOTYPES = {
     "dgcnn_global_max_f32": [c_vp, c_i64, c_int, c_int, c_int, c_vp, c_vp, c_vp],
     "dgcnn_global_max_bwd_f32": [c_vp, c_vp, c_int, c_int, c_int, c_vp, c_i64, c_vp],
     "dgcnn_group_colsum_f32": [c_vp, c_i64, c_int, c_int, c_int, c_vp, c_vp],
+    "dgcnn_tile_rows_f32": [c_vp, c_i64, c_int, c_int, c_int, c_vp, c_i64, c_vp],
     "dgcnn_dropout_f32": [c_vp, c_vp, c_i64, c_f32, c_u64, c_vp],
     "dgcnn_dropout_dev_f32": [c_vp, c_vp, c_i64, c_f32, c_vp, c_vp],
     "dgcnn_add_relu_f32": [c_vp, c_i64, c_vp, c_i64, c_i64, c_int, c_vp, c_i64, c_vp],
@@ -109,12 +110,21 @@ PROTOTYPES = {
     "dgcnn_edge_mlp_bf16_bwd": [c_vp, c_i64, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp,
                                 c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_f32, c_vp, ctypes.c_size_t, c_vp],
     "dgcnn_edge_gather_sum_bf16": [c_vp, c_vp, c_vp, c_i64, c_int, c_vp, c_i64, c_vp],
+    "dgcnn_plan_begin": [],
+    "dgcnn_plan_end": [c_vp],
+    "dgcnn_plan_abort": [],
+    "dgcnn_plan_replay": [c_vp],
+    "dgcnn_plan_info": [c_vp, c_vp, c_vp, c_vp, c_vp],
+    "dgcnn_plan_destroy": [c_vp],
+    "dgcnn_stream_wait": [c_vp, c_vp],
+    "dgcnn_memset_async": [c_vp, c_int, c_sz, c_vp],
     "dgcnn_comm_unique_id": [c_vp],
     "dgcnn_comm_init": [c_int, c_int, c_vp, c_vp],
     "dgcnn_comm_destroy": [c_vp],
     "dgcnn_comm_info": [c_vp, c_vp, c_vp, c_vp],
     "dgcnn_allreduce_f32": [c_vp, c_i64, c_vp, c_vp],
     "dgcnn_broadcast_f32": [c_vp, c_i64, c_int, c_vp, c_vp],
+    "dgcnn_comm_counters": [c_vp, c_vp],
 }
 
 INT64_RESULTS = ("dgcnn_knn_workspace_bytes", "dgcnn_edge_mlp_bf16_bwd_workspace_bytes")      # byte counts; every other entry point returns an int status
@@ -215,6 +225,88 @@ def call(name, *args, tag=None, work=0.0, nbytes=0.0):
         if rc == -1:
             raise ValueError(msg)
         raise HipError("%s failed (%d): %s" % (name, rc, msg))
+
+
+def _check(rc, name):
+    if rc != 0:
+        msg = load().dgcnn_last_error().decode()
+        if rc == -1:
+            raise ValueError(msg)
+        raise HipError("%s failed (%d): %s" % (name, rc, msg))
+
+
+def memset(t, value=0):
+    """hipMemsetAsync of the whole (contiguous) tensor on the current stream -- through the library, so that a launch plan being
+    recorded sees it (a torch .zero_() would be missing from the replay)."""
+    assert t.is_contiguous()
+    n = t.numel() * t.element_size()
+    if n:
+        _check(load().dgcnn_memset_async(t.data_ptr(), int(value), n, _stream()), "dgcnn_memset_async")
+    return t
+
+
+def zeros(shape, dtype, device):
+    return memset(torch.empty(shape, dtype=dtype, device=device))
+
+
+def stream_wait(waiter, signaller):
+    """`waiter` (a torch stream) waits for everything issued so far on `signaller`; recorded by a launch plan under construction."""
+    _check(load().dgcnn_stream_wait(waiter.cuda_stream, signaller.cuda_stream), "dgcnn_stream_wait")
+
+
+class Plan(object):
+    """A recorded launch list (csrc/plan.cc).  `with Plan.record() as p:` runs the enclosed step AND records it; p.replay()
+    re-issues it.  The caller keeps the step's device addresses alive and unchanged (trainval records inside a private memory pool)."""
+
+    def __init__(self):
+        self.handle = None
+
+    class _Rec(object):
+        def __init__(self, plan):
+            self.plan = plan
+
+        def __enter__(self):
+            _check(load().dgcnn_plan_begin(), "dgcnn_plan_begin")
+            return self.plan
+
+        def __exit__(self, et, ev, tb):
+            if et is not None:
+                load().dgcnn_plan_abort()
+                return False
+            h = ctypes.c_void_p()
+            _check(load().dgcnn_plan_end(ctypes.byref(h)), "dgcnn_plan_end")
+            self.plan.handle = h
+            return False
+
+    @classmethod
+    def record(cls):
+        return cls._Rec(cls())
+
+    def replay(self):
+        _check(load().dgcnn_plan_replay(self.handle), "dgcnn_plan_replay")
+
+    def info(self):
+        v = [ctypes.c_int(0) for _ in range(4)]
+        _check(load().dgcnn_plan_info(self.handle, *[ctypes.byref(x) for x in v]), "dgcnn_plan_info")
+        return dict(zip(("kernels", "memsets", "waits", "collectives"), [int(x.value) for x in v]))
+
+    def destroy(self):
+        if self.handle is not None:
+            load().dgcnn_plan_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
+
+
+def comm_counters():
+    """(all-reduce calls, elements) issued through the library so far -- direct calls and replayed launch plans alike."""
+    a, b = ctypes.c_int64(0), ctypes.c_int64(0)
+    _check(load().dgcnn_comm_counters(ctypes.byref(a), ctypes.byref(b)), "dgcnn_comm_counters")
+    return int(a.value), int(b.value)
 
 
 def require_gpu(*tensors):

@@ -49,7 +49,7 @@ _OPTIONS = [
     ("CHECKPOINT_NUM", "-chkn", int, 10, "t", "number of latest checkpoints to keep"),
     ("CHECKPOINT_HOUR", "-chkh", float, 0.4, "t", "period (hours) at which a checkpoint leaving the -chkn window is kept for good"),
     ("WEIGHT_KEY", "-wkey", str, "", "tf", "keyword to fetch weight from file"),
-    ("USE_GRAPH", "-ug", str, "auto", "ti", "replay the tower as a captured HIP graph: 0 | 1 | auto (launch-bound shapes only)"),
+    ("USE_GRAPH", "-ug", str, "auto", "ti", "how towers are launched: 0 eager | plan recorded launch plan | 1 HIP graph | auto (plans for towers up to 65536 points)"),
     ("DETERMINISTIC", "-det", _BOOL, None, "ti", "fixed-order BatchNorm sums / sorted adjacency: bit-reproducible runs (slower)"),
     ("EDGE_MLP_DTYPE", "-emd", str, "f32", "ti", "operands of the edge MLP (conv0 of every EdgeConv layer): f32 | bf16 (literal edge-level "
                                                  "product on the bf16 MFMA pipe, fp32 accumulate: BASELINE configs[2])"),

@@ -43,7 +43,13 @@ def build(point_cloud, flags):
         for f in ecf:
             widths += [2 * f, 64]
         ctot = sum(widths) + 1024
-        big = c.new_buffer(R, ctot)
+        if num_fc < 1:
+            # FC_LAYERS = 0 (model.py:88 + ops.py:151: a loop of zero trips): dropout and Final act on the concat itself, so the tiled
+            # global feature is materialised here -- `big` is the trailing ctot columns of the (R, 1024 + ctot) concat
+            bigfull = c.new_buffer(R, 1024 + ctot)
+            big = bigfull[:, 1024:]
+        else:
+            big = c.new_buffer(R, ctot)
         merged_in = c.new_buffer(R, 64 * num_edge_conv)          # model.py:60-63 concat of the conv1 outputs
         offs = []
         o = 0
@@ -96,8 +102,6 @@ def build(point_cloud, flags):
         return fin.view(B, N, num_class)
 
     fcf = ops._listify(num_fc_filters, num_fc, "num_filters")
-    if num_fc < 1:
-        raise NotImplementedError("FC_LAYERS=0 is not supported by the HIP path (reference default is 2)")
     # Plane mode (E.HEAD_PLANES): MergedEdgeConv, FC0 and FC1 -- 98 % of the GEMM flops -- read their operands as 16-bit planes
     # written once by the producing pass (csrc/gemm_pl.hip, planes_bn.hip).  The EdgeConv outputs (first ctot - 1024 channels
     # of `big`, and the conv1 copies) are split by one pass each; MergedEdgeConv's BatchNorm pass writes its 1024 channels
@@ -116,6 +120,13 @@ def build(point_cloud, flags):
         # epilogue where the tile shape allows) and normalised afterwards: BN + ReLU are non-decreasing
         merged, g = E.conv_bn_act(merged_in, "MergedEdgeConv", 1024, relu=True, out=big[:, ctot - 1024:], gmax=(B, N))
     tensors.append(E.rank4(merged, B, N))                          # model.py:74
+
+    if num_fc < 1:
+        # model.py:80-101 with no FC layer: concat([tile(g)] + tensors) -> (dropout) -> Final
+        E.tile_rows(g, bigfull[:, :1024], N)                        # model.py:80-81
+        net = E.dropout(bigfull, E.DROPOUT_KEEP) if is_training else bigfull      # model.py:90-91
+        fin = E.conv_bn_act(net, "Final", num_class, relu=True)    # model.py:94-101
+        return fin.view(B, N, num_class)
 
     # model.py:80-88: concat([tile(g)] + tensors) -> fc.  FC0 is split as described in the docstring.
     with E.variable_scope("FC0"):

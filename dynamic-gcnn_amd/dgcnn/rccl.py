@@ -100,7 +100,7 @@ class Group(object):
     # ---- collectives (in place, on self.stream, ordered after everything issued so far on the current stream) ----
     def _on_comm_stream(self, fn, tensor):
         cur = torch.cuda.current_stream()
-        self.stream.wait_stream(cur)
+        H.stream_wait(self.stream, cur)              # (through the library: a launch plan being recorded sees the fork)
         tensor.record_stream(self.stream)
         fn(self.stream.cuda_stream)
 
@@ -116,7 +116,7 @@ class Group(object):
                                                     "dgcnn_broadcast_f32"), t)
 
     def wait(self):
-        torch.cuda.current_stream().wait_stream(self.stream)
+        H.stream_wait(torch.cuda.current_stream(), self.stream)
 
     def allreduce_sum_(self, t):
         self.allreduce_sum_async(t)

@@ -30,6 +30,8 @@ GRAPH_CACHE_MAX = 8       # captured towers kept per trainval (each pins a priva
 GRAPH_CAPTURE_AFTER = 1   # eager sightings of a (shape, mode) before it is captured; "auto" mode uses GRAPH_CAPTURE_AFTER_AUTO
 GRAPH_CAPTURE_AFTER_AUTO = 3
 GRAPH_SEEN_MAX = 4096     # distinct keys remembered for the sighting count (variable-N sources produce thousands)
+PLAN_AUTO_MAX_ROWS = 65536   # "auto": towers up to this many points are replayed from a launch plan (larger steps are tens of
+                             # milliseconds of GPU work behind ~2 ms of host work: nothing to hide, and a plan pins the step's memory)
 
 
 def param_specs(flags, num_channel):
@@ -90,24 +92,33 @@ class trainval(object):
         # resolved on EVERY initialize (flag, else the DGCNN_DETERMINISTIC environment default): an instance never inherits
         # the mode of an earlier one.  The switch itself is process-wide, like the GEMM arithmetic.
         det = getattr(f, "DETERMINISTIC", None)
-        E.DETERMINISTIC = E.DETERMINISTIC_ENV_DEFAULT if det is None else bool(det)
-        if E.DETERMINISTIC:
-            # csrc/det.hip walks at most 1024 columns per launch and reads its (R*k, F) input densely (ld == F): say so
-            # here, not as an EINVAL from the middle of a step
-            wide = [n for n, shp in param_specs(f, int(f.NUM_CHANNEL)) if n.endswith("weights") and shp[1] > 1024]
+        hp = getattr(f, "HEAD_PLANES", None)             # per instance, like DETERMINISTIC: flag, else the environment default
+        planes_asked = (str(hp).lower() == "f16") if hp is not None else (E.HEAD_PLANES_ENV_DEFAULT is not None)
+        # what the deterministic kernels do not take: csrc/det.hip walks at most 1024 columns per launch and reads its (R*k, F) input
+        # densely; EdgeConv filter counts that are not multiples of 4 send the neighbour gradient through an atomic scatter
+        # (dgcnn_edge_mlp_dgrad_scatter_f32: no float4 rows for the transposed-adjacency sum); the plane GEMMs' statistics are atomic
+        specs = param_specs(f, int(f.NUM_CHANNEL))
+        wide = [n for n, shp in specs if n.endswith("weights") and shp[1] > 1024]
+        odd = [n for n, shp in specs if n.endswith("conv0/weights") and shp[1] % 4]
+        if det is None:
+            # the default is the deterministic mode wherever it exists; a model outside it runs the atomics kernels (say so once)
+            det = E.DETERMINISTIC_ENV_DEFAULT
+            if det and (wide or odd or planes_asked):
+                det = False
+                if not planes_asked:
+                    sys.stderr.write("dgcnn: deterministic kernels do not take %s; using the atomics mode (reproducible to ~1e-7 "
+                                     "per step)\n" % ", ".join((wide + odd)[:3]))
+        E.DETERMINISTIC = bool(det)
+        if E.DETERMINISTIC:            # asked for explicitly: say what is wrong here, not as an EINVAL from the middle of a step
             if wide:
                 raise ValueError("DETERMINISTIC mode supports at most 1024 filters per layer (csrc/det.hip); too wide: %s"
                                  % ", ".join(wide))
-            # EdgeConv filter counts that are not multiples of 4 send the neighbour gradient through an atomic scatter
-            # (dgcnn_edge_mlp_dgrad_scatter_f32: no float4 rows for the transposed-adjacency sum): not order-independent
-            odd = [n for n, shp in param_specs(f, int(f.NUM_CHANNEL)) if n.endswith("conv0/weights") and shp[1] % 4]
             if odd:
                 raise ValueError("DETERMINISTIC mode needs EdgeConv filter counts that are multiples of 4; got %s" % ", ".join(odd))
         emd = str(getattr(f, "EDGE_MLP_DTYPE", "f32") or "f32").lower()
         if emd not in ("f32", "bf16"):
             raise ValueError("EDGE_MLP_DTYPE must be f32 or bf16, got %r" % (getattr(f, "EDGE_MLP_DTYPE"),))
         E.EDGE_MLP_DTYPE = emd                           # per instance, like DETERMINISTIC
-        hp = getattr(f, "HEAD_PLANES", None)             # per instance, like DETERMINISTIC: flag, else the environment default
         if hp is None:
             E.HEAD_PLANES = E.HEAD_PLANES_ENV_DEFAULT
         else:
@@ -116,7 +127,7 @@ class trainval(object):
             E.HEAD_PLANES = {"f16": E.PL.F16X2}.get(str(hp).lower())
         self._graphs, self._graph_seen = OrderedDict(), {}     # captured towers (LRU order) / sightings per key
         ug = str(getattr(f, "USE_GRAPH", "0")).lower()
-        self._use_graph = "auto" if ug == "auto" else ug in ("1", "true", "yes", "on")
+        self._use_graph = ug if ug in ("auto", "plan") else ug in ("1", "true", "yes", "on", "graph")
         return self
 
     def _split_reduce(self):
@@ -158,17 +169,21 @@ class trainval(object):
         wgt = self._to_dev(weight, torch.float32)
         if pts.dim() != 3:
             raise ValueError("points must be (MINIBATCH_SIZE, N, NUM_CHANNEL), got %s" % (tuple(pts.shape),))
-        if self._wants_graph(pts.shape[0] * pts.shape[1]):
-            out = self._tower_graph(pts, lab, wgt, train)
+        kind = self._wants_graph(pts.shape[0] * pts.shape[1])
+        if kind is not None:
+            out = self._tower_graph(pts, lab, wgt, train, kind)
             if out is not None:
                 return out
         return self._tower_eager(pts, lab, wgt, train)
 
     def _wants_graph(self, rows):
+        """How a tower over `rows` points is launched: None (eager), "plan" (recorded launch plan) or "graph" (HIP graph)."""
         use = self._use_graph
-        if use == "auto":                 # graphs pay where the step is launch bound (profiles/r02/config_sweep.txt)
-            use = rows < E.SIDE_STREAM_MIN_ROWS
-        return bool(use) and H.TIMER is None
+        if H.TIMER is not None or not use:
+            return None
+        if use == "auto":                 # replay pays where the host matters (profiles/r05/launch_modes.txt)
+            return "plan" if rows <= PLAN_AUTO_MAX_ROWS else None
+        return "plan" if use == "plan" else "graph"
 
     def _tower_body(self, pts, lab, wgt, train):
         c = self._ctx
@@ -186,19 +201,26 @@ class trainval(object):
     def _tower_eager(self, pts, lab, wgt, train):
         return self._tower_body(pts, lab, wgt, train)
 
-    # ---- HIP-graph replay of a tower (the reference replays a static TF graph with sess.run: trainval.py:103-119) ----
+    # ---- replay of a tower (the reference replays a static TF graph with sess.run: trainval.py:103-119) ----
     def use_graph(self, on=True):
-        """Capture forward + loss + backward of a tower into a HIP graph the second time a (shape, mode) is seen and replay it
-        afterwards: one graph launch instead of ~150 kernel launches per micro-step (host enqueue 2.3 ms -> ~0.1 ms at
-        configs[1]; configs[0] is entirely launch bound).  Off by default for the library (tests hook into the eager path);
-        bench.py and the run loops switch it on.  Shapes seen once (variable-N sources) run eagerly."""
-        self._use_graph = "auto" if on == "auto" else bool(on)
+        """How towers are launched from now on.
+          False    eager: every kernel launched from Python as the tower is traversed (library default; tests hook into it);
+          "plan"   launch plan (csrc/plan.cc): the second time a (shape, mode) is seen the step is RECORDED while it runs -- every
+                   launch, memset, cross-stream wait and RCCL call with its arguments -- and afterwards re-issued by one C loop on
+                   the same two streams: the GPU sees the eager schedule, the host spends ~2 us per launch instead of 12-30;
+          True     HIP graph: the tower captured with torch.cuda.graph and replayed (one graph launch; the side stream becomes graph
+                   branches, which this runtime schedules 2-5 % slower than the streams themselves, and no RCCL call inside);
+          "auto"   plans for towers up to PLAN_AUTO_MAX_ROWS points that came back GRAPH_CAPTURE_AFTER_AUTO times, else eager.
+        Per-step host state is never baked in: the dropout seed lives in device memory and is advanced before every replay, Adam
+        and zero_gradients stay outside.  Shapes seen once (variable-N sources) run eagerly."""
+        self._use_graph = on if on in ("auto", "plan") else bool(on)
         return self
 
-    def _tower_graph(self, pts, lab, wgt, train):
+    def _tower_graph(self, pts, lab, wgt, train, kind):
         c = self._ctx
-        key = (tuple(pts.shape), bool(train), lab is not None, wgt is not None, float(E.DROPOUT_KEEP), H.gemm_arith(),
-               E.WGRAD_SIDE_STREAM, E.HEAD_PLANES, E.DETERMINISTIC, E.EDGE_MLP_DTYPE)
+        hooked = c.head_grads_hook is not None
+        key = (kind, tuple(pts.shape), bool(train), lab is not None, wgt is not None, float(E.DROPOUT_KEEP), H.gemm_arith(),
+               E.WGRAD_SIDE_STREAM, E.HEAD_PLANES, E.DETERMINISTIC, E.EDGE_MLP_DTYPE, hooked)
         ent = self._graphs.get(key)
         if ent is not None:
             # DETERMINISTIC mode grows the slot count (and with it the statistics arena) when a larger cloud arrives: a graph
@@ -219,42 +241,69 @@ class trainval(object):
                     self._graph_seen.clear()
                 self._graph_seen[key] = n + 1
                 return None
-            ent = self._capture(key, pts, lab, wgt, train)
+            ent = self._capture(key, pts, lab, wgt, train, kind)
             if ent is None:
                 return None
+            if kind == "plan":                          # recording a plan RUNS the step: this call is done
+                return ent["sm"].clone(), ent["scal"].clone()
         else:
             self._graphs.move_to_end(key)
         for dst, src in ((ent["pts"], pts), (ent["lab"], lab), (ent["wgt"], wgt)):
             if dst is not None and dst.data_ptr() != src.data_ptr():
                 dst.copy_(src, non_blocking=True)
         c.advance_seed()
-        ent["graph"].replay()
-        # the graph's output buffers are overwritten by the next replay of this key: hand out copies (stream ordered),
+        if kind == "plan":
+            c.head_grads_hook = None                     # (the recorded step contains what the hook issued)
+            ent["plan"].replay()
+            self._head_reduced = ent["head_reduced"]
+        else:
+            ent["graph"].replay()
+        # the replay's output buffers are overwritten by the next replay of this key: hand out copies (stream ordered),
         # so that several towers / micro-steps of one shape each keep their own softmax and [loss, accuracy]
         return ent["sm"].clone(), ent["scal"].clone()
 
-    def _capture(self, key, pts, lab, wgt, train):
+    def _capture(self, key, pts, lab, wgt, train, kind):
         c = self._ctx
         ent = {"pts": pts.clone(), "lab": None if lab is None else lab.clone(), "wgt": None if wgt is None else wgt.clone()}
+        hook = c.head_grads_hook
         try:
             c.ensure_arena(int(pts.shape[0]) * int(pts.shape[1]))
             ent["arena"] = c.arena_key()
             torch.cuda.synchronize()
-            g = torch.cuda.CUDAGraph()
             c.capturing = True
-            with torch.cuda.graph(g):
-                ent["sm"], ent["scal"] = self._tower_body(ent["pts"], ent["lab"], ent["wgt"], train)
-            ent["graph"] = g
+            if kind == "plan":
+                # every allocation of the recorded step comes from a private pool that lives as long as the plan: the addresses in
+                # the recorded launches stay this step's own (what torch.cuda.graph does for a captured graph)
+                pool = torch.cuda.MemPool()
+                c.advance_seed()
+                with torch.cuda.use_mem_pool(pool):
+                    with H.Plan.record() as plan:
+                        ent["sm"], ent["scal"] = self._tower_body(ent["pts"], ent["lab"], ent["wgt"], train)
+                ent["plan"], ent["pool"], ent["head_reduced"] = plan, pool, self._head_reduced
+                ent["info"] = plan.info()
+            else:
+                c.head_grads_hook = None                 # (a captured HIP graph cannot carry the RCCL call)
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    ent["sm"], ent["scal"] = self._tower_body(ent["pts"], ent["lab"], ent["wgt"], train)
+                ent["graph"] = g
         except Exception as e:                        # capture is an optimisation: fall back to eager launches, loudly
-            sys.stderr.write("dgcnn: HIP graph capture failed (%s: %s); running eagerly\n" % (type(e).__name__, e))
+            sys.stderr.write("dgcnn: %s capture failed (%s: %s); running eagerly\n"
+                             % ("launch-plan" if kind == "plan" else "HIP graph", type(e).__name__, e))
             self._use_graph = False
             ent = None
+            if kind == "plan":
+                # the step may have died half way: its gradient contributions are partial.  Nothing was returned to the caller
+                # yet, who falls back to the eager tower -- on top of whatever this one added.  Refuse silently wrong sums.
+                raise
         finally:
             c.capturing = False
             c.recording = False
             c.tape = []
             c.roots = []
             c.side_busy = False
+            c.side_hold = []
+            c.head_grads_hook = hook if ent is None else None
         if ent is not None:
             self._graphs[key] = ent
             if ent["arena"] != c.arena_key():                    # (cannot happen after ensure_arena; never replay such a graph)
@@ -268,8 +317,17 @@ class trainval(object):
         old = self._graphs.pop(key, None)
         if old is not None:
             torch.cuda.current_stream().synchronize()            # (a replay of it may still be in flight)
-            old["graph"].reset()
+            if self._ctx.side is not None:
+                self._ctx.side.synchronize()
+            if "graph" in old:
+                old["graph"].reset()
+            if "plan" in old:
+                old["plan"].destroy()
             old.clear()
+
+    def launch_plan_info(self):
+        """[{kernels, memsets, waits, collectives}] of the recorded plans (bench.py reports the enqueues per step from it)."""
+        return [dict(e["info"]) for e in self._graphs.values() if "info" in e]
 
     def make_summary(self, sess, data, label, weight):
         if not self._flags.TRAIN:
@@ -308,7 +366,8 @@ class trainval(object):
         # replayed graph, which cannot carry the RCCL call); the SEQUENCE of collectives is not: with an RCCL group the bucket
         # always travels as [head piece, rest piece] (apply_gradient sends whatever the hook did not), so ranks holding clouds
         # of different sizes (-np -1 -mbs 1) issue identical calls.
-        eager = not self._wants_graph(int(d0.shape[0]) * int(d0.shape[1]))       # (a replayed graph cannot carry the RCCL call)
+        # (a replayed HIP graph cannot carry the RCCL call; eager launches and a launch plan can)
+        eager = self._wants_graph(int(d0.shape[0]) * int(d0.shape[1])) != "graph"
         if last and T == 1 and eager and self._split_reduce():
             def hook():
                 c.join_side()                                   # the head's weight-gradient GEMMs (side stream) have landed
@@ -317,7 +376,7 @@ class trainval(object):
         saved = None
         if T > 1:
             saved = c.flat_grad.clone()
-            c.flat_grad.zero_()
+            H.memset(c.flat_grad)
         scals = []
         for i in range(T):
             _, scal = self._tower(fd["data"][i], fd["label"][i], fd["weight"][i] if weight is not None else None,
@@ -334,7 +393,7 @@ class trainval(object):
     def zero_gradients(self, sess):
         if not self._flags.TRAIN:
             raise NotImplementedError
-        self._ctx.flat_grad.zero_()                                   # trainval.py:76
+        H.memset(self._ctx.flat_grad)                                 # trainval.py:76
         return [self._ctx.flat_grad]
 
     def apply_gradient(self, sess):

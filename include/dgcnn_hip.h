@@ -367,6 +367,10 @@ int dgcnn_global_max_bwd_f32(const float* dout, const int32_t* arg, int B, int N
 /* out[g][f] = sum over the rows_per_group rows of group g (tf.tile^T, model.py:81) */
 int dgcnn_group_colsum_f32(const float* x, int64_t ldx, int G, int rows_per_group, int F,
                            float* out, void* stream);
+/* tf.tile (model.py:80-81): dst[g * rows_per_group + i][f] = src[g][f] -- only FC_LAYERS = 0 materialises the tiled global
+ * feature (the dropout of model.py:90-91 then acts on it element by element); FC0 otherwise folds it into a per-cloud bias */
+int dgcnn_tile_rows_f32(const float* src, int64_t lds, int G, int rows_per_group, int F, float* dst, int64_t ldd,
+                        void* stream);
 /* tf.nn.dropout(net, keep) (model.py:91): counter-based RNG keyed by (seed, element index) so the
  * backward regenerates the same mask.  y may alias x. */
 int dgcnn_dropout_f32(const float* x, float* y, int64_t n, float keep, uint64_t seed, void* stream);
@@ -396,6 +400,23 @@ int dgcnn_axpby_f32(const float* x, float a, float* y, float b, int64_t n, void*
 int dgcnn_adam_f32(float* param, const float* grad, float* m, float* v, int64_t n,
                    float lr_t, float b1, float b2, float eps, void* stream);
 
+/* ---- launch plans (csrc/plan.cc): the counterpart of replaying a static TF graph with sess.run (dgcnn/trainval.py:103-129) ----
+ * dgcnn_plan_begin .. dgcnn_plan_end: every launch, memset, cross-stream wait and all-reduce the library issues in between is
+ * executed as usual AND recorded (kernel, geometry, a copy of the argument values, streams); dgcnn_plan_replay re-issues the list
+ * from one C loop on the same streams (the GPU sees the eager schedule; ~2 us of host time per launch).  The caller keeps every
+ * device address of the recorded step valid and unchanged for as long as the plan is replayed, and keeps per-step host values
+ * (dropout seed: device memory; Adam's step size: outside the plan) out of it.  One recorder per process.
+ * dgcnn_stream_wait: `waiter` waits for everything issued so far on `signaller` (event record + wait; recordable).
+ * dgcnn_memset_async: hipMemsetAsync (recordable): the zero-fills of the step go through it. */
+int dgcnn_plan_begin(void);
+int dgcnn_plan_end(void** plan_out);
+int dgcnn_plan_abort(void);
+int dgcnn_plan_replay(void* plan);
+int dgcnn_plan_info(void* plan, int* kernels, int* memsets, int* waits, int* collectives);
+int dgcnn_plan_destroy(void* plan);
+int dgcnn_stream_wait(void* waiter, void* signaller);
+int dgcnn_memset_async(void* ptr, int value, size_t bytes, void* stream);
+
 /* ---- the gradient collective (trainval.py:64-73 mean over the towers; here: one process per GPU, RCCL over xGMI) ----
  * RCCL is dlopen'ed on first use (librccl.so, or $DGCNN_RCCL_LIB); no torch.distributed involved.
  * dgcnn_comm_unique_id: rank 0 fills 128 bytes; the host ships them to the other ranks (dgcnn/rccl.py).
@@ -408,6 +429,8 @@ int dgcnn_comm_destroy(void* comm);
 int dgcnn_comm_info(void* comm, int* nranks, int* rank, int* device);
 int dgcnn_allreduce_f32(float* buf, int64_t count, void* comm, void* stream);
 int dgcnn_broadcast_f32(float* buf, int64_t count, int root, void* comm, void* stream);
+/* all-reduce calls / elements issued through the library so far, replayed launch plans included */
+int dgcnn_comm_counters(int64_t* allreduce_calls, int64_t* allreduce_elems);
 
 #ifdef __cplusplus
 }

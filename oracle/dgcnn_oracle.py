@@ -328,31 +328,22 @@ def init_params(flags, num_channel, seed=1, dtype=np.float32):
 # ----------------------------------------------------------------------------------------
 # dgcnn/model.py:9-106  build   (+ ops.py:75-98 / :100-140 / :142-163)
 # ----------------------------------------------------------------------------------------
-def model_forward(point_cloud, flags, params, idx_list=None, dropout_mask=None):
-    """logits (B,N,num_class) and a cache for model_backward.
-
-    idx_list: optional per-EdgeConv-layer forced neighbour indices.
-    dropout_mask: (B,N,1,Cfc) of {0, 1/0.7} applied when flags.TRAIN (model.py:90-91);
-                  None => no dropout (parity runs)."""
-    dt = point_cloud.dtype
-    P = {n: v.astype(dt) for n, v in params.items()}
-    L = int(flags.EDGE_CONV_LAYERS)
-    kv = _as_list(int(flags.KVALUE), L, "k")
-    name = flags.MODEL_NAME
-    if name not in ("dgcnn", "residual-dgcnn", "residual-dgcnn-nofc"):
-        raise NotImplementedError("Unsupported MODEL_NAME: %s" % name)      # model.py:41-43
-    residual = name != "dgcnn"
-    ecf = _as_list(flags.EDGE_CONV_FILTERS, L, "num_filters")
+def repeat_edge_conv(point_cloud, repeat, k, num_filters, P, residual=False, idx_list=None, edge_mlp_dtype="f32"):
+    """dgcnn/ops.py:75-98 (residual=False) / ops.py:100-140 (residual=True): `repeat` EdgeConv layers, layer i+1 building its graph on
+    squeeze(tensors[-1]).  k and num_filters are ints or lists of length `repeat` (ops.py:77-87: a list of another length prints and
+    raises ValueError).  P: name -> array under the scopes EdgeConv<i>/...  Returns (tensors [3 * repeat], per-layer caches)."""
+    repeat = int(repeat)
+    kv = _as_list(k, repeat, "k")
+    ecf = _as_list(num_filters, repeat, "num_filters")
     net = point_cloud
     tensors, layers = [], []
     shortcut = None
-    for i in range(L):                                                      # ops.py:91-96 / :116-138
+    for i in range(repeat):                                                 # ops.py:91-96 / :116-138
         s = "EdgeConv%d/" % i
         relu1 = not (residual and shortcut is not None)                      # ops.py:123 activation=None
         outs, c = edge_conv(net, kv[i], P[s + "conv0/weights"], P[s + "conv0/BatchNorm/beta"],
                             P[s + "conv1/weights"], P[s + "conv1/BatchNorm/beta"], relu1=relu1,
-                            idx=None if idx_list is None else idx_list[i],
-                            edge_mlp_dtype=str(getattr(flags, "EDGE_MLP_DTYPE", "f32")))
+                            idx=None if idx_list is None else idx_list[i], edge_mlp_dtype=edge_mlp_dtype)
         rec = dict(ec=c, sc=None, pre=None)
         if residual and shortcut is not None:
             sc_in = shortcut
@@ -370,6 +361,27 @@ def model_forward(point_cloud, flags, params, idx_list=None, dropout_mask=None):
         net = outs[2][:, :, 0, :]                                           # ops.py:95-96 squeeze
         if residual:
             shortcut = outs[2]                                               # ops.py:137
+    return tensors, layers
+
+
+def model_forward(point_cloud, flags, params, idx_list=None, dropout_mask=None, k=None):
+    """logits (B,N,num_class) and a cache for model_backward.
+
+    idx_list: optional per-EdgeConv-layer forced neighbour indices.
+    dropout_mask: (B,N,1,Cfc) of {0, 1/0.7} applied when flags.TRAIN (model.py:90-91);
+                  None => no dropout (parity runs).
+    k: None => int(flags.KVALUE) for every layer, as model.py:16 casts it; a list gives one k per EdgeConv layer -- the form
+       ops.repeat_edge_conv itself accepts (ops.py:77-82), which the tests of that operator drive through this function."""
+    dt = point_cloud.dtype
+    P = {n: v.astype(dt) for n, v in params.items()}
+    L = int(flags.EDGE_CONV_LAYERS)
+    name = flags.MODEL_NAME
+    if name not in ("dgcnn", "residual-dgcnn", "residual-dgcnn-nofc"):
+        raise NotImplementedError("Unsupported MODEL_NAME: %s" % name)      # model.py:41-43
+    residual = name != "dgcnn"
+    tensors, layers = repeat_edge_conv(point_cloud, L, int(flags.KVALUE) if k is None else k, flags.EDGE_CONV_FILTERS, P,
+                                       residual=residual, idx_list=idx_list,
+                                       edge_mlp_dtype=str(getattr(flags, "EDGE_MLP_DTYPE", "f32")))
     cache = dict(layers=layers, flags=flags, L=L, P=P, residual=residual)
     if name == "residual-dgcnn-nofc":                                        # model.py:45-58
         fin, cf = conv_bn_act(tensors[-1], P["Final/weights"], P["Final/BatchNorm/beta"], relu=True)

@@ -42,19 +42,20 @@ def as_list(v, n):
     return [int(a) for a in v] if isinstance(v, list) else [int(v)] * n
 
 
-def model(points, flags, P, idx_list=None):
-    """logits (B,N,num_class).  idx_list forces the neighbour graph (tests); None = compute it."""
+def model(points, flags, P, idx_list=None, k=None):
+    """logits (B,N,num_class).  idx_list forces the neighbour graph (tests); None = compute it.  k: None = int(flags.KVALUE) for
+    every layer (model.py:16); a list = one k per layer, the form ops.repeat_edge_conv accepts (ops.py:77-82)."""
     L = int(flags.EDGE_CONV_LAYERS)
     residual = flags.MODEL_NAME != "dgcnn"
     ecf = as_list(flags.EDGE_CONV_FILTERS, L)
-    k = int(flags.KVALUE)
+    kv = as_list(int(flags.KVALUE) if k is None else k, L)
     net = points
     tensors = []
     shortcut = None
     B, N, _ = points.shape
     for i in range(L):
         s = "EdgeConv%d/" % i
-        idx = k_nn(net.detach(), k) if idx_list is None else torch.as_tensor(idx_list[i], dtype=torch.long)
+        idx = k_nn(net.detach(), kv[i]) if idx_list is None else torch.as_tensor(idx_list[i], dtype=torch.long)
         E = edges(net, idx)
         y = conv_bn_act(E, P[s + "conv0/weights"], P[s + "conv0/BatchNorm/beta"])
         mx = y.amax(dim=-2, keepdim=True)

@@ -32,6 +32,14 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     assert r["bound"] in ("hbm", "mfma", "valu") and r["unit"] in ("GB/s", "TFLOP/s")
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and 0.0 < r["frac"] < 1.0
     assert r["traffic"] is None or r["traffic"] > 0
+    c = d["config"]
+    assert c["deterministic"] is True                                 # the default (and benched) mode is the bit-reproducible one
+    assert c["launch_mode"] in ("launch-plan replay", "eager") and set(c["launch_mode_calibration"]) >= {"eager_ms", "plan_ms"}
+    assert c["repeats"] >= 5 and len(c["per_repeat_ms_per_step"]) == c["repeats"]
+    assert sorted(c["per_repeat_ms_per_step"])[c["repeats"] // 2] == d["ms_per_step"]       # the MEDIAN region is the reported one
+    if c["launch_mode"] == "launch-plan replay":
+        lp = c["launches_per_step"]
+        assert 60 < lp["kernels"] < 160 and lp["collectives"] == 0 and c["host_enqueue_ms_per_step"] < 0.5 * d["ms_per_step"]
     s = d["edgeconv_stack"]                                           # the EdgeConv stack alone
     assert s["unit"] == "clouds/s" and s["value"] > d["value"]       # the stack alone is faster than the whole model
 
@@ -56,15 +64,28 @@ def test_bench_gpus_2_from_a_bare_shell_launches_two_ranks_itself():
     assert "roofline" in d and "cpu_baseline" not in d and "edgeconv_stack" not in d
 
 
-def test_bench_deterministic_mode_gives_a_reproducible_line():
-    """bench.py --deterministic: the bit-reproducible kernels are reachable from the bench (two runs: the same final loss)."""
+@pytest.mark.parametrize("graph", ["0", "plan"])
+def test_bench_default_mode_gives_a_reproducible_line(graph):
+    """The benched mode is the deterministic one: two runs of the same command end with the same final loss, launched eagerly
+    and replayed from a launch plan alike (--repeats fixes the number of steps; its default depends on the box's speed)."""
     outs = []
     for _ in range(2):
         p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "2", "--no-cpu-baseline",
-                            "--no-edgeconv-stack", "--deterministic", "--graph", "0"],
+                            "--no-edgeconv-stack", "--graph", graph, "--repeats", "5"],
                            stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, cwd=ROOT)
         assert p.returncode == 0, p.stderr.decode(errors="replace")[-2000:]
         d = json.loads([l for l in p.stdout.decode().splitlines() if l.strip().startswith("{")][0])
-        assert d["config"]["deterministic"] is True and d["config"]["launch_mode"] == "eager" and "edgeconv_stack" not in d
+        want = {"0": "eager", "plan": "launch-plan replay"}[graph]
+        assert d["config"]["deterministic"] is True and d["config"]["launch_mode"] == want and "edgeconv_stack" not in d
+        assert d["config"]["repeats"] == 5
         outs.append(d["config"]["final_loss"])
     assert outs[0] == outs[1], outs
+
+
+def test_bench_atomics_mode_is_reachable():
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "2", "--no-cpu-baseline",
+                        "--no-edgeconv-stack", "--atomics", "--repeats", "5"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, cwd=ROOT)
+    assert p.returncode == 0, p.stderr.decode(errors="replace")[-2000:]
+    d = json.loads([l for l in p.stdout.decode().splitlines() if l.strip().startswith("{")][0])
+    assert d["config"]["deterministic"] is False

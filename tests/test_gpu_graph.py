@@ -1,5 +1,6 @@
-"""HIP-graph replay of the training / inference tower (trainval.use_graph): same results as eager launches, a fresh
-dropout mask on every replay, micro-step accumulation across replays."""
+"""Replay of the training / inference tower (trainval.use_graph) in both replay modes -- the recorded launch plan (csrc/plan.cc:
+"plan") and the captured HIP graph (True): same results as eager launches, a fresh dropout mask on every replay, micro-step
+accumulation across replays, bounded caches; and the launch plan with the second stream and an RCCL call inside it."""
 import numpy as np
 import pytest
 import torch
@@ -8,6 +9,11 @@ import dgcnn
 from dgcnn import _engine as E
 
 pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(params=["plan", True], ids=["launch-plan", "hip-graph"])
+def mode(request):
+    return request.param
 
 
 def _flags(**kw):
@@ -35,14 +41,14 @@ def _train(graph, steps, pts, lab, **kw):
     return tv, np.asarray(losses), dgcnn.ctx().flat_param.cpu().numpy().copy()
 
 
-def test_graph_replay_matches_eager_training():
+def test_graph_replay_matches_eager_training(mode):
     """Same dropout stream (the seed advances per tower call in both modes), same arithmetic.  The default kernels are not
     bit-reproducible run to run (atomically accumulated BatchNorm sums -> last-bit feature differences -> a few different
     layer-1 neighbour lists -> Adam amplifies; two EAGER runs differ by the same amount, which made a noise-relative bar
     flaky): the comparison runs the deterministic kernels, where graph replay must retrace the eager run exactly."""
     pts, lab = _data()
     tv_e, loss_e, p_e = _train(False, 4, pts, lab, DETERMINISTIC=True)
-    tv_g, loss_g, p_g = _train(True, 4, pts, lab, DETERMINISTIC=True)
+    tv_g, loss_g, p_g = _train(mode, 4, pts, lab, DETERMINISTIC=True)
     assert len(tv_g._graphs) == 1 and not tv_e._graphs            # one (shape, mode) -> one captured graph, replayed 6 times
     np.testing.assert_allclose(loss_g, loss_e, rtol=0, atol=1e-6)             # (a wrong mask stream moves the loss by ~1e-2)
     d = np.abs(p_g - p_e)
@@ -50,14 +56,14 @@ def test_graph_replay_matches_eager_training():
     assert d.max() <= 1e-6, d.max()
     assert np.abs(p_g - dgcnn.trainval(_flags()).initialize()._ctx.flat_param.cpu().numpy()).max() > 1e-3   # it trained
     # default kernels: the first two micro-steps (before any update) still agree to the atomics' noise
-    tv_e, loss_e, _ = _train(False, 1, pts, lab)
-    tv_g, loss_g, _ = _train(True, 1, pts, lab)
+    tv_e, loss_e, _ = _train(False, 1, pts, lab, DETERMINISTIC=False)
+    tv_g, loss_g, _ = _train(mode, 1, pts, lab, DETERMINISTIC=False)
     np.testing.assert_allclose(loss_g, loss_e, rtol=0, atol=2e-5)
 
 
-def test_graph_replay_draws_a_new_dropout_mask_and_accumulates():
+def test_graph_replay_draws_a_new_dropout_mask_and_accumulates(mode):
     pts, lab = _data(steps=1)
-    tv = dgcnn.trainval(_flags()).initialize().use_graph(True)
+    tv = dgcnn.trainval(_flags()).initialize().use_graph(mode)
     c = dgcnn.ctx()
     losses, grads = [], []
     for i in range(4):                                           # call 0 eager, call 1 captures + replays, 2..3 replay
@@ -71,7 +77,7 @@ def test_graph_replay_draws_a_new_dropout_mask_and_accumulates():
     # the atomically summed statistics two replays differ by a few flipped near-tie neighbours, ~2e-3 of the gradient norm)
     keep, E.DROPOUT_KEEP = E.DROPOUT_KEEP, 1.0
     try:
-        tv = dgcnn.trainval(_flags(DETERMINISTIC=True)).initialize().use_graph(True)
+        tv = dgcnn.trainval(_flags(DETERMINISTIC=True)).initialize().use_graph(mode)
         c = dgcnn.ctx()
         for i in range(2):
             tv.zero_gradients(None)
@@ -85,11 +91,11 @@ def test_graph_replay_draws_a_new_dropout_mask_and_accumulates():
         E.DETERMINISTIC = E.DETERMINISTIC_ENV_DEFAULT
 
 
-def test_graph_replay_inference_and_new_shapes():
+def test_graph_replay_inference_and_new_shapes(mode):
     pts, lab = _data(steps=3)
     f = _flags(TRAIN=False)
     outs = []
-    tv = dgcnn.trainval(f).initialize().use_graph(True)
+    tv = dgcnn.trainval(f).initialize().use_graph(mode)
     for s in range(3):
         sm = tv.inference(None, [pts[s]], [lab[s]])
         outs.append([o.clone() for o in sm])
@@ -99,13 +105,13 @@ def test_graph_replay_inference_and_new_shapes():
         want = tv.inference(None, [pts[s]], [lab[s]])
         np.testing.assert_allclose(outs[s][0].cpu().numpy(), want[0].cpu().numpy(), rtol=0, atol=2e-4)
         assert abs(float(outs[s][-1]) - float(want[-1])) < 2e-4
-    tv.use_graph(True)
+    tv.use_graph(mode)
     other = torch.rand(2, 300, 3, device="cuda")                 # a shape seen once runs eagerly, no graph is kept for it
     tv.inference(None, [other])
     assert len(tv._graphs) == 1
 
 
-def test_graph_outputs_of_several_towers_and_micro_steps_do_not_alias():
+def test_graph_outputs_of_several_towers_and_micro_steps_do_not_alias(mode):
     """Every replay of one (shape, mode) key writes the same static buffers: the softmax / [loss, accuracy] handed to the
     caller must be copies, or every tower of a multi-tower call (and every gathered micro-step) shows the LAST replay."""
     pts, lab = _data(steps=4, B=2, N=384, seed=3)
@@ -113,7 +119,7 @@ def test_graph_outputs_of_several_towers_and_micro_steps_do_not_alias():
     f = _flags(TRAIN=False)
     tv = dgcnn.trainval(f).initialize().use_graph(False)
     want = tv.inference(None, towers_p, towers_l)
-    tv.use_graph(True)
+    tv.use_graph(mode)
     got = None
     for _ in range(3):                                            # eager sighting, capture + replay, replay
         got = tv.inference(None, towers_p, towers_l)
@@ -134,7 +140,7 @@ def test_graph_outputs_of_several_towers_and_micro_steps_do_not_alias():
             tv.apply_gradient(None)
             return [float(r[2]) for r in res], tv
         le, _ = micro_losses(False)
-        lg, tvg = micro_losses(True)
+        lg, tvg = micro_losses(mode)
         assert len(tvg._graphs) == 1
         assert len({round(x, 6) for x in lg}) == 4, lg           # four different micro-batches, four different losses
         np.testing.assert_allclose(lg, le, rtol=0, atol=2e-5)
@@ -142,11 +148,11 @@ def test_graph_outputs_of_several_towers_and_micro_steps_do_not_alias():
         E.DROPOUT_KEEP = keep
 
 
-def test_graph_cache_is_bounded():
+def test_graph_cache_is_bounded(mode):
     """Variable-N sources: every distinct point count would otherwise pin a captured graph and its activations for ever."""
     import importlib
     TV = importlib.import_module("dgcnn.trainval")               # (the package attribute `dgcnn.trainval` is the class)
-    tv = dgcnn.trainval(_flags(TRAIN=False)).initialize().use_graph(True)
+    tv = dgcnn.trainval(_flags(TRAIN=False)).initialize().use_graph(mode)
     old = TV.GRAPH_CACHE_MAX
     TV.GRAPH_CACHE_MAX = 3
     try:
@@ -156,13 +162,32 @@ def test_graph_cache_is_bounded():
                 out = tv.inference(None, [x])
             assert out[0].shape == (1, n, 2)
         assert len(tv._graphs) == 3
-        assert [k[0][1] for k in tv._graphs] == [320, 352, 384]   # least recently used shapes were dropped
+        assert [k[1][1] for k in tv._graphs] == [320, 352, 384]   # least recently used shapes were dropped
         tv.use_graph("auto")                                      # "auto": a shape must come back a few times first
         x = torch.rand(1, 416, 3, device="cuda")
         for i in range(TV.GRAPH_CAPTURE_AFTER_AUTO):
             tv.inference(None, [x])
-            assert all(k[0][1] != 416 for k in tv._graphs)
+            assert all(k[1][1] != 416 for k in tv._graphs)
         tv.inference(None, [x])
-        assert any(k[0][1] == 416 for k in tv._graphs)
+        assert any(k[1][1] == 416 and k[0] == "plan" for k in tv._graphs)          # "auto" replays from launch plans
     finally:
         TV.GRAPH_CACHE_MAX = old
+
+
+def test_launch_plan_with_the_second_stream_retraces_the_eager_step_bit_for_bit():
+    """The recorded plan contains the cross-stream waits of the step (weight-gradient GEMMs, transposed adjacency and the
+    parameter-only preparation on the side stream): with the deterministic kernels a replayed training run must equal the eager
+    run bit for bit, and the plan must hold more than one wait and no collective."""
+    pts, lab = _data(steps=3, B=4, N=512, seed=5)
+    old_min = E.SIDE_STREAM_MIN_ROWS
+    E.SIDE_STREAM_MIN_ROWS = 0                                   # the test shape is below the production threshold
+    try:
+        tv_e, loss_e, p_e = _train(False, 3, pts, lab, DETERMINISTIC=True)
+        tv_p, loss_p, p_p = _train("plan", 3, pts, lab, DETERMINISTIC=True)
+        info = tv_p.launch_plan_info()
+        assert len(info) == 1 and info[0]["kernels"] > 60 and info[0]["waits"] >= 4 and info[0]["collectives"] == 0, info
+        np.testing.assert_allclose(loss_p, loss_e, rtol=0, atol=1e-6)      # (the REPORTED loss is summed with atomics: last bit)
+        np.testing.assert_array_equal(p_p, p_e)                             # what training depends on: bit for bit
+    finally:
+        E.SIDE_STREAM_MIN_ROWS = old_min
+        E.DETERMINISTIC = E.DETERMINISTIC_ENV_DEFAULT

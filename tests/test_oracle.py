@@ -41,6 +41,38 @@ def test_oracle_backward_matches_autograd(model_name, ecf):
         np.testing.assert_allclose(G[n], P[n].grad.numpy(), rtol=1e-7, atol=1e-9, err_msg=n)
 
 
+def test_oracle_backward_matches_autograd_with_no_fc_layer_and_per_layer_k():
+    """FC_LAYERS = 0 (model.py:88 + ops.py:151: zero trips, Final on the 1024 + sum(2F+64) + 1024 channel concat) and a list-valued k
+    (ops.py:77-82, one k per EdgeConv layer): forward and hand-written backward against autograd of the twin."""
+    rng = np.random.default_rng(4)
+    B, N, C = 2, 24, 3
+    kl = [6, 4, 3]
+    flags = O.Flags(EDGE_CONV_LAYERS=3, EDGE_CONV_FILTERS=[8, 8, 16], FC_LAYERS=0, FC_FILTERS=[], KVALUE=5, NUM_CLASS=3, TRAIN=False)
+    assert dict(O.param_specs(flags, C))["Final/weights"] == (1024 + (16 + 64) * 2 + (32 + 64) + 1024, 3)
+    assert not any(n.startswith("FC") for n, _ in O.param_specs(flags, C))
+    pts = rng.random((B, N, C))
+    labels = rng.integers(0, 3, (B, N))
+    params = O.init_params(flags, C, seed=2, dtype=np.float64)
+    for n in params:
+        if n.endswith("beta"):
+            params[n] = rng.normal(0, 0.3, params[n].shape)
+    logits, cache = O.model_forward(pts, flags, params, k=kl)
+    idx_list = [l["ec"]["idx"] for l in cache["layers"]]
+    assert [i.shape[-1] for i in idx_list] == kl
+    loss, sm, acc, dlogits = O.softmax_xent(logits, labels)
+    G = O.model_backward(dlogits, cache)
+    P = {n: torch.tensor(v, dtype=torch.float64, requires_grad=True) for n, v in params.items()}
+    tl = T.model(torch.tensor(pts), flags, P, k=kl)            # (the twin computes its own graphs: same k per layer)
+    np.testing.assert_allclose(tl.detach().numpy(), logits, rtol=1e-9, atol=1e-10)
+    tloss = torch.nn.functional.cross_entropy(tl.reshape(-1, 3), torch.tensor(labels).reshape(-1))
+    tloss.backward()
+    assert set(G) == set(params)
+    for n in params:
+        np.testing.assert_allclose(G[n], P[n].grad.numpy(), rtol=1e-7, atol=1e-9, err_msg=n)
+    with pytest.raises(ValueError):
+        O.model_forward(pts, flags, params, k=[6, 4])               # ops.py:80-82: Length of k != repeat
+
+
 def test_param_inventory_matches_survey_appendix_b():
     flags = O.Flags(EDGE_CONV_FILTERS=[64, 64, 128])
     specs = O.param_specs(flags, 3)
