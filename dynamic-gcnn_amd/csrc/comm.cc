@@ -102,6 +102,10 @@ int check(int rc, const char* what) {
 
 }  // namespace
 
+// dlopen librccl and resolve its entry points (every other dgcnn_comm_* call does this on first use; a separate entry point lets
+// the host name the stage that failed)
+extern "C" int dgcnn_comm_available(void) { return load_api(); }
+
 extern "C" int dgcnn_comm_unique_id(void* id128) {
   DG_REQUIRE(id128, DGCNN_EINVAL, "dgcnn_comm_unique_id: null pointer");
   int rc = load_api();

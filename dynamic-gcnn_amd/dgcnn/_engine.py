@@ -155,18 +155,24 @@ class Context(object):
     def stats(self, F):
         """Zeroed double[SLOTS][2][F] carved from one arena that is memset once per step."""
         n = H.STAT_SLOTS * 2 * F
-        want = (1 << 20) if H.STAT_SLOTS <= 32 else (1 << 19) * -(-H.STAT_SLOTS // 32)   # 8 MB at 32 slots, 96 MB at 768
+        want = self.arena_want()
         if self.stat_arena is None or self.stat_arena.device != self.device or self.stat_arena.numel() < want:
             # a captured HIP graph has the arena's address (and the slot count) baked into its launches: trainval keys its
             # graphs on arena_key() and drops those recorded against an arena that no longer exists
             self.stat_arena = H.zeros(want, torch.float64, self.device)
             self.stat_off = 0
             self.arena_gen += 1
-        if self.stat_off + n > self.stat_arena.numel():
+        if self.stat_off + n > want:
             return H.zeros(n, torch.float64, self.device)
         s = self.stat_arena[self.stat_off:self.stat_off + n]
         self.stat_off += n
         return s
+
+    @staticmethod
+    def arena_want():
+        """Doubles of the statistics arena a step may use at the current slot count: 8 MB at 32 slots, 96 MB at 768.  The arena
+        itself may be larger (an earlier, larger cloud grew it): a step carves from -- and a captured step zeroes -- only this much."""
+        return (1 << 20) if H.STAT_SLOTS <= 32 else (1 << 19) * -(-H.STAT_SLOTS // 32)
 
     def arena_key(self):
         """What a captured step depends on besides its inputs: the statistics arena it zeroes / writes and the slot count its
@@ -184,11 +190,13 @@ class Context(object):
     def configure_slots(self, rows=0):
         """DETERMINISTIC: every stats / red slot gets a single writer -- as many slots as the producer with the most workgroups has
         (a GEMM over `rows` rows in 64-row tiles; the reduction kernels cap their grids at the slot count) -- so that no sum
-        depends on the order in which workgroups finish.  Default mode: DGCNN_STAT_SLOTS (32) slots, several writers each."""
+        depends on the order in which workgroups finish.  A pure function of `rows`: the reduction kernels' grids follow the slot
+        count, so a count that remembered earlier, larger steps would make a step's rounding depend on the process' history
+        (round 5: the same step in a fresh process and after a 65536-point cloud differed by 4e-4 -- both "deterministic").
+        Atomics mode: DGCNN_STAT_SLOTS (32) slots, several writers each."""
         if DETERMINISTIC:
             n = max(256, -(-int(rows) // 64))                              # (the finalize kernels walk all of them: no rounding up)
             n = -(-n // 64) * 64
-            n = max(n, H.STAT_SLOTS if H.STAT_SLOTS > 32 else 0)       # never shrink inside a run: buffers of this step exist already
         else:
             n = 32
         if n != H.STAT_SLOTS:
@@ -235,7 +243,7 @@ class Context(object):
         if self.stat_arena is None or self.stat_arena.device != self.device:
             self.stats(1)
             self.stat_off = 0
-        if self.stat_off + n > self.stat_arena.numel():
+        if self.stat_off + n > min(self.stat_arena.numel(), self.arena_want()):
             return H.zeros(n, torch.float64, self.device)
         s = self.stat_arena[self.stat_off:self.stat_off + n]
         self.stat_off += n
@@ -252,10 +260,11 @@ class Context(object):
         if not DETERMINISTIC and H.STAT_SLOTS != 32:
             H.set_stat_slots(32)
         elif DETERMINISTIC and H.STAT_SLOTS < 256:
-            self.configure_slots(0)
+            self.configure_slots(0)           # (stand-alone ops; a model step sets its own count in model.build)
         if self.stat_arena is not None:
             if self.capturing:
-                H.memset(self.stat_arena)        # a captured step cannot know what ran before it: whole arena (8 MB memset)
+                # a captured step cannot know what ran before it: everything a step at this slot count may use
+                H.memset(self.stat_arena[:min(self.stat_arena.numel(), self.arena_want())])
             elif self.stat_off > 0:
                 H.memset(self.stat_arena[:self.stat_off])
         self.stat_off = 0
@@ -386,8 +395,8 @@ def reset():
     """Forget all variables / state (tf.reset_default_graph analogue)."""
     global _CTX
     _CTX = Context()
-    if H.STAT_SLOTS != 32 and not DETERMINISTIC:
-        H.set_stat_slots(32)
+    if H.STAT_SLOTS != 32:
+        H.set_stat_slots(32)                 # (the first step picks the count of its mode and shape)
     return _CTX
 
 

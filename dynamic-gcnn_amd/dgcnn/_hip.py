@@ -118,6 +118,7 @@ PROTOTYPES = {
     "dgcnn_plan_destroy": [c_vp],
     "dgcnn_stream_wait": [c_vp, c_vp],
     "dgcnn_memset_async": [c_vp, c_int, c_sz, c_vp],
+    "dgcnn_comm_available": [],
     "dgcnn_comm_unique_id": [c_vp],
     "dgcnn_comm_init": [c_int, c_int, c_vp, c_vp],
     "dgcnn_comm_destroy": [c_vp],

@@ -10,6 +10,7 @@ from __future__ import annotations
 import ctypes
 import os
 import socket
+import sys
 import time
 
 import torch
@@ -30,11 +31,17 @@ def _exchange_id(rank, world, addr, port, make_id, timeout=90.0):
         srv.bind((addr if addr not in ("localhost",) else "127.0.0.1", port))
         srv.listen(world)
         srv.settimeout(timeout)
+        served = 0
         try:
             for _ in range(world - 1):
                 conn, _ = srv.accept()
                 with conn:
                     conn.sendall(ident)
+                served += 1
+        except socket.timeout:
+            raise H.HipError("RCCL rendezvous: rank 0 served the unique id to %d of %d ranks on %s:%d within %.0f s -- the others "
+                             "never connected (not started, another MASTER_ADDR / MASTER_PORT, or a firewall)"
+                             % (served, world - 1, addr, port, timeout))
         finally:
             srv.close()
         return ident
@@ -71,21 +78,46 @@ class Group(object):
             raise H.HipError("RCCL group needs a GPU")
         self.lib = H.load()
         self.device = torch.device("cuda", torch.cuda.current_device())
+        self.comm = None
+        timeout = float(env.get("DGCNN_RCCL_TIMEOUT", "90"))
+        # Four stages, each named in the error it raises (and on stderr with DGCNN_RCCL_TRACE=1: a HANG inside RCCL cannot raise --
+        # profiles/scale_probe.sh reads the last stage a rank announced): dlopen -> unique-id TCP -> ncclCommInitRank -> first collective
+        try:
+            self._stage("dlopen", "librccl via %s" % (env.get("DGCNN_RCCL_LIB") or "the loader's search path"))
+            self._check(self.lib.dgcnn_comm_available(), "dgcnn_comm_available")
 
-        def make_id():
-            buf = ctypes.create_string_buffer(ID_BYTES)
-            self._check(self.lib.dgcnn_comm_unique_id(buf), "dgcnn_comm_unique_id")
-            return buf.raw
-        ident = _exchange_id(self.rank, self.world, addr, int(port), make_id)
-        comm = ctypes.c_void_p()
-        self._check(self.lib.dgcnn_comm_init(self.world, self.rank, ident, ctypes.byref(comm)), "dgcnn_comm_init")
-        self.comm = comm
-        self.stream = torch.cuda.Stream(device=self.device)          # collectives run here
-        # what RCCL itself reports for this communicator must match what the launcher said -- checked once, loudly
-        info = self.info()
-        if (info["nranks"], info["rank"]) != (self.world, self.rank):
-            raise H.HipError("RCCL communicator reports rank %d of %d, the launcher said rank %d of %d"
-                             % (info["rank"], info["nranks"], self.rank, self.world))
+            def make_id():
+                buf = ctypes.create_string_buffer(ID_BYTES)
+                self._check(self.lib.dgcnn_comm_unique_id(buf), "dgcnn_comm_unique_id")
+                return buf.raw
+            self._stage("unique-id TCP", "%s:%d, timeout %.0f s" % (addr, int(port), timeout))
+            ident = _exchange_id(self.rank, self.world, addr, int(port), make_id, timeout=timeout)
+            self._stage("ncclCommInitRank", "device %d, HSA_ENABLE_IPC_MODE_LEGACY=%s, NCCL_SOCKET_IFNAME=%s"
+                        % (self.device.index, env.get("HSA_ENABLE_IPC_MODE_LEGACY"), env.get("NCCL_SOCKET_IFNAME")))
+            comm = ctypes.c_void_p()
+            self._check(self.lib.dgcnn_comm_init(self.world, self.rank, ident, ctypes.byref(comm)), "dgcnn_comm_init")
+            self.comm = comm
+            self.stream = torch.cuda.Stream(device=self.device)          # collectives run here
+            # what RCCL itself reports for this communicator must match what the launcher said -- checked once, loudly
+            info = self.info()
+            if (info["nranks"], info["rank"]) != (self.world, self.rank):
+                raise H.HipError("RCCL communicator reports rank %d of %d, the launcher said rank %d of %d"
+                                 % (info["rank"], info["nranks"], self.rank, self.world))
+            self._stage("first collective", "all-reduce of one float over %d ranks" % self.world)
+            one = torch.ones(1, dtype=torch.float32, device=self.device)
+            self.allreduce_sum_(one)
+            torch.cuda.synchronize()
+            if float(one) != float(self.world):
+                raise H.HipError("the first all-reduce over %d ranks returned %r" % (self.world, float(one)))
+            self._stage("ready", "")
+        except Exception as e:
+            raise H.HipError("RCCL group, rank %d of %d, stage `%s`: %s" % (self.rank, self.world, self.stage, e))
+
+    def _stage(self, name, detail):
+        self.stage = name
+        if os.environ.get("DGCNN_RCCL_TRACE", "0") not in ("0", ""):
+            sys.stderr.write("[dgcnn.rccl rank %d/%d] stage: %s%s\n" % (self.rank, self.world, name, " (%s)" % detail if detail else ""))
+            sys.stderr.flush()
 
     def info(self):
         """{'nranks', 'rank', 'device'} from ncclCommCount / ncclCommUserRank / ncclCommCuDevice (dgcnn_comm_info)."""

@@ -258,6 +258,7 @@ class trainval(object):
             self._head_reduced = ent["head_reduced"]
         else:
             ent["graph"].replay()
+        c.stat_off = max(c.stat_off, ent["stat_used"])       # (the next eager step re-zeroes what this replay dirtied)
         # the replay's output buffers are overwritten by the next replay of this key: hand out copies (stream ordered),
         # so that several towers / micro-steps of one shape each keep their own softmax and [loss, accuracy]
         return ent["sm"].clone(), ent["scal"].clone()
@@ -305,6 +306,7 @@ class trainval(object):
             c.side_hold = []
             c.head_grads_hook = hook if ent is None else None
         if ent is not None:
+            ent["stat_used"] = c.stat_off                        # doubles of the statistics arena the captured step writes
             self._graphs[key] = ent
             if ent["arena"] != c.arena_key():                    # (cannot happen after ensure_arena; never replay such a graph)
                 self._drop_graph(key)

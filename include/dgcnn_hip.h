@@ -422,6 +422,7 @@ int dgcnn_memset_async(void* ptr, int value, size_t bytes, void* stream);
  * dgcnn_comm_unique_id: rank 0 fills 128 bytes; the host ships them to the other ranks (dgcnn/rccl.py).
  * dgcnn_comm_init: ncclCommInitRank for this process' current HIP device -> opaque communicator.
  * dgcnn_allreduce_f32: in-place SUM over the ranks on `stream`;  dgcnn_broadcast_f32: root's buffer to every rank. */
+int dgcnn_comm_available(void);        /* dlopen + symbol lookup only: DGCNN_OK or DGCNN_EUNSUP with the reason in dgcnn_last_error */
 int dgcnn_comm_unique_id(void* id128);
 int dgcnn_comm_init(int world, int rank, const void* id128, void** comm_out);
 int dgcnn_comm_destroy(void* comm);

@@ -41,7 +41,15 @@ class StubGroup(object):
         delay = float(env.get("STUB_RCCL_DELAY_RANK%d" % self.rank, "0"))      # tests make a rank arrive late
         if delay:
             time.sleep(delay)
-        ident = rccl._exchange_id(self.rank, self.world, addr, port, lambda: os.urandom(rccl.ID_BYTES))
+        # the stage announcements of dgcnn.rccl.Group (DGCNN_RCCL_TRACE), and a failure injected at one of them on one rank
+        # (STUB_RCCL_FAIL="<rank>:<stage>"): what profiles/scale_probe.sh diagnoses
+        fail = env.get("STUB_RCCL_FAIL", "")
+        self._fail = fail.split(":", 1)[1] if fail and int(fail.split(":", 1)[0]) == self.rank else None
+        self._stage("dlopen")
+        self._stage("unique-id TCP")
+        ident = rccl._exchange_id(self.rank, self.world, addr, port, lambda: os.urandom(rccl.ID_BYTES),
+                                  timeout=float(env.get("DGCNN_RCCL_TIMEOUT", "90")))
+        self._stage("ncclCommInitRank")
         self.ident = ident
         # data plane: a star through rank 0 on port + 1 (peers announce their rank; late peers retry like the id fetch)
         self.peers = {}
@@ -72,6 +80,19 @@ class StubGroup(object):
                         time.sleep(0.1)
                 self.up.settimeout(120.0)
                 _send(self.up, (self.rank, ident))
+
+        self._stage("first collective")
+        self._reduce([1.0])
+        self._stage("ready")
+
+    def _stage(self, name):
+        import sys
+        if os.environ.get("DGCNN_RCCL_TRACE", "0") not in ("0", ""):
+            sys.stderr.write("[dgcnn.rccl rank %d/%d] stage: %s (stand-in)\n" % (self.rank, self.world, name))
+            sys.stderr.flush()
+        if self._fail == name:
+            raise RuntimeError("RCCL group, rank %d of %d, stage `%s`: injected failure (stand-in communicator)"
+                               % (self.rank, self.world, name))
 
     # ---- the surface bench.py uses -----------------------------------------------------------
     def info(self):
