@@ -81,13 +81,22 @@ __global__ __launch_bounds__(256) void colstats_det_kernel(const float* __restri
   det_store(m, F, s, q, part, lds);
 }
 
-__global__ void det_stage2_kernel(const double* __restrict__ part, int F, double* __restrict__ out) {
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;     // e in [0, 2F): which * F + f
-  if (e >= 2 * F) return;
+// one wave per output (which, f): lane l adds the partials g = l, l + 64, ... in that order (DET_G / 64 independent loads in
+// flight), then the 64 lane sums are added in lane order by a fixed butterfly -- a fixed order, run to run.  (Round 4: one
+// THREAD per output walked the 1024 partials, 68 us for the two columns of the class dimension.)
+__global__ __launch_bounds__(64) void det_stage2_kernel(const double* __restrict__ part, int F, double* __restrict__ out) {
+  const int e = blockIdx.x;                                 // e in [0, 2F): which * F + f
   const int which = e / F, f = e % F;
+  const int l = threadIdx.x;
+  double v[DET_G / 64];
+#pragma unroll
+  for (int i = 0; i < DET_G / 64; ++i) v[i] = part[((int64_t)(l + 64 * i) * 2 + which) * F + f];
   double t = 0.0;
-  for (int g = 0; g < DET_G; ++g) t += part[((int64_t)g * 2 + which) * F + f];
-  out[(int64_t)which * F + f] = t;                         // slot 0
+#pragma unroll
+  for (int i = 0; i < DET_G / 64; ++i) t += v[i];
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) t += __shfl_xor(t, d, 64);
+  if (l == 0) out[(int64_t)which * F + f] = t;              // slot 0
 }
 
 // sum dZ and sum dZ * xhat over all R*k rows (dgcnn_bn_bwd_reduce_f32's quantities, same formulas as bn.hip) from the
@@ -138,17 +147,21 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_det_kernel(
   det_store(m, F, s, q, part, lds);
 }
 
-// every bucket of the transposed adjacency in ascending edge order (the build fills buckets through LDS cursors: any order)
-__global__ void csr_sort_kernel(const int32_t* __restrict__ off, int32_t* __restrict__ rev, int64_t R) {
-  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= R) return;
-  const int b = off[j], e = off[j + 1];
-  for (int i = b + 1; i < e; ++i) {                        // insertion sort: buckets hold ~k entries
-    const int32_t v = rev[i];
-    int p = i - 1;
-    while (p >= b && rev[p] > v) { rev[p + 1] = rev[p]; --p; }
-    rev[p + 1] = v;
-  }
+// every bucket of the transposed adjacency in ascending edge order (the build fills buckets through LDS cursors: any order).
+// Out of place, one thread per stored edge: its bucket is the edge's target point (from idx), its place the number of smaller
+// edge ids in that bucket -- ~k reads of neighbouring words per thread, no dependent chain.  (Round 4: one thread per bucket,
+// insertion sort in global memory, 35-65 us per layer.)
+__global__ __launch_bounds__(256) void csr_sort_kernel(const int32_t* __restrict__ idx, int N, int k, const int32_t* __restrict__ off,
+                                                       const int32_t* __restrict__ rev, int32_t* __restrict__ out, int64_t total) {
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= total) return;
+  const int32_t e = rev[p];                                  // edge id = point * k + m (global point numbering)
+  const int64_t cloud = (int64_t)e / ((int64_t)N * k);
+  const int64_t j = cloud * N + idx[e];
+  const int b = off[j], n = off[j + 1] - b;
+  int rank = 0;
+  for (int q = 0; q < n; ++q) rank += (rev[b + q] < e) ? 1 : 0;
+  out[b + rank] = e;
 }
 
 }  // namespace
@@ -163,7 +176,7 @@ extern "C" int dgcnn_colstats_det_f32(const float* Y, int64_t rows, int F, int64
   DG_REQUIRE(ws_bytes >= sizeof(double) * DET_G * 2 * (size_t)F, DGCNN_ENOSPC, "dgcnn_colstats_det_f32: workspace too small");
   double* part = reinterpret_cast<double*>(ws);
   dg::launch(colstats_det_kernel, dim3(DET_G), dim3(256), 0, ST, Y, rows, F, ld, part);
-  dg::launch(det_stage2_kernel, dim3((unsigned)dg::cdiv(2 * F, 256)), dim3(256), 0, ST, part, F, stats);
+  dg::launch(det_stage2_kernel, dim3((unsigned)(2 * F)), dim3(64), 0, ST, part, F, stats);
   return dg::check_launch("dgcnn_colstats_det_f32");
 }
 
@@ -178,12 +191,15 @@ extern "C" int dgcnn_bn_bwd_reduce_det_f32(const float* Y, int64_t R, int k, int
   double* part = reinterpret_cast<double*>(ws);
   dg::launch(bn_bwd_reduce_det_kernel, dim3(DET_G), dim3(256), 0, ST, Y, R, k, F, mean, rstd, beta, relu, dmax, lddmax,
                      dmean, lddmean, mx_in, ldmx, cnt_in, part);
-  dg::launch(det_stage2_kernel, dim3((unsigned)dg::cdiv(2 * F, 256)), dim3(256), 0, ST, part, F, red);
+  dg::launch(det_stage2_kernel, dim3((unsigned)(2 * F)), dim3(64), 0, ST, part, F, red);
   return dg::check_launch("dgcnn_bn_bwd_reduce_det_f32");
 }
 
-extern "C" int dgcnn_edge_csr_sort(const int32_t* off, int32_t* rev, int64_t R, void* stream) {
-  DG_REQUIRE(off && rev && R > 0, DGCNN_EINVAL, "dgcnn_edge_csr_sort: bad args");
-  dg::launch(csr_sort_kernel, dim3((unsigned)dg::cdiv(R, 256)), dim3(256), 0, ST, off, rev, R);
+extern "C" int dgcnn_edge_csr_sort(const int32_t* idx, int B, int N, int k, const int32_t* off, const int32_t* rev,
+                                   int32_t* rev_sorted, void* stream) {
+  DG_REQUIRE(idx && off && rev && rev_sorted && rev != rev_sorted && B > 0 && N > 0 && k > 0, DGCNN_EINVAL, "dgcnn_edge_csr_sort: bad args");
+  const int64_t total = (int64_t)B * N * k;
+  DG_REQUIRE(total < (int64_t)1 << 31, DGCNN_EINVAL, "dgcnn_edge_csr_sort: more than 2^31 edges");
+  dg::launch(csr_sort_kernel, dim3((unsigned)dg::cdiv(total, 256)), dim3(256), 0, ST, idx, N, k, off, rev, rev_sorted, total);
   return dg::check_launch("dgcnn_edge_csr_sort");
 }

@@ -508,12 +508,17 @@ def colstats_det(T, st):
     H.call("dgcnn_colstats_det_f32", T.data_ptr(), T.shape[0], T.shape[1], H.ld2(T), st.data_ptr(), ws.data_ptr(), ws.numel())
 
 
+def k1_reduce_fixed_order(Y, k, F, mean, rstd, beta, dmx, dmn, mx):
+    """The k = 1 BatchNorm-backward reduce kernel (float4 channels, column-fixed threads) sums in a fixed order by itself."""
+    return (k == 1 and F % 4 == 0 and mx is None and Y.data_ptr() % 16 == 0 and dmx.data_ptr() % 16 == 0 and H.ld2(dmx) % 4 == 0 and
+            mean.data_ptr() % 16 == 0 and rstd.data_ptr() % 16 == 0 and beta.data_ptr() % 16 == 0 and
+            (dmn is None or (dmn.data_ptr() % 16 == 0 and H.ld2(dmn) % 4 == 0)))
+
+
 def bn_bwd_reduce(Y, R, k, F, mean, rstd, beta, relu, dmx, dmn, mx, cnt, red, tag, work):
     """sum dZ / sum dZ*xhat of a materialised Y.  DETERMINISTIC: the column-fixed k = 1 kernel (float4 channels) reduces in a fixed
     order by itself; every other shape (the class dimension, materialised edge tensors) takes the fixed-order twin of det.hip."""
-    k1 = (k == 1 and F % 4 == 0 and mx is None and Y.data_ptr() % 16 == 0 and dmx.data_ptr() % 16 == 0 and H.ld2(dmx) % 4 == 0 and
-          mean.data_ptr() % 16 == 0 and rstd.data_ptr() % 16 == 0 and beta.data_ptr() % 16 == 0 and
-          (dmn is None or (dmn.data_ptr() % 16 == 0 and H.ld2(dmn) % 4 == 0)))
+    k1 = k1_reduce_fixed_order(Y, k, F, mean, rstd, beta, dmx, dmn, mx)
     if DETERMINISTIC and not k1:
         ws = ctx().workspace()
         H.call("dgcnn_bn_bwd_reduce_det_f32", Y.data_ptr(), R, k, F, mean.data_ptr(), rstd.data_ptr(), beta.data_ptr(), int(relu),
@@ -606,7 +611,8 @@ def conv_bn_act(x, leaf_scope, num_outputs, relu=True, out=None, out2=None, gbia
                 return
             d2 = c.grad(out2) if out2 is not None else None
             # (DETERMINISTIC: unaligned parameter slices send the reduce to the fixed-order twin, which takes one gradient)
-            if d2 is not None and (fuse_drop or use_pl or DETERMINISTIC or F % 4 != 0):
+            if d2 is not None and (fuse_drop or use_pl or F % 4 != 0 or
+                                   (DETERMINISTIC and not k1_reduce_fixed_order(T, 1, F, mean, rstd, beta, dout, d2, None))):
                 # the second copy's gradient joins the first (the default passes below read both instead)
                 H.call("dgcnn_copy2d_f32", d2.data_ptr(), H.ld2(d2), dout.data_ptr(), H.ld2(dout), R, F, 1)
                 d2 = None
@@ -780,6 +786,29 @@ def _point_gemm(c, x, W0, R, C, F):
     return Cp, xg, wcat, UV
 
 
+def build_csr(idx, B, N, k, side=None):
+    """Transposed adjacency of idx (B,N,k): (off (R+1), rev (R*k)) -- for every point the ids e = point * k + m of the edges that
+    point at it.  DETERMINISTIC: every bucket in ascending edge order (the build fills buckets through LDS cursors: any order).
+    side = (ctx, rows): the kernels run on the side stream (the buffers are allocated on the current one and handed over)."""
+    R = B * N
+    dev = idx.device
+    cws = torch.empty(2 * R, dtype=torch.int32, device=dev)
+    off = torch.empty(R + 1, dtype=torch.int32, device=dev)
+    rev = torch.empty(R * k, dtype=torch.int32, device=dev)
+    srt = torch.empty(R * k, dtype=torch.int32, device=dev) if DETERMINISTIC else None
+
+    def fill():
+        H.call("dgcnn_edge_csr_build", idx.data_ptr(), B, N, k, cws.data_ptr(), off.data_ptr(), rev.data_ptr())
+        if srt is not None:
+            H.call("dgcnn_edge_csr_sort", idx.data_ptr(), B, N, k, off.data_ptr(), rev.data_ptr(), srt.data_ptr())
+    if side is None:
+        fill()
+    else:
+        with side[0].off_critical_path(*[t for t in (cws, off, rev, srt) if t is not None], rows=side[1]):
+            fill()
+    return off, (rev if srt is None else srt)
+
+
 def edge_conv_block(x, B, N, k, num_filters, relu1=True, outs=None, net2=None):
     """x: (B*N, C) view.  Returns (mm, net, idx): mm = (R,2F) [max | mean], net = (R,64).
     outs = (mm_view, net_view) destination slices (model path) or None (fresh buffers)."""
@@ -901,13 +930,7 @@ def edge_conv_block(x, B, N, k, num_filters, relu1=True, outs=None, net2=None):
     csr = None
     if c.recording and gather and WGRAD_SIDE_STREAM and R >= SIDE_STREAM_MIN_ROWS and not fused_l0:
         # the transposed adjacency depends only on idx: build it now, off the critical path, for the backward
-        cws = torch.empty(2 * R, dtype=torch.int32, device=x.device)
-        off_t = torch.empty(R + 1, dtype=torch.int32, device=x.device)
-        rev_t = torch.empty(R * k, dtype=torch.int32, device=x.device)
-        with c.off_critical_path(cws, off_t, rev_t, rows=R):
-            H.call("dgcnn_edge_csr_build", idx.data_ptr(), B, N, k, cws.data_ptr(), off_t.data_ptr(), rev_t.data_ptr())
-            if DETERMINISTIC:
-                H.call("dgcnn_edge_csr_sort", off_t.data_ptr(), rev_t.data_ptr(), R)
+        off_t, rev_t = build_csr(idx, B, N, k, side=(c, R))
         csr = (off_t, rev_t)
 
     if c.recording:
@@ -946,12 +969,7 @@ def edge_conv_block(x, B, N, k, num_filters, relu1=True, outs=None, net2=None):
                     if csr is not None:
                         off, rev = csr
                     else:
-                        cws = torch.empty(2 * R, dtype=torch.int32, device=x.device)
-                        off = torch.empty(R + 1, dtype=torch.int32, device=x.device)
-                        rev = torch.empty(R * k, dtype=torch.int32, device=x.device)
-                        H.call("dgcnn_edge_csr_build", idx.data_ptr(), B, N, k, cws.data_ptr(), off.data_ptr(), rev.data_ptr())
-                        if DETERMINISTIC:
-                            H.call("dgcnn_edge_csr_sort", off.data_ptr(), rev.data_ptr(), R)
+                        off, rev = build_csr(idx, B, N, k)
                     S = torch.empty((R, F), dtype=torch.float32, device=x.device)
                     H.call("dgcnn_edge_gather_sum_bf16", dYb.data_ptr(), off.data_ptr(), rev.data_ptr(), R, F, S.data_ptr(), F,
                            tag="csr_gather_sum_kernel<bf16>", work=2.0 * R * k * F + 4.0 * R * F)
@@ -1018,12 +1036,7 @@ def edge_conv_block(x, B, N, k, num_filters, relu1=True, outs=None, net2=None):
                 if csr is not None:
                     off, rev = csr                    # built on the side stream during the forward
                 else:
-                    cws = torch.empty(2 * R, dtype=torch.int32, device=x.device)
-                    off = torch.empty(R + 1, dtype=torch.int32, device=x.device)
-                    rev = torch.empty(R * k, dtype=torch.int32, device=x.device)
-                    H.call("dgcnn_edge_csr_build", idx.data_ptr(), B, N, k, cws.data_ptr(), off.data_ptr(), rev.data_ptr())
-                    if DETERMINISTIC:
-                        H.call("dgcnn_edge_csr_sort", off.data_ptr(), rev.data_ptr(), R)
+                    off, rev = build_csr(idx, B, N, k)
                 H.call("dgcnn_edge_gather_sum_f32", dY.data_ptr(), off.data_ptr(), rev.data_ptr(), R, F, S.data_ptr(),
                        H.ld2(S), tag="csr_gather_sum_kernel", work=4.0 * (R * k * F + R * F))
 

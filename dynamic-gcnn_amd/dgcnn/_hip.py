@@ -86,7 +86,7 @@ PROTOTYPES = {
     "dgcnn_colstats_det_f32": [c_vp, c_i64, c_int, c_i64, c_vp, c_vp, c_sz, c_vp],
     "dgcnn_bn_bwd_reduce_det_f32": [c_vp, c_i64, c_int, c_int, c_vp, c_vp, c_vp, c_int, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64,
                                     c_vp, c_vp, c_vp, c_sz, c_vp],
-    "dgcnn_edge_csr_sort": [c_vp, c_vp, c_i64, c_vp],
+    "dgcnn_edge_csr_sort": [c_vp, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp],
     "dgcnn_global_max_f32": [c_vp, c_i64, c_int, c_int, c_int, c_vp, c_vp, c_vp],
     "dgcnn_global_max_bwd_f32": [c_vp, c_vp, c_int, c_int, c_int, c_vp, c_i64, c_vp],
     "dgcnn_group_colsum_f32": [c_vp, c_i64, c_int, c_int, c_int, c_vp, c_vp],

@@ -354,8 +354,9 @@ int dgcnn_bn_bwd_reduce_det_f32(const float* Y, int64_t R, int k, int F, const f
                                 const float* beta, int relu, const float* dmax, int64_t lddmax,
                                 const float* dmean, int64_t lddmean, const float* mx_in, int64_t ldmx,
                                 const float* cnt_in, double* red, void* ws, size_t ws_bytes, void* stream);
-/* sort every bucket of the transposed adjacency (dgcnn_edge_csr_build) by edge number */
-int dgcnn_edge_csr_sort(const int32_t* off, int32_t* rev, int64_t R, void* stream);
+/* every bucket of the transposed adjacency (dgcnn_edge_csr_build: off, rev) in ascending edge order, out of place -> rev_sorted */
+int dgcnn_edge_csr_sort(const int32_t* idx, int B, int N, int k, const int32_t* off, const int32_t* rev,
+                        int32_t* rev_sorted, void* stream);
 
 /* ---- head helpers (model.py:76-91) and residual add (ops.py:134) -------------------------- */
 /* max_pool_v2 over the N points of each cloud: out[b][f] = max_i x[b][i][f], arg[b][f] = first i */

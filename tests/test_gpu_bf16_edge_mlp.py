@@ -320,7 +320,9 @@ def test_fused_backward_pass_against_the_dense_kernels(dg, B, N, C, k, F):
     cws = torch.empty(2 * R, dtype=torch.int32, device="cuda")
     off, rev = torch.empty(R + 1, dtype=torch.int32, device="cuda"), torch.empty(R * k, dtype=torch.int32, device="cuda")
     H.call("dgcnn_edge_csr_build", idx.data_ptr(), B, N, k, cws.data_ptr(), off.data_ptr(), rev.data_ptr())
-    H.call("dgcnn_edge_csr_sort", off.data_ptr(), rev.data_ptr(), R)
+    srt = torch.empty_like(rev)
+    H.call("dgcnn_edge_csr_sort", idx.data_ptr(), B, N, k, off.data_ptr(), rev.data_ptr(), srt.data_ptr())
+    rev = srt
     S1, S2 = torch.empty((R, F), device="cuda"), torch.empty((R, F), device="cuda")
     H.call("dgcnn_edge_gather_sum_f32", dYd.data_ptr(), off.data_ptr(), rev.data_ptr(), R, F, S1.data_ptr(), F)
     H.call("dgcnn_edge_gather_sum_bf16", dYb.data_ptr(), off.data_ptr(), rev.data_ptr(), R, F, S2.data_ptr(), F)

@@ -100,11 +100,16 @@ def test_det_kernels_against_numpy(det):
     off = torch.empty(Rn + 1, dtype=torch.int32, device="cuda")
     rev = torch.empty(Rn * k, dtype=torch.int32, device="cuda")
     H.call("dgcnn_edge_csr_build", idx.data_ptr(), B, N, k, cws.data_ptr(), off.data_ptr(), rev.data_ptr())
-    H.call("dgcnn_edge_csr_sort", off.data_ptr(), rev.data_ptr(), Rn)
-    o, r = host(off), host(rev)
+    srt = torch.full_like(rev, -1)
+    H.call("dgcnn_edge_csr_sort", idx.data_ptr(), B, N, k, off.data_ptr(), rev.data_ptr(), srt.data_ptr())
+    o, r, r0 = host(off), host(srt), host(rev)
+    hidx = host(idx).reshape(-1)
     for j in range(Rn):
         seg = r[o[j]:o[j + 1]]
         assert (np.diff(seg) > 0).all()
+        np.testing.assert_array_equal(seg, np.sort(r0[o[j]:o[j + 1]]))          # the bucket's own entries, reordered
+        assert ((seg // (N * k)) * N + hidx[seg] == j).all()                      # every edge in it points at j
+    rev = srt
 
 
 def test_every_trainval_resolves_the_mode_for_itself():
