@@ -118,9 +118,20 @@ def test_every_trainval_resolves_the_mode_for_itself():
     try:
         dgcnn.trainval(_flags(DETERMINISTIC=True)).initialize()
         assert E.DETERMINISTIC is True
+        dgcnn.trainval(_flags(DETERMINISTIC=False)).initialize()
+        assert E.DETERMINISTIC is False
         dgcnn.trainval(_flags(DETERMINISTIC=None)).initialize()
-        assert E.DETERMINISTIC == E.DETERMINISTIC_ENV_DEFAULT
+        assert E.DETERMINISTIC == E.DETERMINISTIC_ENV_DEFAULT and E.DETERMINISTIC_ENV_DEFAULT is True    # the default since round 5
+        # a model the deterministic kernels do not take (an EdgeConv filter count that is not a multiple of 4): the DEFAULT falls
+        # back to the atomics mode, an explicit request is refused
+        dgcnn.trainval(_flags(DETERMINISTIC=None, EDGE_CONV_FILTERS=[30, 64, 64])).initialize()
+        assert E.DETERMINISTIC is False
+        with pytest.raises(ValueError):
+            dgcnn.trainval(_flags(DETERMINISTIC=True, EDGE_CONV_FILTERS=[30, 64, 64])).initialize()
+        dgcnn.trainval(_flags(DETERMINISTIC=None, HEAD_PLANES="f16")).initialize()      # the opt-in plane GEMMs sum with atomics
+        assert E.DETERMINISTIC is False
     finally:
+        E.HEAD_PLANES = E.HEAD_PLANES_ENV_DEFAULT
         E.DETERMINISTIC = old
         dgcnn.reset()
 
