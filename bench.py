@@ -274,7 +274,7 @@ def main():
                     help="how the forward+backward tower is launched (the reference replays a static TF graph with sess.run): "
                          "plan = recorded launch plan re-issued from one C loop (csrc/plan.cc); 1 = captured HIP graph; 0 = eager "
                          "launches from Python; auto (default) = a few untimed steps of eager and plan during warm-up, then the plan "
-                         "unless eager is more than 3 %% faster AND its host enqueue takes less than half a step (an eager step is "
+                         "unless eager is more than 5 %% faster AND its host enqueue takes less than half a step (an eager step is "
                          "~140 launches from Python: it is the mode a busy host slows down, BENCH_r04)")
     ap.add_argument("--dry-run", action="store_true",
                     help="plumbing check WITHOUT a GPU (tests/test_bench_launch.py): the launch / rendezvous / fence / timing / "
@@ -378,6 +378,7 @@ def main():
         tv.use_graph("plan")
         step()
         step()                                  # sighting + recording
+        rate(12)                                # (the first second of replay runs 3-4 % slow: profiles/r05/bench_stall.txt B)
         t_plan, h_plan = rate()
         # the plan unless eager wins clearly AND has host headroom: an eager step is ~140 launches from Python, the mode that a
         # busy host stretches (BENCH_r04: calibration 4.75 ms, timed region 6.69 ms with 5.4 ms of host enqueue)
@@ -388,11 +389,11 @@ def main():
             vt = torch.tensor(v, dtype=torch.float64, device="cuda")
             dist.all_reduce(vt, op=dist.ReduceOp.MAX)
             v = [float(x) for x in vt]
-        eager_wins = v[0] < 0.97 * v[1] and v[2] < 0.5 * v[0]
+        eager_wins = v[0] < 0.95 * v[1] and v[2] < 0.5 * v[0]
         tv.use_graph(False if eager_wins else "plan")
         calib = {"eager_ms": round(t_eager * 1e3, 3), "plan_ms": round(t_plan * 1e3, 3),
                  "eager_host_enqueue_ms": round(h_eager * 1e3, 3), "plan_host_enqueue_ms": round(h_plan * 1e3, 3),
-                 "rule": "plan unless eager_ms < 0.97 plan_ms and eager_host_enqueue_ms < 0.5 eager_ms (max over ranks)"}
+                 "rule": "plan unless eager_ms < 0.95 plan_ms and eager_host_enqueue_ms < 0.5 eager_ms (max over ranks)"}
     launch_mode = tv._use_graph
     mode_name = {"plan": "launch-plan replay", True: "hip-graph replay", False: "eager"}[launch_mode]
 

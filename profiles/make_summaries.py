@@ -58,7 +58,7 @@ def main():
     one = lambda pat: max(glob.glob(os.path.join(src, pat)), key=os.path.getmtime)   # gpurun MERGES runs into the directory: newest
     steps = 10.0   # collect.sh: --steps 8 --warmup 2
     with open(os.path.join(HERE, "%s_kernel_trace.txt" % tag), "w") as f:
-        f.write("# rocprofv3 --kernel-trace --stats -- python bench.py --steps 8 --warmup 2 --no-cpu-baseline --graph 0 (1x MI355X); per step = per\n"
+        f.write("# rocprofv3 --kernel-trace --stats -- python bench.py --steps 8 --warmup 2 --repeats 1 --no-cpu-baseline (1x MI355X; the default launch mode: calibration steps eager, timed steps replayed from the launch plan); per step = per\n"
                 "# adam_kernel launch (bench.py also runs 13 EdgeConv-stack-only passes after the steps: their launches are in the totals)\n")
         f.write(subprocess.check_output([sys.executable, os.path.join(HERE, "trace_summary.py"),
                                          one("trace/*/*kernel_trace.csv"), str(steps)]).decode())
