@@ -276,6 +276,8 @@ def main():
                          "launches from Python; auto (default) = a few untimed steps of eager and plan during warm-up, then the plan "
                          "unless eager is more than 5 %% faster AND its host enqueue takes less than half a step (an eager step is "
                          "~140 launches from Python: it is the mode a busy host slows down, BENCH_r04)")
+    ap.add_argument("--x3-tile", type=int, default=0, help="tools: dgcnn_gemm_x3_tile_override (256 = the 256 x 128 kernel wherever a "
+                    "big tile is legal, 512 / 448 = the 256 x 256 / 192 x 256 kernel, 0 = the shipped rule)")
     ap.add_argument("--dry-run", action="store_true",
                     help="plumbing check WITHOUT a GPU (tests/test_bench_launch.py): the launch / rendezvous / fence / timing / "
                          "gather / JSON path of an N-rank run with a stand-in step and the communicator class named by "
@@ -320,6 +322,8 @@ def main():
                     torch.cuda.synchronize()
                 else:
                     dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    if args.x3_tile:
+        H.load().dgcnn_gemm_x3_tile_override(args.x3_tile)
     flags = make_flags(dgcnn)
     flags.DETERMINISTIC = not args.atomics
     tv = dgcnn.trainval(flags).initialize()

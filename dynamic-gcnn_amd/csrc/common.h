@@ -76,6 +76,7 @@ static inline int64_t cap_writers(int64_t g) {
 int gemm_arith();
 void set_gemm_arith(int v);
 int x3_tile_m(int M, int N, int K);
+int x3_tile_n(int M, int N, int K);      // 256: the 256 x 256 kernel takes this product; 0: column tile from gemm.hip:tile_n
 void launch_gemm_x3(int asrc, int bsrc, void* pv, hipStream_t st, int bn, int np);
 
 }  // namespace dg

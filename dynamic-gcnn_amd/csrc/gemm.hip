@@ -673,7 +673,7 @@ inline int tile_n(int M, int N, int K) {
 
 template <int ASRC, int BSRC, int EPI>
 int launch(GemmP& p, hipStream_t st, const char* what) {
-  const int bn = tile_n(p.M, p.N, p.K);
+  int bn = tile_n(p.M, p.N, p.K);
   // float4 path: pointers / leading dimensions checked by the caller (avec, bvec); here the extents
   const bool a_ext = (ASRC == A_ROW || ASRC == A_EDGE) ? (p.K % 4 == 0 && p.K >= 4) : (p.M % 4 == 0 && p.M >= 4);
   const bool b_ext = (BSRC == B_ROW) ? (p.N % 4 == 0 && p.N >= 4) : (p.K % 4 == 0 && p.K >= 4);
@@ -685,6 +685,7 @@ int launch(GemmP& p, hipStream_t st, const char* what) {
   constexpr bool plain = (ASRC == A_ROW || ASRC == A_COL) && EPI == E_STORE;
   if (plain && vec && dg::gemm_arith() != 0) {          // bf16-split kernel (gemm_x3.hip)
     p.bm = dg::x3_tile_m(p.M, p.N, p.K);
+    if (dg::x3_tile_n(p.M, p.N, p.K) == 256) bn = 256;
     p.mtiles = (int)dg::cdiv(p.M, p.bm);
     p.ntiles = (int)dg::cdiv(p.N, bn);
     p.xcd_group = (p.ntiles > 1 && p.mtiles >= 16 && p.splits == 1) ? 1 : 0;
@@ -711,13 +712,15 @@ inline bool aligned16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 
 //     8 x (chunks per XCD), sized so that the chunks of an XCD fill its 32 CUs in whole rounds;
 //   native kernels: ~1024 workgroups in flight.
 int plan_splits(GemmP& p, void* ws, size_t ws_bytes, const char* what) {
-  const int bn = tile_n(p.M, p.N, p.K);
+  int bn = tile_n(p.M, p.N, p.K);
+  if (dg::gemm_arith() != 0 && p.avec && p.bvec && dg::x3_tile_n(p.M, p.N, p.K) == 256) bn = 256;
   p.bm = 128;
   p.zmajor = 0;
   const bool x3 = dg::gemm_arith() != 0 && p.avec && p.bvec;
   // the 256-row bf16-split kernel runs one 768-thread workgroup per CU: aim at 2 rounds of 256 workgroups
-  const bool big = x3 && dg::x3_tile_m(p.M, p.N, p.K) == 256;
-  const int64_t tiles = dg::cdiv(p.M, big ? 256 : 128) * dg::cdiv(p.N, bn);
+  const int tm = x3 ? dg::x3_tile_m(p.M, p.N, p.K) : 128;
+  const bool big = tm >= 192;                  // (one workgroup per CU)
+  const int64_t tiles = dg::cdiv(p.M, big ? tm : 128) * dg::cdiv(p.N, bn);
   int64_t s = dg::cdiv(big ? 512 : 1024, tiles);
   const int64_t maxs = p.K / 256 > 0 ? p.K / 256 : 1;
   if (s > maxs) s = maxs;

@@ -95,10 +95,11 @@ __device__ __forceinline__ int imin(int a, int b) { return a < b ? a : b; }
 
 // ---- shared epilogue.  C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
 // WR = wave rows of the block (each wave owns BM/WR rows as TM 32-row tiles), NTH = threads taking part.
-template <int EPI, int BM, int BN, bool VEC, int TM, int TN, int WR = 2, int NTH = NT>
+// WCN = wave columns (each wave owns BN/WCN columns as TN 32-column tiles).
+template <int EPI, int BM, int BN, bool VEC, int TM, int TN, int WR = 2, int NTH = NT, int WCN = 2>
 __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[TM][TN], float* smem, int m0, int n0,
                                               int mt, int z, int t, int wr, int wc, int l31, int lh) {
-  const int colw = n0 + wc * (BN / 2) + l31;
+  const int colw = n0 + wc * (BN / WCN) + l31;
   const int roww = m0 + wr * (BM / WR) + 4 * lh;
   if (EPI == E_SCATTER) {
 #pragma unroll
@@ -154,7 +155,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[TM][
     for (int j = 0; j < TN; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r)
-        tile[(wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * BN + wc * (BN / 2) + j * 32 + l31] = acc[i][j][r];
+        tile[(wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * BN + wc * (BN / WCN) + j * 32 + l31] = acc[i][j][r];
     __syncthreads();
 #pragma unroll
     for (int q0 = 0; q0 < (WR * 32) / RSTEP; ++q0) {

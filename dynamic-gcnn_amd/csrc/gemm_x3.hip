@@ -599,10 +599,225 @@ __global__ __launch_bounds__(768) void gemm_x3w2_kernel(GemmP p) {
   gemm_epilogue<E_STORE, BM, BN, true, TM, TN, 4, 512>(p, acc, reinterpret_cast<float*>(smem_raw), m0, n0, mt, z, t, wr, wc, l31, lh);
 }
 
+// ------------------------------------------------------------------------------------------------------
+// 256 x 256 tile, 512 threads, UNspecialised: waves 4 x 2, 64 x 128 outputs each (128 accumulator registers), every wave fetches,
+// splits and multiplies.  Per flop it stages 2/3 of the 256 x 128 kernel's operand bytes (a 16-k slab of A and B is 512 rows for
+// 256 x 256 outputs; there 384 rows for 256 x 128) and reads 3/4 of its LDS bytes.  k-slab 16 (one MFMA k-step), two LDS buffers,
+// one barrier per slab; raw operands one slab ahead in registers.  (The wave-specialised form does not fit: 8 consumers + 4
+// producers are 3 waves per SIMD, and 128 accumulators + operands exceed the 170 registers that leaves each of them.)
+// LDS image of one bf16 plane of a 256-row x 16-k slab: [2 chunks of 8 k][row ^ ((row >> 3) & 1)][16 B], chunk stride 4160 B
+// (= 64 mod 128).  Checked against the instruction-level bank model (MI355X_MICROARCH.md "LDS"): the MFMA operand reads
+// (ds_read_b128, 32 consecutive rows of one chunk) and both staging stores (k-contiguous source: 8 lanes = 4 rows x 2 chunks;
+// k-strided source: 8 lanes = every second row of one chunk) are conflict free.
+struct ImgQ {
+  static constexpr unsigned CS = 4160u;
+  static constexpr unsigned PB = 2u * CS;
+  static __device__ __forceinline__ unsigned at(int r, int chunk) { return (unsigned)chunk * CS + (unsigned)((r ^ ((r >> 3) & 1)) << 4); }
+};
+
+// one 256-row operand slab (256 x 16 k).  KCONTIG: every thread of the block one chunk (row u >> 1, chunk u & 1: two float4);
+// KSTRIDED: 256 threads (FIRST: u < 256, else u >= 256) two chunks each (rows 2 q, 2 q + 1 of chunk c: eight float2 down k).
+template <int KIND, bool FIRST, int ROWS = 256>
+struct StageQ {
+  static constexpr int NR = (KIND == KCONTIG) ? 8 : 16;       // raw registers
+  const float* p0;
+  int64_t ld;
+  int c, r0;
+  bool on, rok0, rok1;
+
+  __device__ __forceinline__ void init(const float* base, int64_t ld_, int row0, int nrows, int t, int kbeg) {
+    ld = ld_;
+    if constexpr (KIND == KCONTIG) {
+      c = t & 1;
+      r0 = t >> 1;
+      on = r0 < ROWS;
+      const int row = row0 + r0;
+      rok0 = row < nrows;
+      rok1 = false;
+      p0 = base + (int64_t)imin(row, nrows - 1) * ld + (kbeg + 8 * c);
+    } else {
+      const int u = FIRST ? t : t - 256;
+      c = (u >> 7) & 1;
+      r0 = 2 * (u & 127);
+      on = (FIRST ? (t < 256) : (t >= 256)) && r0 < ROWS;
+      const int row = row0 + r0;
+      rok0 = row < nrows;
+      rok1 = row + 1 < nrows;
+      p0 = base + imin(row, nrows - 2) + (int64_t)(kbeg + 8 * c) * ld;
+    }
+  }
+
+  template <bool MASK>
+  __device__ __forceinline__ void load(float (&L)[NR], unsigned& pm, int koff, int klen) const {
+    pm = 0;
+    if (!on) return;
+    if constexpr (KIND == KCONTIG) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int kk = koff + 8 * c + 4 * h;
+        float4 v;
+        if (MASK) {
+          if (rok0 && kk < klen) pm |= 1u << h;
+          v = ld4(p0 + (imin(kk, klen - 4) - 8 * c));
+        } else {
+          v = ld4(p0 + (koff + 4 * h));
+        }
+        L[4 * h + 0] = v.x; L[4 * h + 1] = v.y; L[4 * h + 2] = v.z; L[4 * h + 3] = v.w;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int kk = koff + 8 * c + i;
+        const float* src = MASK ? (p0 + (int64_t)(imin(kk, klen - 1) - 8 * c) * ld) : (p0 + (int64_t)(koff + i) * ld);
+        if (MASK && kk < klen) pm |= 1u << i;
+        const float2 v = *reinterpret_cast<const float2*>(src);
+        L[2 * i] = v.x; L[2 * i + 1] = v.y;
+      }
+    }
+  }
+
+  template <bool MASK, int NPL>
+  __device__ __forceinline__ void stage(const float (&L)[NR], unsigned pm, char* plane0) const {
+    if (!on) return;
+    if constexpr (KIND == KCONTIG) {
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = (!MASK || ((pm >> (e >> 2)) & 1u)) ? L[e] : 0.f;
+      const Packed P = split8(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);
+      const unsigned off = ImgQ::at(r0, c);
+      *reinterpret_cast<uint4*>(plane0 + off) = P.h;
+      if (NPL == 3) {
+        *reinterpret_cast<uint4*>(plane0 + ImgQ::PB + off) = P.m;
+        *reinterpret_cast<uint4*>(plane0 + 2 * ImgQ::PB + off) = P.l;
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        float v[8];
+        const bool rok = j ? rok1 : rok0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = (!MASK || (rok && ((pm >> i) & 1u))) ? L[2 * i + j] : 0.f;
+        const Packed P = split8(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);
+        const unsigned off = ImgQ::at(r0 + j, c);
+        *reinterpret_cast<uint4*>(plane0 + off) = P.h;
+        if (NPL == 3) {
+          *reinterpret_cast<uint4*>(plane0 + ImgQ::PB + off) = P.m;
+          *reinterpret_cast<uint4*>(plane0 + 2 * ImgQ::PB + off) = P.l;
+        }
+      }
+    }
+  }
+};
+
+// BM = 256: waves 4 x 2, 64 x 128 outputs each;  BM = 192: waves 2 x 4, 96 x 64 outputs each (M = 49152 = 256 x 192: one row panel
+// per CU and round, no partial last round for any N).
+template <int AKIND, int BKIND, int NP, int BM>
+__global__ __launch_bounds__(512, 2) void gemm_x3q_kernel(GemmP p) {
+  constexpr int BN = 256, QK = 16;
+  constexpr int WR = (BM == 256) ? 4 : 2, WCN = 8 / WR;
+  constexpr int TM = BM / WR / 32, TN = BN / WCN / 32;
+  constexpr unsigned BUF = 6 * ImgQ::PB;                     // A planes 0-2, B planes 0-2
+  constexpr unsigned EPI_BYTES = WR * 32 * BN * 4;
+  constexpr unsigned SMEM = (2 * BUF > EPI_BYTES) ? 2 * BUF : EPI_BYTES;
+  static_assert(SMEM <= 160 * 1024, "LDS budget");
+  __shared__ __attribute__((aligned(16))) char smem_raw[SMEM];
+  constexpr int NPL = (NP == 1 ? 1 : 3);
+
+  const int t = threadIdx.x;
+  const int lane = t & 63;
+  const int wv = t >> 6;
+  const int wr = wv / WCN, wc = wv % WCN;
+  const int l31 = lane & 31, lh = lane >> 5;
+
+  int mt, nt, z;
+  if (!block_tile(p, mt, nt, z)) return;
+  const int m0 = mt * BM;
+  const int n0 = nt * BN;
+  const int kbeg = z * p.kchunk;
+  const int kend = (kbeg + p.kchunk < p.K) ? (kbeg + p.kchunk) : p.K;
+  const int klen = kend - kbeg;
+  const int nk = (klen + QK - 1) / QK;
+
+  using SA = StageQ<AKIND, true, BM>;
+  using SB = StageQ<BKIND, false>;
+  SA sa;
+  SB sb;
+  sa.init(p.A, p.lda, m0, p.M, t, kbeg);
+  sb.init(p.B, p.ldb, n0, p.N, t, kbeg);
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  unsigned a_off[TM], b_off[TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) a_off[i] = ImgQ::at(wr * (BM / WR) + i * 32 + l31, lh);
+#pragma unroll
+  for (int j = 0; j < TN; ++j) b_off[j] = 3 * ImgQ::PB + ImgQ::at(wc * (BN / WCN) + j * 32 + l31, lh);
+
+  auto run = [&](auto mask_tag) {
+    constexpr bool MASK = decltype(mask_tag)::value;
+    float LA[SA::NR], LB[SB::NR];
+    unsigned pa = 0, pb = 0;
+    auto fetch = [&](int slab) {
+      sa.template load<MASK>(LA, pa, slab * QK, klen);
+      sb.template load<MASK>(LB, pb, slab * QK, klen);
+    };
+    auto stage = [&](int buf) {
+      char* base = smem_raw + buf * BUF;
+      sa.template stage<MASK, NPL>(LA, pa, base);
+      sb.template stage<MASK, NPL>(LB, pb, base + 3 * ImgQ::PB);
+    };
+    fetch(0);
+    stage(0);
+    if (nk > 1) fetch(1);
+    __syncthreads();
+#pragma unroll 1
+    for (int kt = 0; kt < nk; ++kt) {
+      const char* base = smem_raw + (kt & 1) * BUF;
+      if (kt + 1 < nk) stage((kt + 1) & 1);                  // slab kt + 1 into the other buffer (its readers passed the last barrier)
+      if (kt + 2 < nk) fetch(kt + 2);
+      bf16x8 a[TM][3];
+#pragma unroll
+      for (int q = 0; q < 3; ++q)
+#pragma unroll
+        for (int i = 0; i < TM; ++i) a[i][q] = *reinterpret_cast<const bf16x8*>(base + q * ImgQ::PB + a_off[i]);
+      constexpr int PA[9] = {0, 0, 1, 1, 0, 2, 1, 2, 2};
+      constexpr int PB_[9] = {0, 1, 0, 1, 2, 0, 2, 1, 2};
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        bf16x8 b[3];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) b[q] = *reinterpret_cast<const bf16x8*>(base + q * ImgQ::PB + b_off[j]);
+#pragma unroll
+        for (int q = 0; q < NP; ++q)
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][PA[q]], b[PB_[q]], acc[i][j], 0, 0, 0);
+      }
+      __syncthreads();
+    }
+  };
+  const bool edge = (m0 + BM > p.M) || (n0 + BN > p.N) || (klen % QK != 0);
+  if (edge) run(std::true_type{});
+  else run(std::false_type{});
+
+  gemm_epilogue<E_STORE, BM, BN, true, TM, TN, WR, 512, WCN>(p, acc, reinterpret_cast<float*>(smem_raw), m0, n0, mt, z, t, wr, wc, l31, lh);
+}
+
 int g_arith = -1;      // -1: not resolved yet; 0 native fp32 MFMA; 6 / 9 partial products on the bf16 pipe
 
 template <int AKIND, int BKIND>
 void launch_kind(GemmP& p, hipStream_t st, int bn, int np, dim3 grid) {
+  if (bn == 256) {              // the 256-column kernels run the default arithmetic only (other arithmetics: measurements, 256 x 128)
+    if (p.bm == 192) dg::launch((gemm_x3q_kernel<AKIND, BKIND, 6, 192>), grid, dim3(512), 0, st, p);
+    else dg::launch((gemm_x3q_kernel<AKIND, BKIND, 6, 256>), grid, dim3(512), 0, st, p);
+    return;
+  }
   if (p.bm == 256) {
     if (np == 9) dg::launch((gemm_x3w2_kernel<AKIND, BKIND, 9>), grid, dim3(768), 0, st, p);
     else if (np == 1) dg::launch((gemm_x3w2_kernel<AKIND, BKIND, 1>), grid, dim3(768), 0, st, p);
@@ -643,17 +858,69 @@ void set_gemm_arith(int v) { g_arith = v; }
 
 // asrc in {A_ROW, A_COL}, bsrc in {B_ROW, B_COL}; operands float4-loadable (checked by the caller).
 // p.mtiles / ntiles / xcd_group / splits / kchunk (multiple of 32 when splits > 1) are set.
-int g_x3_tile_override = 0;      // dgcnn_gemm_x3_tile_override (tools): 0 = the rule below, 128 / 256 = that row tile where legal
+int g_x3_tile_override = 0;      // dgcnn_gemm_x3_tile_override (tools): 0 = the rule below, 128 / 256 = that row tile where legal,
+                                 // 512 = the 256 x 256 kernel where legal
 
-int x3_tile_m(int M, int N, int K) {
+// Tile choice among the three big kernels (all give bit-identical outputs: the per-element k order is the same):
+//   256 x 128 wave-specialised (gemm_x3w2_kernel), 256 x 256 and 192 x 256 unspecialised (gemm_x3q_kernel).
+// Measured on the head's nine products (profiles/r05/gemm_quad.txt): the wave-specialised main loop is ~10 % better on long
+// reductions (K = 1728: 424 vs 465 us), the 256-column kernels win where tile quantisation or padding hurt the 256 x 128 tiling --
+// N = 256 (384 tiles = 1.5 rounds of the 256 CUs -> 256 tiles of 192 rows: 85 -> 72 us), N = 192 (one padded column tile instead of
+// two: 144 -> 128 us), M = 192 (weight gradient of MergedEdgeConv: no row padding: 134 -> 116 us) -- and on very short reductions
+// (K = 192: 150 -> 134 us).  cost = padding waste x (1 + half the idle share of the last round) / main-loop efficiency; a partial
+// round costs only about half its idle share because the step runs at the package power cap (idle CUs leave power to the busy ones).
+static double x3_cost(int M, int N, int K, int bm, int bn, bool split) {
+  const double mt = (double)cdiv(M, bm), nt = (double)cdiv(N, bn);
+  const double waste = mt * bm * nt * bn / ((double)M * (double)N);
+  double rf = 1.0;
+  if (!split) {
+    const double t = mt * nt / 256.0;
+    rf = 1.0 + 0.5 * (cdiv((int64_t)(mt * nt), 256) / t - 1.0);
+  }
+  const double eff = (bn != 256) ? 1.0 : (K <= 192 ? 1.1 : (K <= 1024 ? 1.0 : 0.9));
+  return waste * rf / eff;
+}
+
+// (bm, bn) of a large product: bn = 256 selects gemm_x3q_kernel<bm>, bn = 0 leaves the column tile to gemm.hip:tile_n
+static void x3_pick(int M, int N, int K, int& bm, int& bn) {
+  bm = 256;
+  bn = 0;
+  if (dg::gemm_arith() != 6 || M <= 128 || N <= 128) return;
+  if (g_x3_tile_override == 512 || g_x3_tile_override == 448) { bm = g_x3_tile_override == 448 ? 192 : 256; bn = 256; return; }
+  if (g_x3_tile_override != 0) return;
+  const bool split = cdiv(M, 256) * cdiv(N, 128) < 128;          // few output tiles: the caller splits the reduction
+  double best = x3_cost(M, N, K, 256, 128, split) * 0.98;      // (ties go to the wave-specialised kernel)
+  const int cand[2] = {256, 192};
+  for (int c = 0; c < 2; ++c) {
+    const double v = x3_cost(M, N, K, cand[c], 256, split);
+    if (v < best) { best = v; bm = cand[c]; bn = 256; }
+  }
+}
+
+int x3_tile_n(int M, int N, int K) {
+  if (x3_tile_m(M, N, K) < 192) return 0;
+  int bm, bn;
+  x3_pick(M, N, K, bm, bn);
+  return bn;
+}
+
+static int x3_tile_m_base(int M, int N, int K) {
   if (g_x3_tile_override == 128) return 128;
-  if (g_x3_tile_override == 256 && M > 128 && N > 64) return 256;
+  if ((g_x3_tile_override == 256 || g_x3_tile_override == 512 || g_x3_tile_override == 448) && M > 128 && N > 64) return 256;
   // short reduction, many rows, one or two column tiles: the kernel is bound by the latency of its few slabs -- 64-row tiles put
   // twice the workgroups (and loads in flight) on a CU
   if (dg::gemm_arith() == 6 && K <= 256 && N <= 256 && M >= 8192 && cdiv(M, 128) * cdiv(N, 128) <= 1024) return 64;
   // small problems (configs[0]: 1024 rows, K ~ 1000): a 256 x 128 tiling, even split over K, leaves most CUs without work
   if (cdiv(M, 256) * cdiv(N, 128) * cdiv(K, 256) < 256) return 128;
   return (M > 128 && N > 64) ? 256 : 128;
+}
+
+int x3_tile_m(int M, int N, int K) {
+  const int base = x3_tile_m_base(M, N, K);
+  if (base != 256) return base;
+  int bm, bn;
+  x3_pick(M, N, K, bm, bn);
+  return bn == 256 ? bm : 256;
 }
 
 void launch_gemm_x3(int asrc, int bsrc, void* pv, hipStream_t st, int bn, int np) {
@@ -677,9 +944,10 @@ extern "C" int dgcnn_gemm_set_arith(int mode) {
 extern "C" int dgcnn_gemm_get_arith(void) { return dg::gemm_arith(); }
 
 extern "C" int dgcnn_gemm_x3_tile_rows(int M, int N, int K) { return dg::x3_tile_m(M, N, K); }
+extern "C" int dgcnn_gemm_x3_tile_cols(int M, int N, int K) { return dg::x3_tile_n(M, N, K); }
 
 extern "C" int dgcnn_gemm_x3_tile_override(int bm) {      // tools: force the 128- or 256-row tile (0 = automatic); returns the previous value
   const int prev = dg::g_x3_tile_override;
-  dg::g_x3_tile_override = (bm == 128 || bm == 256) ? bm : 0;
+  dg::g_x3_tile_override = (bm == 128 || bm == 256 || bm == 512 || bm == 448) ? bm : 0;      // 512: 256 x 256, 448: 192 x 256
   return prev;
 }

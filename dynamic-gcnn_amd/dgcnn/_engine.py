@@ -473,7 +473,10 @@ def _gemm_tag(M, N, K, transA, transB, A, Bm):
     bn = 64 if (N <= 64 or small) else 128
     if vec and arith:
         kinds = ("KSTRIDED" if transA else "KCONTIG", "KCONTIG" if transB else "KSTRIDED")
-        if H.load().dgcnn_gemm_x3_tile_rows(M, N, K) == 256:     # dg::x3_tile_m: the 256 x 128 wave-specialised kernel
+        rows = H.load().dgcnn_gemm_x3_tile_rows(M, N, K)
+        if H.load().dgcnn_gemm_x3_tile_cols(M, N, K) == 256:     # dg::x3_tile_n: the 256-column unspecialised kernels
+            return "gemm_x3q_kernel<%s,%s,%d,bf16x%d>" % (kinds + (rows, arith))
+        if rows == 256:                                           # dg::x3_tile_m: the 256 x 128 wave-specialised kernel
             return "gemm_x3w2_kernel<%s,%s,bf16x%d>" % (kinds + (arith,))
         return "gemm_x3_kernel<%s,%s,%d,bf16x%d>" % (kinds + (bn, arith))
     return "gemm_kernel<%s,%s,STORE,%d,%d>" % ("A_COL" if transA else "A_ROW", "B_COL" if transB else "B_ROW", _tile_m(M, N), bn)

@@ -61,6 +61,7 @@ PROTOTYPES = {
     "dgcnn_gemm_set_arith": [c_int],
     "dgcnn_gemm_get_arith": [],
     "dgcnn_gemm_x3_tile_rows": [c_int, c_int, c_int],
+    "dgcnn_gemm_x3_tile_cols": [c_int, c_int, c_int],
     "dgcnn_gemm_x3_tile_override": [c_int],
     "dgcnn_gemm_f32": [c_int, c_int, c_int, c_int, c_int, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_f32,
                        c_vp, c_i64, c_int, c_vp, c_vp, c_int, c_vp, c_sz, c_vp],

@@ -238,6 +238,8 @@ int dgcnn_gemm_get_arith(void);
 /* Rows of the output tile the bf16-split GEMM picks for an (M,N,K) product: 64 | 128 | 256 (256 = the wave-specialised
  * gemm_x3w2_kernel).  For tools that name kernel instances (bench.py's per-kernel table); no effect on results. */
 int dgcnn_gemm_x3_tile_rows(int M, int N, int K);
+/* 256 when the product runs on a 256-column kernel (gemm_x3q_kernel: 256 x 256 or 192 x 256 tiles, rows from the call above), else 0 */
+int dgcnn_gemm_x3_tile_cols(int M, int N, int K);
 /* tools: force the 128- / 256-row tile of the bf16-split kernels (0 = the automatic rule); returns the previous setting */
 int dgcnn_gemm_x3_tile_override(int bm);
 /* colmax_keys (optional, uint64[M / colmax_rows_per_group][N], zeroed): the per-group column maximum of C and its FIRST row

@@ -32,6 +32,10 @@ def tag_of(name):
     if m:
         kinds = {0: "KCONTIG", 1: "KSTRIDED"}
         return "gemm_x3w2_kernel<%s,%s,bf16x%s>" % (kinds[int(m.group(1))], kinds[int(m.group(2))], m.group(3))
+    m = re.match(r"gemm_x3q_kernel<(\d), (\d), (\d+), (\d+)>", n)
+    if m:
+        kinds = {0: "KCONTIG", 1: "KSTRIDED"}
+        return "gemm_x3q_kernel<%s,%s,%s,bf16x%s>" % (kinds[int(m.group(1))], kinds[int(m.group(2))], m.group(4), m.group(3))
     m = re.match(r"gemm_x3_kernel<(\d), (\d), (\d+), (\d+)(?:, \d+)?>", n)
     if m:
         kinds = {0: "KCONTIG", 1: "KSTRIDED"}
