@@ -443,6 +443,16 @@ __global__ void copy2d_kernel(const float* __restrict__ src, int64_t lds, float*
   }
 }
 
+// dst (R, Cp) <- [src (R, C) | zeros]: the raw coordinates (C = 3) padded to float4 rows for the point-level GEMM, padding written
+// here (a separate memset of dst was a 6-us serial step on the main stream)
+__global__ void pad_copy_kernel(const float* __restrict__ src, int64_t lds, int C, float* __restrict__ dst, int Cp, int64_t R) {
+  GRID_STRIDE(i, R * Cp) {
+    const int64_t r = i / Cp;
+    const int f = (int)(i % Cp);
+    dst[i] = f < C ? src[r * lds + f] : 0.f;
+  }
+}
+
 // tf.tile of the per-cloud global feature over the points of its cloud (model.py:80-81): dst[g * rows + i][f] = src[g][f]
 __global__ void tile_rows_kernel(const float* __restrict__ src, int64_t lds, float* __restrict__ dst, int64_t ldd,
                                  int64_t R, int rows, int F) {
@@ -647,6 +657,12 @@ extern "C" int dgcnn_group_colsum_f32(const float* x, int64_t ldx, int G, int ro
   dg::launch(group_colsum_kernel, dim3((unsigned)dg::cdiv(F, 64), (unsigned)G), dim3(64 * RG), 0, ST, x, ldx,
                      rows_per_group, F, out);
   return dg::check_launch("dgcnn_group_colsum_f32");
+}
+
+extern "C" int dgcnn_pad_copy_f32(const float* src, int64_t lds, int C, float* dst, int Cp, int64_t R, void* stream) {
+  DG_REQUIRE(src && dst && R > 0 && C > 0 && Cp >= C, DGCNN_EINVAL, "dgcnn_pad_copy_f32: bad args");
+  dg::launch(pad_copy_kernel, dim3(grid1d(R * Cp)), dim3(256), 0, ST, src, lds, C, dst, Cp, R);
+  return dg::check_launch("dgcnn_pad_copy_f32");
 }
 
 extern "C" int dgcnn_tile_rows_f32(const float* src, int64_t lds, int G, int rows_per_group, int F, float* dst, int64_t ldd,

@@ -249,6 +249,23 @@ class Context(object):
         self.stat_off += n
         return s
 
+    def zeros_f32(self, n):
+        """n zeroed floats: small requests come out of the statistics arena (zeroed once per step by ONE memset; every separate
+        memset is a ~6-us serial step of its own on the main stream), large ones get their own fill."""
+        if n <= 65536 and self.stat_arena is not None:
+            nd = ((n + 3) // 4) * 2                       # whole 16-byte units, from a 16-byte aligned start
+            off = (self.stat_off + 1) & ~1
+            if off + nd <= min(self.stat_arena.numel(), self.arena_want()):
+                s = self.stat_arena[off:off + nd].view(torch.float32)[:n]
+                self.stat_off = off + nd
+                return s
+        return H.zeros(n, torch.float32, self.device)
+
+    def zeros_like_small(self, t):
+        if t.dtype == torch.float32 and t.is_contiguous():
+            return self.zeros_f32(t.numel()).view(t.shape)
+        return H.memset(torch.empty_like(t))
+
     def begin_step(self):
         """Drop the previous tape / gradient roots, re-zero the statistics arena and advance the dropout stream."""
         self.tape = []
@@ -348,7 +365,7 @@ class Context(object):
             base = root.data_ptr()
             if base <= ptr < base + root.numel() * 4:
                 if slot[0] is None:
-                    slot[0] = H.memset(torch.empty_like(root))
+                    slot[0] = self.zeros_like_small(root)
                 off = (ptr - base) // 4
                 ld = root.shape[1]
                 r0, c0 = off // ld, off % ld
@@ -775,14 +792,14 @@ def _point_gemm(c, x, W0, R, C, F):
     xg = x
     ready = prepared(("wcat", W0.data_ptr()))
     if Cp != C:
-        xg = H.zeros((R, Cp), torch.float32, x.device)
+        xg = torch.empty((R, Cp), dtype=torch.float32, device=x.device)
         wcat = ready if ready is not None else H.zeros((Cp, 2 * F), torch.float32, x.device)
     else:
         wcat = ready if ready is not None else torch.empty((C, 2 * F), dtype=torch.float32, device=x.device)
     UV = torch.empty((R, 2 * F), dtype=torch.float32, device=x.device)
 
     if Cp != C:
-        H.call("dgcnn_copy2d_f32", x.data_ptr(), H.ld2(x), xg.data_ptr(), Cp, R, C, 0)
+        H.call("dgcnn_pad_copy_f32", x.data_ptr(), H.ld2(x), C, xg.data_ptr(), Cp, R)
     if ready is None:
         H.call("dgcnn_edge_weight_split_f32", W0.data_ptr(), C, F, wcat.data_ptr())
     gemm(xg, wcat, UV, arith=None)
@@ -1255,10 +1272,10 @@ def softmax_loss(logits2d, labels, weight, want_grad):
     R, ncls = logits2d.shape
     assert logits2d.is_contiguous()
     sm = torch.empty((R, ncls), dtype=torch.float32, device=logits2d.device)
-    scal = H.zeros(2, torch.float32, logits2d.device)
+    scal = H.zeros(2, torch.float32, logits2d.device)      # (its own tensor: the caller reads it after later towers' begin_step)
     dl = None
     if want_grad:
-        dl = c.grad(logits2d)
+        dl, _ = c.grad_w(logits2d)          # (written, not accumulated: a first touch of a whole root needs no zero fill)
         assert dl is not None and dl.is_contiguous()
     H.call("dgcnn_softmax_xent_f32", logits2d.data_ptr(), H._p(labels), H._p(weight), R, ncls, sm.data_ptr(),
            H._p(dl), scal.data_ptr())

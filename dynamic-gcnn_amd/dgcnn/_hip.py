@@ -96,6 +96,7 @@ PROTOTYPES = {
     "dgcnn_dropout_dev_f32": [c_vp, c_vp, c_i64, c_f32, c_vp, c_vp],
     "dgcnn_add_relu_f32": [c_vp, c_i64, c_vp, c_i64, c_i64, c_int, c_vp, c_i64, c_vp],
     "dgcnn_relu_bwd_f32": [c_vp, c_i64, c_vp, c_i64, c_i64, c_int, c_vp, c_i64, c_vp],
+    "dgcnn_pad_copy_f32": [c_vp, c_i64, c_int, c_vp, c_int, c_i64, c_vp],
     "dgcnn_copy2d_f32": [c_vp, c_i64, c_vp, c_i64, c_i64, c_int, c_int, c_vp],
     "dgcnn_softmax_xent_f32": [c_vp, c_vp, c_vp, c_i64, c_int, c_vp, c_vp, c_vp, c_vp],
     "dgcnn_axpby_f32": [c_vp, c_f32, c_vp, c_f32, c_i64, c_vp],

@@ -385,6 +385,8 @@ int dgcnn_add_relu_f32(const float* a, int64_t lda, const float* b, int64_t ldb,
                        float* out, int64_t ldo, void* stream);
 int dgcnn_relu_bwd_f32(const float* dout, int64_t lddo, const float* out, int64_t ldo, int64_t R, int F,
                        float* d, int64_t ldd, void* stream);
+/* dst (R, Cp) dense <- [src (R, C) | zero columns]: C = 3 coordinates padded to float4 rows */
+int dgcnn_pad_copy_f32(const float* src, int64_t lds, int C, float* dst, int Cp, int64_t R, void* stream);
 /* strided 2-D copy / accumulate: dst (+)= src   (views of concatenated buffers, tf.concat) */
 int dgcnn_copy2d_f32(const float* src, int64_t lds, float* dst, int64_t ldd, int64_t R, int F,
                      int accumulate, void* stream);
