@@ -156,9 +156,12 @@ __global__ __launch_bounds__(256) void edge_mlp_bf16_kernel(EdgeP p) {
       wf[s][j] = __builtin_bit_cast(bf16x8, pk);
     }
 
-  float cs[FB], cq[FB];
+  // BatchNorm sums of this lane's columns: fp32 within a tile (16 values), DOUBLE across the tiles of the persistent workgroup
+  // (5.2 M edge rows at configs[2] are ~640 tiles per lane, ~2500 with the capped grid of the deterministic mode: an fp32 running
+  // sum there loses digits that var = E[y^2] - mean^2 then amplifies)
+  double cs[FB], cq[FB];
 #pragma unroll
-  for (int j = 0; j < FB; ++j) cs[j] = cq[j] = 0.f;
+  for (int j = 0; j < FB; ++j) cs[j] = cq[j] = 0.0;
 
 #pragma unroll 1
   for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -180,12 +183,16 @@ __global__ __launch_bounds__(256) void edge_mlp_bf16_kernel(EdgeP p) {
     if (PASS == 0) {
       // rows past the end of the edge list are zero rows of E: y = 0 exactly, they add nothing
 #pragma unroll
-      for (int j = 0; j < FB; ++j)
+      for (int j = 0; j < FB; ++j) {
+        float ts = 0.f, tq = 0.f;
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
-          cs[j] += acc[j][q];
-          cq[j] += acc[j][q] * acc[j][q];
+          ts += acc[j][q];
+          tq += acc[j][q] * acc[j][q];
         }
+        cs[j] += (double)ts;
+        cq[j] += (double)tq;
+      }
       __syncthreads();                                                  // (E rows are rewritten by the next tile)
     } else if (PASS == 2) {
 #pragma unroll
@@ -229,7 +236,7 @@ __global__ __launch_bounds__(256) void edge_mlp_bf16_kernel(EdgeP p) {
 
   if (PASS == 0) {
     // column sums: lanes l and l + 32 hold the same columns (other rows); then the four waves through LDS, one writer per column
-    float* red = reinterpret_cast<float*>(smem);                        // [4 waves][2][F]
+    double* red = reinterpret_cast<double*>(smem);                      // [4 waves][2][F]
 #pragma unroll
     for (int j = 0; j < FB; ++j) {
       cs[j] += __shfl_xor(cs[j], 32);
@@ -246,7 +253,7 @@ __global__ __launch_bounds__(256) void edge_mlp_bf16_kernel(EdgeP p) {
     __syncthreads();
     const int slot = blockIdx.x % p.nslots;
     for (int i = t; i < 2 * F; i += 256) {
-      const double v = (double)red[i] + (double)red[2 * F + i] + (double)red[4 * F + i] + (double)red[6 * F + i];
+      const double v = red[i] + red[2 * F + i] + red[4 * F + i] + red[6 * F + i];
       atomicAdd(p.stats + (int64_t)slot * 2 * F + i, v);
     }
   }
@@ -571,7 +578,7 @@ int launch_pass(const EdgeP& p, hipStream_t st, const char* what) {
   const int64_t ntiles = (PASS == 1) ? dg::cdiv(R, (int64_t)(RT / p.k)) : dg::cdiv(R * p.k, (int64_t)RT);
   size_t sh = (size_t)RT * (2 * K + 16);
   if (PASS == 1) sh += (size_t)RT * (p.F + 1) * sizeof(float);
-  if (PASS == 0 && sh < (size_t)8 * p.F * sizeof(float)) sh = (size_t)8 * p.F * sizeof(float);
+  if (PASS == 0 && sh < (size_t)8 * p.F * sizeof(double)) sh = (size_t)8 * p.F * sizeof(double);
   int64_t g = ntiles < 1024 ? ntiles : 1024;
   if (PASS == 0) g = dg::cap_writers(g);                               // (reproducible configuration: one writer per slot)
   if (g < 1) g = 1;

@@ -847,10 +847,13 @@ def edge_conv_block(x, B, N, k, num_filters, relu1=True, outs=None, net2=None):
     idx = knn(x, B, N, k)                                               # ops.py:8-19
     virtual = gather and not EDGE_MATERIALIZE_Y and k < 256   # conv0 output never written: recomputed from (V, U, idx)
     #                                                           (the edge BN passes pack tie / positive counts: k < 256)
-    Y = None if virtual else torch.empty((R * k, F), dtype=torch.float32, device=x.device)   # (the fused bf16 path frees it below)
+    # the fused bf16 kernels write neither E nor y: decided BEFORE anything of (R*k, F) is allocated (1.3 GB per layer at configs[2])
+    fused_bf16 = (bf16 and bool(H.load().dgcnn_edge_mlp_bf16_supported(C, k, F)) and W0.is_contiguous() and
+                  (C <= 4 or (H.ld2(x) % 4 == 0 and x.data_ptr() % 16 == 0)))
+    Y = None if (virtual or fused_bf16) else torch.empty((R * k, F), dtype=torch.float32, device=x.device)
     wd = wcat = UV = None
     Ee = W0p = None
-    fused_bf16 = fused_bwd = False
+    fused_bwd = False
     Cp = (C + 3) // 4 * 4
 
     def bf16_operands():
@@ -868,15 +871,12 @@ def edge_conv_block(x, B, N, k, num_filters, relu1=True, outs=None, net2=None):
         return E_, Wp
 
     if bf16:
-        fused_bf16 = (bool(H.load().dgcnn_edge_mlp_bf16_supported(C, k, F)) and W0.is_contiguous() and
-                      (C <= 4 or (H.ld2(x) % 4 == 0 and x.data_ptr() % 16 == 0)))
         bsrc = (x.data_ptr(), H.ld2(x), idx.data_ptr(), W0.data_ptr(), B, N, C, k, F)
         # the backward in one pass over the edges (8 <= k < 256): the forward then packs (#ties, #positives) as the fp32 edge kernels do
         fused_bwd = fused_bf16 and c.recording and BF16_FUSED_BWD and bool(H.load().dgcnn_edge_mlp_bf16_bwd_supported(C, k, F))
         if fused_bf16:
             # csrc/edge_mlp_bf16.hip: E = [x_i, x_j - x_i] gathered, rounded and multiplied tile by tile on the bf16 MFMA pipe;
             # neither E nor y is written: this pass takes the BatchNorm sums, the next one recomputes y for BN + ReLU + max / mean
-            Y = None
             H.call("dgcnn_edge_mlp_bf16_stats", *bsrc, st.data_ptr(), tag="edge_mlp_bf16_kernel<stats>",
                    work=2.0 * R * k * 2 * C * F, nbytes=4.0 * (R * k * C + R * C))
         else:

@@ -67,8 +67,11 @@ class Saver(object):
             self._written.append((name, self._clock()))
             while self._keep > 0 and len(self._written) > self._keep:
                 old, t_old = self._written.pop(0)
-                if self._every > 0.0 and t_old >= self._next_keep:
-                    self._next_keep = t_old + self._every
+                # tf.train.Saver._MaybeDeleteOldCheckpoints: `p[1] > self._next_checkpoint_time` and
+                # `self._next_checkpoint_time += keep_checkpoint_every_n_hours * 3600` (the deadline advances by whole periods;
+                # after a long gap the next few evicted checkpoints are all kept until it has caught up, as in TF)
+                if self._every > 0.0 and t_old > self._next_keep:
+                    self._next_keep += self._every
                     self.kept_forever.append(old)
                     continue
                 if os.path.exists(old + ".npz"):

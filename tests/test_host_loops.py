@@ -286,7 +286,9 @@ def test_saver_keeps_a_checkpoint_every_n_hours(tmp_path):
         now[0] = step * 1800.0
         sv.save(FakeTrainer(), prefix, step)
     left = sorted(int(f.name.split("-")[-1][:-4]) for f in tmp_path.iterdir() if f.name.endswith(".npz"))
-    assert left == [2, 4, 6, 7], left            # window {6, 7} + one per hour from the first full hour on
+    # window {6, 7} + one per hour: TF keeps an evicted checkpoint when its time is strictly PAST the deadline (`>`), and the
+    # deadline advances by whole periods (`+=`): deadlines 3600, 7200, 10800 -> the checkpoints written at 5400 and 9000
+    assert left == [3, 5, 6, 7], left
     assert (tmp_path / "checkpoint").read_text().strip().endswith('snap-7"')
     sv0 = M.Saver(max_to_keep=2, keep_checkpoint_every_n_hours=0.0, clock=lambda: now[0])
     prefix = str(tmp_path / "plain")
