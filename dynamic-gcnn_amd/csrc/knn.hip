@@ -242,7 +242,7 @@ __global__ __launch_bounds__(256, (knn_min_waves<CP, KC>())) void knn_kernel(con
 template <int CP, int KC, bool VEC>
 __global__ __launch_bounds__(256, (KC <= 20 ? 3 : 2)) void knn_mfma_kernel(const float* __restrict__ x, const float* __restrict__ sq,
                                                                            int N, int C, int64_t ldx, int k,
-                                                                           int32_t* __restrict__ idx) {
+                                                                           int32_t* __restrict__ idx, const float* __restrict__ tau0) {
   using f32x16 = __attribute__((ext_vector_type(16))) float;
   constexpr int TJM = 64;                    // candidates per LDS tile: 32 per candidate-half wave
   constexpr int ST = TJM + 2;                // k-major candidate tile [CP][ST]
@@ -277,6 +277,9 @@ __global__ __launch_bounds__(256, (KC <= 20 ? 3 : 2)) void knn_mfma_kernel(const
     bq[s2] = (c < C) ? xb[(int64_t)rowc * ldx + c] : 0.0f;
   }
   const float si = sqb[rowc];
+  // seed bound (dgcnn_knn_seeded_f32): tau0 = the largest distance to k DISTINCT candidates, so the row's k-th distance is <= tau0
+  // and a candidate with d > tau0 can never enter its top k (d == tau0 passes: ties are decided by index in the merge)
+  const float t0 = tau0 ? next_up(tau0[(int64_t)b * N + rowc]) : INFINITY;
 
   float dl[KC];
   int jl[KC];
@@ -378,9 +381,9 @@ __global__ __launch_bounds__(256, (KC <= 20 ? 3 : 2)) void knn_mfma_kernel(const
 #ifdef KNN_SHARE_LATE
       const float o1 = thrw[(lid ^ 1) * ROWS + rslot], o2 = thrw[(lid ^ 2) * ROWS + rslot], o3 = thrw[(lid ^ 3) * ROWS + rslot];
 #endif
-      const float thr = fminf(dl[KC - 1], next_up(fmaxf(fmaxf(dl[KC / 4 - 1], o1), fmaxf(o2, o3))));
+      const float thr = fminf(fminf(dl[KC - 1], t0), next_up(fmaxf(fmaxf(dl[KC / 4 - 1], o1), fmaxf(o2, o3))));
 #else
-      const float thr = dl[KC - 1];
+      const float thr = fminf(dl[KC - 1], t0);
 #endif
       const float* sj = sjs + buf * TJM + cbase + 4 * h;
       unsigned mask = 0u;
@@ -498,7 +501,7 @@ struct Bf16fCfg {
 template <int KC>
 __global__ __launch_bounds__(256, (Bf16fCfg<KC>::OCC)) void knn_bf16f_kernel(const float* __restrict__ x, const float* __restrict__ sq,
                                                                             int N, int C, int64_t ldx, int k,
-                                                                            int32_t* __restrict__ idx) {
+                                                                            int32_t* __restrict__ idx, const float* __restrict__ tau0) {
   using f32x16 = __attribute__((ext_vector_type(16))) float;
   constexpr int CP = 64;
   constexpr int TJM = 64;
@@ -531,6 +534,7 @@ __global__ __launch_bounds__(256, (Bf16fCfg<KC>::OCC)) void knn_bf16f_kernel(con
   const int lid = cs * 2 + h;
   const int rslot = qg * 32 + l31;
   const float si = sqb[rowc];
+  const float t0 = tau0 ? next_up(tau0[(int64_t)b * N + rowc]) : INFINITY;      // seed bound, as in knn_mfma_kernel
   const float* xi_row = xb + (int64_t)rowc * ldx;
 
   // B operand: this lane's query row, channels 16 s + 8 h + (0..7), two bf16 planes
@@ -640,9 +644,9 @@ __global__ __launch_bounds__(256, (Bf16fCfg<KC>::OCC)) void knn_bf16f_kernel(con
       }
       // ---- conservative filter on the approximate distances
 #if KNN_SHARE
-      const float thr = fminf(dl[KC - 1], next_up(fmaxf(fmaxf(dl[KC / 4 - 1], o1), fmaxf(o2, o3))));
+      const float thr = fminf(fminf(dl[KC - 1], t0), next_up(fmaxf(fmaxf(dl[KC / 4 - 1], o1), fmaxf(o2, o3))));
 #else
-      const float thr = dl[KC - 1];
+      const float thr = fminf(dl[KC - 1], t0);
 #endif
       const float* sj = sjs + cbase + 4 * h;
       unsigned mask = 0u;
@@ -755,21 +759,97 @@ int knn_bf16f_mode() {
 int g_knn_valu = 0;            // dgcnn_knn_force_valu (tests): VALU fmaf distances for every C
 bool knn_force_valu() { return g_knn_valu == 1; }
 
+// tau0[row] >= max over the row's first k seed candidates j of D(row, j), D in the normative arithmetic of the scan kernels.
+// One wave per query row; LP = C / 4 lanes per pair (lane = LP * slot + channel quad, 64 / LP pairs per step), every pair's
+// candidate row read as LP consecutive float4 (whole lines), all steps' loads in flight before the first use.  The inner product
+// is summed in a different order than the scan's fmaf chain (4 products per lane, then a butterfly over the LP lanes), so the
+// value differs from the scan's by rounding only: both are within 64 * 2^-24 * sum|x_c y_c| <= 2^-19 (s_i + s_j) of the exact
+// product; adding 2^-16 (s_i + s_j) (> 4x the worst case, and far below anything that matters to the filter) makes
+//     tau0 = max_m [ (s_i + s_j) - 2 p~ + 2^-16 (s_i + s_j) ]
+// an upper bound of the normative distances -- all the proof needs (k distinct candidates at distance <= tau0).
+// Seeds that are not k DISTINCT in-range indices give +inf (no bound).
+template <int LP, int MAXSTEPS>
+__global__ __launch_bounds__(256) void knn_seed_bound_kernel(const float* __restrict__ x, const float* __restrict__ sq, int N,
+                                                             int64_t ldx, const int32_t* __restrict__ seed, int64_t ldseed, int k,
+                                                             int64_t rows, float* __restrict__ tau0) {
+  constexpr int PPS = 64 / LP;                            // pairs per step
+  const int lane = threadIdx.x & 63;
+  const int64_t g = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (g >= rows) return;                                  // (wave-uniform)
+  const int64_t cloud = (rows < 0x7fffffffll) ? (int64_t)((unsigned)g / (unsigned)N) : g / N;
+  const int slot = lane / LP, cq = lane % LP;
+  // the row's seeds, one per lane; validity (in range, pairwise distinct) by k - 1 rotations
+  const int jj = (lane < k) ? seed[g * ldseed + lane] : -1 - lane;
+  bool bad = (lane < k) && (jj < 0 || jj >= N);
+  for (int o = 1; o < k; ++o) {
+    const int src = lane + o - ((lane + o >= 64) ? 64 : 0);
+    const int jo = __shfl(jj, src, 64);
+    bad = bad || (lane < k && src < k && jo == jj);
+  }
+  const bool anybad = __any(bad);
+  const float4 a = *reinterpret_cast<const float4*>(x + g * ldx + 4 * cq);
+  const float si = sq[g];
+  const int steps = (k + PPS - 1) / PPS;
+  float4 v[MAXSTEPS];
+  float sj[MAXSTEPS];
+#pragma unroll
+  for (int s = 0; s < MAXSTEPS; ++s) {
+    if (s < steps) {                                      // (wave-uniform)
+      const int m = s * PPS + slot;
+      int jm = __shfl(jj, m < 64 ? m : 63, 64);
+      jm = (m < k && jm >= 0 && jm < N) ? jm : 0;
+      const int64_t jr = cloud * N + jm;
+      v[s] = *reinterpret_cast<const float4*>(x + jr * ldx + 4 * cq);
+      sj[s] = sq[jr];
+    }
+  }
+  float best = -INFINITY;
+#pragma unroll
+  for (int s = 0; s < MAXSTEPS; ++s) {
+    if (s < steps) {
+      float p = a.x * v[s].x;
+      p = fmaf(a.y, v[s].y, p); p = fmaf(a.z, v[s].z, p); p = fmaf(a.w, v[s].w, p);
+#pragma unroll
+      for (int o = 1; o < LP; o <<= 1) p += __shfl_xor(p, o, 64);
+      const float tt = si + sj[s];
+      const float d = fmaf(-2.0f, p, tt) + tt * (1.0f / 65536.0f);
+      best = (s * PPS + slot < k) ? fmaxf(best, d) : best;
+    }
+  }
+#pragma unroll
+  for (int o = LP; o < 64; o <<= 1) best = fmaxf(best, __shfl_xor(best, o, 64));
+  if (lane == 0) tau0[g] = anybad ? INFINITY : best;
+}
+
+// C in {16, 32, 64} (LP = 4, 8, 16 lanes per pair), rows 16-byte aligned; k <= 64.  Returns false when the shape is not taken.
+bool launch_seed_bound(const float* x, const float* sq, int B, int N, int C, int64_t ldx, const int32_t* seed, int64_t ldseed,
+                       int k, float* tau0, hipStream_t st) {
+  const int64_t rows = (int64_t)B * N;
+  const dim3 grid((unsigned)dg::cdiv(rows, 4));
+#define DG_SB(LPV, MS) dg::launch((knn_seed_bound_kernel<LPV, MS>), grid, dim3(256), 0, st, x, sq, N, ldx, seed, ldseed, k, rows, tau0)
+  if (C == 64) { if (k <= 20) DG_SB(16, 5); else if (k <= 40) DG_SB(16, 10); else DG_SB(16, 16); }
+  else if (C == 32) { if (k <= 24) DG_SB(8, 3); else DG_SB(8, 8); }
+  else if (C == 16) { if (k <= 32) DG_SB(4, 2); else DG_SB(4, 4); }
+  else return false;
+#undef DG_SB
+  return true;
+}
+
 template <int CP, int KC>
 void launch_knn(const float* x, const float* sq, int B, int N, int C, int64_t ldx, int k, int vec_ok,
-                int32_t* idx, hipStream_t st) {
+                int32_t* idx, const float* tau0, hipStream_t st) {
   dim3 grid((unsigned)dg::cdiv(N, ROWS), (unsigned)B);
   if constexpr (CP == 64) {                      // large feature-space graphs: bf16 matrix pipe + exact re-check of the survivors
     const int m = knn_bf16f_mode();
     if (!knn_force_valu() && vec_ok && C % 4 == 0 && C > 16 && (m == 1 || (m == 2 && N >= 8192))) {
-      dg::launch((knn_bf16f_kernel<KC>), grid, dim3(256), 0, st, x, sq, N, C, ldx, k, idx);
+      dg::launch((knn_bf16f_kernel<KC>), grid, dim3(256), 0, st, x, sq, N, C, ldx, k, idx, tau0);
       return;
     }
   }
   if constexpr (CP >= 16 && CP <= 64) {
     if (!knn_force_valu()) {
-      if (vec_ok && C % 4 == 0) dg::launch((knn_mfma_kernel<CP, KC, true>), grid, dim3(256), 0, st, x, sq, N, C, ldx, k, idx);
-      else dg::launch((knn_mfma_kernel<CP, KC, false>), grid, dim3(256), 0, st, x, sq, N, C, ldx, k, idx);
+      if (vec_ok && C % 4 == 0) dg::launch((knn_mfma_kernel<CP, KC, true>), grid, dim3(256), 0, st, x, sq, N, C, ldx, k, idx, tau0);
+      else dg::launch((knn_mfma_kernel<CP, KC, false>), grid, dim3(256), 0, st, x, sq, N, C, ldx, k, idx, tau0);
       return;
     }
   }
@@ -778,11 +858,11 @@ void launch_knn(const float* x, const float* sq, int B, int N, int C, int64_t ld
 
 template <int CP>
 int dispatch_k(const float* x, const float* sq, int B, int N, int C, int64_t ldx, int k, int vec_ok,
-               int32_t* idx, hipStream_t st) {
-  if (k <= 8) launch_knn<CP, 8>(x, sq, B, N, C, ldx, k, vec_ok, idx, st);
-  else if (k <= 20) launch_knn<CP, 20>(x, sq, B, N, C, ldx, k, vec_ok, idx, st);
-  else if (k <= 40) launch_knn<CP, 40>(x, sq, B, N, C, ldx, k, vec_ok, idx, st);
-  else launch_knn<CP, 64>(x, sq, B, N, C, ldx, k, vec_ok, idx, st);
+               int32_t* idx, const float* tau0, hipStream_t st) {
+  if (k <= 8) launch_knn<CP, 8>(x, sq, B, N, C, ldx, k, vec_ok, idx, tau0, st);
+  else if (k <= 20) launch_knn<CP, 20>(x, sq, B, N, C, ldx, k, vec_ok, idx, tau0, st);
+  else if (k <= 40) launch_knn<CP, 40>(x, sq, B, N, C, ldx, k, vec_ok, idx, tau0, st);
+  else launch_knn<CP, 64>(x, sq, B, N, C, ldx, k, vec_ok, idx, tau0, st);
   return dg::check_launch("dgcnn_knn_f32");
 }
 
@@ -812,34 +892,66 @@ static size_t knn_sq_bytes(int B, int N) { return (((size_t)B * (size_t)N * size
 
 extern "C" int64_t dgcnn_knn_workspace_bytes(int B, int N, int C, int k) {
   if (B <= 0 || N <= 0) return 0;
-  size_t n = knn_sq_bytes(B, N);
+  size_t n = 2 * knn_sq_bytes(B, N);                 // s_i, and the seed bounds of dgcnn_knn_seeded_f32
   if (dg::knn_grid_applicable(C, k)) n += dg::knn_grid_workspace_bytes(B, N);
   return (int64_t)n;
 }
 
-extern "C" int dgcnn_knn_f32(const float* x, int B, int N, int C, int64_t ldx, int k, int32_t* idx,
-                             void* ws, size_t ws_bytes, void* stream) {
-  DG_REQUIRE(x && idx && ws, DGCNN_EINVAL, "dgcnn_knn_f32: null pointer");
-  DG_REQUIRE(B > 0 && N > 0 && C > 0 && ldx >= C, DGCNN_EINVAL, "dgcnn_knn_f32: bad shape B=%d N=%d C=%d", B, N, C);
-  DG_REQUIRE(k > 0 && k <= N, DGCNN_EINVAL,
-             "dgcnn_knn_f32: k=%d must be in [1, N=%d] (tf.nn.top_k raises otherwise)", k, N);
-  DG_REQUIRE(k <= 64, DGCNN_EUNSUP, "dgcnn_knn_f32: k=%d > 64 unsupported", k);
-  DG_REQUIRE(C <= 128, DGCNN_EUNSUP, "dgcnn_knn_f32: C=%d > 128 unsupported", C);
+// the seed bound pays from N ~ 4096 on: at (24,2048,64,20) the bound kernel (38 us: 252 MB of gathered rows) costs what the scan
+// saves (-21 ... -37 us); at (8,16384,64,40) the step goes 39.0 -> 35.8 ms, at (8,65536,64,20) 101 -> 97 (profiles/r05/knn_seed.txt)
+static int g_knn_seed_min_n = 4096;
+extern "C" int dgcnn_knn_seed_min_n(int n) {            // tools / tests: smallest N for which seeds are used; returns the previous value
+  const int prev = g_knn_seed_min_n;
+  if (n >= 0) g_knn_seed_min_n = n;
+  return prev;
+}
+
+static int knn_impl(const char* what, const float* x, int B, int N, int C, int64_t ldx, int k, const int32_t* seed, int64_t ldseed,
+                    int kseed, int32_t* idx, void* ws, size_t ws_bytes, void* stream) {
+  DG_REQUIRE(x && idx && ws, DGCNN_EINVAL, "%s: null pointer", what);
+  DG_REQUIRE(B > 0 && N > 0 && C > 0 && ldx >= C, DGCNN_EINVAL, "%s: bad shape B=%d N=%d C=%d", what, B, N, C);
+  DG_REQUIRE(k > 0 && k <= N, DGCNN_EINVAL, "%s: k=%d must be in [1, N=%d] (tf.nn.top_k raises otherwise)", what, k, N);
+  DG_REQUIRE(k <= 64, DGCNN_EUNSUP, "%s: k=%d > 64 unsupported", what, k);
+  DG_REQUIRE(C <= 128, DGCNN_EUNSUP, "%s: C=%d > 128 unsupported", what, C);
   DG_REQUIRE((reinterpret_cast<uintptr_t>(ws) & 15) == 0 && ws_bytes >= knn_sq_bytes(B, N), DGCNN_EINVAL,
-             "dgcnn_knn_f32: workspace must be 16-byte aligned and hold dgcnn_knn_workspace_bytes(B, N, C, k) bytes (got %zu)", ws_bytes);
+             "%s: workspace must be 16-byte aligned and hold dgcnn_knn_workspace_bytes(B, N, C, k) bytes (got %zu)", what, ws_bytes);
   hipStream_t st = (hipStream_t)stream;
   float* sq_ws = reinterpret_cast<float*>(ws);
   const int64_t rows = (int64_t)B * N;
+  const int vec_ok = (ldx % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
+  // the seed bound is used by the matrix-pipe scan kernels (4 < C <= 64) on float4-loadable rows; needs >= k seeds per row
+  const bool seeded = seed && kseed >= k && kseed <= 64 && C > 4 && C <= 64 && C % 4 == 0 && vec_ok && !knn_force_valu() &&
+                      N >= g_knn_seed_min_n && ws_bytes >= 2 * knn_sq_bytes(B, N);
+  const size_t grid_off = 2 * knn_sq_bytes(B, N);
   // raw coordinates (C <= 4) when the caller provided the scratch: exact search over a uniform cell grid (knn_grid.hip)
-  const bool grid_ws = dg::knn_grid_applicable(C, k) && !knn_force_valu() &&
-                       ws_bytes >= knn_sq_bytes(B, N) + dg::knn_grid_workspace_bytes(B, N);
+  const bool grid_ws = dg::knn_grid_applicable(C, k) && !knn_force_valu() && ws_bytes >= grid_off + dg::knn_grid_workspace_bytes(B, N);
   dg::launch(sqnorm_kernel, dim3((unsigned)dg::cdiv(rows, SQ_ROWS)), dim3(256), sizeof(float) * SQ_ROWS * (C + 1), st, x,
                      ldx, rows, C, sq_ws);
   if (grid_ws && N >= dg::knn_grid_min_n())
-    return dg::launch_knn_grid(x, sq_ws, B, N, C, ldx, k, idx, reinterpret_cast<char*>(ws) + knn_sq_bytes(B, N), st);
-  const int vec_ok = (ldx % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
-  if (C <= 4) return dispatch_k<4>(x, sq_ws, B, N, C, ldx, k, vec_ok, idx, st);
-  if (C <= 16) return dispatch_k<16>(x, sq_ws, B, N, C, ldx, k, vec_ok, idx, st);
-  if (C <= 64) return dispatch_k<64>(x, sq_ws, B, N, C, ldx, k, vec_ok, idx, st);
-  return dispatch_k<128>(x, sq_ws, B, N, C, ldx, k, vec_ok, idx, st);
+    return dg::launch_knn_grid(x, sq_ws, B, N, C, ldx, k, idx, reinterpret_cast<char*>(ws) + grid_off, st);
+  float* tau0 = nullptr;
+  if (seeded) {
+    tau0 = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + knn_sq_bytes(B, N));
+    if (!launch_seed_bound(x, sq_ws, B, N, C, ldx, seed, ldseed, k, tau0, st)) tau0 = nullptr;      // (the first k seeds of every row)
+  }
+  if (C <= 4) return dispatch_k<4>(x, sq_ws, B, N, C, ldx, k, vec_ok, idx, tau0, st);
+  if (C <= 16) return dispatch_k<16>(x, sq_ws, B, N, C, ldx, k, vec_ok, idx, tau0, st);
+  if (C <= 64) return dispatch_k<64>(x, sq_ws, B, N, C, ldx, k, vec_ok, idx, tau0, st);
+  return dispatch_k<128>(x, sq_ws, B, N, C, ldx, k, vec_ok, idx, tau0, st);
+}
+
+extern "C" int dgcnn_knn_f32(const float* x, int B, int N, int C, int64_t ldx, int k, int32_t* idx,
+                             void* ws, size_t ws_bytes, void* stream) {
+  return knn_impl("dgcnn_knn_f32", x, B, N, C, ldx, k, nullptr, 0, 0, idx, ws, ws_bytes, stream);
+}
+
+// The same search, seeded: `seed` (B, N, >= kseed; row stride ldseed) lists kseed >= k DISTINCT candidates of every row (any:
+// the previous EdgeConv layer's graph in dgcnn/ops.py:95-96's stack).  Their largest distance bounds the row's k-th distance from
+// above, so the scan can drop farther candidates from its first tile on instead of inserting them into lists that are still
+// filling up (~k (1 + ln(N / k)) inserts per row become ~k + the candidates between the k-th distance and the bound).  The result
+// is the unseeded one bit for bit; rows whose seeds are not distinct in-range indices simply get no bound.
+extern "C" int dgcnn_knn_seeded_f32(const float* x, int B, int N, int C, int64_t ldx, int k, const int32_t* seed, int64_t ldseed,
+                                    int kseed, int32_t* idx, void* ws, size_t ws_bytes, void* stream) {
+  DG_REQUIRE(!seed || (ldseed >= kseed && kseed > 0), DGCNN_EINVAL, "dgcnn_knn_seeded_f32: bad seed shape");
+  return knn_impl("dgcnn_knn_seeded_f32", x, B, N, C, ldx, k, seed, ldseed, kseed, idx, ws, ws_bytes, stream);
 }

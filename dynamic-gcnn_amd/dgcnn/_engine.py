@@ -460,15 +460,25 @@ def rank4(v, B, N):
 # ----------------------------------------------------------------------------------------------
 # thin kernel wrappers (2-D views in, explicit leading dimensions out)
 # ----------------------------------------------------------------------------------------------
-def knn(x2d, B, N, k):
+KNN_SEED = os.environ.get("DGCNN_KNN_SEED", "1") != "0"   # seed a layer's k-NN filter with the previous layer's graph (A/B switch)
+
+
+def knn(x2d, B, N, k, seed=None):
+    """idx (B,N,k) of x2d (B*N, C).  seed: an earlier graph of the same clouds, (B,N,ks) int32 with ks >= k -- ks distinct candidates
+    per row whose largest distance bounds the row's k-th distance from above (dgcnn_knn_seeded_f32); the result does not depend on it."""
     C = x2d.shape[1]
     idx = torch.empty((B, N, k), dtype=torch.int32, device=x2d.device)
-    nws = int(H.load().dgcnn_knn_workspace_bytes(B, N, C, k))           # s_i (+ the cell grid's scratch for raw coordinates)
+    nws = int(H.load().dgcnn_knn_workspace_bytes(B, N, C, k))           # s_i, seed bounds (+ the cell grid's scratch for raw coordinates)
     ws = torch.empty((nws,), dtype=torch.uint8, device=x2d.device)
-    H.call("dgcnn_knn_f32", x2d.data_ptr(), B, N, C, H.ld2(x2d), k, idx.data_ptr(), ws.data_ptr(), nws,
-           tag="knn_kernel<C%d,k%d>" % (4 if C <= 4 else 16 if C <= 16 else 64 if C <= 64 else 128,
-                                         8 if k <= 8 else 20 if k <= 20 else 40 if k <= 40 else 64),
-           work=2.0 * B * N * N * C)
+    tag = "knn_kernel<C%d,k%d>" % (4 if C <= 4 else 16 if C <= 16 else 64 if C <= 64 else 128,
+                                   8 if k <= 8 else 20 if k <= 20 else 40 if k <= 40 else 64)
+    if (KNN_SEED and seed is not None and seed.dim() == 3 and seed.shape[0] == B and seed.shape[1] == N and seed.shape[2] >= k and
+            seed.dtype == torch.int32 and seed.is_contiguous()):
+        H.call("dgcnn_knn_seeded_f32", x2d.data_ptr(), B, N, C, H.ld2(x2d), k, seed.data_ptr(), int(seed.shape[2]), int(seed.shape[2]),
+               idx.data_ptr(), ws.data_ptr(), nws, tag=tag, work=2.0 * B * N * N * C)
+    else:
+        H.call("dgcnn_knn_f32", x2d.data_ptr(), B, N, C, H.ld2(x2d), k, idx.data_ptr(), ws.data_ptr(), nws, tag=tag,
+               work=2.0 * B * N * N * C)
     return idx
 
 
@@ -829,9 +839,10 @@ def build_csr(idx, B, N, k, side=None):
     return off, (rev if srt is None else srt)
 
 
-def edge_conv_block(x, B, N, k, num_filters, relu1=True, outs=None, net2=None):
+def edge_conv_block(x, B, N, k, num_filters, relu1=True, outs=None, net2=None, seed=None):
     """x: (B*N, C) view.  Returns (mm, net, idx): mm = (R,2F) [max | mean], net = (R,64).
-    outs = (mm_view, net_view) destination slices (model path) or None (fresh buffers)."""
+    outs = (mm_view, net_view) destination slices (model path) or None (fresh buffers).
+    seed: the previous EdgeConv layer's graph (B,N,k') or None: seeds this layer's k-NN filter (same result, fewer inserts)."""
     c = ctx()
     R, C = x.shape
     F = int(num_filters)
@@ -844,7 +855,7 @@ def edge_conv_block(x, B, N, k, num_filters, relu1=True, outs=None, net2=None):
     bf16 = EDGE_MLP_DTYPE == "bf16"
     literal = EDGE_MLP_LITERAL or bf16
     gather = (not literal) and (not EDGE_MLP_NBR_GEMM) and F % 4 == 0 and F <= 1024
-    idx = knn(x, B, N, k)                                               # ops.py:8-19
+    idx = knn(x, B, N, k, seed=seed)                                    # ops.py:8-19
     virtual = gather and not EDGE_MATERIALIZE_Y and k < 256   # conv0 output never written: recomputed from (V, U, idx)
     #                                                           (the edge BN passes pack tie / positive counts: k < 256)
     # the fused bf16 kernels write neither E nor y: decided BEFORE anything of (R*k, F) is allocated (1.3 GB per layer at configs[2])

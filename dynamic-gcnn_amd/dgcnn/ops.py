@@ -49,11 +49,12 @@ def edges(points, k=20):
     return out
 
 
-def edge_conv(point_cloud, k, num_filters, trainable, activation=relu, debug=False, _outs=None, _net2=None):
-    """dgcnn/ops.py:42-73.  Returns the list [net_max, net_mean, net], each (B,N,1,ch)."""
+def edge_conv(point_cloud, k, num_filters, trainable, activation=relu, debug=False, _outs=None, _net2=None, _seed=None):
+    """dgcnn/ops.py:42-73.  Returns the list [net_max, net_mean, net], each (B,N,1,ch).
+    _seed: the previous layer's neighbour graph (the stacks pass it): only speeds this layer's k-NN up."""
     x, B, N = E.as2d(point_cloud)
     F = int(num_filters)
-    mm, net, idx = E.edge_conv_block(x, B, N, int(k), F, relu1=_is_relu(activation), outs=_outs, net2=_net2)
+    mm, net, idx = E.edge_conv_block(x, B, N, int(k), F, relu1=_is_relu(activation), outs=_outs, net2=_net2, seed=_seed)
     res = [E.rank4(mm[:, :F], B, N), E.rank4(mm[:, F:], B, N), E.rank4(net, B, N)]
     if debug:
         for t in res:
@@ -82,10 +83,12 @@ def repeat_edge_conv(point_cloud, repeat, k, num_filters, trainable, debug=False
     num_filters = _listify(num_filters, repeat, "num_filters")
     net = point_cloud
     tensors = []
+    seed = None
     for i in range(repeat):
         with E.variable_scope("EdgeConv%d" % i):
             outs, net2 = _plan(i) if _plan is not None else (None, None)
-            tensors += edge_conv(net, k[i], num_filters[i], trainable, debug=debug, _outs=outs, _net2=net2)
+            tensors += edge_conv(net, k[i], num_filters[i], trainable, debug=debug, _outs=outs, _net2=net2, _seed=seed)
+            seed = edge_conv.last_idx                    # layer i's graph seeds layer i + 1's search (same points)
             net = tensors[-1][:, :, 0, :]
     return tensors
 
@@ -99,15 +102,16 @@ def repeat_residual_edge_conv(point_cloud, repeat, k, num_filters, trainable, de
     net = point_cloud
     tensors = []
     shortcut = None
+    seed = None
     for i in range(repeat):
         with E.variable_scope("EdgeConv%d" % i):
             outs, net2 = _plan(i) if _plan is not None else (None, None)
             if shortcut is None:
-                tensors += edge_conv(net, k[i], num_filters[i], trainable, debug=debug, _outs=outs, _net2=net2)
+                tensors += edge_conv(net, k[i], num_filters[i], trainable, debug=debug, _outs=outs, _net2=net2, _seed=seed)
             else:
                 # conv1 (no activation) goes to a scratch buffer; relu(shortcut + conv1) takes the planned slot
                 tensors += edge_conv(net, k[i], num_filters[i], trainable, activation=None, debug=debug,
-                                     _outs=None if outs is None else (outs[0], None))
+                                     _outs=None if outs is None else (outs[0], None), _seed=seed)
                 sc, B, N = E.as2d(shortcut)
                 if not num_filters[i] == num_filters[i - 1]:
                     sc = E.conv_bn_act(sc, "shortcut", num_filters[i], relu=False)       # ops.py:125-133
@@ -118,6 +122,7 @@ def repeat_residual_edge_conv(point_cloud, repeat, k, num_filters, trainable, de
                            res.shape[0], res.shape[1], 0)
                     E_copy_grad(res, net2)
                 tensors[-1] = E.rank4(res, B, N)
+            seed = edge_conv.last_idx                    # layer i's graph seeds layer i + 1's search (same points)
             net = tensors[-1]
             shortcut = tensors[-1]
             net = net[:, :, 0, :]

@@ -70,6 +70,14 @@ int dgcnn_knn_force_valu(int on);
 int dgcnn_knn_bf16_filter(int mode);
 int dgcnn_knn_f32(const float* x, int B, int N, int C, int64_t ldx, int k, int32_t* idx,
                   void* ws, size_t ws_bytes, void* stream);
+/* The same search with a per-row upper bound taken from `seed` (B, N, >= kseed int32, row stride ldseed): kseed >= k DISTINCT
+ * candidates of every row -- in the EdgeConv stack the previous layer's graph (ops.py:95-96).  Identical result, fewer list inserts
+ * (csrc/knn.hip).  seed == NULL or kseed < k: plain dgcnn_knn_f32.  Workspace as dgcnn_knn_workspace_bytes says. */
+int dgcnn_knn_seeded_f32(const float* x, int B, int N, int C, int64_t ldx, int k, const int32_t* seed, int64_t ldseed,
+                         int kseed, int32_t* idx, void* ws, size_t ws_bytes, void* stream);
+/* smallest N for which the seeds are used (default 4096: below, computing the bound costs what it saves); n < 0 only queries.
+ * Returns the previous value.  (tools / tests) */
+int dgcnn_knn_seed_min_n(int n);
 
 /* ---- K3 in its bf16-operand form (BASELINE configs[2] "bf16 edge-MLP MFMA"): conv0 of an EdgeConv layer, ops.py:21-52 ------
  * E[e] = [x_i, x_j - x_i] formed in fp32 and rounded to bf16 once (RNE), W0 (2C x F, row-major) rounded to bf16 once,

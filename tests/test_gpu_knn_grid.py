@@ -120,3 +120,45 @@ def test_workspace_too_small_for_the_grid_selects_the_all_pairs_kernel(dg):
     np.testing.assert_array_equal(host(idx), O.k_nn(pts, k))
     with pytest.raises(ValueError):          # DGCNN_EINVAL: not even room for the s_i
         H.call("dgcnn_knn_f32", x.data_ptr(), B, N, C, C, k, idx.data_ptr(), ws.data_ptr(), small - 256)
+
+
+# ------------------------------------------------------------------------------------------------------
+# seeded search (dgcnn_knn_seeded_f32): any k distinct candidates per row bound the row's k-th distance from above
+# ------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("B,N,C,k", [(2, 512, 64, 20), (1, 700, 32, 8), (2, 2048, 64, 20), (1, 9000, 64, 40)])
+def test_seeded_knn_equals_the_unseeded_search_whatever_the_seeds(B, N, C, k):
+    """The result must not depend on the seeds: true neighbours (a tight bound), random distinct candidates (a loose one), the row's
+    own index repeated (not distinct: the row gets no bound), out-of-range indices (no bound), more seeds than k (the first k count).
+    All against the oracle, bit for bit."""
+    from dgcnn import _engine as E, _hip as H
+    prev = H.load().dgcnn_knn_seed_min_n(0)                                       # (the library seeds from N = 4096 on by default)
+    try:
+        _seeded_cases(E, B, N, C, k)
+    finally:
+        H.load().dgcnn_knn_seed_min_n(prev)
+
+
+def _seeded_cases(E, B, N, C, k):
+    rng = np.random.default_rng(N + C)
+    x = np.maximum(rng.normal(size=(B, N, C)), 0).astype(np.float32)             # ReLU features: many zeros, near-ties
+    x[:, 5] = x[:, 3]                                                             # duplicate rows: exact distance ties
+    ref = O.k_nn(x, k)
+    xd = dev(x.reshape(B * N, C))
+    plain = host(E.knn(xd, B, N, k))
+    np.testing.assert_array_equal(plain, ref)
+    seeds = {
+        "true neighbours": ref,
+        "true neighbours + extra columns": np.concatenate([ref, (ref[..., :3] + 1) % N], -1),
+        "random distinct": np.stack([np.stack([rng.permutation(N)[:k] for _ in range(N)]) for _ in range(B)]),
+        "not distinct": np.broadcast_to(np.arange(N)[None, :, None], (B, N, k)).copy(),
+        "out of range": np.full((B, N, k), N + 7),
+    }
+    if N >= 2048:
+        del seeds["random distinct"]                                              # (host-side generation is slow; covered at small N)
+    for name, sd in seeds.items():
+        got = host(E.knn(xd, B, N, k, seed=dev(np.ascontiguousarray(sd.astype(np.int32)))))
+        np.testing.assert_array_equal(got, ref, err_msg=name)
+    # mixed: half of the rows seeded well, half badly, in one launch
+    mix = ref.copy()
+    mix[:, ::2] = N + 1
+    np.testing.assert_array_equal(host(E.knn(xd, B, N, k, seed=dev(mix.astype(np.int32)))), ref)
