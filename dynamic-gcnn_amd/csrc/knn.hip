@@ -773,59 +773,86 @@ __global__ __launch_bounds__(256) void knn_seed_bound_kernel(const float* __rest
                                                              int64_t ldx, const int32_t* __restrict__ seed, int64_t ldseed, int k,
                                                              int64_t rows, float* __restrict__ tau0) {
   constexpr int PPS = 64 / LP;                            // pairs per step
+  constexpr int RW = 2;                                   // query rows per wave: their loads are all in flight together
   const int lane = threadIdx.x & 63;
-  const int64_t g = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (g >= rows) return;                                  // (wave-uniform)
-  const int64_t cloud = (rows < 0x7fffffffll) ? (int64_t)((unsigned)g / (unsigned)N) : g / N;
+  // XCD x (= block id % 8; each XCD has its own 4 MB L2) owns the x-th eighth of the rows: the neighbour rows its waves gather
+  // are then those of a few clouds (1.5 MB at the headline shape) instead of all of them (12.6 MB through every L2: 38 us)
+  const int64_t per = ((rows + 7) / 8 + 4 * RW - 1) / (4 * RW) * (4 * RW);       // rows per XCD, a whole number of blocks
+  const int64_t g0 = (int64_t)(blockIdx.x & 7) * per + ((int64_t)(blockIdx.x >> 3) * 4 + (threadIdx.x >> 6)) * RW;
+  if (g0 >= rows || ((int64_t)(blockIdx.x >> 3) * 4 + (threadIdx.x >> 6)) * RW >= per) return;       // (wave-uniform)
   const int slot = lane / LP, cq = lane % LP;
-  // the row's seeds, one per lane; validity (in range, pairwise distinct) by k - 1 rotations
-  const int jj = (lane < k) ? seed[g * ldseed + lane] : -1 - lane;
-  bool bad = (lane < k) && (jj < 0 || jj >= N);
-  for (int o = 1; o < k; ++o) {
-    const int src = lane + o - ((lane + o >= 64) ? 64 : 0);
-    const int jo = __shfl(jj, src, 64);
-    bad = bad || (lane < k && src < k && jo == jj);
-  }
-  const bool anybad = __any(bad);
-  const float4 a = *reinterpret_cast<const float4*>(x + g * ldx + 4 * cq);
-  const float si = sq[g];
   const int steps = (k + PPS - 1) / PPS;
-  float4 v[MAXSTEPS];
-  float sj[MAXSTEPS];
+  int jj[RW];
+  int64_t gr[RW];
+  const float* xc[RW];                                    // the row's cloud: x and s_i of its first point (wave-uniform)
+  const float* sc[RW];
 #pragma unroll
-  for (int s = 0; s < MAXSTEPS; ++s) {
-    if (s < steps) {                                      // (wave-uniform)
-      const int m = s * PPS + slot;
-      int jm = __shfl(jj, m < 64 ? m : 63, 64);
-      jm = (m < k && jm >= 0 && jm < N) ? jm : 0;
-      const int64_t jr = cloud * N + jm;
-      v[s] = *reinterpret_cast<const float4*>(x + jr * ldx + 4 * cq);
-      sj[s] = sq[jr];
+  for (int w = 0; w < RW; ++w) {
+    gr[w] = (g0 + w < rows) ? g0 + w : rows - 1;
+    jj[w] = (lane < k) ? seed[gr[w] * ldseed + lane] : -1 - lane;      // the row's seeds, one per lane
+    const int64_t cloud = (rows < 0x7fffffffll) ? (int64_t)((unsigned)gr[w] / (unsigned)N) : gr[w] / N;
+    xc[w] = x + cloud * N * ldx;
+    sc[w] = sq + cloud * N;
+  }
+  const unsigned uld = (unsigned)ldx;                     // (N * ldx < 2^31: checked by the host)
+  float4 a[RW], v[RW][MAXSTEPS];
+  float si[RW], sj[RW][MAXSTEPS];
+#pragma unroll
+  for (int w = 0; w < RW; ++w) {
+    a[w] = *reinterpret_cast<const float4*>(x + gr[w] * ldx + 4 * cq);
+    si[w] = sq[gr[w]];
+#pragma unroll
+    for (int s = 0; s < MAXSTEPS; ++s) {
+      if (s < steps) {                                    // (wave-uniform)
+        const int m = s * PPS + slot;
+        int jm = __shfl(jj[w], m < 64 ? m : 63, 64);
+        jm = (m < k && (unsigned)jm < (unsigned)N) ? jm : 0;
+        v[w][s] = *reinterpret_cast<const float4*>(xc[w] + ((unsigned)jm * uld + 4u * (unsigned)cq));
+        sj[w][s] = sc[w][jm];
+      }
     }
   }
-  float best = -INFINITY;
+  // validity of the seeds (k in-range, pairwise distinct indices), under the loads: every seed is broadcast from its lane
+  // (v_readlane -> SGPR) and must match exactly one of the k lanes
+  const unsigned long long kmask = (k >= 64) ? ~0ull : ((1ull << k) - 1ull);
+  bool anybad[RW];
 #pragma unroll
-  for (int s = 0; s < MAXSTEPS; ++s) {
-    if (s < steps) {
-      float p = a.x * v[s].x;
-      p = fmaf(a.y, v[s].y, p); p = fmaf(a.z, v[s].z, p); p = fmaf(a.w, v[s].w, p);
-#pragma unroll
-      for (int o = 1; o < LP; o <<= 1) p += __shfl_xor(p, o, 64);
-      const float tt = si + sj[s];
-      const float d = fmaf(-2.0f, p, tt) + tt * (1.0f / 65536.0f);
-      best = (s * PPS + slot < k) ? fmaxf(best, d) : best;
+  for (int w = 0; w < RW; ++w) {
+    bool b = false;
+    for (int t = 0; t < k; ++t) {
+      const int st = __builtin_amdgcn_readlane(jj[w], t);
+      const unsigned long long eq = __ballot(jj[w] == st) & kmask;
+      b = b || (__popcll(eq) != 1) || ((unsigned)st >= (unsigned)N);
     }
+    anybad[w] = b;
   }
 #pragma unroll
-  for (int o = LP; o < 64; o <<= 1) best = fmaxf(best, __shfl_xor(best, o, 64));
-  if (lane == 0) tau0[g] = anybad ? INFINITY : best;
+  for (int w = 0; w < RW; ++w) {
+    float best = -INFINITY;
+#pragma unroll
+    for (int s = 0; s < MAXSTEPS; ++s) {
+      if (s < steps) {
+        float p = a[w].x * v[w][s].x;
+        p = fmaf(a[w].y, v[w][s].y, p); p = fmaf(a[w].z, v[w][s].z, p); p = fmaf(a[w].w, v[w][s].w, p);
+#pragma unroll
+        for (int o = 1; o < LP; o <<= 1) p += __shfl_xor(p, o, 64);
+        const float tt = si[w] + sj[w][s];
+        const float d = fmaf(-2.0f, p, tt) + tt * (1.0f / 65536.0f);
+        best = (s * PPS + slot < k) ? fmaxf(best, d) : best;
+      }
+    }
+#pragma unroll
+    for (int o = LP; o < 64; o <<= 1) best = fmaxf(best, __shfl_xor(best, o, 64));
+    if (lane == 0 && g0 + w < rows) tau0[g0 + w] = anybad[w] ? INFINITY : best;
+  }
 }
 
 // C in {16, 32, 64} (LP = 4, 8, 16 lanes per pair), rows 16-byte aligned; k <= 64.  Returns false when the shape is not taken.
 bool launch_seed_bound(const float* x, const float* sq, int B, int N, int C, int64_t ldx, const int32_t* seed, int64_t ldseed,
                        int k, float* tau0, hipStream_t st) {
   const int64_t rows = (int64_t)B * N;
-  const dim3 grid((unsigned)dg::cdiv(rows, 4));
+  const int64_t per = dg::cdiv(dg::cdiv(rows, 8), 8) * 8;  // rows per XCD (blocks of 4 waves x 2 rows)
+  const dim3 grid((unsigned)(per / 8 * 8));                // block id = 8 * (block within the XCD's share) + XCD
 #define DG_SB(LPV, MS) dg::launch((knn_seed_bound_kernel<LPV, MS>), grid, dim3(256), 0, st, x, sq, N, ldx, seed, ldseed, k, rows, tau0)
   if (C == 64) { if (k <= 20) DG_SB(16, 5); else if (k <= 40) DG_SB(16, 10); else DG_SB(16, 16); }
   else if (C == 32) { if (k <= 24) DG_SB(8, 3); else DG_SB(8, 8); }
@@ -921,7 +948,7 @@ static int knn_impl(const char* what, const float* x, int B, int N, int C, int64
   const int vec_ok = (ldx % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
   // the seed bound is used by the matrix-pipe scan kernels (4 < C <= 64) on float4-loadable rows; needs >= k seeds per row
   const bool seeded = seed && kseed >= k && kseed <= 64 && C > 4 && C <= 64 && C % 4 == 0 && vec_ok && !knn_force_valu() &&
-                      N >= g_knn_seed_min_n && ws_bytes >= 2 * knn_sq_bytes(B, N);
+                      N >= g_knn_seed_min_n && (int64_t)N * ldx < ((int64_t)1 << 31) && ws_bytes >= 2 * knn_sq_bytes(B, N);
   const size_t grid_off = 2 * knn_sq_bytes(B, N);
   // raw coordinates (C <= 4) when the caller provided the scratch: exact search over a uniform cell grid (knn_grid.hip)
   const bool grid_ws = dg::knn_grid_applicable(C, k) && !knn_force_valu() && ws_bytes >= grid_off + dg::knn_grid_workspace_bytes(B, N);

@@ -6,7 +6,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "dynamic-gcnn_amd")); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch
 import dgcnn
-from dgcnn import _engine as E
+from dgcnn import _engine as E, _hip as H
+H.load().dgcnn_knn_seed_min_n(0)            # (the library seeds from N = 4096 on: this script measures N = 2048)
 from gpu_helpers import capture_layers
 B, N, K = 24, 2048, 20
 flags = dgcnn.DGCNN_FLAGS(MODEL_NAME="dgcnn", EDGE_CONV_LAYERS=3, EDGE_CONV_FILTERS=[64, 64, 128], FC_LAYERS=2, FC_FILTERS=[512, 256],
