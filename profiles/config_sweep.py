@@ -25,6 +25,8 @@ if "--only" in sys.argv:
 
 def main():
     graph = "--graph" in sys.argv                  # replay the tower as a captured HIP graph (trainval.use_graph)
+    if "--plan" in sys.argv:
+        graph = "plan"                             # ... or from a recorded launch plan
     extra = {"HEAD_PLANES": "f16"} if "--f16-planes" in sys.argv else {}
     print("# graph replay: %s%s" % (graph, "  head GEMMs from fp16 operand planes" if extra else ""))
     for name, cfg, B, N, C in CONFIGS:
