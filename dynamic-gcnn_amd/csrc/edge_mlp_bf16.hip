@@ -65,45 +65,7 @@ __device__ __forceinline__ void gather_tile(const EdgeP& p, char* Es, int64_t ti
   constexpr int K = 16 * CK;
   constexpr int S = 2 * K + 16;
   const int C = p.C, k = p.k;
-  if constexpr (CK != 1) {
-    // C = 64: 16 consecutive lanes fetch one row as consecutive float4 (x_j: a whole 256-byte row = two full lines per 16 lanes;
-    // x_i: the same row for the k edges of a point, an L1 hit), 16 rows per pass of the 256 threads, all 8 passes' loads in flight
-    // before the first use.  (Round 4: a lane walked half a row by itself -- every wave load touched 64 lines for 16 bytes each.)
-    const int cq = t & 15;
-    float4 xi[8], xj[8];
-#pragma unroll
-    for (int ps = 0; ps < 8; ++ps) {
-      const int r = 16 * ps + (t >> 4);
-      int64_t e, gp;
-      bool valid;
-      if (POINTS) {
-        const int pi = r / k;
-        gp = tile * P + pi;
-        valid = pi < P && gp < R;
-        e = gp * k + (r - pi * k);
-      } else {
-        e = tile * RT + r;
-        valid = e < Me;
-        gp = e / k;
-      }
-      xi[ps] = xj[ps] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (valid) {
-        const int64_t nb = (gp / p.N) * p.N + p.idx[e];
-        xi[ps] = *reinterpret_cast<const float4*>(p.x + gp * p.ldx + 4 * cq);
-        xj[ps] = *reinterpret_cast<const float4*>(p.x + nb * p.ldx + 4 * cq);
-      }
-    }
-#pragma unroll
-    for (int ps = 0; ps < 8; ++ps) {
-      const int r = 16 * ps + (t >> 4);
-      char* dst = Es + r * S + 8 * cq;                               // 4 channels = 8 bytes of bf16
-      const float4 a = xi[ps], b = xj[ps];
-      *reinterpret_cast<uint2*>(dst) = make_uint2(pk_bf16(a.x, a.y), pk_bf16(a.z, a.w));
-      *reinterpret_cast<uint2*>(dst + 128) = make_uint2(pk_bf16(b.x - a.x, b.y - a.y), pk_bf16(b.z - a.z, b.w - a.w));
-    }
-    return;
-  }
-  const int r = 32 * w + l31;
+  const int r = (CK == 1) ? (32 * w + l31) : (t >> 1);            // (t >> 1 lies in [32 w, 32 w + 32))
   int64_t e, gp;
   bool valid;
   if (POINTS) {
@@ -117,21 +79,45 @@ __device__ __forceinline__ void gather_tile(const EdgeP& p, char* Es, int64_t ti
     gp = e / k;
   }
   char* dst = Es + r * S;
-  if (lh == 0) {
-    float xi[4] = {0.f, 0.f, 0.f, 0.f}, d[4] = {0.f, 0.f, 0.f, 0.f};
+  if (CK == 1) {
+    if (lh == 0) {
+      float xi[4] = {0.f, 0.f, 0.f, 0.f}, d[4] = {0.f, 0.f, 0.f, 0.f};
+      if (valid) {
+        const int64_t nb = (gp / p.N) * p.N + p.idx[e];
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+          if (c < C) {
+            xi[c] = p.x[gp * p.ldx + c];
+            d[c] = p.x[nb * p.ldx + c] - xi[c];
+          }
+      }
+      const u32x4 a = {pk_bf16(xi[0], xi[1]), pk_bf16(xi[2], xi[3]), 0u, 0u};
+      const u32x4 b = {pk_bf16(d[0], d[1]), pk_bf16(d[2], d[3]), 0u, 0u};
+      *reinterpret_cast<u32x4*>(dst) = a;
+      *reinterpret_cast<u32x4*>(dst + 16) = b;
+    }
+  } else {
+    const int h = t & 1;                                            // channels 32 h .. 32 h + 31 of x_i and of x_j - x_i
+    float4 xi[8], xj[8];
     if (valid) {
       const int64_t nb = (gp / p.N) * p.N + p.idx[e];
+      const float4* pi4 = reinterpret_cast<const float4*>(p.x + gp * p.ldx + 32 * h);
+      const float4* pj4 = reinterpret_cast<const float4*>(p.x + nb * p.ldx + 32 * h);
 #pragma unroll
-      for (int c = 0; c < 4; ++c)
-        if (c < C) {
-          xi[c] = p.x[gp * p.ldx + c];
-          d[c] = p.x[nb * p.ldx + c] - xi[c];
-        }
+      for (int q = 0; q < 8; ++q) { xi[q] = pi4[q]; xj[q] = pj4[q]; }
+    } else {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) xi[q] = xj[q] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    const u32x4 a = {pk_bf16(xi[0], xi[1]), pk_bf16(xi[2], xi[3]), 0u, 0u};
-    const u32x4 b = {pk_bf16(d[0], d[1]), pk_bf16(d[2], d[3]), 0u, 0u};
-    *reinterpret_cast<u32x4*>(dst) = a;
-    *reinterpret_cast<u32x4*>(dst + 16) = b;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {                                   // 8 channels per 16-byte store
+      const float4 a0 = xi[2 * q], a1 = xi[2 * q + 1], b0 = xj[2 * q], b1 = xj[2 * q + 1];
+      const u32x4 ci = {pk_bf16(a0.x, a0.y), pk_bf16(a0.z, a0.w), pk_bf16(a1.x, a1.y), pk_bf16(a1.z, a1.w)};
+      const u32x4 di = {pk_bf16(b0.x - a0.x, b0.y - a0.y), pk_bf16(b0.z - a0.z, b0.w - a0.w),
+                        pk_bf16(b1.x - a1.x, b1.y - a1.y), pk_bf16(b1.z - a1.z, b1.w - a1.w)};
+      *reinterpret_cast<u32x4*>(dst + 64 * h + 16 * q) = ci;
+      *reinterpret_cast<u32x4*>(dst + 128 + 64 * h + 16 * q) = di;
+    }
   }
 }
 
@@ -325,49 +311,40 @@ __global__ __launch_bounds__(512) void edge_mlp_bf16_bwd_kernel(EdgeBwdP bp) {
     const int u = t - 256;
     // one row (CK = 1: threads 0..127) or half a row (32 channels of x_i and of x_j) per thread, in flight between its global loads
     // and its LDS image; same arithmetic as gather_tile<CK, true>
-    // CK = 1: one row per thread (threads 0..127).  CK = 8: 16 consecutive threads fetch one row as consecutive float4 (whole lines;
-    // round 4: half a row per thread, 64 lines touched per wave load), 16 rows per pass, 8 passes -- NQ float4 of x_i and of x_j in
-    // flight per thread between the global loads and the LDS image; same arithmetic as gather_tile
     constexpr int NQ = CK == 1 ? 1 : 8;
+    const int gr = CK == 1 ? u : (u >> 1), gh = CK == 1 ? 0 : (u & 1);
     const bool gactive = CK == 1 ? (u < RT) : true;
-    const int cq = u & 15;
-    int gpi[NQ], gm[NQ];
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-      const int r = CK == 1 ? u : 16 * q + (u >> 4);
-      gpi[q] = r / k;
-      gm[q] = r - gpi[q] * k;
-    }
+    const int gpi = gr / k, gm = gr - gpi * k;
     float4 xi[NQ], xj[NQ];
     auto issue_row = [&](int64_t tile) {
+      const int64_t gp = tile * P + gpi;
+      const bool valid = gactive && gpi < P && gp < R;
 #pragma unroll
-      for (int q = 0; q < NQ; ++q) {
-        const int64_t gp = tile * P + gpi[q];
-        const bool valid = gactive && gpi[q] < P && gp < R;
-        xi[q] = xj[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (valid) {
-          const int64_t nb = (gp / p.N) * p.N + p.idx[gp * k + gm[q]];
-          if (CK == 1) {
-            float a[4] = {0.f, 0.f, 0.f, 0.f}, b[4] = {0.f, 0.f, 0.f, 0.f};
+      for (int q = 0; q < NQ; ++q) xi[q] = xj[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (valid) {
+        const int64_t nb = (gp / p.N) * p.N + p.idx[gp * k + gm];
+        if (CK == 1) {
+          float a[4] = {0.f, 0.f, 0.f, 0.f}, b[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int c = 0; c < 4; ++c)
-              if (c < C) {
-                a[c] = p.x[gp * p.ldx + c];
-                b[c] = p.x[nb * p.ldx + c];
-              }
-            xi[q] = make_float4(a[0], a[1], a[2], a[3]);
-            xj[q] = make_float4(b[0], b[1], b[2], b[3]);
-          } else {
-            xi[q] = *reinterpret_cast<const float4*>(p.x + gp * p.ldx + 4 * cq);
-            xj[q] = *reinterpret_cast<const float4*>(p.x + nb * p.ldx + 4 * cq);
-          }
+          for (int c = 0; c < 4; ++c)
+            if (c < C) {
+              a[c] = p.x[gp * p.ldx + c];
+              b[c] = p.x[nb * p.ldx + c];
+            }
+          xi[0] = make_float4(a[0], a[1], a[2], a[3]);
+          xj[0] = make_float4(b[0], b[1], b[2], b[3]);
+        } else {
+          const float4* pi4 = reinterpret_cast<const float4*>(p.x + gp * p.ldx + 32 * gh);
+          const float4* pj4 = reinterpret_cast<const float4*>(p.x + nb * p.ldx + 32 * gh);
+#pragma unroll
+          for (int q = 0; q < NQ; ++q) { xi[q] = pi4[q]; xj[q] = pj4[q]; }
         }
       }
     };
     auto commit_row = [&](char* Es) {
       if (!gactive) return;
+      char* dst = Es + gr * S;
       if (CK == 1) {
-        char* dst = Es + u * S;
         const float4 a = xi[0], b = xj[0];                               // (channels >= C are zeros on both sides)
         const u32x4 ci = {pk_bf16(a.x, a.y), pk_bf16(a.z, a.w), 0u, 0u};
         const u32x4 di = {pk_bf16(b.x - a.x, b.y - a.y), pk_bf16(b.z - a.z, b.w - a.w), 0u, 0u};
@@ -375,11 +352,13 @@ __global__ __launch_bounds__(512) void edge_mlp_bf16_bwd_kernel(EdgeBwdP bp) {
         *reinterpret_cast<u32x4*>(dst + 16) = di;
       } else {
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-          char* dst = Es + (16 * q + (u >> 4)) * S + 8 * cq;             // 4 channels = 8 bytes of bf16
-          const float4 a = xi[q], b = xj[q];
-          *reinterpret_cast<uint2*>(dst) = make_uint2(pk_bf16(a.x, a.y), pk_bf16(a.z, a.w));
-          *reinterpret_cast<uint2*>(dst + 128) = make_uint2(pk_bf16(b.x - a.x, b.y - a.y), pk_bf16(b.z - a.z, b.w - a.w));
+        for (int q = 0; q < NQ / 2; ++q) {
+          const float4 a0 = xi[2 * q], a1 = xi[2 * q + 1], b0 = xj[2 * q], b1 = xj[2 * q + 1];
+          const u32x4 ci = {pk_bf16(a0.x, a0.y), pk_bf16(a0.z, a0.w), pk_bf16(a1.x, a1.y), pk_bf16(a1.z, a1.w)};
+          const u32x4 di = {pk_bf16(b0.x - a0.x, b0.y - a0.y), pk_bf16(b0.z - a0.z, b0.w - a0.w),
+                            pk_bf16(b1.x - a1.x, b1.y - a1.y), pk_bf16(b1.z - a1.z, b1.w - a1.w)};
+          *reinterpret_cast<u32x4*>(dst + 64 * gh + 16 * q) = ci;
+          *reinterpret_cast<u32x4*>(dst + 128 + 64 * gh + 16 * q) = di;
         }
       }
     };
