@@ -671,6 +671,15 @@ inline int tile_n(int M, int N, int K) {
   return (N <= 64 || dg::cdiv(M, 128) * dg::cdiv(N, 128) * dg::cdiv(K, 256) < 256) ? 64 : 128;
 }
 
+// row tiles (= writer workgroups of the epilogue's column sums) of a product without transA, as launch<> below picks them
+inline int stat_writers(const GemmP& p, bool b_col) {
+  const bool a_ext = (p.K % 4 == 0 && p.K >= 4);
+  const bool b_ext = b_col ? (p.K % 4 == 0 && p.K >= 4) : (p.N % 4 == 0 && p.N >= 4);
+  const bool vec = p.avec && p.bvec && a_ext && b_ext;
+  const int rows = (vec && dg::gemm_arith() != 0) ? dg::x3_tile_m(p.M, p.N, p.K) : 128;
+  return (int)dg::cdiv(p.M, rows);
+}
+
 template <int ASRC, int BSRC, int EPI>
 int launch(GemmP& p, hipStream_t st, const char* what) {
   int bn = tile_n(p.M, p.N, p.K);
@@ -689,9 +698,15 @@ int launch(GemmP& p, hipStream_t st, const char* what) {
     p.mtiles = (int)dg::cdiv(p.M, p.bm);
     p.ntiles = (int)dg::cdiv(p.N, bn);
     p.xcd_group = (p.ntiles > 1 && p.mtiles >= 16 && p.splits == 1) ? 1 : 0;
+    // reproducible configuration (more slots than DGCNN_STAT_SLOTS): every row tile must own its slot -- refuse loudly instead of
+    // letting two tiles share one (the host sizes the buffer from dgcnn_gemm_stat_writers)
+    DG_REQUIRE(!(p.stats && p.splits == 1 && p.stat_slots > DGCNN_STAT_SLOTS && p.mtiles > p.stat_slots), DGCNN_EINVAL,
+               "%s: %d row tiles write column sums into %d statistics slots (dgcnn_set_stat_slots)", what, p.mtiles, p.stat_slots);
     dg::launch_gemm_x3(ASRC, BSRC, &p, st, bn, dg::gemm_arith());
   } else {
     p.bm = 128;
+    DG_REQUIRE(!(p.stats && p.splits == 1 && p.stat_slots > DGCNN_STAT_SLOTS && dg::cdiv(p.M, 128) > p.stat_slots), DGCNN_EINVAL,
+               "%s: %d row tiles write column sums into %d statistics slots (dgcnn_set_stat_slots)", what, (int)dg::cdiv(p.M, 128), p.stat_slots);
     launch_bm<ASRC, BSRC, EPI, 128>(p, st, vec, bn);
   }
   int rc = dg::check_launch(what);
@@ -857,6 +872,19 @@ extern "C" int dgcnn_gemm_f32(int transA, int transB, int M, int N, int K,
   }
   if (transB) return launch<A_ROW, B_COL, E_STORE>(p, st, "dgcnn_gemm_f32(NT)");
   return launch<A_ROW, B_ROW, E_STORE>(p, st, "dgcnn_gemm_f32(NN)");
+}
+
+// Row tiles of the dgcnn_gemm_f32 launch with these operands (transA = 0), i.e. how many workgroups add column sums into a `stats`
+// buffer: the host sizes that buffer's slot count from it in the reproducible configuration (one writer per slot).  0: the launch
+// takes a kernel whose grid follows the slot count by itself (class-dimension products).
+extern "C" int dgcnn_gemm_stat_writers(int transB, int M, int N, int K, const float* A, int64_t lda, const float* B, int64_t ldb) {
+  if (M <= 0 || N <= 0 || K <= 0) return 0;
+  GemmP p = {};
+  p.M = M; p.N = N; p.K = K;
+  p.avec = (lda % 4 == 0) && aligned16(A);
+  p.bvec = (ldb % 4 == 0) && aligned16(B);
+  if (!transB && N <= 4 && K % 4 == 0 && K <= 4096 && p.avec) return 0;      // skinny_nn_kernel: grid = cap_writers(...)
+  return stat_writers(p, transB != 0);
 }
 
 extern "C" int dgcnn_edge_mlp_f32(const float* x, int64_t ldx, const int32_t* idx, const float* W0,

@@ -88,6 +88,9 @@ class Context(object):
         self.side = None                 # second HIP stream: weight-gradient GEMMs (nothing on the critical path needs them)
         self.side_busy = False
         self.side_hold = []              # recording a launch plan: tensors the side stream touches, kept until the join
+        self._slot_stack = []
+        self.step_slots = 32             # slot count the step's arena is sized for (configure_slots); ops may use fewer (op_slots)
+        self.capture_extent = None       # recording: doubles of the arena the recorded step zeroes (what an eager run of it used)
         self.seed = 1
         self._rng = None
         self.stat_arena = None
@@ -168,11 +171,11 @@ class Context(object):
         self.stat_off += n
         return s
 
-    @staticmethod
-    def arena_want():
-        """Doubles of the statistics arena a step may use at the current slot count: 8 MB at 32 slots, 96 MB at 768.  The arena
-        itself may be larger (an earlier, larger cloud grew it): a step carves from -- and a captured step zeroes -- only this much."""
-        return (1 << 20) if H.STAT_SLOTS <= 32 else (1 << 19) * -(-H.STAT_SLOTS // 32)
+    def arena_want(self):
+        """Doubles of the statistics arena a step may use at its slot count: 8 MB at 32 slots, 96 MB at 768.  The arena itself may
+        be larger (an earlier, larger cloud grew it): a step carves from -- and a captured step zeroes -- at most this much."""
+        n = max(self.step_slots, H.STAT_SLOTS)
+        return (1 << 20) if n <= 32 else (1 << 19) * -(-n // 32)
 
     def arena_key(self):
         """What a captured step depends on besides its inputs: the statistics arena it zeroes / writes and the slot count its
@@ -199,8 +202,41 @@ class Context(object):
             n = -(-n // 64) * 64
         else:
             n = 32
+        self.step_slots = n
         if n != H.STAT_SLOTS:
             H.set_stat_slots(n)
+
+    def push_slots(self, writers=0):
+        """op_slots() as a pair of calls (the producer and its finalize sit far apart in the block functions)."""
+        self._slot_stack.append(H.STAT_SLOTS)
+        if DETERMINISTIC:
+            n = max(256, -(-int(writers) // 64) * 64)
+            if n != H.STAT_SLOTS:
+                H.set_stat_slots(n)
+
+    def pop_slots(self):
+        prev = self._slot_stack.pop()
+        if H.STAT_SLOTS != prev:
+            H.set_stat_slots(prev)
+
+    @contextlib.contextmanager
+    def op_slots(self, writers=0):
+        """DETERMINISTIC: the slot count of ONE op's statistics buffers -- its producer's writer workgroups (a GEMM's row tiles:
+        dgcnn_gemm_stat_writers; 0 for the reduction kernels, whose grids follow the slot count), at least 256 -- instead of the
+        step-wide maximum: the head's GEMMs run 192 row tiles where conv1's run 768, and every finalize kernel walks (and every
+        step zeroes) all slots of its buffer.  Producer and finalize are issued inside the block: they see the same count."""
+        if not DETERMINISTIC:
+            yield
+            return
+        n = max(256, -(-int(writers) // 64) * 64)
+        prev = H.STAT_SLOTS
+        if n != prev:
+            H.set_stat_slots(n)
+        try:
+            yield
+        finally:
+            if H.STAT_SLOTS != prev:
+                H.set_stat_slots(prev)
 
     # ---- operand planes of the head GEMMs (csrc/gemm_pl.hip, planes_bn.hip) ------------------------------
     @staticmethod
@@ -274,14 +310,19 @@ class Context(object):
         self.pl_scales_ready = False
         self.wprep = {}
         self.wprep_event = None
+        self._slot_stack = []
         if not DETERMINISTIC and H.STAT_SLOTS != 32:
             H.set_stat_slots(32)
         elif DETERMINISTIC and H.STAT_SLOTS < 256:
             self.configure_slots(0)           # (stand-alone ops; a model step sets its own count in model.build)
         if self.stat_arena is not None:
             if self.capturing:
-                # a captured step cannot know what ran before it: everything a step at this slot count may use
-                H.memset(self.stat_arena[:min(self.stat_arena.numel(), self.arena_want())])
+                # a captured step cannot know what ran before it: everything the step uses -- as measured on an eager run of the
+                # same shape (trainval passes it) -- else everything a step at this slot count may use
+                ext = min(self.stat_arena.numel(), self.arena_want())
+                if self.capture_extent is not None:
+                    ext = min(ext, max(int(self.capture_extent), 1))
+                H.memset(self.stat_arena[:ext])
             elif self.stat_off > 0:
                 H.memset(self.stat_arena[:self.stat_off])
         self.stat_off = 0
@@ -594,6 +635,10 @@ def conv_bn_act(x, leaf_scope, num_outputs, relu=True, out=None, out2=None, gbia
         bname, beta = c.get_variable("BatchNorm/beta", (num_outputs,))
     F = num_outputs
     T = torch.empty((R, F), dtype=torch.float32, device=x.device)
+    # slots of this layer's statistics buffer = row tiles of its GEMM (asked from the library; another arithmetic: the step's maximum)
+    # (0 = a kernel whose grid FOLLOWS the slot count -- the class dimension's streaming product: the step's maximum, more writers)
+    c.push_slots((H.load().dgcnn_gemm_stat_writers(0, R, F, Cin, x.data_ptr(), H.ld2(x), Wx.data_ptr(), H.ld2(Wx)) or c.step_slots)
+                 if arith is None else c.step_slots)
     st = c.stats(F)
     use_pl = arith is None and planes_ok(R, Cin, F)
     xp = None
@@ -613,6 +658,7 @@ def conv_bn_act(x, leaf_scope, num_outputs, relu=True, out=None, out2=None, gbia
         plane_out, f32_out = None, True
         gemm(x, Wx, T, gbias=gbias, rpg=rpg, stats=st, arith=arith, colmax=keys, colmax_rpg=0 if keys is None else gmax[1])
     mean, rstd = bn_finalize(st, F, R)
+    c.pop_slots()
     if out is None:
         out = c.new_buffer(R, F)
     fuse_drop = (drop_keep is not None and FUSE_DROPOUT and not use_pl and F % 4 == 0 and out2 is None and
@@ -636,6 +682,13 @@ def conv_bn_act(x, leaf_scope, num_outputs, relu=True, out=None, out2=None, gbia
 
     if c.recording:
         def bwd():
+            c.push_slots(0)                      # (the reduction kernels' grids follow the slot count: 256 writers)
+            try:
+                bwd_body()
+            finally:
+                c.pop_slots()
+
+        def bwd_body():
             dout = c.grad(out)
             if dout is None:
                 return
@@ -851,6 +904,7 @@ def edge_conv_block(x, B, N, k, num_filters, relu1=True, outs=None, net2=None, s
     with variable_scope("conv0"):
         w0name, W0 = c.get_variable("weights", (2 * C, F))
         b0name, beta0 = c.get_variable("BatchNorm/beta", (F,))
+    c.push_slots(c.step_slots)                   # conv0's statistics come from passes whose grids FOLLOW the slot count: the maximum
     st = c.stats(F)
     bf16 = EDGE_MLP_DTYPE == "bf16"
     literal = EDGE_MLP_LITERAL or bf16
@@ -934,6 +988,7 @@ def edge_conv_block(x, B, N, k, num_filters, relu1=True, outs=None, net2=None, s
         if DETERMINISTIC:
             colstats_det(Y, st)
     mean, rstd = bn_finalize(st, F, R * k)                              # ops.py:53
+    c.pop_slots()
     if outs is None:
         mm = c.new_buffer(R, 2 * F)
         net_out = None
@@ -966,6 +1021,13 @@ def edge_conv_block(x, B, N, k, num_filters, relu1=True, outs=None, net2=None, s
 
     if c.recording:
         def bwd():
+            c.push_slots(0)
+            try:
+                bwd_body()
+            finally:
+                c.pop_slots()
+
+        def bwd_body():
             nonlocal Y, Ee, W0p
             dmm = c.grad(mm)
             if dmm is None:

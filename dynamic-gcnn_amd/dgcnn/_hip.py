@@ -62,6 +62,7 @@ PROTOTYPES = {
     "dgcnn_get_stat_slots": [],
     "dgcnn_gemm_set_arith": [c_int],
     "dgcnn_gemm_get_arith": [],
+    "dgcnn_gemm_stat_writers": [c_int, c_int, c_int, c_int, c_vp, c_i64, c_vp, c_i64],
     "dgcnn_gemm_x3_tile_rows": [c_int, c_int, c_int],
     "dgcnn_gemm_x3_tile_cols": [c_int, c_int, c_int],
     "dgcnn_gemm_x3_tile_override": [c_int],

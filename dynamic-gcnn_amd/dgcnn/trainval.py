@@ -126,6 +126,7 @@ class trainval(object):
                 raise ValueError("HEAD_PLANES must be 0 or f16, got %r" % (hp,))
             E.HEAD_PLANES = {"f16": E.PL.F16X2}.get(str(hp).lower())
         self._graphs, self._graph_seen = OrderedDict(), {}     # captured towers (LRU order) / sightings per key
+        self._graph_used, self._sighting_key = {}, None         # key -> doubles of the statistics arena an eager run of it used
         ug = str(getattr(f, "USE_GRAPH", "0")).lower()
         self._use_graph = ug if ug in ("auto", "plan") else ug in ("1", "true", "yes", "on", "graph")
         return self
@@ -171,9 +172,14 @@ class trainval(object):
             raise ValueError("points must be (MINIBATCH_SIZE, N, NUM_CHANNEL), got %s" % (tuple(pts.shape),))
         kind = self._wants_graph(pts.shape[0] * pts.shape[1])
         if kind is not None:
+            self._sighting_key = None
             out = self._tower_graph(pts, lab, wgt, train, kind)
             if out is not None:
                 return out
+            out = self._tower_eager(pts, lab, wgt, train)
+            if self._sighting_key is not None:          # an eager sighting of a key that will be captured: what the step uses of the
+                self._graph_used[self._sighting_key] = self._ctx.stat_off     # statistics arena (the capture zeroes that much)
+            return out
         return self._tower_eager(pts, lab, wgt, train)
 
     def _wants_graph(self, rows):
@@ -239,7 +245,9 @@ class trainval(object):
             if n < need:
                 if len(self._graph_seen) >= GRAPH_SEEN_MAX and key not in self._graph_seen:
                     self._graph_seen.clear()
+                    self._graph_used.clear()
                 self._graph_seen[key] = n + 1
+                self._sighting_key = key
                 return None
             ent = self._capture(key, pts, lab, wgt, train, kind)
             if ent is None:
@@ -272,6 +280,7 @@ class trainval(object):
             ent["arena"] = c.arena_key()
             torch.cuda.synchronize()
             c.capturing = True
+            c.capture_extent = self._graph_used.get(key)
             if kind == "plan":
                 # every allocation of the recorded step comes from a private pool that lives as long as the plan: the addresses in
                 # the recorded launches stay this step's own (what torch.cuda.graph does for a captured graph)
@@ -288,6 +297,9 @@ class trainval(object):
                 with torch.cuda.graph(g):
                     ent["sm"], ent["scal"] = self._tower_body(ent["pts"], ent["lab"], ent["wgt"], train)
                 ent["graph"] = g
+            if c.capture_extent is not None and c.stat_off > c.capture_extent:      # (same shape, same mode: cannot happen)
+                raise H.HipError("the captured step uses %d doubles of the statistics arena, its eager sighting used %d"
+                                 % (c.stat_off, c.capture_extent))
         except Exception as e:                        # capture is an optimisation: fall back to eager launches, loudly
             sys.stderr.write("dgcnn: %s capture failed (%s: %s); running eagerly\n"
                              % ("launch-plan" if kind == "plan" else "HIP graph", type(e).__name__, e))
@@ -299,6 +311,7 @@ class trainval(object):
                 raise
         finally:
             c.capturing = False
+            c.capture_extent = None
             c.recording = False
             c.tape = []
             c.roots = []

@@ -245,6 +245,9 @@ int dgcnn_gemm_set_arith(int mode);
 int dgcnn_gemm_get_arith(void);
 /* Rows of the output tile the bf16-split GEMM picks for an (M,N,K) product: 64 | 128 | 256 (256 = the wave-specialised
  * gemm_x3w2_kernel).  For tools that name kernel instances (bench.py's per-kernel table); no effect on results. */
+/* row tiles (= workgroups that add column sums into `stats`) of the dgcnn_gemm_f32 launch with these operands (transA = 0); 0 when
+ * the launch sizes its grid from the slot count by itself.  The host picks the slot count of that buffer from it (deterministic mode). */
+int dgcnn_gemm_stat_writers(int transB, int M, int N, int K, const float* A, int64_t lda, const float* B, int64_t ldb);
 int dgcnn_gemm_x3_tile_rows(int M, int N, int K);
 /* 256 when the product runs on a 256-column kernel (gemm_x3q_kernel: 256 x 256 or 192 x 256 tiles, rows from the call above), else 0 */
 int dgcnn_gemm_x3_tile_cols(int M, int N, int K);
