@@ -256,9 +256,17 @@ class trainval(object):
                 return ent["sm"].clone(), ent["scal"].clone()
         else:
             self._graphs.move_to_end(key)
-        for dst, src in ((ent["pts"], pts), (ent["lab"], lab), (ent["wgt"], wgt)):
-            if dst is not None and dst.data_ptr() != src.data_ptr():
+        # the recorded step reads its OWN input buffers: stage the caller's tensors into them -- unless this very tensor OBJECT (kept
+        # referenced here, so its address cannot be handed to another tensor), unmodified since (torch's version counter, shared by
+        # all views of it), is what they already hold.  (An eager step does not copy its device-resident inputs either.)
+        staged = ent.setdefault("staged", {})
+        for name, dst, src in (("pts", ent["pts"], pts), ("lab", ent["lab"], lab), ("wgt", ent["wgt"], wgt)):
+            if dst is None or dst.data_ptr() == src.data_ptr():
+                continue
+            prev = staged.get(name)
+            if prev is None or prev[0] is not src or prev[1] != src._version:
                 dst.copy_(src, non_blocking=True)
+                staged[name] = (src, src._version)
         c.advance_seed()
         if kind == "plan":
             c.head_grads_hook = None                     # (the recorded step contains what the hook issued)

@@ -191,3 +191,29 @@ def test_launch_plan_with_the_second_stream_retraces_the_eager_step_bit_for_bit(
     finally:
         E.SIDE_STREAM_MIN_ROWS = old_min
         E.DETERMINISTIC = E.DETERMINISTIC_ENV_DEFAULT
+
+
+def test_replay_restages_inputs_that_changed_in_place_or_are_new_objects(mode):
+    """A replayed tower reads its own input buffers; the caller's tensor is copied into them unless the SAME tensor object,
+    unmodified, was staged last time.  In-place edits (also through a view) and new tensors at a recycled address must be seen."""
+    f = _flags(TRAIN=False)
+    tv = dgcnn.trainval(f).initialize()
+    rng = np.random.default_rng(8)
+    a = torch.from_numpy(rng.random((2, 384, 3), dtype=np.float32)).cuda()
+    b = torch.from_numpy(rng.random((2, 384, 3), dtype=np.float32)).cuda()
+    want_a = tv.inference(None, [a])[0].clone()
+    want_b = tv.inference(None, [b])[0].clone()
+    assert float((want_a - want_b).abs().max()) > 1e-3
+    tv.use_graph(mode)
+    x = a.clone()
+    for _ in range(3):                                            # sighting, capture, replay (staged once, then skipped)
+        got = tv.inference(None, [x])[0]
+    np.testing.assert_allclose(got.cpu().numpy(), want_a.cpu().numpy(), rtol=0, atol=2e-4)
+    x.view(-1)[:] = b.view(-1)                                    # in-place edit through a view: the version counter moves
+    np.testing.assert_allclose(tv.inference(None, [x])[0].cpu().numpy(), want_b.cpu().numpy(), rtol=0, atol=2e-4)
+    addr = x.data_ptr()
+    del x, got
+    y = a.clone()                                                 # a NEW tensor, very likely at the recycled address, version 0
+    out = tv.inference(None, [y])[0]
+    np.testing.assert_allclose(out.cpu().numpy(), want_a.cpu().numpy(), rtol=0, atol=2e-4)
+    print("recycled address: %s" % (y.data_ptr() == addr))
