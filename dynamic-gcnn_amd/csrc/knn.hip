@@ -744,6 +744,394 @@ __global__ __launch_bounds__(256, (Bf16fCfg<KC>::OCC)) void knn_bf16f_kernel(con
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Seeded scan, append form (round 5).  With a rigorous bound tau_r >= the row's k-th distance known IN ADVANCE (the seed bound), the
+// scan does not need sorted lists at all: a candidate is either farther than tau_r (dropped) or it is APPENDED, unsorted, to the row's
+// candidate buffer in global memory -- a superset of the row's true top k, ~1.7 ... 3 k entries (profiles/r05/knn_seed.txt) -- and a
+// second kernel picks the k smallest of every buffer in (d, j) order.  What that removes from the bf16-filter kernel above is its
+// dominant cost at N = 2048 (116 of 168 us; the filter alone runs in 52): the per-lane sorted insert (90 VALU ops per round, rounds
+// = the maximum over 64 lanes of a count whose mean is 0.4), and most of the exact re-check, because the survivors of a wave are
+// first COMPACTED across lanes through a small LDS queue (any lane re-checks any (row, candidate) pair: both rows are in LDS): one
+// re-check round per tile at ~40 % lane use instead of ~2.5 rounds at 15 %.
+//   entry  = 64-bit key (orderable bits of d << 32 | j): unsigned order == (d, j) lexicographic order (d never NaN / -0)
+//   buffer = cap entries per row, cap >= k + 64; invariant at the start of every tile: count <= cap - 64 (a tile adds at most 64).
+//            A row that crosses the mark is compacted at the next tile boundary by one wave: its k smallest entries stay, its bound
+//            becomes their largest distance (rigorous again: k candidates at distance <= it).  Rows without a usable seed (tau0 =
+//            +inf) work the same way -- they just compact after their first tiles.
+// Append order is arbitrary (LDS atomics), the result is not: the selection is by a total order on distinct keys, and WHEN a row
+// compacts depends only on its counts at tile boundaries.  Distances are the normative ones (same chain as above): bit-exact indices.
+__device__ __forceinline__ unsigned long long knn_key(float d, int j) {
+  const unsigned u = __float_as_uint(d + 0.0f);
+  const unsigned o = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+  return ((unsigned long long)o << 32) | (unsigned)j;
+}
+__device__ __forceinline__ float knn_key_dist(unsigned long long key) {
+  const unsigned o = (unsigned)(key >> 32);
+  return __uint_as_float((o & 0x80000000u) ? (o & 0x7fffffffu) : ~o);
+}
+__device__ __forceinline__ unsigned long long readlane64(unsigned long long v, int l) {
+  const unsigned lo = __builtin_amdgcn_readlane((int)(unsigned)v, l), hi = __builtin_amdgcn_readlane((int)(unsigned)(v >> 32), l);
+  return ((unsigned long long)hi << 32) | lo;
+}
+
+constexpr int KA_MAXE = 8;                   // entries per lane: cap <= 512
+// Levels of the append-form scan's bound tightening: T 0.9^m, m = 0..6 (down to 0.53 T: the seed bound is ~1.3 ... 1.5 x the true
+// k-th distance, profiles/r05/knn_seed.txt).  The SAME float product T * ka_level(m) is what candidates are counted under and what
+// the bound becomes, so the rounding of the constants does not matter.
+constexpr int KA_LEVELS = 7;
+__device__ __forceinline__ constexpr float ka_level(int m) {
+  constexpr float L[KA_LEVELS] = {1.0f, 0.9f, 0.81f, 0.729f, 0.6561f, 0.59049f, 0.531441f};
+  return L[m];
+}
+
+__device__ __forceinline__ unsigned long long shfl_xor64(unsigned long long v, int m) {
+  const unsigned lo = __shfl_xor((unsigned)v, m, 64), hi = __shfl_xor((unsigned)(v >> 32), m, 64);
+  return ((unsigned long long)hi << 32) | lo;
+}
+// bitonic merge: a bitonic sequence of one key per lane -> ascending by lane
+__device__ __forceinline__ unsigned long long wave_merge64(unsigned long long key, int lane) {
+#pragma unroll
+  for (int j2 = 32; j2 > 0; j2 >>= 1) {
+    const unsigned long long pk = shfl_xor64(key, j2);
+    const bool lower = (lane & j2) == 0;
+    key = (lower == (pk < key)) ? pk : key;
+  }
+  return key;
+}
+// bitonic sort of one key per lane across the wave, ascending by lane
+__device__ __forceinline__ unsigned long long wave_sort64(unsigned long long key, int lane) {
+#pragma unroll
+  for (int k2 = 2; k2 < 64; k2 <<= 1) {
+#pragma unroll
+    for (int j2 = k2 >> 1; j2 > 0; j2 >>= 1) {
+      const unsigned long long pk = shfl_xor64(key, j2);
+      const bool take_min = ((lane & j2) == 0) == ((lane & k2) == 0);
+      key = (take_min == (pk < key)) ? pk : key;
+    }
+  }
+  return wave_merge64(key, lane);
+}
+// One wave: the 64 smallest of the S (<= 64 E) keys of a row, ascending by lane.  key[q] = entry lane + 64 q (~0 beyond S): every
+// register is sorted across the lanes, then folded into the running lowest 64: min(a[l], b[63 - l]) is a bitonic sequence that
+// holds the 64 smallest of a and b (the half-cleaner), one merge sorts it.
+template <int E>
+__device__ __forceinline__ unsigned long long wave_lowest64(const unsigned long long (&key)[E], int S, int lane) {
+  unsigned long long res = wave_sort64(key[0], lane);
+#pragma unroll
+  for (int q = 1; q < E; ++q) {
+    if (64 * q < S) {                        // wave-uniform
+      const unsigned long long sq = wave_sort64(key[q], lane);
+      const unsigned lo = __shfl((unsigned)sq, 63 - lane, 64), hi = __shfl((unsigned)(sq >> 32), 63 - lane, 64);
+      const unsigned long long rb = ((unsigned long long)hi << 32) | lo;
+      res = wave_merge64(rb < res ? rb : res, lane);
+    }
+  }
+  return res;
+}
+
+__global__ __launch_bounds__(256, 3) void knn_bf16a_kernel(const float* __restrict__ x, const float* __restrict__ sq, int N, int C,
+                                                           int64_t ldx, int k, const float* __restrict__ tau0, int cap,
+                                                           unsigned long long* __restrict__ ent, int* __restrict__ cnt) {
+  using f32x16 = __attribute__((ext_vector_type(16))) float;
+  constexpr int CP = 64;
+  constexpr int TJM = 64;
+  constexpr unsigned CS = TJM * 16 + 16;
+  constexpr unsigned PB = 8 * CS;
+  constexpr unsigned TILE_B = 2 * PB;
+  constexpr int RS = CP + 4;
+  constexpr int QN = 128;                    // queue entries per wave
+  // [planes | xq (64 x 64, 16-byte granules XOR-swizzled by the row: no padding) | xc (padded rows) | sjs | thr_s | cnt_s | hist |
+  //  queue (4 x 128 u16) | flags]
+  constexpr unsigned SH_B = TILE_B + 4 * (ROWS * CP + TJM * RS + TJM + ROWS + ROWS + 4 * ROWS) + 2 * 4 * QN + 16;
+  __shared__ __attribute__((aligned(16))) char smem_raw[SH_B];
+  float* xq = reinterpret_cast<float*>(smem_raw + TILE_B);
+  float* xc = xq + ROWS * CP;
+  float* sjs = xc + TJM * RS;
+  volatile float* thr_s = sjs + TJM;                               // [64 rows]: a candidate stays iff d < thr_s
+  int* cnt_s = reinterpret_cast<int*>(const_cast<float*>(thr_s) + ROWS);   // [64 rows]: entries in the row's buffer
+  // [64 rows][4 words]: level histogram of the row's candidates (below).  word 0 = bin 0 << 16 | upper half of T's bits, words 1-3 =
+  // bins 1..6, two 16-bit counters each
+  unsigned* hist = reinterpret_cast<unsigned*>(cnt_s + ROWS);
+  volatile unsigned short* queue = reinterpret_cast<unsigned short*>(hist + 4 * ROWS);
+  volatile int* flags = reinterpret_cast<int*>(const_cast<unsigned short*>(queue) + 4 * QN);   // [2]: a row crossed the mark in tile t (t & 1)
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int w = tid >> 6;
+  const int l31 = lane & 31, h = lane >> 5;
+  const int qg = w & 1;
+  const int cs = w >> 1;
+  const int b = blockIdx.y;
+  const int row0 = blockIdx.x * ROWS;
+  const int row = row0 + qg * 32 + l31;
+  const float* xb = x + (int64_t)b * N * ldx;
+  const float* sqb = sq + (int64_t)b * N;
+  const int rowc = row < N ? row : N - 1;
+  const int cbase = cs * 32;
+  const int rslot = qg * 32 + l31;
+  const float si = sqb[rowc];
+  const float* xi_row = xb + (int64_t)rowc * ldx;
+  const int64_t grow0 = (int64_t)b * N + row0;                     // global row of the block's first query row
+  const int trig = cap - 64;
+  volatile unsigned short* myq = queue + w * QN;
+
+  bf16x8 q1[4], q2[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int c = 16 * s + 8 * h + 4 * e;
+      float4 t4 = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (c < C) t4 = *reinterpret_cast<const float4*>(xi_row + c);
+      v[4 * e] = t4.x; v[4 * e + 1] = t4.y; v[4 * e + 2] = t4.z; v[4 * e + 3] = t4.w;
+    }
+    unsigned hh[4], mm[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) split2_pair(v[2 * e], v[2 * e + 1], hh[e], mm[e]);
+    const uint4 H4 = make_uint4(hh[0], hh[1], hh[2], hh[3]), M4 = make_uint4(mm[0], mm[1], mm[2], mm[3]);
+    q1[s] = *reinterpret_cast<const bf16x8*>(&H4);
+    q2[s] = *reinterpret_cast<const bf16x8*>(&M4);
+  }
+  for (int e = tid; e < ROWS * (CP / 4); e += 256) {
+    const int r = e / (CP / 4), c4 = (e % (CP / 4)) * 4;
+    const int rr = (row0 + r < N) ? row0 + r : N - 1;
+    float4 t4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c4 < C) t4 = *reinterpret_cast<const float4*>(xb + (int64_t)rr * ldx + c4);
+    *reinterpret_cast<float4*>(xq + r * CP + ((((c4 >> 2) ^ r) & 15) << 2)) = t4;
+  }
+  if (tid < ROWS) {
+    const int rr = (row0 + tid < N) ? row0 + tid : N - 1;
+    const float t0 = tau0[(int64_t)b * N + rr];
+    thr_s[tid] = next_up(t0);
+    cnt_s[tid] = 0;
+    // levels T c_m, T = t0 truncated to its upper 16 bits (any positive T <= t0 serves; 16 bits fit beside a counter).  Rows
+    // without a finite positive bound, and clouds whose candidates could overflow a 16-bit counter, do not count (T = 0).
+    const bool lv = (t0 > 1e-30f) && (t0 < INFINITY) && (N <= 65536);
+    hist[4 * tid] = lv ? (__float_as_uint(t0) >> 16) : 0u;
+    hist[4 * tid + 1] = 0u; hist[4 * tid + 2] = 0u; hist[4 * tid + 3] = 0u;
+  }
+  if (tid < 2) flags[tid] = 0;
+
+  constexpr int NV = (TJM * (CP / 4)) / 256;   // 4
+  float4 pre[NV];
+  float pre_s = INFINITY;
+  auto fetch = [&](int j0) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int e = tid + 256 * i;
+      const int r = e / (CP / 4);
+      const int c4 = (e % (CP / 4)) * 4;
+      const int j = j0 + r;
+      const int jc = j < N ? j : N - 1;
+      const int cc = c4 < C ? c4 : C - 4;
+      const float4 t4 = *reinterpret_cast<const float4*>(xb + (int64_t)jc * ldx + cc);
+      const bool ok = c4 < C;
+      pre[i] = make_float4(ok ? t4.x : 0.f, ok ? t4.y : 0.f, ok ? t4.z : 0.f, ok ? t4.w : 0.f);
+    }
+    if (tid < TJM) pre_s = (j0 + tid < N) ? sqb[j0 + tid] : INFINITY;
+  };
+  auto stash = [&]() {
+    char* base = smem_raw;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int e = tid + 256 * i;
+      const int r = e / (CP / 4);
+      const int c4 = (e % (CP / 4)) * 4;
+      unsigned h0, m0, h1, m1;
+      split2_pair(pre[i].x, pre[i].y, h0, m0);
+      split2_pair(pre[i].z, pre[i].w, h1, m1);
+      const unsigned off = (unsigned)(c4 >> 3) * CS + (unsigned)r * 16u + (unsigned)(c4 & 4) * 2u;
+      *reinterpret_cast<uint2*>(base + off) = make_uint2(h0, h1);
+      *reinterpret_cast<uint2*>(base + PB + off) = make_uint2(m0, m1);
+      *reinterpret_cast<float4*>(xc + r * RS + c4) = pre[i];
+    }
+    if (tid < TJM) sjs[tid] = pre_s;
+  };
+
+  // exact re-check of the queued (row, candidate) pairs of this wave, one per lane, and the append
+  auto process = [&](int nvalid, int j0, int par) {
+    const bool on = lane < nvalid;
+    const unsigned e = on ? myq[lane] : 0u;
+    const int rl = (int)(e >> 5), ci = (int)(e & 31u);
+    const int rs = qg * 32 + rl;
+    const float* xi = xq + rs * CP;
+    const int rx = (rs & 15) << 2;                                   // granule q of the row sits at float offset (4 q) ^ rx
+    const float* xj = xc + (cbase + ci) * RS;
+    float p = 0.f;
+    if (C == 64) {
+      float4 a[3], v[3];
+      a[0] = *reinterpret_cast<const float4*>(xi + (0 ^ rx)); v[0] = *reinterpret_cast<const float4*>(xj);
+      a[1] = *reinterpret_cast<const float4*>(xi + (4 ^ rx)); v[1] = *reinterpret_cast<const float4*>(xj + 4);
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        if (q + 2 < 16) {
+          a[(q + 2) % 3] = *reinterpret_cast<const float4*>(xi + ((4 * (q + 2)) ^ rx));
+          v[(q + 2) % 3] = *reinterpret_cast<const float4*>(xj + 4 * (q + 2));
+        }
+        const float4 aa = a[q % 3], vv = v[q % 3];
+        p = fmaf(aa.x, vv.x, p); p = fmaf(aa.y, vv.y, p); p = fmaf(aa.z, vv.z, p); p = fmaf(aa.w, vv.w, p);
+      }
+    } else {
+#pragma unroll 2
+      for (int c0 = 0; c0 < C; c0 += 4) {
+        const float4 aa = *reinterpret_cast<const float4*>(xi + (c0 ^ rx));
+        const float4 vv = *reinterpret_cast<const float4*>(xj + c0);
+        p = fmaf(aa.x, vv.x, p); p = fmaf(aa.y, vv.y, p); p = fmaf(aa.z, vv.z, p); p = fmaf(aa.w, vv.w, p);
+      }
+    }
+    const float sir = __shfl(si, rl, 64);                            // lane rl (h = 0) holds s_i of row rl of this wave
+    const float tt = sir + sjs[cbase + ci];
+    const float tp = 2.0f * p;
+    const float d = tt - tp;
+    if (on && d < thr_s[rs]) {
+      const int pos = atomicAdd(&cnt_s[rs], 1);                      // < cap by the invariant
+      const int j = j0 + cbase + ci;
+      ent[(grow0 + rs) * cap + pos] = knn_key(d, j);
+      if (pos >= trig) flags[par] = 1;
+      // level histogram: the finest level T c_m the candidate lies under (the row itself is left out: one count less can
+      // never overflow a 16-bit counter at N <= 65536)
+      const float T = __uint_as_float(hist[4 * rs] << 16);
+      int m = 0;
+#pragma unroll
+      for (int u = 0; u < KA_LEVELS; ++u) m += (d < T * ka_level(u)) ? 1 : 0;
+      if (m > 0 && j != row0 + rs) atomicAdd(&hist[4 * rs + (m >> 1)], 1u << ((m & 1) << 4));      // bin m - 1 = 16-bit field m
+    }
+  };
+
+  const int nt = (N + TJM - 1) / TJM;
+  fetch(0);
+  const unsigned a_off = (unsigned)h * CS + (unsigned)(cbase + l31) * 16u;
+  const float kappa = 1.0f / 8192.0f;
+
+#pragma unroll 1
+  for (int t = 0; t < nt; ++t) {
+    const int j0 = t * TJM;
+    const int par = t & 1;
+    __syncthreads();                         // every wave is done with tile t-1 (planes, fp32 copy, appends; first trip: the set-up)
+    stash();
+    if (t + 1 < nt) fetch(j0 + TJM);
+    if (tid == 0) flags[par] = 0;            // (last read between the barriers of tile t-1, next set behind the barrier below)
+    if (t > 0 && lane < 16) {
+      // Bound tightening from the histogram: k candidates seen under T c_m  =>  the row's k-th distance is < T c_m, and a candidate
+      // at d >= T c_m has k candidates strictly before it.  (Rows r = w + 4 lane': the wave that would also compact the row.)
+      const int r = w + 4 * lane;
+      const uint4 hw = *reinterpret_cast<const uint4*>(hist + 4 * r);
+      const float T = __uint_as_float(hw.x << 16);
+      const unsigned bin[KA_LEVELS] = {hw.x >> 16, hw.y & 0xffffu, hw.y >> 16, hw.z & 0xffffu, hw.z >> 16, hw.w & 0xffffu, hw.w >> 16};
+      unsigned c = 0u;
+      float tn = INFINITY;
+#pragma unroll
+      for (int u = KA_LEVELS - 1; u >= 0; --u) {
+        c += bin[u];
+        if (c >= (unsigned)k && tn == INFINITY) tn = T * ka_level(u);
+      }
+      if (T > 0.f && tn < thr_s[r]) thr_s[r] = tn;
+    }
+    if (t > 0 && flags[par ^ 1]) {           // block-uniform: some row crossed the mark in tile t-1 -> compact it to its k smallest
+#pragma unroll 1
+      for (int r = w; r < ROWS; r += 4) {
+        const int S = cnt_s[r];
+        if (S > trig) {                      // wave-uniform
+          unsigned long long* buf = ent + (grow0 + r) * cap;
+          unsigned long long key[KA_MAXE];
+#pragma unroll
+          for (int q = 0; q < KA_MAXE; ++q) {
+            const int e = lane + 64 * q;
+            key[q] = (e < S) ? __hip_atomic_load(buf + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ~0ull;
+          }
+          const unsigned long long best = wave_lowest64<KA_MAXE>(key, S, lane);       // lane l: the row's (l + 1)-th smallest key
+          if (lane < k) buf[lane] = best;
+          if (lane == k - 1) {
+            thr_s[r] = next_up(knn_key_dist(best));
+            cnt_s[r] = k;
+          }
+        }
+      }
+    }
+    __syncthreads();
+    if (j0 + cbase < N) {                    // wave-uniform
+      const char* base = smem_raw + a_off;
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(base + 2 * s * CS);
+        const bf16x8 a2 = *reinterpret_cast<const bf16x8*>(base + PB + 2 * s * CS);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, q1[s], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, q2[s], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, q1[s], acc, 0, 0, 0);
+      }
+      const float thr = (row < N) ? thr_s[rslot] : -INFINITY;        // rows past N: nothing survives
+      const float* sj = sjs + cbase + 4 * h;
+      unsigned mask = 0u;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 s4 = *reinterpret_cast<const float4*>(sj + 8 * q);
+        const float sv[4] = {s4.x, s4.y, s4.z, s4.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int r = 4 * q + e;
+          const float tt = si + sv[e];
+          const float tp = 2.0f * acc[r];
+          const float da = tt - tp;
+          const float lim = fmaf(tt, kappa, thr);
+          mask |= sel_01(m_flt(da, lim)) << r;
+        }
+      }
+      // survivors -> this wave's queue, compacted across lanes; a full batch of 64 is re-checked at once
+      int qn = 0;
+      while (true) {
+        const bool has = mask != 0u;
+        const unsigned long long bal = __ballot(has);
+        if (bal == 0ull) break;
+        const int g = __builtin_ctz(mask | 0x80000000u) & 15;
+        const int before = __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
+        if (has) {
+          myq[qn + before] = (unsigned short)((l31 << 5) | ((g & 3) + 8 * (g >> 2) + 4 * h));
+          mask &= mask - 1u;
+        }
+        qn += __popcll(bal);
+        if (qn >= 64) {
+          process(64, j0, par);
+          qn -= 64;
+          const unsigned short mv = myq[64 + lane];
+          if (lane < qn) myq[lane] = mv;
+        }
+      }
+      if (qn > 0) process(qn, j0, par);
+    }
+  }
+  __syncthreads();
+  if (tid < ROWS && row0 + tid < N) cnt[grow0 + tid] = cnt_s[tid];
+}
+
+// the k smallest keys of every row's buffer, ascending: one wave per row
+__global__ __launch_bounds__(256) void knn_select_kernel(const unsigned long long* __restrict__ ent, const int* __restrict__ cnt,
+                                                         int64_t rows, int cap, int k, int32_t* __restrict__ idx) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int S = cnt[row];
+  const unsigned long long* buf = ent + row * cap;
+  int32_t* out = idx + row * k;
+  if (S <= 64) {
+    unsigned long long key = (lane < S) ? buf[lane] : ~0ull;
+    key = wave_sort64(key, lane);
+    if (lane < k) out[lane] = (int32_t)(unsigned)key;
+    return;
+  }
+  unsigned long long key[KA_MAXE];
+#pragma unroll
+  for (int q = 0; q < KA_MAXE; ++q) {
+    const int e = lane + 64 * q;
+    key[q] = (e < S) ? buf[e] : ~0ull;
+  }
+  const unsigned long long best = wave_lowest64<KA_MAXE>(key, S, lane);
+  if (lane < k) out[lane] = (int32_t)(unsigned)best;
+}
+
 // Dispatch threshold: with the pipelined re-check the kernel also wins in isolation at (24,2048,64,20) (0.253 vs 0.272 ms), but
 // inside the training step it LOSES there (5.19 vs 5.05 ms/step with the side stream on, 5.06 vs 5.11 with it off): its 54 KB x 3
 // workgroups leave no LDS for the transposed-adjacency build that runs on the side stream.  So: N >= 8192 only.
@@ -868,7 +1256,7 @@ void launch_knn(const float* x, const float* sq, int B, int N, int C, int64_t ld
   dim3 grid((unsigned)dg::cdiv(N, ROWS), (unsigned)B);
   if constexpr (CP == 64) {                      // large feature-space graphs: bf16 matrix pipe + exact re-check of the survivors
     const int m = knn_bf16f_mode();
-    if (!knn_force_valu() && vec_ok && C % 4 == 0 && C > 16 && (m == 1 || (m == 2 && N >= 8192))) {
+    if (!knn_force_valu() && vec_ok && C % 4 == 0 && C > 16 && (m == 1 || (m == 2 && (N >= 8192 || tau0)))) {
       dg::launch((knn_bf16f_kernel<KC>), grid, dim3(256), 0, st, x, sq, N, C, ldx, k, idx, tau0);
       return;
     }
@@ -914,22 +1302,57 @@ int knn_grid_min_n();
 int launch_knn_grid(const float* x, const float* sq, int B, int N, int C, int64_t ldx, int k, int32_t* idx, void* ws, hipStream_t st);
 }  // namespace dg
 
-// workspace = [s_i of every row (B*N floats, padded to 256 bytes) | scratch of the cell-grid search (C <= 4, k <= 40)]
+// workspace = [s_i of every row (B*N floats, padded to 256 bytes) | seed bounds (same size) | scratch of the cell-grid search (C <= 4,
+//              k <= 40) or of the append-form scan (16 < C <= 64: one count and knn_append_cap(k) 8-byte entries per row)]
 static size_t knn_sq_bytes(int B, int N) { return (((size_t)B * (size_t)N * sizeof(float)) + 255) & ~(size_t)255; }
+static int knn_append_cap(int k) {
+  static int ov = -1;
+  if (ov < 0) { const char* e = getenv("DGCNN_KNN_APPEND_CAP"); ov = e ? atoi(e) : 0; }
+  if (ov >= k + 64 && ov <= 512 && ov % 64 == 0) return ov;
+  return k <= 20 ? 256 : (k <= 40 ? 384 : 512);
+}      // entries per row buffer: >= k + 64, <= 64 KA_MAXE
+static bool knn_append_shape(int C, int k) { return C > 16 && C <= 64 && C % 4 == 0 && k <= 64; }
+static size_t knn_append_bytes(int B, int N, int k) {
+  const size_t rows = (size_t)B * (size_t)N;
+  return ((rows * sizeof(int) + 255) & ~(size_t)255) + rows * (size_t)knn_append_cap(k) * sizeof(unsigned long long);
+}
 
 extern "C" int64_t dgcnn_knn_workspace_bytes(int B, int N, int C, int k) {
   if (B <= 0 || N <= 0) return 0;
   size_t n = 2 * knn_sq_bytes(B, N);                 // s_i, and the seed bounds of dgcnn_knn_seeded_f32
   if (dg::knn_grid_applicable(C, k)) n += dg::knn_grid_workspace_bytes(B, N);
+  else if (knn_append_shape(C, k)) n += knn_append_bytes(B, N, k);       // counts + candidate buffers of the append-form scan
   return (int64_t)n;
 }
 
-// the seed bound pays from N ~ 4096 on: at (24,2048,64,20) the bound kernel (38 us: 252 MB of gathered rows) costs what the scan
-// saves (-21 ... -37 us); at (8,16384,64,40) the step goes 39.0 -> 35.8 ms, at (8,65536,64,20) 101 -> 97 (profiles/r05/knn_seed.txt)
-static int g_knn_seed_min_n = 4096;
-extern "C" int dgcnn_knn_seed_min_n(int n) {            // tools / tests: smallest N for which seeds are used; returns the previous value
-  const int prev = g_knn_seed_min_n;
-  if (n >= 0) g_knn_seed_min_n = n;
+// Seeds are used (a) whenever the append-form scan takes the shape (C in {32, 64}: the bound is what makes it possible) and (b) by
+// the list-keeping kernels from N ~ 4096 on: at (24,2048,64,20) the bound kernel (33 us: 252 MB of gathered rows) costs them what
+// the scan saves; at (8,16384,64,40) the step goes 39.0 -> 35.8 ms, at (8,65536,64,20) 101 -> 97 (profiles/r05/knn_seed.txt).
+static int g_knn_seed_min_n = -2;            // -2: not resolved; -1: auto (the rule above); >= 0: explicit
+static int knn_seed_min_n() {
+  if (g_knn_seed_min_n == -2) {
+    const char* e = getenv("DGCNN_KNN_SEED_MIN_N");       // A/B switch
+    g_knn_seed_min_n = e ? atoi(e) : -1;
+  }
+  return g_knn_seed_min_n;
+}
+extern "C" int dgcnn_knn_seed_min_n(int n) {            // tools / tests: smallest N for which seeds are used (-1: the rule); returns the previous value
+  const int prev = knn_seed_min_n();
+  if (n >= -1) g_knn_seed_min_n = n;
+  return prev;
+}
+
+static int g_knn_append = -1;                // DGCNN_KNN_APPEND=0: seeded searches keep per-lane lists (A/B switch)
+static bool knn_append_on() {
+  if (g_knn_append < 0) {
+    const char* e = getenv("DGCNN_KNN_APPEND");
+    g_knn_append = e ? atoi(e) : 1;
+  }
+  return g_knn_append != 0;
+}
+extern "C" int dgcnn_knn_append(int on) {               // tools / tests; returns the previous setting
+  const int prev = knn_append_on() ? 1 : 0;
+  if (on >= 0) g_knn_append = on ? 1 : 0;
   return prev;
 }
 
@@ -947,9 +1370,12 @@ static int knn_impl(const char* what, const float* x, int B, int N, int C, int64
   const int64_t rows = (int64_t)B * N;
   const int vec_ok = (ldx % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
   // the seed bound is used by the matrix-pipe scan kernels (4 < C <= 64) on float4-loadable rows; needs >= k seeds per row
-  const bool seeded = seed && kseed >= k && kseed <= 64 && C > 4 && C <= 64 && C % 4 == 0 && vec_ok && !knn_force_valu() &&
-                      N >= g_knn_seed_min_n && (int64_t)N * ldx < ((int64_t)1 << 31) && ws_bytes >= 2 * knn_sq_bytes(B, N);
   const size_t grid_off = 2 * knn_sq_bytes(B, N);
+  const bool append = knn_append_on() && knn_append_shape(C, k) && vec_ok && !knn_force_valu() && knn_bf16f_mode() != 0 &&
+                      ws_bytes >= grid_off + knn_append_bytes(B, N, k);
+  const int min_n = knn_seed_min_n() >= 0 ? knn_seed_min_n() : (append ? 0 : 4096);
+  const bool seeded = seed && kseed >= k && kseed <= 64 && C > 4 && C <= 64 && C % 4 == 0 && vec_ok && !knn_force_valu() &&
+                      N >= min_n && (int64_t)N * ldx < ((int64_t)1 << 31) && ws_bytes >= 2 * knn_sq_bytes(B, N);
   // raw coordinates (C <= 4) when the caller provided the scratch: exact search over a uniform cell grid (knn_grid.hip)
   const bool grid_ws = dg::knn_grid_applicable(C, k) && !knn_force_valu() && ws_bytes >= grid_off + dg::knn_grid_workspace_bytes(B, N);
   dg::launch(sqnorm_kernel, dim3((unsigned)dg::cdiv(rows, SQ_ROWS)), dim3(256), sizeof(float) * SQ_ROWS * (C + 1), st, x,
@@ -960,6 +1386,17 @@ static int knn_impl(const char* what, const float* x, int B, int N, int C, int64
   if (seeded) {
     tau0 = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + knn_sq_bytes(B, N));
     if (!launch_seed_bound(x, sq_ws, B, N, C, ldx, seed, ldseed, k, tau0, st)) tau0 = nullptr;      // (the first k seeds of every row)
+  }
+  if (tau0 && append) {                          // bound known in advance: append-form scan + one selection per row
+    char* base = reinterpret_cast<char*>(ws) + grid_off;
+    int* cnt = reinterpret_cast<int*>(base);
+    unsigned long long* ent = reinterpret_cast<unsigned long long*>(base + (((size_t)rows * sizeof(int) + 255) & ~(size_t)255));
+    const int cap = knn_append_cap(k);
+    dg::launch(knn_bf16a_kernel, dim3((unsigned)dg::cdiv(N, ROWS), (unsigned)B), dim3(256), 0, st, x, (const float*)sq_ws, N, C, ldx, k,
+               (const float*)tau0, cap, ent, cnt);
+    dg::launch(knn_select_kernel, dim3((unsigned)dg::cdiv(rows, 4)), dim3(256), 0, st, (const unsigned long long*)ent, (const int*)cnt, rows,
+               cap, k, idx);
+    return dg::check_launch(what);
   }
   if (C <= 4) return dispatch_k<4>(x, sq_ws, B, N, C, ldx, k, vec_ok, idx, tau0, st);
   if (C <= 16) return dispatch_k<16>(x, sq_ws, B, N, C, ldx, k, vec_ok, idx, tau0, st);

@@ -75,9 +75,14 @@ int dgcnn_knn_f32(const float* x, int B, int N, int C, int64_t ldx, int k, int32
  * (csrc/knn.hip).  seed == NULL or kseed < k: plain dgcnn_knn_f32.  Workspace as dgcnn_knn_workspace_bytes says. */
 int dgcnn_knn_seeded_f32(const float* x, int B, int N, int C, int64_t ldx, int k, const int32_t* seed, int64_t ldseed,
                          int kseed, int32_t* idx, void* ws, size_t ws_bytes, void* stream);
-/* smallest N for which the seeds are used (default 4096: below, computing the bound costs what it saves); n < 0 only queries.
+/* smallest N for which the seeds are used; -1 = the library's rule (always where the append-form scan applies -- 16 < C <= 64,
+ * C % 4 == 0 -- else from 4096 on: below, computing the bound costs the list-keeping kernels what it saves); n < -1 only queries.
  * Returns the previous value.  (tools / tests) */
 int dgcnn_knn_seed_min_n(int n);
+/* 1 (default) / 0: seeded searches of feature-space rows (16 < C <= 64) run the append-form scan (candidates under the seed bound are
+ * appended to a per-row buffer, one selection per row at the end: csrc/knn.hip) / keep per-lane sorted lists; on < 0 only queries.
+ * Identical indices either way.  Returns the previous setting.  (tools / tests; env DGCNN_KNN_APPEND) */
+int dgcnn_knn_append(int on);
 
 /* ---- K3 in its bf16-operand form (BASELINE configs[2] "bf16 edge-MLP MFMA"): conv0 of an EdgeConv layer, ops.py:21-52 ------
  * E[e] = [x_i, x_j - x_i] formed in fp32 and rounded to bf16 once (RNE), W0 (2C x F, row-major) rounded to bf16 once,

@@ -113,7 +113,9 @@ def test_workspace_too_small_for_the_grid_selects_the_all_pairs_kernel(dg):
     x = dev(pts)
     full = int(lib.dgcnn_knn_workspace_bytes(B, N, C, k))
     small = (B * N * 4 + 255) // 256 * 256
-    assert full > 2 * small and int(lib.dgcnn_knn_workspace_bytes(B, N, 64, k)) == 2 * small     # [s_i | seed bounds | grid scratch]
+    # [s_i | seed bounds | grid scratch];  feature-space rows: [s_i | seed bounds | counts | 256 candidates per row] (append-form scan)
+    assert full > 2 * small and int(lib.dgcnn_knn_workspace_bytes(B, N, 64, k)) == 3 * small + B * N * 256 * 8
+    assert int(lib.dgcnn_knn_workspace_bytes(B, N, 128, k)) == 2 * small
     idx = torch.empty((B, N, k), dtype=torch.int32, device="cuda")
     ws = torch.empty(small, dtype=torch.uint8, device="cuda")
     H.call("dgcnn_knn_f32", x.data_ptr(), B, N, C, C, k, idx.data_ptr(), ws.data_ptr(), small)
@@ -125,17 +127,21 @@ def test_workspace_too_small_for_the_grid_selects_the_all_pairs_kernel(dg):
 # ------------------------------------------------------------------------------------------------------
 # seeded search (dgcnn_knn_seeded_f32): any k distinct candidates per row bound the row's k-th distance from above
 # ------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("B,N,C,k", [(2, 512, 64, 20), (1, 700, 32, 8), (2, 2048, 64, 20), (1, 9000, 64, 40)])
-def test_seeded_knn_equals_the_unseeded_search_whatever_the_seeds(B, N, C, k):
+@pytest.mark.parametrize("append", [1, 0], ids=["append-scan", "lists"])
+@pytest.mark.parametrize("B,N,C,k", [(2, 512, 64, 20), (1, 700, 32, 8), (2, 2048, 64, 20), (1, 9000, 64, 40), (1, 333, 48, 64)])
+def test_seeded_knn_equals_the_unseeded_search_whatever_the_seeds(B, N, C, k, append):
     """The result must not depend on the seeds: true neighbours (a tight bound), random distinct candidates (a loose one), the row's
     own index repeated (not distinct: the row gets no bound), out-of-range indices (no bound), more seeds than k (the first k count).
-    All against the oracle, bit for bit."""
+    All against the oracle, bit for bit -- with the append-form scan (rows without a bound fill and compact their candidate buffers
+    over and over: the slow path of that kernel) and with the list-keeping kernels."""
     from dgcnn import _engine as E, _hip as H
-    prev = H.load().dgcnn_knn_seed_min_n(0)                                       # (the library seeds from N = 4096 on by default)
+    prev = H.load().dgcnn_knn_seed_min_n(0)                                       # (lists: the library seeds from N = 4096 on by default)
+    prev_a = H.load().dgcnn_knn_append(append)
     try:
         _seeded_cases(E, B, N, C, k)
     finally:
         H.load().dgcnn_knn_seed_min_n(prev)
+        H.load().dgcnn_knn_append(prev_a)
 
 
 def _seeded_cases(E, B, N, C, k):
