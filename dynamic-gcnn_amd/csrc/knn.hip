@@ -14,6 +14,7 @@
 // with a branch-free v_med3/v_cndmask network, skipped wave-uniformly when no lane improves.
 // The four per-wave lists are merged through LDS at the end.  The (B,N,N) matrix never exists.
 #include "knn_common.h"
+#include <type_traits>
 #include <stdlib.h>
 
 namespace {
@@ -778,6 +779,8 @@ constexpr int KA_MAXE = 8;                   // entries per lane: cap <= 512
 // Levels of the append-form scan's bound tightening: T 0.9^m, m = 0..6 (down to 0.53 T: the seed bound is ~1.3 ... 1.5 x the true
 // k-th distance, profiles/r05/knn_seed.txt).  The SAME float product T * ka_level(m) is what candidates are counted under and what
 // the bound becomes, so the rounding of the constants does not matter.
+constexpr int KA_SLACK = 192;                // appends a row can receive between two tile boundaries: 2 waves x (32 new + < 64 waiting)
+constexpr int KA_SLACK_LX = 64;              // ... when nothing waits across tiles: the tile's 64 candidates
 constexpr int KA_LEVELS = 7;
 __device__ __forceinline__ constexpr float ka_level(int m) {
   constexpr float L[KA_LEVELS] = {1.0f, 0.9f, 0.81f, 0.729f, 0.6561f, 0.59049f, 0.531441f};
@@ -829,6 +832,10 @@ __device__ __forceinline__ unsigned long long wave_lowest64(const unsigned long 
   return res;
 }
 
+// LX: the candidates' fp32 rows are kept in LDS next to the tile and a wave's survivors are re-checked tile by tile (N < 8192: ~10
+// pairs per wave and tile, LDS is the cheaper source); !LX: pairs wait in the queue across tiles until 64 are there and read the
+// candidate row from global memory (L2) -- at N = 65536 a wave meets a survivor every other tile.
+template <bool LX>
 __global__ __launch_bounds__(256, 3) void knn_bf16a_kernel(const float* __restrict__ x, const float* __restrict__ sq, int N, int C,
                                                            int64_t ldx, int k, const float* __restrict__ tau0, int cap,
                                                            unsigned long long* __restrict__ ent, int* __restrict__ cnt) {
@@ -838,22 +845,25 @@ __global__ __launch_bounds__(256, 3) void knn_bf16a_kernel(const float* __restri
   constexpr unsigned CS = TJM * 16 + 16;
   constexpr unsigned PB = 8 * CS;
   constexpr unsigned TILE_B = 2 * PB;
-  constexpr int RS = CP + 4;
+  constexpr int RS = CP + 4;                 // (LX) fp32 row stride of the candidate copy: bank = 4 row + c
   constexpr int QN = 128;                    // queue entries per wave
-  // [planes | xq (64 x 64, 16-byte granules XOR-swizzled by the row: no padding) | xc (padded rows) | sjs | thr_s | cnt_s | hist |
-  //  queue (4 x 128 u16) | flags]
-  constexpr unsigned SH_B = TILE_B + 4 * (ROWS * CP + TJM * RS + TJM + ROWS + ROWS + 4 * ROWS) + 2 * 4 * QN + 16;
+  using qent_t = typename std::conditional<LX, unsigned short, unsigned>::type;
+  // [planes | xq (64 query rows x 64 fp32, 16-byte granules XOR-swizzled by the row) | LX: xc (the tile's rows, fp32, padded) |
+  //  sjs | thr_s | cnt_s | hist | queue | flags]
+  constexpr unsigned SH_B = TILE_B + 4 * (ROWS * CP + (LX ? TJM * RS : 0) + TJM + ROWS + ROWS + 4 * ROWS) + sizeof(qent_t) * 4 * QN + 16;
   __shared__ __attribute__((aligned(16))) char smem_raw[SH_B];
   float* xq = reinterpret_cast<float*>(smem_raw + TILE_B);
   float* xc = xq + ROWS * CP;
-  float* sjs = xc + TJM * RS;
+  float* sjs = xc + (LX ? TJM * RS : 0);
   volatile float* thr_s = sjs + TJM;                               // [64 rows]: a candidate stays iff d < thr_s
   int* cnt_s = reinterpret_cast<int*>(const_cast<float*>(thr_s) + ROWS);   // [64 rows]: entries in the row's buffer
   // [64 rows][4 words]: level histogram of the row's candidates (below).  word 0 = bin 0 << 16 | upper half of T's bits, words 1-3 =
   // bins 1..6, two 16-bit counters each
   unsigned* hist = reinterpret_cast<unsigned*>(cnt_s + ROWS);
-  volatile unsigned short* queue = reinterpret_cast<unsigned short*>(hist + 4 * ROWS);
-  volatile int* flags = reinterpret_cast<int*>(const_cast<unsigned short*>(queue) + 4 * QN);   // [2]: a row crossed the mark in tile t (t & 1)
+  // per wave: survivors of the conservative filter waiting for their exact distance: (row of the wave, candidate) as
+  // LX: row << 6 | candidate of the tile;  !LX: row << 27 | candidate of the cloud
+  volatile qent_t* queue = reinterpret_cast<qent_t*>(hist + 4 * ROWS);
+  volatile int* flags = reinterpret_cast<int*>(const_cast<qent_t*>(queue) + 4 * QN);   // [2]: a row crossed the mark in tile t (t & 1)
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -872,8 +882,8 @@ __global__ __launch_bounds__(256, 3) void knn_bf16a_kernel(const float* __restri
   const float si = sqb[rowc];
   const float* xi_row = xb + (int64_t)rowc * ldx;
   const int64_t grow0 = (int64_t)b * N + row0;                     // global row of the block's first query row
-  const int trig = cap - 64;
-  volatile unsigned short* myq = queue + w * QN;
+  const int trig = cap - (LX ? KA_SLACK_LX : KA_SLACK);
+  volatile qent_t* myq = queue + w * QN;
 
   bf16x8 q1[4], q2[4];
 #pragma unroll
@@ -944,32 +954,39 @@ __global__ __launch_bounds__(256, 3) void knn_bf16a_kernel(const float* __restri
       const unsigned off = (unsigned)(c4 >> 3) * CS + (unsigned)r * 16u + (unsigned)(c4 & 4) * 2u;
       *reinterpret_cast<uint2*>(base + off) = make_uint2(h0, h1);
       *reinterpret_cast<uint2*>(base + PB + off) = make_uint2(m0, m1);
-      *reinterpret_cast<float4*>(xc + r * RS + c4) = pre[i];
+      if (LX) *reinterpret_cast<float4*>(xc + r * RS + c4) = pre[i];
     }
     if (tid < TJM) sjs[tid] = pre_s;
   };
 
-  // exact re-check of the queued (row, candidate) pairs of this wave, one per lane, and the append
+  // exact distance of the queued (row, candidate) pairs of this wave, one per lane, and the append.  x_i from the block's fp32 LDS
+  // copy, x_j from global memory (L2: the cloud's rows) -- pairs wait in the queue until 64 of them are there, whatever tile they
+  // came from (at N = 2048 a wave meets ~10 survivors per tile, at N = 65536 one every other tile: re-checking them tile by tile
+  // runs the 64-step chain for a handful of lanes).  The row's bound is applied when the pair is appended, as it stands then.
   auto process = [&](int nvalid, int j0, int par) {
     const bool on = lane < nvalid;
-    const unsigned e = on ? myq[lane] : 0u;
-    const int rl = (int)(e >> 5), ci = (int)(e & 31u);
+    const unsigned e = on ? (unsigned)myq[lane] : 0u;
+    const int rl = LX ? (int)(e >> 6) : (int)(e >> 27);
+    const int j = LX ? j0 + (int)(e & 63u) : (int)(e & 0x7ffffffu);
     const int rs = qg * 32 + rl;
     const float* xi = xq + rs * CP;
     const int rx = (rs & 15) << 2;                                   // granule q of the row sits at float offset (4 q) ^ rx
-    const float* xj = xc + (cbase + ci) * RS;
+    const float* xj = LX ? xc + (j - j0) * RS : xb + (int64_t)j * ldx;
+    const float sjv = LX ? sjs[j - j0] : sqb[j];
     float p = 0.f;
     if (C == 64) {
-      float4 a[3], v[3];
-      a[0] = *reinterpret_cast<const float4*>(xi + (0 ^ rx)); v[0] = *reinterpret_cast<const float4*>(xj);
-      a[1] = *reinterpret_cast<const float4*>(xi + (4 ^ rx)); v[1] = *reinterpret_cast<const float4*>(xj + 4);
+      constexpr int VR = LX ? 3 : 8;                                 // ring of candidate quads: LDS two ahead, global eight ahead
+      float4 v[VR], a[3];
+#pragma unroll
+      for (int q = 0; q < VR - (LX ? 1 : 0); ++q) v[q] = *reinterpret_cast<const float4*>(xj + 4 * q);
+      a[0] = *reinterpret_cast<const float4*>(xi + (0 ^ rx));
+      a[1] = *reinterpret_cast<const float4*>(xi + (4 ^ rx));
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
-        if (q + 2 < 16) {
-          a[(q + 2) % 3] = *reinterpret_cast<const float4*>(xi + ((4 * (q + 2)) ^ rx));
-          v[(q + 2) % 3] = *reinterpret_cast<const float4*>(xj + 4 * (q + 2));
-        }
-        const float4 aa = a[q % 3], vv = v[q % 3];
+        if (q + 2 < 16) a[(q + 2) % 3] = *reinterpret_cast<const float4*>(xi + ((4 * (q + 2)) ^ rx));
+        if (LX && q + 2 < 16) v[(q + 2) % 3] = *reinterpret_cast<const float4*>(xj + 4 * (q + 2));
+        const float4 aa = a[q % 3], vv = v[q % VR];
+        if (!LX && q + 8 < 16) v[q % 8] = *reinterpret_cast<const float4*>(xj + 4 * (q + 8));
         p = fmaf(aa.x, vv.x, p); p = fmaf(aa.y, vv.y, p); p = fmaf(aa.z, vv.z, p); p = fmaf(aa.w, vv.w, p);
       }
     } else {
@@ -981,12 +998,11 @@ __global__ __launch_bounds__(256, 3) void knn_bf16a_kernel(const float* __restri
       }
     }
     const float sir = __shfl(si, rl, 64);                            // lane rl (h = 0) holds s_i of row rl of this wave
-    const float tt = sir + sjs[cbase + ci];
+    const float tt = sir + sjv;
     const float tp = 2.0f * p;
     const float d = tt - tp;
     if (on && d < thr_s[rs]) {
       const int pos = atomicAdd(&cnt_s[rs], 1);                      // < cap by the invariant
-      const int j = j0 + cbase + ci;
       ent[(grow0 + rs) * cap + pos] = knn_key(d, j);
       if (pos >= trig) flags[par] = 1;
       // level histogram: the finest level T c_m the candidate lies under (the row itself is left out: one count less can
@@ -1003,6 +1019,7 @@ __global__ __launch_bounds__(256, 3) void knn_bf16a_kernel(const float* __restri
   fetch(0);
   const unsigned a_off = (unsigned)h * CS + (unsigned)(cbase + l31) * 16u;
   const float kappa = 1.0f / 8192.0f;
+  int qn = 0;                                // pairs waiting in this wave's queue (wave-uniform)
 
 #pragma unroll 1
   for (int t = 0; t < nt; ++t) {
@@ -1081,7 +1098,6 @@ __global__ __launch_bounds__(256, 3) void knn_bf16a_kernel(const float* __restri
         }
       }
       // survivors -> this wave's queue, compacted across lanes; a full batch of 64 is re-checked at once
-      int qn = 0;
       while (true) {
         const bool has = mask != 0u;
         const unsigned long long bal = __ballot(has);
@@ -1089,20 +1105,25 @@ __global__ __launch_bounds__(256, 3) void knn_bf16a_kernel(const float* __restri
         const int g = __builtin_ctz(mask | 0x80000000u) & 15;
         const int before = __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
         if (has) {
-          myq[qn + before] = (unsigned short)((l31 << 5) | ((g & 3) + 8 * (g >> 2) + 4 * h));
+          const unsigned ci = (unsigned)(cbase + (g & 3) + 8 * (g >> 2) + 4 * h);
+          myq[qn + before] = LX ? (qent_t)(((unsigned)l31 << 6) | ci) : (qent_t)(((unsigned)l31 << 27) | ((unsigned)j0 + ci));
           mask &= mask - 1u;
         }
         qn += __popcll(bal);
         if (qn >= 64) {
           process(64, j0, par);
           qn -= 64;
-          const unsigned short mv = myq[64 + lane];
+          const qent_t mv = myq[64 + lane];
           if (lane < qn) myq[lane] = mv;
         }
       }
-      if (qn > 0) process(qn, j0, par);
+      if (LX && qn > 0) {                    // the tile's rows leave LDS at the next barrier
+        process(qn, j0, par);
+        qn = 0;
+      }
     }
   }
+  if (qn > 0) process(qn, 0, (nt - 1) & 1);
   __syncthreads();
   if (tid < ROWS && row0 + tid < N) cnt[grow0 + tid] = cnt_s[tid];
 }
@@ -1303,18 +1324,17 @@ int launch_knn_grid(const float* x, const float* sq, int B, int N, int C, int64_
 }  // namespace dg
 
 // workspace = [s_i of every row (B*N floats, padded to 256 bytes) | seed bounds (same size) | scratch of the cell-grid search (C <= 4,
-//              k <= 40) or of the append-form scan (16 < C <= 64: one count and knn_append_cap(k) 8-byte entries per row)]
+//              k <= 40) or of the append-form scan (16 < C <= 64: one count and knn_append_cap(k, N) 8-byte entries per row)]
 static size_t knn_sq_bytes(int B, int N) { return (((size_t)B * (size_t)N * sizeof(float)) + 255) & ~(size_t)255; }
-static int knn_append_cap(int k) {
-  static int ov = -1;
-  if (ov < 0) { const char* e = getenv("DGCNN_KNN_APPEND_CAP"); ov = e ? atoi(e) : 0; }
-  if (ov >= k + 64 && ov <= 512 && ov % 64 == 0) return ov;
-  return k <= 20 ? 256 : (k <= 40 ? 384 : 512);
-}      // entries per row buffer: >= k + 64, <= 64 KA_MAXE
+static bool knn_append_lx(int N) { return N < 8192; }     // which form of the append scan (knn_bf16a_kernel<LX>)
+static int knn_append_cap(int k, int N) {    // entries per row buffer: >= k + slack of the form, <= 64 KA_MAXE
+  if (knn_append_lx(N)) return k <= 20 ? 256 : (k <= 40 ? 384 : 512);
+  return k <= 20 ? 320 : (k <= 40 ? 448 : 512);
+}
 static bool knn_append_shape(int C, int k) { return C > 16 && C <= 64 && C % 4 == 0 && k <= 64; }
 static size_t knn_append_bytes(int B, int N, int k) {
   const size_t rows = (size_t)B * (size_t)N;
-  return ((rows * sizeof(int) + 255) & ~(size_t)255) + rows * (size_t)knn_append_cap(k) * sizeof(unsigned long long);
+  return ((rows * sizeof(int) + 255) & ~(size_t)255) + rows * (size_t)knn_append_cap(k, N) * sizeof(unsigned long long);
 }
 
 extern "C" int64_t dgcnn_knn_workspace_bytes(int B, int N, int C, int k) {
@@ -1391,9 +1411,10 @@ static int knn_impl(const char* what, const float* x, int B, int N, int C, int64
     char* base = reinterpret_cast<char*>(ws) + grid_off;
     int* cnt = reinterpret_cast<int*>(base);
     unsigned long long* ent = reinterpret_cast<unsigned long long*>(base + (((size_t)rows * sizeof(int) + 255) & ~(size_t)255));
-    const int cap = knn_append_cap(k);
-    dg::launch(knn_bf16a_kernel, dim3((unsigned)dg::cdiv(N, ROWS), (unsigned)B), dim3(256), 0, st, x, (const float*)sq_ws, N, C, ldx, k,
-               (const float*)tau0, cap, ent, cnt);
+    const int cap = knn_append_cap(k, N);
+    const dim3 grid((unsigned)dg::cdiv(N, ROWS), (unsigned)B);
+    if (knn_append_lx(N)) dg::launch(knn_bf16a_kernel<true>, grid, dim3(256), 0, st, x, (const float*)sq_ws, N, C, ldx, k, (const float*)tau0, cap, ent, cnt);
+    else dg::launch(knn_bf16a_kernel<false>, grid, dim3(256), 0, st, x, (const float*)sq_ws, N, C, ldx, k, (const float*)tau0, cap, ent, cnt);
     dg::launch(knn_select_kernel, dim3((unsigned)dg::cdiv(rows, 4)), dim3(256), 0, st, (const unsigned long long*)ent, (const int*)cnt, rows,
                cap, k, idx);
     return dg::check_launch(what);
