@@ -781,37 +781,56 @@ constexpr int KA_MAXE = 8;                   // entries per lane: cap <= 512
 // the bound becomes, so the rounding of the constants does not matter.
 constexpr int KA_SLACK = 192;                // appends a row can receive between two tile boundaries: 2 waves x (32 new + < 64 waiting)
 constexpr int KA_SLACK_LX = 64;              // ... when nothing waits across tiles: the tile's 64 candidates
+constexpr float KA_C1 = 0.5f * (1.0f - 1.0f / 8192.0f);
 constexpr int KA_LEVELS = 7;
 __device__ __forceinline__ constexpr float ka_level(int m) {
   constexpr float L[KA_LEVELS] = {1.0f, 0.9f, 0.81f, 0.729f, 0.6561f, 0.59049f, 0.531441f};
   return L[m];
 }
 
-__device__ __forceinline__ unsigned long long shfl_xor64(unsigned long long v, int m) {
-  const unsigned lo = __shfl_xor((unsigned)v, m, 64), hi = __shfl_xor((unsigned)(v >> 32), m, 64);
+// value of lane (l ^ M): quad permutes and bank-masked row shifts on the DPP path for M < 16 (no LDS round trip, no address register),
+// ds_swizzle for 16, ds_bpermute for 32
+template <int M>
+__device__ __forceinline__ unsigned xchg32(unsigned v) {
+  if constexpr (M == 1) return (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0xB1, 0xF, 0xF, false);        // quad_perm [1,0,3,2]
+  else if constexpr (M == 2) return (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x4E, 0xF, 0xF, false);   // quad_perm [2,3,0,1]
+  else if constexpr (M == 4) {
+    const int t = __builtin_amdgcn_update_dpp((int)v, (int)v, 0x104, 0xF, 0x5, false);       // row_shl:4 into banks 0, 2 (lanes with bit 2 clear)
+    return (unsigned)__builtin_amdgcn_update_dpp(t, (int)v, 0x114, 0xF, 0xA, false);         // row_shr:4 into banks 1, 3
+  } else if constexpr (M == 8) {
+    const int t = __builtin_amdgcn_update_dpp((int)v, (int)v, 0x108, 0xF, 0x3, false);       // row_shl:8 into banks 0, 1
+    return (unsigned)__builtin_amdgcn_update_dpp(t, (int)v, 0x118, 0xF, 0xC, false);         // row_shr:8 into banks 2, 3
+  } else if constexpr (M == 16) return (unsigned)__builtin_amdgcn_ds_swizzle((int)v, 0x401F);   // bit mode: and 0x1f, or 0, xor 16
+  else return __shfl_xor(v, M, 64);
+}
+template <int M>
+__device__ __forceinline__ unsigned long long xchg64(unsigned long long v) {
+  const unsigned lo = xchg32<M>((unsigned)v), hi = xchg32<M>((unsigned)(v >> 32));
   return ((unsigned long long)hi << 32) | lo;
+}
+template <int J2>
+__device__ __forceinline__ unsigned long long bitonic_step(unsigned long long key, int lane, bool up) {
+  const unsigned long long pk = xchg64<J2>(key);
+  const bool take_min = ((lane & J2) == 0) == up;
+  return (take_min == (pk < key)) ? pk : key;
+}
+template <int J2>
+__device__ __forceinline__ unsigned long long bitonic_steps_down(unsigned long long key, int lane, bool up) {
+  key = bitonic_step<J2>(key, lane, up);
+  if constexpr (J2 > 1) key = bitonic_steps_down<J2 / 2>(key, lane, up);
+  return key;
 }
 // bitonic merge: a bitonic sequence of one key per lane -> ascending by lane
 __device__ __forceinline__ unsigned long long wave_merge64(unsigned long long key, int lane) {
-#pragma unroll
-  for (int j2 = 32; j2 > 0; j2 >>= 1) {
-    const unsigned long long pk = shfl_xor64(key, j2);
-    const bool lower = (lane & j2) == 0;
-    key = (lower == (pk < key)) ? pk : key;
-  }
-  return key;
+  return bitonic_steps_down<32>(key, lane, true);
 }
 // bitonic sort of one key per lane across the wave, ascending by lane
 __device__ __forceinline__ unsigned long long wave_sort64(unsigned long long key, int lane) {
-#pragma unroll
-  for (int k2 = 2; k2 < 64; k2 <<= 1) {
-#pragma unroll
-    for (int j2 = k2 >> 1; j2 > 0; j2 >>= 1) {
-      const unsigned long long pk = shfl_xor64(key, j2);
-      const bool take_min = ((lane & j2) == 0) == ((lane & k2) == 0);
-      key = (take_min == (pk < key)) ? pk : key;
-    }
-  }
+  key = bitonic_steps_down<1>(key, lane, (lane & 2) == 0);
+  key = bitonic_steps_down<2>(key, lane, (lane & 4) == 0);
+  key = bitonic_steps_down<4>(key, lane, (lane & 8) == 0);
+  key = bitonic_steps_down<8>(key, lane, (lane & 16) == 0);
+  key = bitonic_steps_down<16>(key, lane, (lane & 32) == 0);
   return wave_merge64(key, lane);
 }
 // One wave: the 64 smallest of the S (<= 64 E) keys of a row, ascending by lane.  key[q] = entry lane + 64 q (~0 beyond S): every
@@ -956,7 +975,7 @@ __global__ __launch_bounds__(256, 3) void knn_bf16a_kernel(const float* __restri
       *reinterpret_cast<uint2*>(base + PB + off) = make_uint2(m0, m1);
       if (LX) *reinterpret_cast<float4*>(xc + r * RS + c4) = pre[i];
     }
-    if (tid < TJM) sjs[tid] = pre_s;
+    if (tid < TJM) sjs[tid] = pre_s * KA_C1;          // the filter's per-candidate term (below); rows past N: +inf
   };
 
   // exact distance of the queued (row, candidate) pairs of this wave, one per lane, and the append.  x_i from the block's fp32 LDS
@@ -972,7 +991,7 @@ __global__ __launch_bounds__(256, 3) void knn_bf16a_kernel(const float* __restri
     const float* xi = xq + rs * CP;
     const int rx = (rs & 15) << 2;                                   // granule q of the row sits at float offset (4 q) ^ rx
     const float* xj = LX ? xc + (j - j0) * RS : xb + (int64_t)j * ldx;
-    const float sjv = LX ? sjs[j - j0] : sqb[j];
+    const float sjv = sqb[j];
     float p = 0.f;
     if (C == 64) {
       constexpr int VR = LX ? 3 : 8;                                 // ring of candidate quads: LDS two ahead, global eight ahead
@@ -1018,7 +1037,6 @@ __global__ __launch_bounds__(256, 3) void knn_bf16a_kernel(const float* __restri
   const int nt = (N + TJM - 1) / TJM;
   fetch(0);
   const unsigned a_off = (unsigned)h * CS + (unsigned)(cbase + l31) * 16u;
-  const float kappa = 1.0f / 8192.0f;
   int qn = 0;                                // pairs waiting in this wave's queue (wave-uniform)
 
 #pragma unroll 1
@@ -1080,7 +1098,12 @@ __global__ __launch_bounds__(256, 3) void knn_bf16a_kernel(const float* __restri
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, q2[s], acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, q1[s], acc, 0, 0, 0);
       }
-      const float thr = (row < N) ? thr_s[rslot] : -INFINITY;        // rows past N: nothing survives
+      // Conservative filter on the approximate inner products a: the exact rule "d < thr" can only hold if  t - 2 a < thr + 2^-14 t
+      // (t = s_i + s_j; bound on |d' - d| above), i.e.  a > (1 - 2^-14) t / 2 - thr / 2.  Tested with 2^-13 for 2^-14 and the right
+      // side as  c1 s_j + (c1 s_i - thr / 2),  c1 = (1 - 2^-13) / 2: the roundings of that sum (< 2^-20 t) sit far inside the
+      // 2^-15 t of slack; one add and one compare per candidate.  thr = +inf: everything passes; rows past N: nothing does.
+      const float thr = (row < N) ? thr_s[rslot] : -INFINITY;
+      const float gi = si * KA_C1 - 0.5f * thr;
       const float* sj = sjs + cbase + 4 * h;
       unsigned mask = 0u;
 #pragma unroll
@@ -1090,11 +1113,7 @@ __global__ __launch_bounds__(256, 3) void knn_bf16a_kernel(const float* __restri
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int r = 4 * q + e;
-          const float tt = si + sv[e];
-          const float tp = 2.0f * acc[r];
-          const float da = tt - tp;
-          const float lim = fmaf(tt, kappa, thr);
-          mask |= sel_01(m_flt(da, lim)) << r;
+          mask |= sel_01(m_flt(sv[e] + gi, acc[r])) << r;
         }
       }
       // survivors -> this wave's queue, compacted across lanes; a full batch of 64 is re-checked at once
