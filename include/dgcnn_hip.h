@@ -53,8 +53,10 @@ const char* dgcnn_last_error(void);
  * ws: caller scratch (16-byte aligned) of dgcnn_knn_workspace_bytes(B,N,C,k) bytes: the s_i of ops.py:14 and, for raw
  *   coordinates (C <= 4, k <= 40), the sorted copy / cell table of the exact cell-grid search (csrc/knn_grid.hip: the points of
  *   a cloud are bucketed into a uniform grid and a row only meets the candidates of the cells around its own until its k-th
- *   distance provably beats everything further out -- same pairs' arithmetic, same (D, j) order, same indices).  A workspace
- *   that only holds the s_i (B*N floats rounded up to 256 bytes) selects the all-pairs kernels. */
+ *   distance provably beats everything further out -- same pairs' arithmetic, same (D, j) order, same indices); for feature-space
+ *   rows (16 < C <= 64) the seed bounds and the per-row candidate buffers of the append-form scan of dgcnn_knn_seeded_f32 (one count
+ *   + 256 ... 512 eight-byte entries per row).  A workspace that only holds the s_i (B*N floats rounded up to 256 bytes) selects the
+ *   all-pairs, list-keeping kernels. */
 int64_t dgcnn_knn_workspace_bytes(int B, int N, int C, int k);
 /* 0 = all-pairs kernel for C <= 4 too, 1 (default) = cell grid where it pays (N >= 4096: $DGCNN_KNN_GRID_MIN_N), 2 = cell grid
  * whenever applicable (tests); returns the previous setting ($DGCNN_KNN_GRID=0 switches it off). */
@@ -66,13 +68,16 @@ int dgcnn_knn_force_valu(int on);
 /* Large feature-space graphs (16 < C <= 64, C % 4 == 0, 16-byte aligned rows): approximate distances from the two leading bf16
  * terms of every operand on the bf16 matrix pipe with a rigorous error bound as a conservative filter, the normative fp32 fmaf
  * chain only for the survivors -- the same indices, bit for bit.  mode 0 = never, 1 = whenever applicable, 2 (default) = for
- * N >= 8192 ($DGCNN_KNN_BF16F = 0 | 1 | auto).  Returns the previous mode. */
+ * N >= 8192 and wherever a seed bound exists ($DGCNN_KNN_BF16F = 0 | 1 | auto).  Returns the previous mode. */
 int dgcnn_knn_bf16_filter(int mode);
 int dgcnn_knn_f32(const float* x, int B, int N, int C, int64_t ldx, int k, int32_t* idx,
                   void* ws, size_t ws_bytes, void* stream);
 /* The same search with a per-row upper bound taken from `seed` (B, N, >= kseed int32, row stride ldseed): kseed >= k DISTINCT
- * candidates of every row -- in the EdgeConv stack the previous layer's graph (ops.py:95-96).  Identical result, fewer list inserts
- * (csrc/knn.hip).  seed == NULL or kseed < k: plain dgcnn_knn_f32.  Workspace as dgcnn_knn_workspace_bytes says. */
+ * candidates of every row -- in the EdgeConv stack the previous layer's graph (ops.py:95-96).  Their largest distance bounds the
+ * row's k-th distance before the scan starts: feature-space rows (16 < C <= 64) then run the append-form scan (no sorted lists: a
+ * candidate under the bound is appended to the row's buffer, one selection per row at the end), other shapes filter their list
+ * inserts with it.  Identical result (csrc/knn.hip).  seed == NULL or kseed < k: plain dgcnn_knn_f32.  Workspace as
+ * dgcnn_knn_workspace_bytes says. */
 int dgcnn_knn_seeded_f32(const float* x, int B, int N, int C, int64_t ldx, int k, const int32_t* seed, int64_t ldseed,
                          int kseed, int32_t* idx, void* ws, size_t ws_bytes, void* stream);
 /* smallest N for which the seeds are used; -1 = the library's rule (always where the append-form scan applies -- 16 < C <= 64,
