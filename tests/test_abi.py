@@ -80,3 +80,33 @@ def test_stat_slots_setter_and_gemm_tile_query_work_without_a_gpu():
     assert lib.dgcnn_gemm_x3_tile_rows(49152, 512, 1728) == 256     # FC0 forward: the wave-specialised 256 x 128 kernel
     assert lib.dgcnn_gemm_x3_tile_rows(49152, 64, 128) == 64        # conv1: short reduction over many rows
     assert lib.dgcnn_gemm_x3_tile_rows(1024, 512, 192) == 128       # configs[0]-sized problems
+
+
+def test_knn_workspace_sizes_and_switches_are_plain_host_state():
+    """dgcnn_knn_workspace_bytes: [s_i | seed bounds] for every shape; + the cell grid's scratch for raw coordinates; + one count and
+    256 ... 512 eight-byte candidate entries per row for the shapes the append-form scan takes (16 < C <= 64, C % 4 == 0, k <= 64),
+    the capacity following k and the form (tile-by-tile re-check below N = 8192, carried queue above)."""
+    from dgcnn import _hip as H
+    lib = H.load()
+    pad = lambda n: (n + 255) // 256 * 256
+    for B, N in ((24, 2048), (2, 300), (8, 16384)):
+        sq = pad(4 * B * N)
+        assert lib.dgcnn_knn_workspace_bytes(B, N, 128, 20) == 2 * sq                      # C > 64: lists only
+        assert lib.dgcnn_knn_workspace_bytes(B, N, 16, 20) == 2 * sq                       # C <= 16: lists only
+        assert lib.dgcnn_knn_workspace_bytes(B, N, 3, 20) > 2 * sq                         # raw coordinates: + cell grid
+        for k, cap_lx, cap_cq in ((8, 256, 320), (20, 256, 320), (40, 384, 448), (64, 512, 512)):
+            cap = cap_lx if N < 8192 else cap_cq
+            assert cap >= k + (64 if N < 8192 else 192)
+            for C in (32, 64):
+                assert lib.dgcnn_knn_workspace_bytes(B, N, C, k) == 2 * sq + pad(4 * B * N) + 8 * cap * B * N, (B, N, C, k)
+    prev = lib.dgcnn_knn_append(0)
+    try:
+        assert lib.dgcnn_knn_append(-1) == 0 and lib.dgcnn_knn_append(1) == 0 and lib.dgcnn_knn_append(-1) == 1
+    finally:
+        lib.dgcnn_knn_append(prev)
+    prev = lib.dgcnn_knn_seed_min_n(-2)                                                    # query only
+    try:
+        assert lib.dgcnn_knn_seed_min_n(4096) == prev and lib.dgcnn_knn_seed_min_n(-2) == 4096
+        assert lib.dgcnn_knn_seed_min_n(-1) == 4096 and lib.dgcnn_knn_seed_min_n(-2) == -1  # -1: the library's rule
+    finally:
+        lib.dgcnn_knn_seed_min_n(prev)
