@@ -7,11 +7,15 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "dynamic-gcnn_am
 import numpy as np, torch
 import dgcnn
 from dgcnn import _engine as E, _hip as H
-H.load().dgcnn_knn_seed_min_n(0)            # (the library seeds from N = 4096 on: this script measures N = 2048)
 from gpu_helpers import capture_layers
-B, N, K = 24, 2048, 20
-flags = dgcnn.DGCNN_FLAGS(MODEL_NAME="dgcnn", EDGE_CONV_LAYERS=3, EDGE_CONV_FILTERS=[64, 64, 128], FC_LAYERS=2, FC_FILTERS=[512, 256],
-                          NUM_CLASS=2, KVALUE=K, NUM_CHANNEL=3, TRAIN=True, SEED=1)
+if os.environ.get("KNN_BENCH_CONFIG") == "2":      # BASELINE configs[2]: (8,16384,k=40), residual x6 -- layers 1 and 5
+    B, N, K, LAYERS = 8, 16384, 40, (1, 5)
+    flags = dgcnn.DGCNN_FLAGS(MODEL_NAME="residual-dgcnn", EDGE_CONV_LAYERS=6, EDGE_CONV_FILTERS=64, FC_LAYERS=2, FC_FILTERS=[512, 256],
+                              NUM_CLASS=2, KVALUE=K, NUM_CHANNEL=3, TRAIN=True, SEED=1)
+else:
+    B, N, K, LAYERS = 24, 2048, 20, (1, 2)
+    flags = dgcnn.DGCNN_FLAGS(MODEL_NAME="dgcnn", EDGE_CONV_LAYERS=3, EDGE_CONV_FILTERS=[64, 64, 128], FC_LAYERS=2, FC_FILTERS=[512, 256],
+                              NUM_CLASS=2, KVALUE=K, NUM_CHANNEL=3, TRAIN=True, SEED=1)
 tv = dgcnn.trainval(flags).initialize()
 rng = np.random.default_rng(0)
 pts = torch.from_numpy(rng.random((B, N, 3), dtype=np.float32)).cuda()
@@ -31,7 +35,7 @@ def timeit(fn, n=20, warm=3):
     return a.elapsed_time(b) / n * 1e3
 
 
-for i in (1, 2):
+for i in LAYERS:
     xin, idx = cap.layers["EdgeConv%d" % i]
     _, prev = cap.layers["EdgeConv%d" % (i - 1)]
     x = torch.from_numpy(xin.reshape(B * N, -1)).cuda()
