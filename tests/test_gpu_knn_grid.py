@@ -128,7 +128,8 @@ def test_workspace_too_small_for_the_grid_selects_the_all_pairs_kernel(dg):
 # seeded search (dgcnn_knn_seeded_f32): any k distinct candidates per row bound the row's k-th distance from above
 # ------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("append", [1, 0], ids=["append-scan", "lists"])
-@pytest.mark.parametrize("B,N,C,k", [(2, 512, 64, 20), (1, 700, 32, 8), (2, 2048, 64, 20), (1, 9000, 64, 40), (1, 333, 48, 64)])
+@pytest.mark.parametrize("B,N,C,k", [(2, 512, 64, 20), (1, 700, 32, 8), (2, 2048, 64, 20), (1, 9000, 64, 40), (1, 333, 48, 64),
+                                     (1, 40, 64, 20), (3, 64, 32, 10), (2, 130, 64, 8), (1, 8200, 20, 20), (2, 65, 64, 64)])
 def test_seeded_knn_equals_the_unseeded_search_whatever_the_seeds(B, N, C, k, append):
     """The result must not depend on the seeds: true neighbours (a tight bound), random distinct candidates (a loose one), the row's
     own index repeated (not distinct: the row gets no bound), out-of-range indices (no bound), more seeds than k (the first k count).
