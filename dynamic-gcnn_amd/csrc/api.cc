@@ -10,7 +10,9 @@ void set_error(const char* fmt, ...) {
   vsnprintf(g_err, sizeof(g_err), fmt, ap);
   va_end(ap);
 }
-static int g_stat_slots = DGCNN_STAT_SLOTS;
+// per calling thread: a host that drives several streams from several threads gives each its own count (the count is read on
+// the host when a launch is prepared and travels to the kernel as an argument; nothing on the device is shared)
+static thread_local int g_stat_slots = DGCNN_STAT_SLOTS;
 int stat_slots() { return g_stat_slots; }
 }  // namespace dg
 

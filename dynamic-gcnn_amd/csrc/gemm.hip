@@ -304,7 +304,7 @@ __global__ __launch_bounds__(NT) void gemm_kernel(GemmP p) {
   auto prefetch_slot = [&](int sl, bool more) {     // one prefetch load per MFMA group (slots 0..NVA+NVB-1)
     // VEC: unconditional (addresses are clamped into the operand, so the extra fetch after the last
     // tile is harmless) -- a branch here would split the block and make hipcc drain vmcnt(0) per load
-    if ((!VEC && !more) || DGCNN_ABLATE == 4) return;
+    if (!VEC && !more) return;
 #pragma unroll
     for (int i = 0; i < NVA; ++i)
       if (sl == i) ra[i] = fetch_a(i, knext);
@@ -315,13 +315,13 @@ __global__ __launch_bounds__(NT) void gemm_kernel(GemmP p) {
 #pragma unroll 1
   for (int kt = 0; kt < nk; ++kt) {
     const int buf = kt & 1;
-    const bool more = (DGCNN_ABLATE == 1 || DGCNN_ABLATE == 2) ? false : (kt + 1 < nk);
+    const bool more = kt + 1 < nk;
     knext = kbeg + (kt + 1) * BK;
     // The prefetch of tile kt+1 is NOT issued up front: its NVA+NVB loads (and their address VALU) are
     // slotted one per MFMA group below, so they issue in the shadow of this wave's own MFMAs
     // (measured: up-front prefetch costs 15 % of the MFMA rate, profiles/r01_gemm_ablation.txt).
-    const float* as = As + ((DGCNN_ABLATE >= 1 && DGCNN_ABLATE != 4) ? 0 : buf) * BK * SA + lh * SA + a_off;
-    const float* bs = Bs + ((DGCNN_ABLATE >= 1 && DGCNN_ABLATE != 4) ? 0 : buf) * BK * SB + lh * SB + b_off;
+    const float* as = As + buf * BK * SA + lh * SA + a_off;
+    const float* bs = Bs + buf * BK * SB + lh * SB + b_off;
     // operand reads run one k-pair ahead of the MFMAs (two register sets, static indices); the
     // sched_barriers pin "issue next reads -> MFMAs of the current pair" so the LDS latency of pair
     // s+1 hides under the 8 MFMAs of pair s (hipcc otherwise sinks each read next to its use).
@@ -359,20 +359,13 @@ __global__ __launch_bounds__(NT) void gemm_kernel(GemmP p) {
       prefetch_slot(s + 1, more);
       __builtin_amdgcn_sched_barrier(0);
     }
-    if (DGCNN_ABLATE == 3) {   // keep the loads alive without writing LDS
-#pragma unroll
-      for (int i = 0; i < NVA; ++i) asm volatile("" ::"v"(ra[i].x), "v"(ra[i].w));
-#pragma unroll
-      for (int i = 0; i < NVB; ++i) asm volatile("" ::"v"(rb[i].x), "v"(rb[i].w));
-    }
-    if (DGCNN_ABLATE == 5) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (more && DGCNN_ABLATE != 3 && DGCNN_ABLATE != 5) {
+    if (more) {
 #pragma unroll
       for (int i = 0; i < NVA; ++i) store_a(buf ^ 1, i, ra[i]);
 #pragma unroll
       for (int i = 0; i < NVB; ++i) store_b(buf ^ 1, i, rb[i]);
     }
-    if (DGCNN_ABLATE < 2) __syncthreads();
+    __syncthreads();
   }
 
   gemm_epilogue<EPI, BM, BN, VEC, TM, TN>(p, acc, smem, m0, n0, mt, z, t, wr, wc, l31, lh);

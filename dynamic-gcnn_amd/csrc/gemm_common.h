@@ -4,9 +4,6 @@
 #include "common.h"
 #include <stdlib.h>
 
-#ifndef DGCNN_ABLATE
-#define DGCNN_ABLATE 0   // experiments only: 1 = no prefetch/LDS refill, 2 = +no barrier, 3 = prefetch but no LDS refill, 4 = LDS refill of stale registers, no prefetch
-#endif
 
 namespace {
 
@@ -84,11 +81,7 @@ __device__ __forceinline__ bool block_tile(const GemmP& p, int& mt, int& nt, int
 }
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
-#if DGCNN_ABLATE == 5   // experiment: prefetch by LDS-DMA into a dummy LDS area (results are garbage)
-#define LD4(ptr) (__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ptr), (__attribute__((address_space(3))) void*)(smem + (threadIdx.x >> 6) * 256), 16, 0, 0), make_float4(0.f, 0.f, 0.f, 0.f))
-#else
 #define LD4(ptr) ld4(ptr)
-#endif
 
 __device__ __forceinline__ float4 sub4(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
 __device__ __forceinline__ int imin(int a, int b) { return a < b ? a : b; }

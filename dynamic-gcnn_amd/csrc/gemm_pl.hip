@@ -60,8 +60,6 @@ struct PlP {
   const char* Ap; int64_t a_ps; int64_t a_rows;      // plane 0 of the operand (at its first octet), plane stride [B], rows_alloc
   const char* Bp; int64_t b_ps; int64_t b_rows;
   const float* a_scale; const float* b_scale;        // device scalars (powers of two) the planes were multiplied by, or null
-  int ablate;                    // experiments ($DGCNN_PL_ABLATE, wrong results): 1 no DMA after slab 1, 2 DMA of the same two slabs,
-                                 // 3 no MFMAs, 4 no LDS operand reads after the first
 };
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
@@ -143,7 +141,7 @@ __global__ __launch_bounds__(768) void gemm_pl_kernel(PlP q) {
     const int64_t stepB = (FORM == PL_KC) ? q.b_rows * 16 * OS : KS * 16;
     auto issue = [&](int slab) {
       const int buf = slab % NS;
-      const int sl = q.ablate == 2 ? buf : slab;
+      const int sl = slab;
 #pragma unroll
       for (int i = 0; i < PER; ++i) {
         const bool isA = (lw + 4 * i) < NIA;
@@ -169,7 +167,7 @@ __global__ __launch_bounds__(768) void gemm_pl_kernel(PlP q) {
     __syncthreads();
 #pragma unroll 1
     for (int kt = 0; kt < nk; ++kt) {
-      if (issued < nk && !(q.ablate == 1 && kt >= 1)) { issue(issued); ++issued; }
+      if (issued < nk) { issue(issued); ++issued; }
 #pragma unroll
       for (int bb = 0; bb < NB - 1; ++bb) __syncthreads();
       wait_all_but(issued - (kt + 2) > 0 ? issued - (kt + 2) : 0);        // slabs after kt + 1 may still be in flight
@@ -272,9 +270,9 @@ __global__ __launch_bounds__(768) void gemm_pl_kernel(PlP q) {
     stage = (stage + 1 == NS) ? 0 : stage + 1;
 #pragma unroll
     for (int h = 0; h < PH; ++h) {
-      if (!(q.ablate == 4 && kt > 0)) load_ops(base, h);
+      load_ops(base, h);
       phase_barrier();
-      if (q.ablate != 3) compute();
+      compute();
       if (!(grp && kt == nk - 1 && h == PH - 1)) phase_barrier();      // (group 1's last compute is the kernel's last phase)
     }
   }
@@ -452,7 +450,6 @@ extern "C" int dgcnn_gemm_planes_f32(int form, int fmt, int M, int N, int K,
   q.Ap = (const char*)A; q.a_ps = a_plane_stride; q.a_rows = a_rows_alloc;
   q.Bp = (const char*)B; q.b_ps = b_plane_stride; q.b_rows = b_rows_alloc;
   q.a_scale = a_scale_dev; q.b_scale = b_scale_dev;
-  q.ablate = 0;
   p.mtiles = (int)dg::cdiv(M, 256);
   p.ntiles = (int)dg::cdiv(N, 128);
   if (form == DGCNN_PL_KC) {

@@ -26,9 +26,6 @@
 #include "gemm_common.h"
 #include <type_traits>
 
-#ifndef X3_ABLATE
-#define X3_ABLATE 0      // experiments only (profiles/x3_ablate.sh)
-#endif
 
 #ifndef DGCNN_GEMM_ARITH_DEFAULT
 #define DGCNN_GEMM_ARITH_DEFAULT 6
@@ -240,24 +237,9 @@ __global__ __launch_bounds__(NT, (BM == 64 ? 3 : 2)) void gemm_x3_kernel(GemmP p
 #pragma unroll
   for (int j = 0; j < TN; ++j) b_off[j] = IB::at(wc * (BN / 2) + j * 32 + l31, lh);
 
-#if X3_ABLATE == 8 || X3_ABLATE == 9
-  bf16x8 a[TM][3], b[TN][3];     // experiments: operands read once (8: random-ish data, 9: zeros), MFMAs only
-#pragma unroll
-  for (int q = 0; q < 3; ++q) {
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int e = 0; e < 8; ++e) a[i][q][e] = (X3_ABLATE == 9) ? (__bf16)0.f : (__bf16)(float)(p.A[(t * 8 + e + q * 2048 + i * 77) & 0xffff]);
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int e = 0; e < 8; ++e) b[j][q][e] = (X3_ABLATE == 9) ? (__bf16)0.f : (__bf16)(float)(p.B[(t * 8 + e + q * 2048 + j * 131) & 0xffff]);
-  }
-#endif
   auto mfma_slab = [&]() {
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-#if !(X3_ABLATE == 8 || X3_ABLATE == 9)
       bf16x8 a[TM][3], b[TN][3];
 #pragma unroll
       for (int q = 0; q < 3; ++q) {
@@ -268,7 +250,6 @@ __global__ __launch_bounds__(NT, (BM == 64 ? 3 : 2)) void gemm_x3_kernel(GemmP p
         for (int j = 0; j < TN; ++j)
           b[j][q] = *reinterpret_cast<const bf16x8*>(Bs + q * IB::PB + b_off[j] + 2 * s * IB::CS);
       }
-#endif
       // partial products, largest first: (1,1) (1,2) (2,1) (2,2) (1,3) (3,1) [(2,3) (3,2) (3,3)]
       constexpr int PA[9] = {0, 0, 1, 1, 0, 2, 1, 2, 2};
       constexpr int PB[9] = {0, 1, 0, 1, 2, 0, 2, 1, 2};
@@ -310,53 +291,12 @@ __global__ __launch_bounds__(NT, (BM == 64 ? 3 : 2)) void gemm_x3_kernel(GemmP p
     __syncthreads();
 #pragma unroll 1
     for (int kt = 0; kt < nk; ++kt) {
-#if X3_ABLATE == 0
       do_split();                               // slab kt+1 (garbage-but-valid after the last one; not written)
       fetch(imin(kt + 2, nk - 1));
       mfma_slab();
       __syncthreads();
       if (kt + 1 < nk) do_write();
       __syncthreads();
-#elif X3_ABLATE == 1 || X3_ABLATE == 8 || X3_ABLATE == 9   // experiments (wrong results): LDS reads + MFMAs only / MFMAs only
-      mfma_slab();
-#elif X3_ABLATE == 2                            // + barriers
-      mfma_slab();
-      __syncthreads();
-      __syncthreads();
-#elif X3_ABLATE == 3                            // + fetch and LDS refill, no split (stale P)
-      fetch(imin(kt + 2, nk - 1));
-      mfma_slab();
-      asm volatile("" ::"v"(L[0].x), "v"(L[1].x), "v"(L[2].x), "v"(L[3].x), "v"(L[4].x), "v"(L[5].x), "v"(L[6].x), "v"(L[7].x));
-      __syncthreads();
-      if (kt + 1 < nk) do_write();
-      __syncthreads();
-#elif X3_ABLATE == 4                            // split but no LDS refill
-      do_split();
-      fetch(imin(kt + 2, nk - 1));
-      mfma_slab();
-      asm volatile("" ::"v"(P[0].h.x), "v"(P[1].m.y), "v"(P[2].l.z), "v"(P[3].h.w), "v"(P[0].l.x), "v"(P[1].h.y), "v"(P[2].m.z), "v"(P[3].l.w));
-      __syncthreads();
-      __syncthreads();
-#elif X3_ABLATE == 5                            // fetch only
-      fetch(imin(kt + 2, nk - 1));
-      mfma_slab();
-      asm volatile("" ::"v"(L[0].x), "v"(L[1].x), "v"(L[2].x), "v"(L[3].x), "v"(L[4].x), "v"(L[5].x), "v"(L[6].x), "v"(L[7].x));
-      __syncthreads();
-      __syncthreads();
-#elif X3_ABLATE == 6                            // fetch only, always the same slab (L1/L2 resident)
-      fetch(kt & 1);
-      mfma_slab();
-      asm volatile("" ::"v"(L[0].x), "v"(L[1].x), "v"(L[2].x), "v"(L[3].x), "v"(L[4].x), "v"(L[5].x), "v"(L[6].x), "v"(L[7].x));
-      __syncthreads();
-      __syncthreads();
-#elif X3_ABLATE == 7                            // everything, but always the same two slabs (no L2/HBM streaming)
-      do_split();
-      fetch(kt & 1);
-      mfma_slab();
-      __syncthreads();
-      if (kt + 1 < nk) do_write();
-      __syncthreads();
-#endif
     }
   };
   const bool edge = (m0 + BM > p.M) || (n0 + BN > p.N) || (klen % XK != 0);
@@ -527,14 +467,10 @@ __global__ __launch_bounds__(768) void gemm_x3w2_kernel(GemmP p) {
         for (int d = 0; d < 2; ++d) {
           const int kt = kt0 + d;
           if (kt < nk) {
-#if X3_ABLATE != 11
             if (kt + 1 < nk) {
-#if X3_ABLATE != 13
               stage((d + 1) & 1, (d + 1) & 1);
-#endif
               fetch((d + 1) & 1, imin(kt + 3, nk - 1));
             }
-#endif
             __syncthreads();
           }
         }
@@ -565,10 +501,6 @@ __global__ __launch_bounds__(768) void gemm_x3w2_kernel(GemmP p) {
   __syncthreads();                                 // buffer 0 is ready
 #pragma unroll 1
   for (int kt = 0; kt < nk; ++kt) {
-#if X3_ABLATE == 12
-    __syncthreads();
-    continue;
-#endif
     const char* base = smem_raw + (kt & 1) * BUF;
     bf16x8 a[2][TM][3], b[2][TN][3];
 #pragma unroll

@@ -51,15 +51,6 @@ __global__ __launch_bounds__(256) void sqnorm_kernel(const float* __restrict__ x
   }
 }
 
-#ifndef KNN_SHARE
-#define KNN_SHARE 1      // MFMA kernel; 0: every list filters with its own k-th distance only (A/B switch, profiles/r02/knn_experiments.txt)
-#endif
-#ifndef KNN_SHARE_VALU
-#define KNN_SHARE_VALU 0 // the same bound in the VALU kernel (C <= 4): faster at N = 2048 (0.155 vs 0.163 ms), slower at N = 16384 (2.22 vs 2.05)
-#endif
-#ifndef KNN_ABLATE
-#define KNN_ABLATE 0     // experiments only: 1 = no selection at all (distances + parking only; wrong results)
-#endif
 
 // Shared selection bound.  The candidates of a query row are split over FOUR sorted lists (KC entries each, KC % 4 == 0).
 // If every list holds at least KC/4 entries, the row has seen KC candidates with d <= tau := max_i list_i[KC/4 - 1], so a
@@ -145,13 +136,7 @@ __global__ __launch_bounds__(256, (knn_min_waves<CP, KC>())) void knn_kernel(con
     // the channel loop is fully unrolled so x_i stays in registers, fenced every 16 channels so
     // the scheduler cannot hoist every LDS read).  Each lane parks d in its LDS slot and keeps a
     // 32-bit mask of the candidates that beat its current k-th distance. ----
-#if KNN_SHARE_VALU
-    const float tau = fmaxf(fmaxf(dl[KC / 4 - 1], thrw[((w + 1) & 3) * ROWS + lane]),
-                            fmaxf(thrw[((w + 2) & 3) * ROWS + lane], thrw[((w + 3) & 3) * ROWS + lane]));
-    const float thr = fminf(dl[KC - 1], next_up(tau));
-#else
     const float thr = dl[KC - 1];
-#endif
     unsigned mask = 0u;
 #pragma unroll 1
     for (int g = 0; g < PERW; g += 2) {
@@ -176,9 +161,6 @@ __global__ __launch_bounds__(256, (knn_min_waves<CP, KC>())) void knn_kernel(con
       mask |= (unsigned)sel_i(m_flt(d0, thr), (int)(1u << g), 0);
       mask |= (unsigned)sel_i(m_flt(d1, thr), (int)(2u << g), 0);
     }
-#if KNN_ABLATE == 1
-    mask = 0u;
-#endif
     // ---- phase B: drain.  Every iteration each lane pops ITS lowest surviving candidate (ascending
     // j, which the tie rule needs) and all lanes run one insert: max-over-lanes(popcount) inserts
     // per 32 candidates instead of one per candidate with any taker. ----
@@ -189,9 +171,6 @@ __global__ __launch_bounds__(256, (knn_min_waves<CP, KC>())) void knn_kernel(con
       mask &= mask - 1u;
       list_insert<KC, false>(dl, jl, d, j0 + w * PERW + g);
     }
-#if KNN_SHARE_VALU
-    thrw[w * ROWS + lane] = dl[KC / 4 - 1];
-#endif
   }
 
   // ---- merge the 4 per-wave lists into wave 0 through LDS (lexicographic (d, j)) ----
@@ -348,17 +327,13 @@ __global__ __launch_bounds__(256, (KC <= 20 ? 3 : 2)) void knn_mfma_kernel(const
   for (int t = 0; t < nt; ++t) {
     const int buf = t & 1;
     const int j0 = t * TJM;
-#if KNN_SHARE
     thrw[lid * ROWS + rslot] = dl[KC / 4 - 1];       // publish this list's KC/4-th entry (as of the previous tile)
-#endif
     if (t + 1 < nt) fetch(j0 + TJM);
     const int cbase = cs * 32;
     if (j0 + cbase < N) {                    // wave-uniform
       const float* xsT = smem + buf * TILE_F;
-#if KNN_SHARE && !defined(KNN_SHARE_LATE)
       // the other three lists' KC/4-th entries (shared selection bound): requested before the chain, needed after it
       const float o1 = thrw[(lid ^ 1) * ROWS + rslot], o2 = thrw[(lid ^ 2) * ROWS + rslot], o3 = thrw[(lid ^ 3) * ROWS + rslot];
-#endif
       f32x16 acc;
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -378,14 +353,7 @@ __global__ __launch_bounds__(256, (KC <= 20 ? 3 : 2)) void knn_mfma_kernel(const
       }
 
       // ---- distances of this lane's 16 candidates; park them, flag the ones that can still enter the row's top KC ----
-#if KNN_SHARE
-#ifdef KNN_SHARE_LATE
-      const float o1 = thrw[(lid ^ 1) * ROWS + rslot], o2 = thrw[(lid ^ 2) * ROWS + rslot], o3 = thrw[(lid ^ 3) * ROWS + rslot];
-#endif
       const float thr = fminf(fminf(dl[KC - 1], t0), next_up(fmaxf(fmaxf(dl[KC / 4 - 1], o1), fmaxf(o2, o3))));
-#else
-      const float thr = fminf(dl[KC - 1], t0);
-#endif
       const float* sj = sjs + buf * TJM + cbase + 4 * h;
       unsigned mask = 0u;
 #pragma unroll
@@ -402,9 +370,6 @@ __global__ __launch_bounds__(256, (KC <= 20 ? 3 : 2)) void knn_mfma_kernel(const
           mask |= sel_01(m_flt(d, thr)) << r;
         }
       }
-#if KNN_ABLATE == 1
-      mask = 0u;
-#endif
       // drain: the parked distance of the NEXT surviving candidate is fetched before the insert of
       // the current one (LDS round trip hidden behind ~90 VALU ops)
       int g = __builtin_ctz(mask | 0x80000000u) & 15;
@@ -622,15 +587,11 @@ __global__ __launch_bounds__(256, (Bf16fCfg<KC>::OCC)) void knn_bf16f_kernel(con
     const int j0 = t * TJM;
     if (t > 0) __syncthreads();              // every wave is done with tile t-1 (planes, fp32 copy)
     stash();                                 // tile t: registers -> LDS
-#if KNN_SHARE
     thrw[lid * ROWS + rslot] = dl[KC / 4 - 1];
-#endif
     if (t + 1 < nt) fetch(j0 + TJM);         // tile t+1: global -> registers, in flight during this step
     __syncthreads();
     if (j0 + cbase < N) {                    // wave-uniform
-#if KNN_SHARE
       const float o1 = thrw[(lid ^ 1) * ROWS + rslot], o2 = thrw[(lid ^ 2) * ROWS + rslot], o3 = thrw[(lid ^ 3) * ROWS + rslot];
-#endif
       const char* base = smem_raw + a_off;
       f32x16 acc;
 #pragma unroll
@@ -644,11 +605,7 @@ __global__ __launch_bounds__(256, (Bf16fCfg<KC>::OCC)) void knn_bf16f_kernel(con
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, q1[s], acc, 0, 0, 0);
       }
       // ---- conservative filter on the approximate distances
-#if KNN_SHARE
       const float thr = fminf(fminf(dl[KC - 1], t0), next_up(fmaxf(fmaxf(dl[KC / 4 - 1], o1), fmaxf(o2, o3))));
-#else
-      const float thr = fminf(dl[KC - 1], t0);
-#endif
       const float* sj = sjs + cbase + 4 * h;
       unsigned mask = 0u;
 #pragma unroll
@@ -665,9 +622,6 @@ __global__ __launch_bounds__(256, (Bf16fCfg<KC>::OCC)) void knn_bf16f_kernel(con
           mask |= sel_01(m_flt(da, lim)) << r;
         }
       }
-#if KNN_ABLATE == 2
-      mask = 0u;                             // experiment: no re-check, no insert (wrong results): the filter's floor
-#endif
       // ---- survivors: the normative distance on the VALU, the exact filter, the insert
       while (__any(mask != 0u)) {
         const lmask_t live = m_ine((int)mask, 0);

@@ -69,6 +69,8 @@ class DGCNN_FLAGS(object):
         self.SEED = 1         # library default; the CLI default stays -1 (= time based) as in flags.py:20
         self.USE_GRAPH = "0"  # library default: eager launches (the CLI default is "auto")
         self.NUM_CHANNEL = 3
+        self.STATIC_INPUTS = False   # replayed towers skip re-staging an input that is the same, unmodified tensor object (opt-in:
+                                     # only torch's version counter is consulted)
         self.update(kw)
 
     # ------------------------------------------------------------------ flags.py:124-148

@@ -27,11 +27,22 @@ from . import parallel
 
 TF_SCOPE = "dgcnn/"       # tf.variable_scope('dgcnn', reuse=tf.AUTO_REUSE): trainval.py:29
 GRAPH_CACHE_MAX = 8       # captured towers kept per trainval (each pins a private pool with that shape's activations)
+GRAPH_CACHE_MAX_FRACTION = 0.25   # ... and at most this share of the device's memory pinned by their pools together (LRU eviction)
 GRAPH_CAPTURE_AFTER = 1   # eager sightings of a (shape, mode) before it is captured; "auto" mode uses GRAPH_CAPTURE_AFTER_AUTO
 GRAPH_CAPTURE_AFTER_AUTO = 3
 GRAPH_SEEN_MAX = 4096     # distinct keys remembered for the sighting count (variable-N sources produce thousands)
 PLAN_AUTO_MAX_ROWS = 65536   # "auto": towers up to this many points are replayed from a launch plan (larger steps are tens of
                              # milliseconds of GPU work behind ~2 ms of host work: nothing to hide, and a plan pins the step's memory)
+
+
+def _pool_bytes(pool):
+    """Bytes of device memory a recorded plan's private pool holds (0 for HIP graphs, whose pool torch owns)."""
+    if pool is None:
+        return 0
+    try:
+        return int(sum(seg.get("total_size", 0) for seg in pool.snapshot()))
+    except Exception:
+        return 0
 
 
 def param_specs(flags, num_channel):
@@ -129,6 +140,7 @@ class trainval(object):
         self._graph_used, self._sighting_key = {}, None         # key -> doubles of the statistics arena an eager run of it used
         ug = str(getattr(f, "USE_GRAPH", "0")).lower()
         self._use_graph = ug if ug in ("auto", "plan") else ug in ("1", "true", "yes", "on", "graph")
+        self._static_inputs = bool(getattr(f, "STATIC_INPUTS", False))
         return self
 
     def _split_reduce(self):
@@ -226,7 +238,8 @@ class trainval(object):
         c = self._ctx
         hooked = c.head_grads_hook is not None
         key = (kind, tuple(pts.shape), bool(train), lab is not None, wgt is not None, float(E.DROPOUT_KEEP), H.gemm_arith(),
-               E.WGRAD_SIDE_STREAM, E.HEAD_PLANES, E.DETERMINISTIC, E.EDGE_MLP_DTYPE, hooked)
+               E.WGRAD_SIDE_STREAM, E.HEAD_PLANES, E.DETERMINISTIC, E.EDGE_MLP_DTYPE, hooked,
+               int(torch.cuda.current_stream().cuda_stream))     # (a plan bakes in the streams that were current at record time)
         ent = self._graphs.get(key)
         if ent is not None:
             # DETERMINISTIC mode grows the slot count (and with it the statistics arena) when a larger cloud arrives: a graph
@@ -259,14 +272,22 @@ class trainval(object):
         # the recorded step reads its OWN input buffers: stage the caller's tensors into them -- unless this very tensor OBJECT (kept
         # referenced here, so its address cannot be handed to another tensor), unmodified since (torch's version counter, shared by
         # all views of it), is what they already hold.  (An eager step does not copy its device-resident inputs either.)
+        # That skip is OPT-IN (flag STATIC_INPUTS, set by bench.py for its resident batch): a write that bypasses torch (another
+        # library through data_ptr / DLPack) does not move the version counter.
         staged = ent.setdefault("staged", {})
         for name, dst, src in (("pts", ent["pts"], pts), ("lab", ent["lab"], lab), ("wgt", ent["wgt"], wgt)):
             if dst is None or dst.data_ptr() == src.data_ptr():
                 continue
+            ver = None
+            if self._static_inputs:
+                try:
+                    ver = src._version
+                except RuntimeError:                     # (inference-mode tensors have no version counter)
+                    ver = None
             prev = staged.get(name)
-            if prev is None or prev[0] is not src or prev[1] != src._version:
+            if ver is None or prev is None or prev[0] is not src or prev[1] != ver:
                 dst.copy_(src, non_blocking=True)
-                staged[name] = (src, src._version)
+                staged[name] = (src, ver)
         c.advance_seed()
         if kind == "plan":
             c.head_grads_hook = None                     # (the recorded step contains what the hook issued)
@@ -286,6 +307,12 @@ class trainval(object):
         try:
             c.ensure_arena(int(pts.shape[0]) * int(pts.shape[1]))
             ent["arena"] = c.arena_key()
+            # The recorded step zeroes only what IT uses of the statistics arena; whatever the steps before it dirtied beyond that
+            # (a larger cloud, a train step before an eval capture, a replay) is zeroed HERE, outside the recording, so that "all
+            # of the arena behind stat_off is zero" still holds for the eager steps that follow.
+            if c.stat_arena is not None and c.stat_off > 0:
+                H.memset(c.stat_arena[:min(c.stat_off, c.stat_arena.numel())])
+                c.stat_off = 0
             torch.cuda.synchronize()
             c.capturing = True
             c.capture_extent = self._graph_used.get(key)
@@ -305,9 +332,12 @@ class trainval(object):
                 with torch.cuda.graph(g):
                     ent["sm"], ent["scal"] = self._tower_body(ent["pts"], ent["lab"], ent["wgt"], train)
                 ent["graph"] = g
-            if c.capture_extent is not None and c.stat_off > c.capture_extent:      # (same shape, same mode: cannot happen)
-                raise H.HipError("the captured step uses %d doubles of the statistics arena, its eager sighting used %d"
-                                 % (c.stat_off, c.capture_extent))
+            if c.capture_extent is not None and c.stat_off > c.capture_extent:
+                # the recorded memset covers less than the step writes (the slot count or the arena changed between the sighting and
+                # the recording).  THIS execution was right -- everything behind the recorded extent was zeroed just above -- but a
+                # replay would not be: keep the results, drop the recording, and let the next one zero the full extent.
+                self._graph_used.pop(key, None)
+                ent["discard"] = True
         except Exception as e:                        # capture is an optimisation: fall back to eager launches, loudly
             sys.stderr.write("dgcnn: %s capture failed (%s: %s); running eagerly\n"
                              % ("launch-plan" if kind == "plan" else "HIP graph", type(e).__name__, e))
@@ -328,12 +358,25 @@ class trainval(object):
             c.head_grads_hook = hook if ent is None else None
         if ent is not None:
             ent["stat_used"] = c.stat_off                        # doubles of the statistics arena the captured step writes
+            ent["pool_bytes"] = _pool_bytes(ent.get("pool"))
             self._graphs[key] = ent
+            if ent.pop("discard", False):                        # results stand, the recording does not (see above)
+                self._graph_seen[key] = 0
+                out = {"sm": ent["sm"].clone(), "scal": ent["scal"].clone()}
+                self._drop_graph(key)
+                return out if kind == "plan" else None
             if ent["arena"] != c.arena_key():                    # (cannot happen after ensure_arena; never replay such a graph)
                 self._drop_graph(key)
                 return None
-            while len(self._graphs) > GRAPH_CACHE_MAX:           # least recently replayed first; frees its private pool
-                self._drop_graph(next(iter(self._graphs)))
+            # least recently replayed first; frees its private pool.  Bounded by count AND by the bytes the pools pin together
+            # (a variable-N source that repeats a handful of large shapes pins GBs per key that eager steps cannot reclaim).
+            cap = GRAPH_CACHE_MAX_FRACTION * torch.cuda.get_device_properties(c.device).total_memory
+            while len(self._graphs) > 1 and (len(self._graphs) > GRAPH_CACHE_MAX
+                                             or sum(e.get("pool_bytes", 0) for e in self._graphs.values()) > cap):
+                victim = next(iter(self._graphs))
+                if victim == key:
+                    break
+                self._drop_graph(victim)
         return ent
 
     def _drop_graph(self, key):

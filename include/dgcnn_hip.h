@@ -35,7 +35,8 @@ extern "C" {
 #define DGCNN_EUNSUP (-4)   /* shape not supported by this build */
 
 #define DGCNN_STAT_SLOTS 32
-/* Slots of every stats / red buffer from now on (process-wide; default DGCNN_STAT_SLOTS).  A producer workgroup adds its partial
+/* Slots of every stats / red buffer prepared by THE CALLING THREAD from now on (thread-local; default DGCNN_STAT_SLOTS; read on
+ * the host at launch time and passed to the kernels as an argument, so calls of other threads / streams are not affected).  A producer workgroup adds its partial
  * sums -- themselves formed in a fixed order -- to slot (writer index mod slots) with a double atomic; with slots >= the number of
  * writers (the library then also caps the grids of its reduction kernels at `slots`) every slot has ONE writer, and the finalize
  * kernels add the slots in a fixed order: sums, hence whole training steps, are bit-reproducible run to run at the speed of the

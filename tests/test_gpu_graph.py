@@ -196,7 +196,7 @@ def test_launch_plan_with_the_second_stream_retraces_the_eager_step_bit_for_bit(
 def test_replay_restages_inputs_that_changed_in_place_or_are_new_objects(mode):
     """A replayed tower reads its own input buffers; the caller's tensor is copied into them unless the SAME tensor object,
     unmodified, was staged last time.  In-place edits (also through a view) and new tensors at a recycled address must be seen."""
-    f = _flags(TRAIN=False)
+    f = _flags(TRAIN=False, STATIC_INPUTS=True)                  # the skip is opt-in; without the flag every replay stages
     tv = dgcnn.trainval(f).initialize()
     rng = np.random.default_rng(8)
     a = torch.from_numpy(rng.random((2, 384, 3), dtype=np.float32)).cuda()
@@ -217,3 +217,58 @@ def test_replay_restages_inputs_that_changed_in_place_or_are_new_objects(mode):
     out = tv.inference(None, [y])[0]
     np.testing.assert_allclose(out.cpu().numpy(), want_a.cpu().numpy(), rtol=0, atol=2e-4)
     print("recycled address: %s" % (y.data_ptr() == addr))
+
+
+def test_default_replay_stages_inputs_written_behind_torchs_back(mode):
+    """Without STATIC_INPUTS a replay always copies the caller's tensors in: a write that does not move torch's version counter
+    (here: one of the library's own kernels through data_ptr) must be seen."""
+    from dgcnn import _hip as H
+    tv = dgcnn.trainval(_flags(TRAIN=False)).initialize()
+    rng = np.random.default_rng(9)
+    a = torch.from_numpy(rng.random((2, 320, 3), dtype=np.float32)).cuda()
+    b = torch.from_numpy(rng.random((2, 320, 3), dtype=np.float32)).cuda()
+    want_b = tv.inference(None, [b])[0].clone()
+    tv.use_graph(mode)
+    x = a.clone()
+    for _ in range(3):
+        tv.inference(None, [x])
+    v = x._version
+    H.call("dgcnn_copy2d_f32", b.data_ptr(), 3, x.data_ptr(), 3, 2 * 320, 3, 0)       # x <- b, invisible to the version counter
+    assert x._version == v
+    got = tv.inference(None, [x])[0]
+    np.testing.assert_allclose(got.cpu().numpy(), want_b.cpu().numpy(), rtol=0, atol=2e-4)
+
+
+def test_capture_of_a_small_step_after_a_large_one_leaves_the_arena_zeroed(mode):
+    """a recorded step zeroes only what IT uses of the statistics arena.  Eager large step -> capture of a small step ->
+    eager large step: the last one must equal the same step in a run that never captured (deterministic kernels: bit for bit)."""
+    rng = np.random.default_rng(21)
+    big = torch.from_numpy(rng.random((6, 1024, 3), dtype=np.float32)).cuda()
+    bigl = torch.from_numpy(rng.integers(0, 2, (6, 1024)).astype(np.int32)).cuda()
+    small = torch.from_numpy(rng.random((1, 256, 3), dtype=np.float32)).cuda()
+    smalll = torch.from_numpy(rng.integers(0, 2, (1, 256)).astype(np.int32)).cuda()
+    keep, E.DROPOUT_KEEP = E.DROPOUT_KEEP, 1.0
+    try:
+        def run(graph):
+            tv = dgcnn.trainval(_flags(DETERMINISTIC=True)).initialize().use_graph(False)
+            c = dgcnn.ctx()
+            tv.zero_gradients(None)
+            tv.accum_gradient(None, [big], [bigl])                # eager, dirties a large extent of the arena
+            big_off = c.stat_off
+            tv.use_graph(graph)
+            for _ in range(3):                                    # sighting, capture, replay of the SMALL inference step
+                tv.inference(None, [small], [smalll])
+            if graph:
+                assert len(tv._graphs) == 1
+            tv.use_graph(False)
+            tv.zero_gradients(None)
+            res = tv.accum_gradient(None, [big], [bigl])          # eager again: assumes everything behind stat_off is zero
+            assert c.stat_off == big_off
+            return float(res[2]), c.flat_grad.cpu().numpy().copy()
+        l0, g0 = run(False)
+        l1, g1 = run(mode)
+        assert l0 == l1
+        np.testing.assert_array_equal(g1, g0)
+    finally:
+        E.DROPOUT_KEEP = keep
+        E.DETERMINISTIC = E.DETERMINISTIC_ENV_DEFAULT
