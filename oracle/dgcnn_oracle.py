@@ -32,39 +32,68 @@ BN_EPS = 1e-3  # slim.batch_norm default epsilon [TF1-lib], SURVEY Appendix A.3
 # ----------------------------------------------------------------------------------------
 # C restatement (exact fp32 k-NN arithmetic)
 # ----------------------------------------------------------------------------------------
-def build_c(force: bool = False) -> str:
-    """Compile oracle/knn_oracle.c -> oracle/_build/liboracle.so (gcc, -ffp-contract=off)."""
+def build_c(force: bool = False, fma: bool = True) -> str:
+    """Compile oracle/knn_oracle.c -> oracle/_build/liboracle.so (gcc, -ffp-contract=off); fma=False: the -DORACLE_NO_FMA variant
+    (liboracle_nofma.so: p_ij without fused multiply-add -- the chain SURVEY A.1 did NOT choose)."""
     out_dir = os.path.join(_HERE, "_build")
-    so = os.path.join(out_dir, "liboracle.so")
+    so = os.path.join(out_dir, "liboracle.so" if fma else "liboracle_nofma.so")
     src = os.path.join(_HERE, "knn_oracle.c")
     if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
         os.makedirs(out_dir, exist_ok=True)
         subprocess.check_call(
-            ["gcc", "-O2", "-fopenmp", "-ffp-contract=off", "-fno-fast-math", "-shared", "-fPIC", "-o", so, src, "-lm"]
+            ["gcc", "-O2", "-fopenmp", "-ffp-contract=off", "-fno-fast-math"] + ([] if fma else ["-DORACLE_NO_FMA"])
+            + ["-shared", "-fPIC", "-o", so, src, "-lm"]
         )
     return so
 
 
+_LIB_NOFMA = None
+KNN_FMA = True        # the normative chain; knn_chain(fma=False) switches the float32 k_nn to the non-FMA variant (sensitivity tests)
+
+
+class knn_chain(object):
+    """with knn_chain(fma=False): ...  -- every float32 k_nn inside (also those of model_forward) uses the non-FMA p_ij chain."""
+    def __init__(self, fma):
+        self.fma = bool(fma)
+
+    def __enter__(self):
+        global KNN_FMA
+        self.prev, KNN_FMA = KNN_FMA, self.fma
+        return self
+
+    def __exit__(self, *exc):
+        global KNN_FMA
+        KNN_FMA = self.prev
+
+
 def _lib():
-    global _LIB
+    global _LIB, _LIB_NOFMA
+    if not KNN_FMA:
+        if _LIB_NOFMA is None:
+            _LIB_NOFMA = _bind(ctypes.CDLL(build_c(fma=False)))
+        return _LIB_NOFMA
     if _LIB is None:
-        _LIB = ctypes.CDLL(build_c())
-        _LIB.oracle_knn_f32.restype = ctypes.c_int
-        _LIB.oracle_knn_f32.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
-                                        ctypes.c_long, ctypes.c_int, ctypes.c_void_p]
-        _LIB.oracle_knn_rows_f32.restype = ctypes.c_int
-        _LIB.oracle_knn_rows_f32.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_long, ctypes.c_int,
-                                             ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
-        _LIB.oracle_dist_pairs_f32.restype = None
-        _LIB.oracle_dist_pairs_f32.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_long, ctypes.c_void_p,
-                                               ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
-        _LIB.oracle_dist_f32.restype = None
-        _LIB.oracle_dist_f32.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_long,
-                                         ctypes.c_void_p]
-        _LIB.oracle_edges_f32.restype = None
-        _LIB.oracle_edges_f32.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
-                                          ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+        _LIB = _bind(ctypes.CDLL(build_c()))
     return _LIB
+
+
+def _bind(lib):
+    lib.oracle_knn_f32.restype = ctypes.c_int
+    lib.oracle_knn_f32.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                    ctypes.c_long, ctypes.c_int, ctypes.c_void_p]
+    lib.oracle_knn_rows_f32.restype = ctypes.c_int
+    lib.oracle_knn_rows_f32.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_long, ctypes.c_int,
+                                         ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+    lib.oracle_dist_pairs_f32.restype = None
+    lib.oracle_dist_pairs_f32.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_long, ctypes.c_void_p,
+                                           ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+    lib.oracle_dist_f32.restype = None
+    lib.oracle_dist_f32.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_long,
+                                     ctypes.c_void_p]
+    lib.oracle_edges_f32.restype = None
+    lib.oracle_edges_f32.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
+                                      ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    return lib
 
 
 def dist_matrix_f32(x: np.ndarray) -> np.ndarray:

@@ -32,9 +32,19 @@ static inline float sq_norm(const float *x, int C) {
   return s;
 }
 
+/* -DORACLE_NO_FMA (liboracle_nofma.so): the other chain SURVEY A.1 leaves open -- a GEMM micro-kernel WITHOUT fused multiply-add
+ * (an SSE2-only TensorFlow build): p = fl(p + fl(a*b)), same order.  Not normative; tests/test_oracle.py measures how many rows'
+ * neighbour lists (and how far the logits) move between the two chains -- what "parity unpinned" could cost. */
 static inline float inner(const float *a, const float *b, int C) {
   float p = 0.0f;
+#ifdef ORACLE_NO_FMA
+  for (int c = 0; c < C; ++c) {
+    float q = a[c] * b[c];
+    p = p + q;
+  }
+#else
   for (int c = 0; c < C; ++c) p = fmaf(a[c], b[c], p);
+#endif
   return p;
 }
 
