@@ -153,6 +153,36 @@ class stdout_to_stderr(object):
         return False
 
 
+METRIC = "point-clouds/sec fwd+bwd at (B,N,k,C)=(24,2048,20,3), 1/2/4/8 MI355X"
+
+
+def make_guard(args, rank, world):
+    """Multi-rank runs only: every phase that contains a collective for the first time (communicator bring-up, the first EAGER step
+    with the gradient all-reduce, the recording of a launch plan that holds the ncclAllReduce, then each timed region) runs under a
+    dgcnn.rccl.Deadline.  A hang inside RCCL raises nothing; when the deadline passes rank 0 prints ONE JSON line
+    {"error": "<stage>", "value": null, ...} and every rank exits non-zero -- within $DGCNN_BENCH_DEADLINE seconds (default 120),
+    not at the driver's 1800.  Ranks other than 0 wait 10 s longer so that rank 0's line gets out before the launcher reaps it."""
+    import contextlib
+    if world <= 1:
+        return lambda stage, factor=1.0: contextlib.nullcontext()
+    from dgcnn import rccl
+    seconds = float(os.environ.get("DGCNN_BENCH_DEADLINE", "120"))
+
+    def expire(stage, secs):
+        if rank == 0:
+            sys.stdout.write(json.dumps({"metric": METRIC, "value": None, "unit": "clouds/s", "n_gpus": world, "steps": args.steps,
+                                         "warmup": args.warmup, "ms_per_step": None, "higher_is_better": True, "scaling": "weak",
+                                         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                                         "error": "%s did not finish within %.0f s" % (stage, secs),
+                                         "config": {"workload": "aborted multi-rank run", "parallelism": "dp%d" % world}}) + "\n")
+            sys.stdout.flush()
+
+    def guard(stage, factor=1.0):
+        st = (lambda: "%s [%s]" % (stage, rccl.LAST_STAGE[0])) if stage.startswith("communicator") else stage
+        return rccl.Deadline(st, seconds * factor + (0 if rank == 0 else 10), on_expire=expire)
+    return guard
+
+
 def comm_fields(group, dist, world, per_rank_elapsed, steps, exposed_ms, bucket_elems):
     """The multi-rank evidence of a bench line (rank 0): how many ranks the gradient all-reduce ran on ACCORDING TO RCCL
     (ncclCommCount / ncclCommUserRank through dgcnn_comm_info -- not what the launcher said), every rank's own ms/step, and the
@@ -211,7 +241,9 @@ def dry_run(args, rank, world):
     stand-in step (a host-side all-reduce of a bucket-sized buffer through the communicator class $DGCNN_BENCH_GROUP names)."""
     import importlib
     mod, cls = os.environ["DGCNN_BENCH_GROUP"].split(":")
-    group = getattr(importlib.import_module(mod), cls)(rank=rank, world=world)
+    guard = make_guard(args, rank, world)
+    with guard("communicator bring-up"):
+        group = getattr(importlib.import_module(mod), cls)(rank=rank, world=world)
     bucket = torch.full((1797186,), float(rank + 1))
     state = {"sum": 0.0}
 
@@ -220,15 +252,17 @@ def dry_run(args, rank, world):
         group.allreduce_sum_(g)                      # every rank must issue the same collectives
         state["sum"] += float(g[0])
 
-    for _ in range(args.warmup):
-        step()
-    group.barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    group.barrier()
-    elapsed = time.perf_counter() - t0
-    allv = group.gather_scalars([elapsed, state["sum"]])
+    with guard("first step with the gradient all-reduce"):
+        for _ in range(args.warmup):
+            step()
+        group.barrier()
+    with guard("timed region"):
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        group.barrier()
+        elapsed = time.perf_counter() - t0
+        allv = group.gather_scalars([elapsed, state["sum"]])
     per_rank = [float(x) for x in allv[:, 0]]
     if not bool((allv[:, 1] == allv[0, 1]).all()):
         raise SystemExit("replicas diverged: checksums differ across ranks")
@@ -237,7 +271,7 @@ def dry_run(args, rank, world):
         raise SystemExit("stand-in all-reduce returned %r, expected %r" % (state["sum"], want))
     comm = comm_fields_dry(group, per_rank, args.steps)
     if rank == 0:
-        print(json.dumps({"metric": "point-clouds/sec fwd+bwd at (B,N,k,C)=(24,2048,20,3), 1/2/4/8 MI355X", "dry_run": True,
+        print(json.dumps({"metric": METRIC, "dry_run": True,
                           "value": None, "unit": "clouds/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                           "ms_per_step": round(max(per_rank) / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
                           "vs_baseline": None, "dtype": "f32", "data": "none (dry run: no model, no GPU)",
@@ -304,12 +338,14 @@ def main():
     from dgcnn import _hip as H
     from dgcnn import parallel
     dist = group = None
+    guard = make_guard(args, rank, world)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         backend = args.backend
         if backend == "rccl":
             try:
-                group = parallel.init_rccl(rank=rank, world=world)
+                with guard("communicator bring-up", 1.5):
+                    group = parallel.init_rccl(rank=rank, world=world)
             except Exception as e:          # every rank fails alike (no library / rendezvous): fall back together, loudly
                 sys.stderr.write("bench.py: own RCCL communicator unavailable (%s); using torch.distributed nccl\n" % e)
                 backend = "nccl"
@@ -350,7 +386,16 @@ def main():
 
     # ---- warm-up; the SECOND warm-up step (code objects already loaded) is event-timed per kernel to
     # find the dominant one ----
-    step()
+    # N > 1: the FIRST step is eager whatever --graph says (a recorded plan would hold the ncclAllReduce) and runs, fence included,
+    # under a deadline; only after it came back clean may a plan be recorded (make_guard)
+    first_mode = tv._use_graph
+    if world > 1:
+        tv.use_graph(False)
+    with guard("first eager step with the gradient all-reduce (broadcast of the parameters, head-bucket all-reduce from inside "
+               "the backward, rest piece, Adam)"):
+        step()
+        fence()
+    tv.use_graph(first_mode)
     # kernel table from a step with the side stream switched off (launches serialised): per-kernel event times are
     # then those of each kernel ALONE; in the timed region weight-gradient GEMMs overlap the backward chain
     from dgcnn import _engine as E
@@ -381,8 +426,11 @@ def main():
         tv.use_graph(False)
         t_eager, h_eager = rate()
         tv.use_graph("plan")
-        step()
-        step()                                  # sighting + recording
+        with guard("recording the launch plan (holds the ncclAllReduce) and its first replay"):
+            step()
+            step()                              # sighting + recording
+            step()
+            fence()
         rate(12)                                # (the first second of replay runs 3-4 % slow: profiles/r05/bench_stall.txt B)
         t_plan, h_plan = rate()
         # the plan unless eager wins clearly AND has host headroom: an eager step is ~140 launches from Python, the mode that a
@@ -421,13 +469,16 @@ def main():
         R = int(vt[0])
     regions, issues = [], []
     for _ in range(R):
-        fence()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            res = step()
-        issues.append(time.perf_counter() - t0)  # host time to enqueue K steps (launch-bound check)
-        fence()
-        regions.append(time.perf_counter() - t0)
+        with guard("timed region of %d steps" % args.steps):
+            fence()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                res = step()
+            issues.append(time.perf_counter() - t0)  # host time to enqueue K steps (launch-bound check)
+            fence()
+            regions.append(time.perf_counter() - t0)
+    tail_guard = guard("post-region measurements (event-timed eager steps, exposed all-reduce, gathers over the ranks)", 2.0)
+    tail_guard.__enter__()
     # ---- the dominant kernel, live: HIP events (on the launch stream) around its launches in eager steps that follow the
     # timed regions immediately (same process, same buffers, same two-stream schedule) ----
     tv.use_graph(False)
@@ -465,6 +516,7 @@ def main():
         dist.all_reduce(hi, op=dist.ReduceOp.MAX)
         if not torch.equal(lo, hi):
             raise SystemExit("replicas diverged: parameter checksums differ across ranks")
+    tail_guard.__exit__(None, None, None)
     region_max = [max(r[i] for r in per_rank_regions) for i in range(R)]          # per region: the slowest rank
     order = sorted(range(R), key=lambda i: region_max[i])
     mid = order[R // 2]                                                            # the median region
@@ -564,7 +616,7 @@ def main():
             for t, (n, s, w, _b) in sorted(table.items(), key=lambda kv: -kv[1][1]):
                 sys.stderr.write("%-46s launches %3d  %8.3f ms  %5.1f%%  work/s %.3e\n" % (t, n, s * 1e3, 100 * s / tot, w / s))
         out = {
-            "metric": "point-clouds/sec fwd+bwd at (B,N,k,C)=(24,2048,20,3), 1/2/4/8 MI355X",
+            "metric": METRIC,
             "value": round(world * B * args.steps / elapsed, 2),
             "unit": "clouds/s",
             "n_gpus": world,

@@ -18,6 +18,44 @@ import torch
 from . import _hip as H
 
 ID_BYTES = 128
+LAST_STAGE = [None]          # the bring-up stage this process announced last (Deadline reports it when a bring-up hangs)
+
+
+class Deadline(object):
+    """`with Deadline(stage, seconds, on_expire):` -- a watchdog THREAD for code that can hang inside RCCL, where nothing raises:
+    ncclCommInitRank waiting for a rank that never arrives, the first multi-rank collective on a fabric that does not come up.  The
+    guarded calls are ctypes / torch calls that release the GIL while they block, so the thread gets to run; if the body has not
+    left the block `seconds` after entering it, on_expire(stage_text, seconds) is called -- by default one line on stderr and
+    os._exit(124): a hung communicator cannot be torn down in-process, and a launcher (torch.distributed.run) that sees one rank die
+    stops the others.  `stage` may be a callable (evaluated at expiry: the LAST stage announced)."""
+
+    def __init__(self, stage, seconds, on_expire=None):
+        self.stage, self.seconds, self.on_expire = stage, float(seconds), on_expire
+        self._done = None
+
+    def _text(self):
+        return str(self.stage() if callable(self.stage) else self.stage)
+
+    def _run(self):
+        if self._done.wait(self.seconds):
+            return
+        text = self._text()
+        if self.on_expire is not None:
+            self.on_expire(text, self.seconds)
+        sys.stderr.write("[dgcnn.rccl] `%s` did not finish within %.0f s: giving up (exit 124)\n" % (text, self.seconds))
+        sys.stderr.flush()
+        os._exit(124)
+
+    def __enter__(self):
+        import threading
+        self._done = threading.Event()
+        self._thread = threading.Thread(target=self._run, name="dgcnn-deadline", daemon=True)
+        self._thread.start()
+        return self
+
+    def __exit__(self, *exc):
+        self._done.set()
+        return False
 
 
 def _exchange_id(rank, world, addr, port, make_id, timeout=90.0):
@@ -115,6 +153,7 @@ class Group(object):
 
     def _stage(self, name, detail):
         self.stage = name
+        LAST_STAGE[0] = "RCCL bring-up: " + name
         if os.environ.get("DGCNN_RCCL_TRACE", "0") not in ("0", ""):
             sys.stderr.write("[dgcnn.rccl rank %d/%d] stage: %s%s\n" % (self.rank, self.world, name, " (%s)" % detail if detail else ""))
             sys.stderr.flush()

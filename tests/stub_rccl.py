@@ -43,6 +43,12 @@ class StubGroup(object):
             time.sleep(delay)
         # the stage announcements of dgcnn.rccl.Group (DGCNN_RCCL_TRACE), and a failure injected at one of them on one rank
         # (STUB_RCCL_FAIL="<rank>:<stage>"): what profiles/scale_probe.sh diagnoses
+        # STUB_RCCL_HANG="<rank>:<n>": that rank's n-th collective (0-based, counted from the constructor's first one) never
+        # completes -- the rank sits in it for ever and its peers block waiting for its contribution: what a fabric that does not
+        # come up looks like.  Nothing raises; only a deadline outside the communicator can end the run (bench.py's guard).
+        hang = env.get("STUB_RCCL_HANG", "")
+        self._hang_at = int(hang.split(":", 1)[1]) if hang and int(hang.split(":", 1)[0]) == self.rank else None
+        self._ncoll = 0
         fail = env.get("STUB_RCCL_FAIL", "")
         self._fail = fail.split(":", 1)[1] if fail and int(fail.split(":", 1)[0]) == self.rank else None
         self._stage("dlopen")
@@ -87,6 +93,7 @@ class StubGroup(object):
 
     def _stage(self, name):
         import sys
+        rccl.LAST_STAGE[0] = "RCCL bring-up: " + name
         if os.environ.get("DGCNN_RCCL_TRACE", "0") not in ("0", ""):
             sys.stderr.write("[dgcnn.rccl rank %d/%d] stage: %s (stand-in)\n" % (self.rank, self.world, name))
             sys.stderr.flush()
@@ -102,6 +109,10 @@ class StubGroup(object):
 
     def _reduce(self, values):
         """SUM of a list of floats / a tensor over the ranks, result on every rank."""
+        n, self._ncoll = self._ncoll, self._ncoll + 1
+        if self._hang_at is not None and n >= self._hang_at:
+            while True:                              # "collective never completes"
+                time.sleep(3600)
         if self.world == 1:
             return values
         if self.rank == 0:

@@ -70,3 +70,33 @@ def test_gpus_8_end_to_end_with_a_stand_in_communicator():
     assert cfg["rccl_ranks"] == 8 and cfg["rccl_rank"] == 0 and cfg["parallelism"] == "dp8" and cfg["global_batch"] == 192
     pr = cfg["per_rank_ms_per_step"]
     assert len(pr["all"]) == 8 and pr["min"] <= pr["max"] and abs(out["ms_per_step"] - pr["max"]) < 1e-6
+
+
+def test_a_collective_that_never_completes_ends_the_run_with_one_error_line():
+    """the first multi-rank contact must not be able to hang its caller.  Rank 1's third collective (the first
+    one of the first step: bring-up holds two) never completes -- nothing raises anywhere, rank 0 blocks waiting for rank 1's
+    contribution.  bench.py's deadline (6 s here, 120 s by default) must end the run: ONE JSON line on stdout naming the stage, a
+    non-zero exit code, well inside the test's own timeout."""
+    import json
+    import subprocess
+    import time
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "DGCNN_BENCH_SELF_LAUNCHED"):
+        env.pop(k, None)
+    env["PYTHONPATH"] = os.pathsep.join([ROOT, os.path.join(ROOT, "dynamic-gcnn_amd"), os.path.join(ROOT, "tests")] +
+                                        [p for p in env.get("PYTHONPATH", "").split(os.pathsep) if p])
+    env["DGCNN_BENCH_GROUP"] = "stub_rccl:StubGroup"
+    env["DGCNN_BENCH_DEADLINE"] = "6"
+    env["OMP_NUM_THREADS"] = "1"
+    for hang, stage in (("1:1", "first step with the gradient all-reduce"), ("1:0", "communicator bring-up")):
+        env["STUB_RCCL_HANG"] = hang
+        t0 = time.time()
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--dry-run"],
+                           env=env, capture_output=True, text=True, timeout=300)
+        took = time.time() - t0
+        assert r.returncode != 0, (r.stdout, r.stderr[-2000:])
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1, (r.stdout, r.stderr[-2000:])
+        out = json.loads(lines[0])
+        assert out["value"] is None and out["n_gpus"] == 2 and stage in out["error"] and "did not finish within" in out["error"], out
+        assert took < 120, took

@@ -267,7 +267,7 @@ def test_capture_of_a_small_step_after_a_large_one_leaves_the_arena_zeroed(mode)
             return float(res[2]), c.flat_grad.cpu().numpy().copy()
         l0, g0 = run(False)
         l1, g1 = run(mode)
-        assert l0 == l1
+        assert abs(l0 - l1) < 1e-6                                # (the REPORTED loss is summed with atomics: last bit)
         np.testing.assert_array_equal(g1, g0)
     finally:
         E.DROPOUT_KEEP = keep

@@ -1,0 +1,119 @@
+"""Oracle comparison of logits AND gradients at the production sizes of BASELINE configs[2] / configs[4].
+
+Until round 5 the full-size runs of these configurations checked finiteness and k-NN rows only; the architecture was compared
+with the float64 twin at N = 2048.  A bug that only shows at N >= 8192 (the carried-queue form of the feature-space k-NN scan,
+the eager path above 65536 points, arena sizes, 32-bit row offsets) would have passed as long as the loss stayed near ln 2.
+
+  configs[2]  residual-dgcnn x 6, k = 40 (scripts/lsf/train_dgcnn.sh:8-9,28), B = 2 clouds of N = 16384:
+              inference logits within 1e-3 (north_star) and -- one training micro-step, dropout off -- loss within 1e-4 and every
+              gradient tensor within 5e-3 relative Frobenius of the float64 twin fed the HIP path's own neighbour graphs;
+  configs[4]  one cloud of N = 65536, dgcnn 3 x (64,64,128), k = 20: logits likewise.
+
+Each layer's graph is checked bit-exact against the C oracle on a seeded sample of rows (all rows would be minutes of scalar work
+per layer; tests/test_gpu_baseline_sizes.py checks every row of single k-NN calls at these N).
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import dgcnn_oracle as O
+from gpu_helpers import dev, host, run_model, capture_layers, set_vars
+
+pytestmark = pytest.mark.gpu
+
+LOGIT_BAR = 1e-3           # north_star: logits within 1e-3 fp32
+GRAD_BAR = 5e-3            # relative Frobenius, every tensor
+
+
+@pytest.fixture()
+def dg():
+    import dgcnn
+    dgcnn.reset()
+    yield dgcnn
+    dgcnn.reset()
+    torch.cuda.empty_cache()
+
+
+def _check_graph_rows(xin, idx, k, nrows, seed):
+    B, N = idx.shape[0], idx.shape[1]
+    for b in range(B):
+        rows = np.sort(np.random.default_rng(seed + b).permutation(N)[:nrows]).astype(np.int32)
+        np.testing.assert_array_equal(idx[b][rows], O.k_nn_rows(xin[b], k, rows))
+    assert ((idx == np.arange(N)[None, :, None]).sum(-1) == 1).all()                    # self among the k (ops.py:18)
+
+
+def _inference_logits_vs_twin(dg, flags, pts, params, L, k, nrows, what):
+    dg.trainval(flags).initialize()
+    set_vars(dg, params)
+    dg.ctx().begin_step()
+    with capture_layers() as capl:
+        logits = host(dg.build(dev(pts), flags))
+    idx_list = []
+    for i in range(L):
+        xin, idx = capl.layers["EdgeConv%d" % i]
+        _check_graph_rows(xin, idx, k, nrows, 1000 * i)
+        idx_list.append(idx)
+    del capl
+    p64 = {n: v.astype(np.float64) for n, v in params.items()}
+    ref64, cache = O.model_forward(pts.astype(np.float64), flags, p64, idx_list=idx_list)
+    del cache
+    err = np.abs(logits - ref64)
+    print("%s: logits max|diff| vs the fp64 twin on the HIP graphs %.3e (mean %.1e), logits range [%.3f, %.3f]"
+          % (what, err.max(), err.mean(), ref64.min(), ref64.max()))
+    assert logits.shape == ref64.shape
+    assert ref64.max() - ref64.min() > 0.1                        # a model that says something (Final has ReLU: logits >= 0)
+    np.testing.assert_allclose(logits, ref64, rtol=0, atol=LOGIT_BAR)
+    return idx_list
+
+
+def _randomised_betas(params, rng):
+    for n in params:
+        if n.endswith("beta"):
+            params[n] = rng.normal(0, 0.2, params[n].shape).astype(np.float32)
+    return params
+
+
+def test_config2_production_size_logits_and_gradients(dg):
+    """residual-dgcnn x 6, k = 40, B = 2, N = 16384 (the size `scripts/lsf/train_dgcnn.sh:8-9,28` trains at)."""
+    B, N, C, L, k = 2, 16384, 3, 6, 40
+    mk = lambda train: dg.DGCNN_FLAGS(MODEL_NAME="residual-dgcnn", EDGE_CONV_LAYERS=L, EDGE_CONV_FILTERS=64, FC_LAYERS=2,
+                                      FC_FILTERS=[512, 256], NUM_CLASS=2, KVALUE=k, NUM_CHANNEL=C, TRAIN=train)
+    rng = np.random.default_rng(216384)
+    pts = rng.random((B, N, C), dtype=np.float32)
+    labels = rng.integers(0, 2, (B, N)).astype(np.int32)
+    params = _randomised_betas(O.init_params(mk(False), C, seed=5), rng)
+    _inference_logits_vs_twin(dg, mk(False), pts, params, L, k, nrows=1024, what="configs[2] B=2 N=16384 residual x6 k=40")
+
+    # one training micro-step, dropout off (the mask stream is the HIP path's own), graphs of THIS forward fed to the twin
+    from dgcnn import _engine as E
+    dg.reset()
+    flags = mk(True)
+    keep, E.DROPOUT_KEEP = E.DROPOUT_KEEP, 1.0
+    try:
+        tv, res, cap = run_model(dg, flags, dev(pts), params, train=True, labels=dev(labels))
+    finally:
+        E.DROPOUT_KEEP = keep
+    idx_list = [cap["EdgeConv%d" % i][1] for i in range(L)]
+    del cap
+    p64 = {n: v.astype(np.float64) for n, v in params.items()}
+    G64, loss64, _, _ = O.train_step_grads(pts.astype(np.float64), labels, flags, p64, idx_list=idx_list)
+    assert abs(float(res[2]) - float(loss64)) < 1e-4, (float(res[2]), float(loss64))
+    rel = lambda a, b: np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30)
+    r = {n: rel(host(tv.gradients[n]).astype(np.float64), G64[n]) for n in params}
+    worst = max(r, key=r.get)
+    print("configs[2] B=2 N=16384: loss %.6f (twin %.6f); relative Frobenius gradient error vs the fp64 twin: worst %.2e (%s), "
+          "median %.2e" % (float(res[2]), float(loss64), r[worst], worst, float(np.median(list(r.values())))))
+    assert set(r) == set(tv.gradients)
+    assert r[worst] < GRAD_BAR, r
+
+
+def test_config4_one_cloud_n65536_logits(dg):
+    """One cloud of N = 65536 (LArTPC scale), dgcnn 3 x (64,64,128), k = 20: the tiled-distance k-NN forms (cell grid on raw
+    coordinates, carried-queue scan on features) inside the model, logits against the float64 twin on the same graphs."""
+    B, N, C, L, k = 1, 65536, 3, 3, 20
+    flags = dg.DGCNN_FLAGS(MODEL_NAME="dgcnn", EDGE_CONV_LAYERS=L, EDGE_CONV_FILTERS=[64, 64, 128], FC_LAYERS=2,
+                           FC_FILTERS=[512, 256], NUM_CLASS=2, KVALUE=k, NUM_CHANNEL=C, TRAIN=False)
+    rng = np.random.default_rng(465536)
+    pts = rng.random((B, N, C), dtype=np.float32)
+    params = _randomised_betas(O.init_params(flags, C, seed=6), rng)
+    _inference_logits_vs_twin(dg, flags, pts, params, L, k, nrows=2048, what="configs[4] one cloud N=65536 3 layers k=20")
