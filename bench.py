@@ -574,14 +574,23 @@ def main():
             if t == dominant or sec <= 0:
                 continue
             if t.startswith("knn"):
+                # a k-NN CALL (dgcnn_knn_f32 / dgcnn_knn_seeded_f32) is several kernels; the tag lists them and names the pipe the
+                # 2 B N^2 C distance flops run on: the raw-coordinate kernel forms them on the fp32 VALU, the list-keeping feature kernel
+                # on the fp32 MFMA, the append-form scan as a conservative bf16-MFMA filter with an exact fp32 re-check of the survivors
                 c_in = int(t.split("<C")[1].split(",")[0])
-                extra.append({"kernel": t, "bound": "valu+mfma (fp32 MFMA and the selection share the vector pipe)",
-                              "achieved": round(work / sec / 1e12, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                              "frac": round(work / sec / 1e12 / PEAK_F32_MFMA_TFLOPS, 4), "launches": n,
+                if "knn_bf16a_kernel" in t:
+                    pipe, pk = "bf16 MFMA filter (+ exact fp32 VALU re-check of the survivors); staging / barrier bound", PEAK_BF16_MFMA_TFLOPS
+                elif c_in <= 4:
+                    pipe, pk = "fp32 VALU (distances and sorted inserts share the vector pipe)", PEAK_F32_MFMA_TFLOPS
+                else:
+                    pipe, pk = "fp32 MFMA (blocks VALU issue: shares the vector pipe with the selection)", PEAK_F32_MFMA_TFLOPS
+                extra.append({"kernel": t, "bound": pipe,
+                              "achieved": round(work / sec / 1e12, 2), "peak": pk, "unit": "TFLOP/s",
+                              "frac": round(work / sec / 1e12 / pk, 4), "launches": n,
                               "avg_us": round(sec / n * 1e6, 1),
                               "materialised_equiv_GBs": round(n * 2.0 * B * N * N * 4 / sec / 1e9, 1),
-                              "note": "flops = 2 B N^2 C (C = %d padded); materialised_equiv = the 2 B N^2 4-byte write+read of the "
-                                      "reference's (B,N,N) distance tensor that never touches HBM here" % c_in})
+                              "note": "one CALL = the kernels in the tag; flops = 2 B N^2 C (C = %d padded); materialised_equiv = the "
+                                      "2 B N^2 4-byte write+read of the reference's (B,N,N) distance tensor that never touches HBM here" % c_in})
             elif t.startswith("gemm"):
                 pk = PEAK_F32_MFMA_TFLOPS
                 if "bf16x" in t:
@@ -611,6 +620,20 @@ def main():
                 extra.append({"kernel": t, "bound": "hbm", "achieved": round(work / sec / 1e9, 1), "peak": PEAK_HBM_GBS,
                               "unit": "GB/s", "frac": round(work / sec / 1e9 / PEAK_HBM_GBS, 4), "launches": n,
                               "avg_us": round(sec / n * 1e6, 1)})
+        # the step as a whole: executed fp32-equivalent flops (GEMMs 2 M N K as launched -- the fold and the FC0 global-feature split
+        # already taken out -- plus the k-NN distance products) and algorithmic HBM bytes (every tagged launch's compulsory operand +
+        # result bytes) per step, over the MEDIAN region's ms_per_step, against both peaks
+        st_flops = sum(v[2] for t, v in table.items() if t.startswith("gemm") or t.startswith("knn"))
+        st_bytes = sum((v[3] if t.startswith("gemm") else (v[2] if not t.startswith("knn") else 0.0)) for t, v in table.items())
+        st_ms = elapsed / args.steps * 1e3
+        roof["step"] = {"executed_GFLOP": round(st_flops / 1e9, 1), "TFLOP/s": round(st_flops / st_ms / 1e9, 1),
+                        "frac_of_mfma_peak": round(st_flops / st_ms / 1e9 / (PEAK_BF16_MFMA_TFLOPS / 6), 4),
+                        "mfma_peak": round(PEAK_BF16_MFMA_TFLOPS / 6, 1),
+                        "hbm_GB": round(st_bytes / 1e9, 2), "GB/s": round(st_bytes / st_ms / 1e6, 1),
+                        "frac_of_hbm_peak": round(st_bytes / st_ms / 1e6 / PEAK_HBM_GBS, 4),
+                        "kernel_ms_serialised": round(sum(v[1] for v in table.values()) * 1e3, 3), "ms_per_step": round(st_ms, 3),
+                        "note": "sums over the tagged launches of one step (event-timed with the side stream off): fp32-equivalent "
+                                "flops of the GEMMs and k-NN products as executed, compulsory operand/result bytes of every launch"}
         if args.kernel_table:
             tot = sum(v[1] for v in table.values())
             for t, (n, s, w, _b) in sorted(table.items(), key=lambda kv: -kv[1][1]):

@@ -511,8 +511,16 @@ def knn(x2d, B, N, k, seed=None):
     idx = torch.empty((B, N, k), dtype=torch.int32, device=x2d.device)
     nws = int(H.load().dgcnn_knn_workspace_bytes(B, N, C, k))           # s_i, seed bounds (+ the cell grid's scratch for raw coordinates)
     ws = torch.empty((nws,), dtype=torch.uint8, device=x2d.device)
-    tag = "knn_kernel<C%d,k%d>" % (4 if C <= 4 else 16 if C <= 16 else 64 if C <= 64 else 128,
-                                   8 if k <= 8 else 20 if k <= 20 else 40 if k <= 40 else 64)
+    Cp, kc = (4 if C <= 4 else 16 if C <= 16 else 64 if C <= 64 else 128), (8 if k <= 8 else 20 if k <= 20 else 40 if k <= 40 else 64)
+    seeded = (KNN_SEED and seed is not None and seed.dim() == 3 and seed.shape[0] == B and seed.shape[1] == N and seed.shape[2] >= k
+              and seed.dtype == torch.int32 and seed.is_contiguous())
+    # bench.py's tag of the CALL: the kernels it launches (the library picks the form: knn.hip:knn_dispatch)
+    if seeded and 16 < C <= 64:
+        tag = "knn_call<C%d,k%d>[sqnorm_kernel+knn_seed_bound_kernel+knn_bf16a_kernel+knn_select_kernel]" % (Cp, kc)
+    elif C <= 4:
+        tag = "knn_call<C%d,k%d>[%s]" % (Cp, kc, "knn_grid_*" if N >= 4096 else "sqnorm_kernel+knn_kernel")
+    else:
+        tag = "knn_call<C%d,k%d>[sqnorm_kernel+%s]" % (Cp, kc, "knn_bf16f_kernel" if N >= 8192 else "knn_mfma_kernel")
     if (KNN_SEED and seed is not None and seed.dim() == 3 and seed.shape[0] == B and seed.shape[1] == N and seed.shape[2] >= k and
             seed.dtype == torch.int32 and seed.is_contiguous()):
         H.call("dgcnn_knn_seeded_f32", x2d.data_ptr(), B, N, C, H.ld2(x2d), k, seed.data_ptr(), int(seed.shape[2]), int(seed.shape[2]),
