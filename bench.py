@@ -334,6 +334,8 @@ def main():
     if args.same_device:
         local_rank = 0
     torch.cuda.set_device(local_rank)
+    if os.environ.get("DGCNN_BENCH_MAIN_PRIORITY"):          # A/B switch (profiles/r06/side_stream_ab.sh): the step's own stream
+        torch.cuda.set_stream(torch.cuda.Stream(priority=int(os.environ["DGCNN_BENCH_MAIN_PRIORITY"])))
     import dgcnn
     from dgcnn import _hip as H
     from dgcnn import parallel

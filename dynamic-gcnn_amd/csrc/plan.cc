@@ -246,3 +246,50 @@ extern "C" int dgcnn_memset_async(void* ptr, int value, size_t bytes, void* stre
   if (rc) dg::set_error("dgcnn_memset_async: %s", hipGetErrorString(hipGetLastError()));
   return rc;
 }
+
+// ---- the side stream (weight-gradient GEMMs, transposed adjacency, parameter-only preparation): nothing on the critical path waits
+// for it before the optimizer, so it is created at the LOWEST priority the device offers and, optionally, on a CU mask that leaves
+// `reserve_cus` compute units (spread evenly over the XCDs: the mask's bits are interleaved across them) to the main stream alone --
+// a 256-workgroup GEMM with all of a CU's LDS otherwise makes a 4-workgroup BatchNorm finalize of the main stream wait for one of its
+// workgroups to retire (profiles/r06/timeline_*.txt: 6 us alone, 66-113 us beside a weight-gradient GEMM).
+extern "C" int dgcnn_stream_create(int low_priority, int reserve_cus, void** stream_out) {
+  DG_REQUIRE(stream_out, DGCNN_EINVAL, "dgcnn_stream_create: null output");
+  int least = 0, greatest = 0;
+  (void)hipDeviceGetStreamPriorityRange(&least, &greatest);           // numerically: least >= greatest (lower number = higher priority)
+  const int prio = low_priority ? least : 0;
+  hipStream_t st = nullptr;
+  hipError_t e;
+  if (reserve_cus > 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    (void)hipGetDevice(&dev);
+    e = hipGetDeviceProperties(&prop, dev);
+    DG_REQUIRE(e == hipSuccess, DGCNN_ELAUNCH, "dgcnn_stream_create: %s", hipGetErrorString(e));
+    const int ncu = prop.multiProcessorCount;
+    DG_REQUIRE(reserve_cus < ncu, DGCNN_EINVAL, "dgcnn_stream_create: cannot reserve %d of %d CUs", reserve_cus, ncu);
+    const int words = (ncu + 31) / 32;
+    uint32_t mask[32] = {0};
+    DG_REQUIRE(words <= 32, DGCNN_EUNSUP, "dgcnn_stream_create: %d CUs", ncu);
+    for (int i = 0; i < ncu - reserve_cus; ++i) mask[i / 32] |= 1u << (i % 32);   // the LAST reserve_cus bits stay clear
+    e = hipExtStreamCreateWithCUMask(&st, (uint32_t)words, mask);
+    DG_REQUIRE(e == hipSuccess, DGCNN_ELAUNCH, "dgcnn_stream_create: hipExtStreamCreateWithCUMask: %s", hipGetErrorString(e));
+    (void)prio;                                                        // (the CU-mask entry point takes no priority)
+  } else {
+    e = hipStreamCreateWithPriority(&st, hipStreamNonBlocking, prio);
+    DG_REQUIRE(e == hipSuccess, DGCNN_ELAUNCH, "dgcnn_stream_create: hipStreamCreateWithPriority(%d): %s", prio, hipGetErrorString(e));
+  }
+  *stream_out = (void*)st;
+  return DGCNN_OK;
+}
+
+extern "C" int dgcnn_stream_destroy(void* stream) {
+  if (stream) (void)hipStreamDestroy((hipStream_t)stream);
+  return DGCNN_OK;
+}
+
+extern "C" int dgcnn_stream_priority_range(int* least, int* greatest) {
+  DG_REQUIRE(least && greatest, DGCNN_EINVAL, "dgcnn_stream_priority_range: null output");
+  hipError_t e = hipDeviceGetStreamPriorityRange(least, greatest);
+  DG_REQUIRE(e == hipSuccess, DGCNN_ELAUNCH, "dgcnn_stream_priority_range: %s", hipGetErrorString(e));
+  return DGCNN_OK;
+}

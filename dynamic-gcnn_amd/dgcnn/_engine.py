@@ -43,6 +43,10 @@ FUSE_DROPOUT = True        # tf.nn.dropout inside the last FC layer's BatchNorm 
 BF16_FUSED_BWD = True      # bf16 edge-MLP: the layer's backward in one pass over the edges (tests switch it off to compare)
 EDGE_BWD_REDUCE_POINTS = True   # BN backward sums of conv0 from per-point data (False: a pass over the edges)
 SIDE_STREAM_MIN_ROWS = 16384   # below this many points the side stream is not used
+# the side stream's work is off the critical path: least priority / a CU mask that leaves some compute units to the main stream alone
+# (csrc/plan.cc:dgcnn_stream_create; A/B switches -- neither helps, the mask costs 40 %: profiles/r06/side_stream.txt)
+SIDE_STREAM_LOW_PRIORITY = os.environ.get("DGCNN_SIDE_LOW_PRIORITY", "0") not in ("0", "")
+SIDE_STREAM_RESERVE_CUS = int(os.environ.get("DGCNN_SIDE_RESERVE_CUS", "0"))
 # conv0 of every EdgeConv layer with bf16 OPERANDS (BASELINE.json configs[2] "bf16 edge-MLP MFMA"): E = [x_i, x_j - x_i] is formed
 # in fp32, E and W0 are rounded to bf16 once, the literal (B*N*k) x 2C x F product runs on v_mfma_f32_32x32x16_bf16 with fp32
 # accumulation; the two gradient products round their operands the same way.  "f32" (default): the fp32-class folded form.
@@ -136,7 +140,7 @@ class Context(object):
             return
         main = torch.cuda.current_stream()
         if self.side is None or self.side.device != self.device:
-            self.side = torch.cuda.Stream(device=self.device)
+            self.side = H.make_stream(self.device, low_priority=SIDE_STREAM_LOW_PRIORITY, reserve_cus=SIDE_STREAM_RESERVE_CUS)
         H.stream_wait(self.side, main)
         for t in temporaries:
             t.record_stream(self.side)

@@ -123,6 +123,9 @@ PROTOTYPES = {
     "dgcnn_plan_info": [c_vp, c_vp, c_vp, c_vp, c_vp],
     "dgcnn_plan_destroy": [c_vp],
     "dgcnn_stream_wait": [c_vp, c_vp],
+    "dgcnn_stream_create": [c_int, c_int, c_vp],
+    "dgcnn_stream_destroy": [c_vp],
+    "dgcnn_stream_priority_range": [c_vp, c_vp],
     "dgcnn_memset_async": [c_vp, c_int, c_sz, c_vp],
     "dgcnn_comm_available": [],
     "dgcnn_comm_unique_id": [c_vp],
@@ -254,6 +257,18 @@ def memset(t, value=0):
 
 def zeros(shape, dtype, device):
     return memset(torch.empty(shape, dtype=dtype, device=device))
+
+
+def make_stream(device, low_priority=False, reserve_cus=0):
+    """A torch view (ExternalStream) of a HIP stream the library creates: at the device's LEAST priority and / or on a CU mask that
+    keeps `reserve_cus` compute units free for the other streams (dgcnn_stream_create).  Plain torch streams only go from normal
+    priority upwards and know no CU masks.  The stream lives as long as the process (a handful per process)."""
+    if not low_priority and reserve_cus <= 0:
+        return torch.cuda.Stream(device=device)
+    h = ctypes.c_void_p()
+    with torch.cuda.device(device):
+        _check(load().dgcnn_stream_create(int(bool(low_priority)), int(reserve_cus), ctypes.byref(h)), "dgcnn_stream_create")
+    return torch.cuda.ExternalStream(h.value, device=device)
 
 
 def stream_wait(waiter, signaller):

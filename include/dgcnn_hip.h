@@ -443,6 +443,13 @@ int dgcnn_plan_info(void* plan, int* kernels, int* memsets, int* waits, int* col
 int dgcnn_plan_destroy(void* plan);
 int dgcnn_stream_wait(void* waiter, void* signaller);
 int dgcnn_memset_async(void* ptr, int value, size_t bytes, void* stream);
+/* A stream for work nothing on the critical path waits for (the reference has no counterpart: TF schedules its graph itself):
+ * low_priority != 0 -> the device's least stream priority; reserve_cus > 0 -> created on a CU mask that leaves that many compute
+ * units (evenly over the XCDs) to the other streams (then at the default priority: the masked entry point takes none).
+ * The caller owns the stream (dgcnn_stream_destroy). */
+int dgcnn_stream_create(int low_priority, int reserve_cus, void** stream_out);
+int dgcnn_stream_destroy(void* stream);
+int dgcnn_stream_priority_range(int* least, int* greatest);
 
 /* ---- the gradient collective (trainval.py:64-73 mean over the towers; here: one process per GPU, RCCL over xGMI) ----
  * RCCL is dlopen'ed on first use (librccl.so, or $DGCNN_RCCL_LIB); no torch.distributed involved.
