@@ -808,10 +808,16 @@ __device__ __forceinline__ unsigned long long wave_lowest64(const unsigned long 
 // LX: the candidates' fp32 rows are kept in LDS next to the tile and a wave's survivors are re-checked tile by tile (N < 8192: ~10
 // pairs per wave and tile, LDS is the cheaper source); !LX: pairs wait in the queue across tiles until 64 are there and read the
 // candidate row from global memory (L2) -- at N = 65536 a wave meets a survivor every other tile.
-template <bool LX>
+// NPR = products of the filter's inner product: 3 = a1 q1 + a1 q2 + a2 q1 (two bf16 terms per operand; |d' - d| <= 2^-14 t), 1 = a1 q1
+// only (plain bf16 operands, unit roundoff 2^-8: |p' - p| <= sum |a q| (2^-7 + 2^-16) <= (t / 2) 2^-7 (1 + 2^-9), fp32 accumulation of
+// exact products on top: |d' - d| <= 2^-7 t (1 + 2^-8); tested with 2^-6 t): a third of the MFMAs, a quarter of the staging
+// arithmetic, one plane in LDS -- for a wider margin, i.e. more pairs re-checked exactly.  The result is the same bit for bit (the
+// re-check decides).
+template <bool LX, int NPR = 3>
 __global__ __launch_bounds__(256, 3) void knn_bf16a_kernel(const float* __restrict__ x, const float* __restrict__ sq, int N, int C,
                                                            int64_t ldx, int k, const float* __restrict__ tau0, int cap,
-                                                           unsigned long long* __restrict__ ent, int* __restrict__ cnt) {
+                                                           unsigned long long* __restrict__ ent, int* __restrict__ cnt,
+                                                           int ka_tight_mask) {
   using f32x16 = __attribute__((ext_vector_type(16))) float;
   constexpr int CP = 64;
   constexpr int TJM = 64;
@@ -857,6 +863,8 @@ __global__ __launch_bounds__(256, 3) void knn_bf16a_kernel(const float* __restri
   const int64_t grow0 = (int64_t)b * N + row0;                     // global row of the block's first query row
   const int trig = cap - (LX ? KA_SLACK_LX : KA_SLACK);
   volatile qent_t* myq = queue + w * QN;
+  constexpr float C1 = (NPR == 3) ? KA_C1 : 0.5f * (1.0f - 1.0f / 64.0f);       // the filter's (1 - E') / 2
+  const int tight_mask = ka_tight_mask;
 
   bf16x8 q1[4], q2[4];
 #pragma unroll
@@ -922,14 +930,19 @@ __global__ __launch_bounds__(256, 3) void knn_bf16a_kernel(const float* __restri
       const int r = e / (CP / 4);
       const int c4 = (e % (CP / 4)) * 4;
       unsigned h0, m0, h1, m1;
-      split2_pair(pre[i].x, pre[i].y, h0, m0);
-      split2_pair(pre[i].z, pre[i].w, h1, m1);
       const unsigned off = (unsigned)(c4 >> 3) * CS + (unsigned)r * 16u + (unsigned)(c4 & 4) * 2u;
+      if (NPR == 3) {
+        split2_pair(pre[i].x, pre[i].y, h0, m0);
+        split2_pair(pre[i].z, pre[i].w, h1, m1);
+        *reinterpret_cast<uint2*>(base + PB + off) = make_uint2(m0, m1);
+      } else {
+        h0 = cvt_pk_bf16(pre[i].x, pre[i].y);
+        h1 = cvt_pk_bf16(pre[i].z, pre[i].w);
+      }
       *reinterpret_cast<uint2*>(base + off) = make_uint2(h0, h1);
-      *reinterpret_cast<uint2*>(base + PB + off) = make_uint2(m0, m1);
       if (LX) *reinterpret_cast<float4*>(xc + r * RS + c4) = pre[i];
     }
-    if (tid < TJM) sjs[tid] = pre_s * KA_C1;          // the filter's per-candidate term (below); rows past N: +inf
+    if (tid < TJM) sjs[tid] = pre_s * C1;             // the filter's per-candidate term (below); rows past N: +inf
   };
 
   // exact distance of the queued (row, candidate) pairs of this wave, one per lane, and the append.  x_i from the block's fp32 LDS
@@ -1001,7 +1014,9 @@ __global__ __launch_bounds__(256, 3) void knn_bf16a_kernel(const float* __restri
     stash();
     if (t + 1 < nt) fetch(j0 + TJM);
     if (tid == 0) flags[par] = 0;            // (last read between the barriers of tile t-1, next set behind the barrier below)
-    if (t > 0 && lane < 16) {
+    if (t > 0 && ((t & tight_mask) == 0 || t < 8) && lane < 16) {
+      // (every tile for the first 8 tiles, where the bounds move most, then every (tight_mask + 1)-th: the ~80 instructions below
+      //  were a third of a tile's vector work)
       // Bound tightening from the histogram: k candidates seen under T c_m  =>  the row's k-th distance is < T c_m, and a candidate
       // at d >= T c_m has k candidates strictly before it.  (Rows r = w + 4 lane': the wave that would also compact the row.)
       const int r = w + 4 * lane;
@@ -1047,17 +1062,19 @@ __global__ __launch_bounds__(256, 3) void knn_bf16a_kernel(const float* __restri
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
         const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(base + 2 * s * CS);
-        const bf16x8 a2 = *reinterpret_cast<const bf16x8*>(base + PB + 2 * s * CS);
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, q1[s], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, q2[s], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, q1[s], acc, 0, 0, 0);
+        if (NPR == 3) {
+          const bf16x8 a2 = *reinterpret_cast<const bf16x8*>(base + PB + 2 * s * CS);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, q2[s], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, q1[s], acc, 0, 0, 0);
+        }
       }
       // Conservative filter on the approximate inner products a: the exact rule "d < thr" can only hold if  t - 2 a < thr + 2^-14 t
       // (t = s_i + s_j; bound on |d' - d| above), i.e.  a > (1 - 2^-14) t / 2 - thr / 2.  Tested with 2^-13 for 2^-14 and the right
       // side as  c1 s_j + (c1 s_i - thr / 2),  c1 = (1 - 2^-13) / 2: the roundings of that sum (< 2^-20 t) sit far inside the
       // 2^-15 t of slack; one add and one compare per candidate.  thr = +inf: everything passes; rows past N: nothing does.
       const float thr = (row < N) ? thr_s[rslot] : -INFINITY;
-      const float gi = si * KA_C1 - 0.5f * thr;
+      const float gi = si * C1 - 0.5f * thr;
       const float* sj = sjs + cbase + 4 * h;
       unsigned mask = 0u;
 #pragma unroll
@@ -1349,6 +1366,26 @@ extern "C" int dgcnn_knn_append(int on) {               // tools / tests; return
   return prev;
 }
 
+// products of the append-form scan's filter per form (LX: N < 8192): 1 since round 6 (profiles/r06/knn_npr.txt: 187 -> 176 us per call
+// at (24,2048,64,20), 2.05 -> 1.82 ms at (8,16384,64,40), 22.3 -> 18.9 ms at (8,65536,64,20)); DGCNN_KNN_APPEND_NPR="<lx>,<big>"
+// (A/B switch; tests run both)
+static int g_knn_npr[2] = {-1, -1};
+static int knn_append_products(bool lx) {
+  if (g_knn_npr[0] < 0) {
+    int a = 1, b = 1;
+    const char* e = getenv("DGCNN_KNN_APPEND_NPR");
+    if (e) sscanf(e, "%d,%d", &a, &b);
+    g_knn_npr[0] = (a == 3) ? 3 : 1;
+    g_knn_npr[1] = (b == 3) ? 3 : 1;
+  }
+  return g_knn_npr[lx ? 0 : 1];
+}
+extern "C" int dgcnn_knn_append_products(int n) {       // tools / tests: 1 or 3 for both forms (other values: query only); returns the previous setting of the N < 8192 form
+  const int prev = knn_append_products(true);
+  if (n == 1 || n == 3) g_knn_npr[0] = g_knn_npr[1] = n;
+  return prev;
+}
+
 static int knn_impl(const char* what, const float* x, int B, int N, int C, int64_t ldx, int k, const int32_t* seed, int64_t ldseed,
                     int kseed, int32_t* idx, void* ws, size_t ws_bytes, void* stream) {
   DG_REQUIRE(x && idx && ws, DGCNN_EINVAL, "%s: null pointer", what);
@@ -1386,8 +1423,14 @@ static int knn_impl(const char* what, const float* x, int B, int N, int C, int64
     unsigned long long* ent = reinterpret_cast<unsigned long long*>(base + (((size_t)rows * sizeof(int) + 255) & ~(size_t)255));
     const int cap = knn_append_cap(k, N);
     const dim3 grid((unsigned)dg::cdiv(N, ROWS), (unsigned)B);
-    if (knn_append_lx(N)) dg::launch(knn_bf16a_kernel<true>, grid, dim3(256), 0, st, x, (const float*)sq_ws, N, C, ldx, k, (const float*)tau0, cap, ent, cnt);
-    else dg::launch(knn_bf16a_kernel<false>, grid, dim3(256), 0, st, x, (const float*)sq_ws, N, C, ldx, k, (const float*)tau0, cap, ent, cnt);
+    const int npr = knn_append_products(knn_append_lx(N));
+    static int tight = -1;                     // DGCNN_KNN_TIGHTEN_EVERY (power of two; A/B switch): bound tightening every n-th tile
+    if (tight < 0) { const char* e = getenv("DGCNN_KNN_TIGHTEN_EVERY"); tight = e ? atoi(e) : 4; if (tight < 1 || (tight & (tight - 1))) tight = 1; }
+    const int tmask = tight - 1;
+#define DG_KA(LXV, NPRV) dg::launch((knn_bf16a_kernel<LXV, NPRV>), grid, dim3(256), 0, st, x, (const float*)sq_ws, N, C, ldx, k, (const float*)tau0, cap, ent, cnt, tmask)
+    if (knn_append_lx(N)) { if (npr == 1) DG_KA(true, 1); else DG_KA(true, 3); }
+    else { if (npr == 1) DG_KA(false, 1); else DG_KA(false, 3); }
+#undef DG_KA
     dg::launch(knn_select_kernel, dim3((unsigned)dg::cdiv(rows, 4)), dim3(256), 0, st, (const unsigned long long*)ent, (const int*)cnt, rows,
                cap, k, idx);
     return dg::check_launch(what);

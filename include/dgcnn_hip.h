@@ -89,6 +89,10 @@ int dgcnn_knn_seed_min_n(int n);
  * appended to a per-row buffer, one selection per row at the end: csrc/knn.hip) / keep per-lane sorted lists; on < 0 only queries.
  * Identical indices either way.  Returns the previous setting.  (tools / tests; env DGCNN_KNN_APPEND) */
 int dgcnn_knn_append(int on);
+/* Products of the append-form scan's bf16 filter: 1 (default since round 6: plain bf16 operands, margin 2^-6 (s_i + s_j)) or 3 (two bf16
+ * terms per operand, margin 2^-13 (s_i + s_j)); any other n only queries.  Identical indices either way (survivors of the filter get
+ * their normative distance).  Returns the previous setting.  (tools / tests; env DGCNN_KNN_APPEND_NPR="<N < 8192>,<N >= 8192>") */
+int dgcnn_knn_append_products(int n);
 
 /* ---- K3 in its bf16-operand form (BASELINE configs[2] "bf16 edge-MLP MFMA"): conv0 of an EdgeConv layer, ops.py:21-52 ------
  * E[e] = [x_i, x_j - x_i] formed in fp32 and rounded to bf16 once (RNE), W0 (2C x F, row-major) rounded to bf16 once,

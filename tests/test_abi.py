@@ -104,6 +104,12 @@ def test_knn_workspace_sizes_and_switches_are_plain_host_state():
         assert lib.dgcnn_knn_append(-1) == 0 and lib.dgcnn_knn_append(1) == 0 and lib.dgcnn_knn_append(-1) == 1
     finally:
         lib.dgcnn_knn_append(prev)
+    prev = lib.dgcnn_knn_append_products(0)                                                # query only
+    try:
+        assert prev in (1, 3)
+        assert lib.dgcnn_knn_append_products(3) == prev and lib.dgcnn_knn_append_products(7) == 3 and lib.dgcnn_knn_append_products(1) == 3
+    finally:
+        lib.dgcnn_knn_append_products(prev)
     prev = lib.dgcnn_knn_seed_min_n(-2)                                                    # query only
     try:
         assert lib.dgcnn_knn_seed_min_n(4096) == prev and lib.dgcnn_knn_seed_min_n(-2) == 4096

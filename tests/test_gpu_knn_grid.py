@@ -127,7 +127,7 @@ def test_workspace_too_small_for_the_grid_selects_the_all_pairs_kernel(dg):
 # ------------------------------------------------------------------------------------------------------
 # seeded search (dgcnn_knn_seeded_f32): any k distinct candidates per row bound the row's k-th distance from above
 # ------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("append", [1, 0], ids=["append-scan", "lists"])
+@pytest.mark.parametrize("append", [1, 3, 0], ids=["append-scan", "append-scan-3-products", "lists"])
 @pytest.mark.parametrize("B,N,C,k", [(2, 512, 64, 20), (1, 700, 32, 8), (2, 2048, 64, 20), (1, 9000, 64, 40), (1, 333, 48, 64),
                                      (1, 40, 64, 20), (3, 64, 32, 10), (2, 130, 64, 8), (1, 8200, 20, 20), (2, 65, 64, 64)])
 def test_seeded_knn_equals_the_unseeded_search_whatever_the_seeds(B, N, C, k, append):
@@ -137,12 +137,14 @@ def test_seeded_knn_equals_the_unseeded_search_whatever_the_seeds(B, N, C, k, ap
     over and over: the slow path of that kernel) and with the list-keeping kernels."""
     from dgcnn import _engine as E, _hip as H
     prev = H.load().dgcnn_knn_seed_min_n(0)                                       # (lists: the library seeds from N = 4096 on by default)
-    prev_a = H.load().dgcnn_knn_append(append)
+    prev_a = H.load().dgcnn_knn_append(1 if append else 0)
+    prev_p = H.load().dgcnn_knn_append_products(3 if append == 3 else 1)       # the filter's products: 1 (default) / 3
     try:
         _seeded_cases(E, B, N, C, k)
     finally:
         H.load().dgcnn_knn_seed_min_n(prev)
         H.load().dgcnn_knn_append(prev_a)
+        H.load().dgcnn_knn_append_products(prev_p)
 
 
 def _seeded_cases(E, B, N, C, k):
