@@ -540,6 +540,7 @@ __global__ __launch_bounds__(256, (Bf16fCfg<KC>::OCC)) void knn_bf16f_kernel(con
   }
 
   // candidate tile: 64 rows x 64 channels -> registers (float4 pieces) -> two bf16 planes in LDS
+  const int fr = tid >> 4, fc4 = (tid & 15) << 2;
   constexpr int NV = (TJM * (CP / 4)) / 256;   // 4
   float4 pre[NV];
   float pre_s = INFINITY;
@@ -904,6 +905,7 @@ __global__ __launch_bounds__(256, 3) void knn_bf16a_kernel(const float* __restri
   }
   if (tid < 2) flags[tid] = 0;
 
+  const int fr = tid >> 4, fc4 = (tid & 15) << 2;
   constexpr int NV = (TJM * (CP / 4)) / 256;   // 4
   float4 pre[NV];
   float pre_s = INFINITY;
@@ -926,9 +928,8 @@ __global__ __launch_bounds__(256, 3) void knn_bf16a_kernel(const float* __restri
     char* base = smem_raw;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-      const int e = tid + 256 * i;
-      const int r = e / (CP / 4);
-      const int c4 = (e % (CP / 4)) * 4;
+      const int r = fr + 16 * i;
+      const int c4 = fc4;
       unsigned h0, m0, h1, m1;
       const unsigned off = (unsigned)(c4 >> 3) * CS + (unsigned)r * 16u + (unsigned)(c4 & 4) * 2u;
       if (NPR == 3) {
@@ -1425,8 +1426,9 @@ static int knn_impl(const char* what, const float* x, int B, int N, int C, int64
     const dim3 grid((unsigned)dg::cdiv(N, ROWS), (unsigned)B);
     const int npr = knn_append_products(knn_append_lx(N));
     static int tight = -1;                     // DGCNN_KNN_TIGHTEN_EVERY (power of two; A/B switch): bound tightening every n-th tile
-    if (tight < 0) { const char* e = getenv("DGCNN_KNN_TIGHTEN_EVERY"); tight = e ? atoi(e) : 4; if (tight < 1 || (tight & (tight - 1))) tight = 1; }
-    const int tmask = tight - 1;
+    if (tight < 0) { const char* e = getenv("DGCNN_KNN_TIGHTEN_EVERY"); tight = e ? atoi(e) : 0; if (tight < 0 || (tight & (tight - 1))) tight = 1; }
+    // default: every 4th tile below N = 8192, every 8th above (profiles/r06/knn_tight.txt: 175 -> 168 us, 1.83 -> 1.70 ms, 19.2 -> 17.6 ms per call)
+    const int tmask = (tight ? tight : (knn_append_lx(N) ? 4 : 8)) - 1;
 #define DG_KA(LXV, NPRV) dg::launch((knn_bf16a_kernel<LXV, NPRV>), grid, dim3(256), 0, st, x, (const float*)sq_ws, N, C, ldx, k, (const float*)tau0, cap, ent, cnt, tmask)
     if (knn_append_lx(N)) { if (npr == 1) DG_KA(true, 1); else DG_KA(true, 3); }
     else { if (npr == 1) DG_KA(false, 1); else DG_KA(false, 3); }
