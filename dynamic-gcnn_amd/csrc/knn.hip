@@ -540,7 +540,6 @@ __global__ __launch_bounds__(256, (Bf16fCfg<KC>::OCC)) void knn_bf16f_kernel(con
   }
 
   // candidate tile: 64 rows x 64 channels -> registers (float4 pieces) -> two bf16 planes in LDS
-  const int fr = tid >> 4, fc4 = (tid & 15) << 2;
   constexpr int NV = (TJM * (CP / 4)) / 256;   // 4
   float4 pre[NV];
   float pre_s = INFINITY;
