@@ -814,7 +814,9 @@ __device__ __forceinline__ unsigned long long wave_lowest64(const unsigned long 
 // arithmetic, one plane in LDS -- for a wider margin, i.e. more pairs re-checked exactly.  The result is the same bit for bit (the
 // re-check decides).
 template <bool LX, int NPR = 3>
-__global__ __launch_bounds__(256, 3) void knn_bf16a_kernel(const float* __restrict__ x, const float* __restrict__ sq, int N, int C,
+// N >= 8192 with the one-product filter: 4 workgroups per CU (128 VGPRs; the re-check's candidate ring 8 -> 4 deep keeps it out of
+// scratch): (8,16384,64,40) 2048 workgroups = 2 rounds of 1024 instead of 2.67 of 768, 1.71 -> 1.54 ms (profiles/r06/knn_occ.txt)
+__global__ __launch_bounds__(256, ((LX || NPR != 1) ? 3 : 4)) void knn_bf16a_kernel(const float* __restrict__ x, const float* __restrict__ sq, int N, int C,
                                                            int64_t ldx, int k, const float* __restrict__ tau0, int cap,
                                                            unsigned long long* __restrict__ ent, int* __restrict__ cnt,
                                                            int ka_tight_mask) {
@@ -961,7 +963,7 @@ __global__ __launch_bounds__(256, 3) void knn_bf16a_kernel(const float* __restri
     const float sjv = sqb[j];
     float p = 0.f;
     if (C == 64) {
-      constexpr int VR = LX ? 3 : 8;                                 // ring of candidate quads: LDS two ahead, global eight ahead
+      constexpr int VR = LX ? 3 : (NPR == 1 ? 4 : 8);                                 // ring of candidate quads: LDS two ahead, global eight ahead
       float4 v[VR], a[3];
 #pragma unroll
       for (int q = 0; q < VR - (LX ? 1 : 0); ++q) v[q] = *reinterpret_cast<const float4*>(xj + 4 * q);
@@ -972,7 +974,7 @@ __global__ __launch_bounds__(256, 3) void knn_bf16a_kernel(const float* __restri
         if (q + 2 < 16) a[(q + 2) % 3] = *reinterpret_cast<const float4*>(xi + ((4 * (q + 2)) ^ rx));
         if (LX && q + 2 < 16) v[(q + 2) % 3] = *reinterpret_cast<const float4*>(xj + 4 * (q + 2));
         const float4 aa = a[q % 3], vv = v[q % VR];
-        if (!LX && q + 8 < 16) v[q % 8] = *reinterpret_cast<const float4*>(xj + 4 * (q + 8));
+        if (!LX && q + VR < 16) v[q % VR] = *reinterpret_cast<const float4*>(xj + 4 * (q + VR));
         p = fmaf(aa.x, vv.x, p); p = fmaf(aa.y, vv.y, p); p = fmaf(aa.z, vv.z, p); p = fmaf(aa.w, vv.w, p);
       }
     } else {
