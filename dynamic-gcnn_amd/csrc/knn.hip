@@ -52,6 +52,111 @@ __global__ __launch_bounds__(256) void sqnorm_kernel(const float* __restrict__ x
 }
 
 
+// ------------------------------------------------------------------------------------------------
+// A bound for the raw-coordinate layer (C <= 4, no previous graph to seed from; round 6).  One thread per query row counts the
+// cloud's candidates (every STRIDE-th: k of a SAMPLE within t still puts the row's k-th distance below t) into half-octave bins of the
+// NORMATIVE distance -- bin = (float bits of max(d, 0)) >> 22, i.e. exponent and leading mantissa bit, taken relative to the cloud's
+// largest possible distance so that 48 bins span 24 octaves of d whatever the cloud's scale -- and reports the upper edge of the first
+// bin at which the count reaches k.  The scan then drops every candidate at or above that edge before it reaches the sorted lists:
+// ~1.3 k candidates pass per row instead of ~k (1 + ln(N / k)) per LIST (four lists per row), and the sorted inserts were three
+// quarters of the scan's instructions (r05_pmc_sq.txt).  Rigorous for any input: a candidate dropped has k candidates strictly below it;
+// a coarse bin (many equal distances) only makes the bound looser.  Per candidate: one LDS broadcast read, the 6-operation distance,
+// clamp, shift, one ds_add_u32 into the thread's own column of the histogram ([bin][thread]: bank = thread, conflict free).
+constexpr int HB_NB = 48;
+template <int STRIDE>
+__global__ __launch_bounds__(256) void knn_hist_bound_kernel(const float* __restrict__ x, const float* __restrict__ sq, int N, int C,
+                                                             int64_t ldx, int k, float* __restrict__ tau0) {
+  // 64 query rows per workgroup (lane = row); wave w counts quarter w of every 256-candidate tile into its own histogram
+  // ([wave][bin][lane]: bank = lane), the four are added at the end -- 3072 waves at (24,2048) instead of 768: the per-candidate chain
+  // (two LDS broadcast reads -> distance -> bin -> ds_add) is latency bound with one wave per SIMD (125 us; 4 waves per row: see
+  // profiles/r06/knn_hist.txt)
+  __shared__ unsigned hist[4 * HB_NB * 64];
+  __shared__ float4 tile[256];                          // the sampled candidates' coordinates (zero padded to 4)
+  __shared__ float ts[256];                             // ... and their s_j
+  __shared__ float wmax[4];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int w = tid >> 6;
+  const int b = blockIdx.y;
+  const int row = blockIdx.x * 64 + lane;
+  const float* xb = x + (int64_t)b * N * ldx;
+  const float* sqb = sq + (int64_t)b * N;
+  const int rowc = row < N ? row : N - 1;
+  float xi[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) xi[c] = (c < C) ? xb[(int64_t)rowc * ldx + c] : 0.0f;
+  const float si = sqb[rowc];
+  unsigned* myh = hist + w * HB_NB * 64 + lane;
+#pragma unroll
+  for (int q = 0; q < HB_NB; ++q) myh[q * 64] = 0u;
+  // the cloud's largest s_j bounds every distance: d <= 2 (s_i + s_j) <= 4 max s (4.5: room for the roundings of d)
+  float m = 0.f;
+  for (int j = tid; j < N; j += 256) m = fmaxf(m, sqb[j]);
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  if (lane == 0) wmax[w] = m;
+  __syncthreads();
+  m = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+  const int raw_top = (int)(__float_as_uint(4.5f * m) >> 22);
+  const int bin0 = raw_top - (HB_NB - 1);
+  const int ns = (N + STRIDE - 1) / STRIDE;            // sampled candidates j = STRIDE u, u < ns
+#pragma unroll 1
+  for (int u0 = 0; u0 < ns; u0 += 256) {
+    __syncthreads();
+    if (u0 + tid < ns) {
+      const int64_t j = (int64_t)(u0 + tid) * STRIDE;
+      const float* src = xb + j * ldx;
+      tile[tid] = make_float4(src[0], (C > 1) ? src[1] : 0.f, (C > 2) ? src[2] : 0.f, (C > 3) ? src[3] : 0.f);
+      ts[tid] = sqb[j];
+    }
+    __syncthreads();
+    const int lo = 64 * w;
+    const int hi = (ns - u0 < lo + 64) ? ns - u0 : lo + 64;
+    // the scan's arithmetic, operation for operation (knn_kernel<4, KC>): a candidate counted below an edge here IS below it there
+    auto bin_of = [&](const float4& v, float sj) -> int {
+      float p = 0.f;
+      p = fmaf(xi[0], v.x, p);
+      p = fmaf(xi[1], v.y, p);
+      p = fmaf(xi[2], v.z, p);
+      p = fmaf(xi[3], v.w, p);
+      const float tt = si + sj;
+      const float tp = 2.0f * p;
+      const float d = fmaxf(tt - tp, 0.0f);
+      const int bin = (int)(__float_as_uint(d) >> 22) - bin0;
+      return bin < 0 ? 0 : (bin > HB_NB - 1 ? HB_NB - 1 : bin);
+    };
+    int t = lo;
+    // groups of 8: all LDS reads of a group first, then the arithmetic, then the 8 adds (hipcc will not move a read across a
+    // ds_add that may alias it: candidate by candidate the loop was one LDS round trip per candidate)
+    for (; t + 8 <= hi; t += 8) {
+      float4 v[8];
+      float sj[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) { v[q] = tile[t + q]; sj[q] = ts[t + q]; }
+      int bn[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) bn[q] = bin_of(v[q], sj[q]);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) atomicAdd(&myh[bn[q] * 64], 1u);
+    }
+    for (; t < hi; ++t) atomicAdd(&myh[bin_of(tile[t], ts[t]) * 64], 1u);
+  }
+  __syncthreads();
+  if (w != 0) return;
+  // first bin at which the count reaches k; its upper edge bounds the row's k-th distance (the top bin has none: +inf)
+  unsigned cum = 0u;
+  int bsel = HB_NB - 1;
+#pragma unroll 1
+  for (int q = 0; q < HB_NB; ++q) {
+    cum += hist[q * 64 + lane] + hist[(HB_NB + q) * 64 + lane] + hist[(2 * HB_NB + q) * 64 + lane] + hist[(3 * HB_NB + q) * 64 + lane];
+    if (cum >= (unsigned)k) { bsel = q; break; }
+  }
+  float tau = INFINITY;
+  const int eraw = bin0 + bsel + 1;
+  if (bsel < HB_NB - 1 && eraw > 0 && eraw < 0x1FE) tau = __uint_as_float((unsigned)eraw << 22);
+  if (row < N) tau0[(int64_t)b * N + row] = tau;
+}
+
 // Shared selection bound.  The candidates of a query row are split over FOUR sorted lists (KC entries each, KC % 4 == 0).
 // If every list holds at least KC/4 entries, the row has seen KC candidates with d <= tau := max_i list_i[KC/4 - 1], so a
 // candidate with d > tau has KC candidates strictly before it in (d, j) order and can never enter the row's top KC:
@@ -69,7 +174,7 @@ template <int CP, int KC>
 __global__ __launch_bounds__(256, (knn_min_waves<CP, KC>())) void knn_kernel(const float* __restrict__ x,
                                                                             const float* __restrict__ sq, int N, int C,
                                                                             int64_t ldx, int k, int vec_ok,
-                                                                            int32_t* __restrict__ idx) {
+                                                                            int32_t* __restrict__ idx, const float* __restrict__ tau0) {
   constexpr int TILE_F = TJ * CP;
   constexpr int DQ_F = PERW * 256;           // per-lane distance slots of the current 32 candidates
   constexpr int MERGE_F = ROWS * KC * 2;
@@ -93,6 +198,8 @@ __global__ __launch_bounds__(256, (knn_min_waves<CP, KC>())) void knn_kernel(con
 #pragma unroll
   for (int c = 0; c < CP; ++c) xi[c] = (c < C) ? xb[(int64_t)rowc * ldx + c] : 0.0f;
   const float si = sqb[rowc];
+  // a bound known in advance (knn_hist_bound_kernel: the row's k-th distance is < tau_row): candidates at or above it never enter
+  const float tau_row = tau0 ? tau0[(int64_t)b * N + rowc] : INFINITY;
 
   float dl[KC];
   int jl[KC];
@@ -136,7 +243,7 @@ __global__ __launch_bounds__(256, (knn_min_waves<CP, KC>())) void knn_kernel(con
     // the channel loop is fully unrolled so x_i stays in registers, fenced every 16 channels so
     // the scheduler cannot hoist every LDS read).  Each lane parks d in its LDS slot and keeps a
     // 32-bit mask of the candidates that beat its current k-th distance. ----
-    const float thr = dl[KC - 1];
+    const float thr = fminf(dl[KC - 1], tau_row);
     unsigned mask = 0u;
 #pragma unroll 1
     for (int g = 0; g < PERW; g += 2) {
@@ -1281,7 +1388,7 @@ void launch_knn(const float* x, const float* sq, int B, int N, int C, int64_t ld
       return;
     }
   }
-  dg::launch((knn_kernel<CP, KC>), grid, dim3(256), 0, st, x, sq, N, C, ldx, k, vec_ok, idx);
+  dg::launch((knn_kernel<CP, KC>), grid, dim3(256), 0, st, x, sq, N, C, ldx, k, vec_ok, idx, (CP <= 4) ? tau0 : (const float*)nullptr);
 }
 
 template <int CP>
@@ -1388,6 +1495,22 @@ extern "C" int dgcnn_knn_append_products(int n) {       // tools / tests: 1 or 3
   return prev;
 }
 
+// raw-coordinate layer (C <= 4): sample stride of the histogram bound (knn_hist_bound_kernel); 0 = no bound.  DGCNN_KNN_HIST=<0|1|2|4>
+static int g_knn_hist = -1;
+static int knn_hist_stride(int N) {
+  if (g_knn_hist < 0) {
+    const char* e = getenv("DGCNN_KNN_HIST");
+    g_knn_hist = e ? atoi(e) : 2;
+    if (g_knn_hist != 0 && g_knn_hist != 1 && g_knn_hist != 2 && g_knn_hist != 4) g_knn_hist = 2;
+  }
+  return N >= 256 ? g_knn_hist : 0;
+}
+extern "C" int dgcnn_knn_hist(int stride) {              // tools / tests: 0 off, 1 / 2 / 4 = sample stride; other values only query; returns the previous setting
+  const int prev = knn_hist_stride(1 << 20);
+  if (stride == 0 || stride == 1 || stride == 2 || stride == 4) g_knn_hist = stride;
+  return prev;
+}
+
 static int knn_impl(const char* what, const float* x, int B, int N, int C, int64_t ldx, int k, const int32_t* seed, int64_t ldseed,
                     int kseed, int32_t* idx, void* ws, size_t ws_bytes, void* stream) {
   DG_REQUIRE(x && idx && ws, DGCNN_EINVAL, "%s: null pointer", what);
@@ -1438,7 +1561,19 @@ static int knn_impl(const char* what, const float* x, int B, int N, int C, int64
                cap, k, idx);
     return dg::check_launch(what);
   }
-  if (C <= 4) return dispatch_k<4>(x, sq_ws, B, N, C, ldx, k, vec_ok, idx, tau0, st);
+  if (C <= 4) {
+    // raw coordinates below the cell grid's range: a histogram bound first (the workspace's second s_i-sized region holds it)
+    const int hs = knn_hist_stride(N);
+    if (hs > 0 && !knn_force_valu() && k <= 64 && N >= 4 * k * hs && ws_bytes >= 2 * knn_sq_bytes(B, N)) {
+      float* tb = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + knn_sq_bytes(B, N));
+      const dim3 hg((unsigned)dg::cdiv(N, 64), (unsigned)B);
+      if (hs == 1) dg::launch(knn_hist_bound_kernel<1>, hg, dim3(256), 0, st, x, (const float*)sq_ws, N, C, ldx, k, tb);
+      else if (hs == 2) dg::launch(knn_hist_bound_kernel<2>, hg, dim3(256), 0, st, x, (const float*)sq_ws, N, C, ldx, k, tb);
+      else dg::launch(knn_hist_bound_kernel<4>, hg, dim3(256), 0, st, x, (const float*)sq_ws, N, C, ldx, k, tb);
+      tau0 = tb;
+    }
+    return dispatch_k<4>(x, sq_ws, B, N, C, ldx, k, vec_ok, idx, tau0, st);
+  }
   if (C <= 16) return dispatch_k<16>(x, sq_ws, B, N, C, ldx, k, vec_ok, idx, tau0, st);
   if (C <= 64) return dispatch_k<64>(x, sq_ws, B, N, C, ldx, k, vec_ok, idx, tau0, st);
   return dispatch_k<128>(x, sq_ws, B, N, C, ldx, k, vec_ok, idx, tau0, st);

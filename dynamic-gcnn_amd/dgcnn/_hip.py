@@ -31,6 +31,7 @@ PROTOTYPES = {
     "dgcnn_knn_seed_min_n": [c_int],
     "dgcnn_knn_append": [c_int],
     "dgcnn_knn_append_products": [c_int],
+    "dgcnn_knn_hist": [c_int],
     "dgcnn_knn_seeded_f32": [c_vp, c_int, c_int, c_int, c_i64, c_int, c_vp, c_i64, c_int, c_vp, c_vp, c_sz, c_vp],
     "dgcnn_edge_gather_f32": [c_vp, c_i64, c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp],
     "dgcnn_edge_gather_bwd_f32": [c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp, c_i64, c_vp],

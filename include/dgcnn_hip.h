@@ -93,6 +93,11 @@ int dgcnn_knn_append(int on);
  * terms per operand, margin 2^-13 (s_i + s_j)); any other n only queries.  Identical indices either way (survivors of the filter get
  * their normative distance).  Returns the previous setting.  (tools / tests; env DGCNN_KNN_APPEND_NPR="<N < 8192>,<N >= 8192>") */
 int dgcnn_knn_append_products(int n);
+/* Raw-coordinate rows (C <= 4) below the cell grid's range: a histogram pass over every `stride`-th candidate (half-octave bins of the
+ * normative distance) bounds every row's k-th distance before the scan starts, so that ~1.3 k candidates reach the sorted lists instead
+ * of ~k (1 + ln(N / k)) per list.  stride 0 = off, 1 / 2 (default) / 4; any other value only queries.  Identical indices either way.
+ * Returns the previous setting.  (tools / tests; env DGCNN_KNN_HIST) */
+int dgcnn_knn_hist(int stride);
 
 /* ---- K3 in its bf16-operand form (BASELINE configs[2] "bf16 edge-MLP MFMA"): conv0 of an EdgeConv layer, ops.py:21-52 ------
  * E[e] = [x_i, x_j - x_i] formed in fp32 and rounded to bf16 once (RNE), W0 (2C x F, row-major) rounded to bf16 once,

@@ -171,3 +171,54 @@ def _seeded_cases(E, B, N, C, k):
     mix = ref.copy()
     mix[:, ::2] = N + 1
     np.testing.assert_array_equal(host(E.knn(xd, B, N, k, seed=dev(mix.astype(np.int32)))), ref)
+
+
+# ------------------------------------------------------------------------------------------------------
+# raw-coordinate rows below the cell grid's range: the histogram bound (knn_hist_bound_kernel, round 6)
+# ------------------------------------------------------------------------------------------------------
+def _raw_cloud(kind, rng, B, N, C):
+    if kind == "uniform":
+        return rng.random((B, N, C), dtype=np.float32)
+    if kind == "lattice":                       # integer coordinates: many exact ties and duplicate points
+        return rng.integers(0, 5, (B, N, C)).astype(np.float32)
+    if kind == "far":                           # far from the origin: s_i ~ 3e6, distances ~ 1e-2 (cancellation; everything in the lowest bins)
+        return (rng.random((B, N, C)) + 1000.0).astype(np.float32)
+    if kind == "tiny":                          # a cloud of extent 1e-4
+        return (rng.random((B, N, C)) * 1e-4).astype(np.float32)
+    if kind == "huge":
+        return (rng.random((B, N, C)) * 3e4).astype(np.float32)
+    if kind == "track":                         # points along a line + noise
+        t = rng.random((B, N, 1))
+        return (t * np.array([1.0, 0.5, 0.25, 0.1][:C]) + rng.normal(0, 1e-3, (B, N, C))).astype(np.float32)
+    if kind == "same":                          # every point identical: all distances 0, ties decided by index
+        return np.broadcast_to(rng.random((B, 1, C), dtype=np.float32), (B, N, C)).copy()
+    if kind == "clusters":                      # two tight clusters far apart + one outlier per cloud
+        c = np.where(rng.random((B, N, 1)) < 0.5, 0.0, 50.0)
+        x = (c + rng.normal(0, 1e-2, (B, N, C))).astype(np.float32)
+        x[:, 0] = 1e3
+        return x
+    raise ValueError(kind)
+
+
+@pytest.mark.parametrize("stride", [1, 2, 4])
+@pytest.mark.parametrize("kind", ["uniform", "lattice", "far", "tiny", "huge", "track", "same", "clusters"])
+def test_histogram_bound_never_changes_the_raw_coordinate_graph(dg, kind, stride):
+    """The bound is rigorous for any input: with every sample stride, on clouds that stress the bins (scales from 1e-4 to 3e4,
+    cancellation far from the origin, lattices with hundreds of equal distances, a cloud of identical points, clusters with an
+    outlier that sets the cloud's largest distance), at ragged N and every list size, the graph equals the C oracle's -- and the
+    search without the bound."""
+    from dgcnn import _hip as H
+    lib = H.load()
+    rng = np.random.default_rng(sum(map(ord, kind)) + stride)
+    prev = lib.dgcnn_knn_hist(stride)
+    try:
+        for (B, N, C, k) in [(2, 2048, 3, 20), (1, 1000, 3, 40), (2, 300, 4, 8), (1, 257, 3, 64), (1, 3000, 2, 20), (1, 600, 1, 5)]:
+            pts = _raw_cloud(kind, rng, B, N, C)
+            ref = O.k_nn(pts, k)
+            got = host(dg.ops.k_nn(dev(pts), k))
+            np.testing.assert_array_equal(got, ref, err_msg="%s stride %d %s" % (kind, stride, (B, N, C, k)))
+        assert lib.dgcnn_knn_hist(0) == stride
+        pts = _raw_cloud(kind, rng, 2, 1500, 3)
+        np.testing.assert_array_equal(host(dg.ops.k_nn(dev(pts), 20)), O.k_nn(pts, 20))          # the search without the bound
+    finally:
+        lib.dgcnn_knn_hist(prev)
