@@ -522,7 +522,7 @@ def knn(x2d, B, N, k, seed=None):
     if seeded and 16 < C <= 64:
         tag = "knn_call<C%d,k%d>[sqnorm_kernel+knn_seed_bound_kernel+knn_bf16a_kernel+knn_select_kernel]" % (Cp, kc)
     elif C <= 4:
-        tag = "knn_call<C%d,k%d>[%s]" % (Cp, kc, "knn_grid_*" if N >= 4096 else "sqnorm_kernel+knn_kernel")
+        tag = "knn_call<C%d,k%d>[%s]" % (Cp, kc, "knn_grid_*" if N >= 4096 else "sqnorm_kernel+knn_hist_bound_kernel+knn_kernel")
     else:
         tag = "knn_call<C%d,k%d>[sqnorm_kernel+%s]" % (Cp, kc, "knn_bf16f_kernel" if N >= 8192 else "knn_mfma_kernel")
     if (KNN_SEED and seed is not None and seed.dim() == 3 and seed.shape[0] == B and seed.shape[1] == N and seed.shape[2] >= k and
