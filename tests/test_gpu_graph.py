@@ -163,6 +163,16 @@ def test_graph_cache_is_bounded(mode):
             assert out[0].shape == (1, n, 2)
         assert len(tv._graphs) == 3
         assert [k[1][1] for k in tv._graphs] == [320, 352, 384]   # least recently used shapes were dropped
+        if mode == "plan":                                        # ... and the bytes a plan's private pool pins are known (the second bound)
+            assert all(e["pool_bytes"] > 0 for e in tv._graphs.values())
+            oldf, TV.GRAPH_CACHE_MAX_FRACTION = TV.GRAPH_CACHE_MAX_FRACTION, 0.0
+            try:
+                x = torch.rand(1, 448, 3, device="cuda")
+                for _ in range(3):
+                    tv.inference(None, [x])
+                assert len(tv._graphs) == 1 and next(iter(tv._graphs))[1][1] == 448      # a zero byte budget keeps only the newest plan
+            finally:
+                TV.GRAPH_CACHE_MAX_FRACTION = oldf
         tv.use_graph("auto")                                      # "auto": a shape must come back a few times first
         x = torch.rand(1, 416, 3, device="cuda")
         for i in range(TV.GRAPH_CAPTURE_AFTER_AUTO):
