@@ -160,8 +160,8 @@ def make_guard(args, rank, world):
     """Multi-rank runs only: every phase that contains a collective for the first time (communicator bring-up, the first EAGER step
     with the gradient all-reduce, the recording of a launch plan that holds the ncclAllReduce, then each timed region) runs under a
     dgcnn.rccl.Deadline.  A hang inside RCCL raises nothing; when the deadline passes rank 0 prints ONE JSON line
-    {"error": "<stage>", "value": null, ...} and every rank exits non-zero -- within $DGCNN_BENCH_DEADLINE seconds (default 120),
-    not at the driver's 1800.  Ranks other than 0 wait 10 s longer so that rank 0's line gets out before the launcher reaps it."""
+    {"error": "<stage>", "value": null, ...} and every rank exits non-zero -- within $DGCNN_BENCH_DEADLINE seconds (default 120;
+    the communicator bring-up gets 2.5 x that: topology detection on a cold 8-GPU node), not at the driver's 1800.  Ranks other than 0 wait 10 s longer so that rank 0's line gets out before the launcher reaps it."""
     import contextlib
     if world <= 1:
         return lambda stage, factor=1.0: contextlib.nullcontext()
@@ -346,7 +346,7 @@ def main():
         backend = args.backend
         if backend == "rccl":
             try:
-                with guard("communicator bring-up", 1.5):
+                with guard("communicator bring-up", 2.5):
                     group = parallel.init_rccl(rank=rank, world=world)
             except Exception as e:          # every rank fails alike (no library / rendezvous): fall back together, loudly
                 sys.stderr.write("bench.py: own RCCL communicator unavailable (%s); using torch.distributed nccl\n" % e)
