@@ -282,3 +282,33 @@ def test_capture_of_a_small_step_after_a_large_one_leaves_the_arena_zeroed(mode)
     finally:
         E.DROPOUT_KEEP = keep
         E.DETERMINISTIC = E.DETERMINISTIC_ENV_DEFAULT
+
+
+def test_a_recording_whose_zeroed_extent_is_too_small_is_discarded_not_fatal():
+    """the arena extent a recording zeroes comes from an earlier eager sighting; if the step then uses more (slot count
+    or arena changed in between), the run must go on: the recording step's own results are right (everything behind the recorded
+    extent was zeroed before the recording), the plan is dropped, and the next recording zeroes the full extent."""
+    pts, lab = _data(steps=1, B=4, N=512, seed=13)
+    keep, E.DROPOUT_KEEP = E.DROPOUT_KEEP, 1.0
+    try:
+        def run(sabotage):
+            tv = dgcnn.trainval(_flags(DETERMINISTIC=True)).initialize().use_graph("plan")
+            c = dgcnn.ctx()
+            grads = []
+            for i in range(5):
+                if sabotage and i == 1:
+                    assert len(tv._graph_used) == 1                      # the sighting measured the step's extent ...
+                    for k in tv._graph_used:
+                        tv._graph_used[k] = 8                            # ... and something made it far too small
+                tv.zero_gradients(None)
+                tv.accum_gradient(None, [pts[0]], [lab[0]])
+                grads.append(c.flat_grad.cpu().numpy().copy())
+            return tv, grads
+        tv0, g0 = run(False)
+        tv1, g1 = run(True)
+        for a, b in zip(g0, g1):
+            np.testing.assert_array_equal(a, b)                          # every step, the discarded recording's included
+        assert len(tv1._graphs) == 1                                     # a later recording (full extent) took over
+    finally:
+        E.DROPOUT_KEEP = keep
+        E.DETERMINISTIC = E.DETERMINISTIC_ENV_DEFAULT
