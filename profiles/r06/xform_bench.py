@@ -1,3 +1,4 @@
+# NOTE: needs profiles/patches/a_operand_transform_experiment.patch applied (dgcnn_gemm_x3_test_xform exists only in the experiment build).
 import os, sys, ctypes
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "dynamic-gcnn_amd"))
 import torch
