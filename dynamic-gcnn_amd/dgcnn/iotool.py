@@ -194,20 +194,34 @@ class io_npz(io_base):
         self._out = None
 
 
+def _h5min_module():
+    """dgcnn/_h5min.py, also when this file was loaded by path outside the package (tests/h5_roundtrip.py does)."""
+    try:
+        from . import _h5min
+        return _h5min
+    except ImportError:
+        import importlib.util
+        import os
+        spec = importlib.util.spec_from_file_location("dgcnn_h5min", os.path.join(os.path.dirname(os.path.abspath(__file__)), "_h5min.py"))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        return mod
+
+
 class io_h5(io_npz):
     """HDF5 flavour of the same layouts (iotool.py:199-280): datasets DATA_KEY (entries, N, C),
-    LABEL_KEY / WEIGHT_KEY (entries, N), or the ragged form with `<DATA_KEY>_offsets`.  Needs h5py, which is optional: without it the factory raises
-    NotImplementedError naming the missing module.  Output is written with h5py too (the reference
-    uses PyTables earrays for the same three datasets, iotool.py:233-245)."""
+    LABEL_KEY / WEIGHT_KEY (entries, N), or the ragged form with `<DATA_KEY>_offsets`.  With h5py where it is installed; otherwise
+    through dgcnn/_h5min.py -- a plain-Python reader of what h5py / PyTables / the HDF5 library write by default (contiguous, compact
+    and chunked datasets with deflate / shuffle / fletcher32, superblock 0-3) and a writer of contiguous datasets that the HDF5
+    library reads back (the reference writes its output with PyTables earrays: the same three datasets, iotool.py:233-245)."""
 
     def __init__(self, flags):
         super(io_h5, self).__init__(flags)
         try:
             import h5py
-        except ImportError as e:
-            raise NotImplementedError("IO_TYPE 'h5' needs h5py (%s); convert the file to .npz (same dense arrays) "
-                                      "and use IO_TYPE 'npz'" % e)
-        self._h5 = h5py
+            self._h5 = h5py
+        except ImportError:
+            self._h5 = _h5min_module()
 
     def _open(self, path):
         return self._h5.File(path, "r")

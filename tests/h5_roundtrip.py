@@ -5,7 +5,9 @@ is /opt/conda/bin/python3.9, which has numpy + h5py but no torch -- so iotool.py
 Writes, with h5py, a file in the reference's dense layout (datasets DATA_KEY (entries,N,C) f32, LABEL_KEY (entries,N),
 WEIGHT_KEY (entries,N): dgcnn/iotool.py:212-231, flags.py:42-44) and one in the ragged layout (<DATA_KEY>_offsets),
 reads them back through io_h5 (sequential wrap-around and shuffle), stores softmax rows and re-opens the output file.
-Prints H5_ROUNDTRIP_OK on success.   usage: h5_roundtrip.py <workdir>"""
+Then the other direction for dgcnn/_h5min.py (the plain-Python stand-in of h5py on hosts without it): files IT writes are opened with
+the real HDF5 library here, and files h5py writes in every storage variant it claims are read by it and compared with h5py's own
+reading.  Prints H5_ROUNDTRIP_OK on success.   usage: h5_roundtrip.py <workdir>"""
 import importlib.util
 import os
 import sys
@@ -28,7 +30,37 @@ class Flags(object):
             setattr(self, k, v)
 
 
+def h5min_against_the_library(work):
+    M = iotool._h5min_module()
+    rng = np.random.default_rng(5)
+    arrs = {"data": rng.random((3, 17, 4), dtype=np.float32), "label": rng.integers(-3, 3, (3, 17)).astype(np.int64),
+            "softmax": rng.random((3, 17, 2)), "idx": np.arange(3, dtype=np.int64), "u8": np.arange(9, dtype=np.uint8),
+            "s": np.float32(1.5), "e": np.zeros((0, 4), np.float32)}
+    path = os.path.join(work, "written_by_h5min.h5")
+    with M.File(path, "w") as f:
+        for k, v in arrs.items():
+            f.create_dataset(k, data=v)
+    with h5py.File(path, "r") as f:                                   # the HDF5 library is a strict parser
+        assert sorted(f.keys()) == sorted(arrs)
+        for k, v in arrs.items():
+            assert f[k].shape == np.shape(v) and f[k].dtype == np.asarray(v).dtype and np.array_equal(f[k][()], v), k
+    # ... and h5py-written storage variants read by _h5min
+    variants = dict(contiguous={}, chunked=dict(chunks=(2, 5, 3)), gzip=dict(chunks=(2, 5, 3), compression="gzip"),
+                    shuffle_gzip_fletcher=dict(chunks=(3, 17, 2), shuffle=True, compression="gzip", fletcher32=True))
+    for libver in ("earliest", "latest"):
+        for name, kw in variants.items():
+            p = os.path.join(work, "v_%s_%s.h5" % (libver, name))
+            a = rng.random((5, 17, 4), dtype=np.float32)
+            b = rng.integers(0, 1000, (5, 17)).astype(np.int32)
+            with h5py.File(p, "w", libver=libver) as f:
+                f.create_dataset("a", data=a, **kw)
+                f.create_dataset("b", data=b, **({k: (v[:2] if k == "chunks" else v) for k, v in kw.items()}))
+            with M.File(p) as f:
+                assert np.array_equal(f["a"], a) and np.array_equal(f["b"], b), (libver, name)
+
+
 def main(work):
+    h5min_against_the_library(work)
     rng = np.random.default_rng(0)
     # ---- dense layout, two files (the reference's multi-file concatenate, iotool.py:227-229, with the intent implemented)
     files = []

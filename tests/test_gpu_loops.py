@@ -195,3 +195,35 @@ def test_train_and_inference_on_a_variable_n_source(tmp_path, capsys):
     bad = _flags(tmp_path, ITERATION=1, CHECKPOINT_STEP=0, LOG_DIR="", **dict(common, MINIBATCH_SIZE=2))
     with pytest.raises(ValueError, match="minibatch_size 1"):
         M.train(bad)
+
+
+def test_train_and_inference_from_real_hdf5_files(tmp_path, capsys):
+    """N2 on the GPU box: `-io h5` on files the HDF5 library wrote (tests/golden/h5: the reference's dense layout, contiguous and
+    chunked + gzip + shuffle), read here by dgcnn/_h5min.py where h5py is absent -- a short training run (CSV, finite losses), then
+    inference with an output file (iotool.py:233-245) that is re-read."""
+    h5 = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "h5")
+    files = [os.path.join(h5, "contiguous.h5"), os.path.join(h5, "chunked_gzip_shuffle.h5")]
+    exp = np.load(os.path.join(h5, "expected.npz"))
+    f = _flags(tmp_path, IO_TYPE="h5", INPUT_FILE=files, DATA_KEY="data", LABEL_KEY="label", WEIGHT_KEY="weight", NUM_CHANNEL=4,
+               NUM_CLASS=3, BATCH_SIZE=5, MINIBATCH_SIZE=5, KVALUE=6, ITERATION=4, CHECKPOINT_STEP=4, SUMMARY_STEP=0, REPORT_STEP=0)
+    M.train(f)
+    rows = _rows(tmp_path / "log" / "train_log-0000000.csv")
+    assert len(rows) == 4 and all(np.isfinite(float(r["loss"])) for r in rows)
+    out = str(tmp_path / "pred.h5")
+    g = _flags(tmp_path, IO_TYPE="h5", INPUT_FILE=files, DATA_KEY="data", LABEL_KEY="label", NUM_CHANNEL=4, NUM_CLASS=3, BATCH_SIZE=5,
+               MINIBATCH_SIZE=5, KVALUE=6, ITERATION=2, SHUFFLE=0, MODEL_PATH=f.WEIGHT_PREFIX + "-3", OUTPUT_FILE=out, LOG_DIR=str(tmp_path / "ilog"))
+    M.inference(g)
+    capsys.readouterr()
+    try:
+        import h5py
+        opener = lambda p: h5py.File(p, "r")
+    except ImportError:
+        from dgcnn import _h5min
+        opener = _h5min.File
+    with opener(out) as z:
+        assert sorted(z.keys()) == ["data", "idx", "label", "softmax"]
+        idx = np.asarray(z["idx"])
+        assert idx.tolist() == list(range(10))
+        sm = np.asarray(z["softmax"])
+        assert sm.shape == (10, 37, 3) and np.allclose(sm.sum(-1), 1.0, atol=1e-5)
+        np.testing.assert_array_equal(np.asarray(z["data"])[:5], exp["data"])
