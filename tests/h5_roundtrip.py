@@ -57,6 +57,19 @@ def h5min_against_the_library(work):
                 f.create_dataset("b", data=b, **({k: (v[:2] if k == "chunks" else v) for k, v in kw.items()}))
             with M.File(p) as f:
                 assert np.array_equal(f["a"], a) and np.array_equal(f["b"], b), (libver, name)
+    # an extendable dataset with attributes, the way PyTables' earrays of the reference's output are stored (iotool.py:233-245)
+    p = os.path.join(work, "v_earray_like.h5")
+    a = rng.random((7, 17, 4), dtype=np.float32)
+    with h5py.File(p, "w") as f:
+        d = f.create_dataset("softmax", shape=(0, 17, 4), maxshape=(None, 17, 4), dtype="f4", chunks=(2, 17, 4), compression="gzip")
+        d.attrs["CLASS"] = "EARRAY"
+        d.attrs["TITLE"] = "softmax"
+        for i in range(7):
+            d.resize(i + 1, axis=0)
+            d[i] = a[i]
+        f.attrs["PYTABLES_FORMAT_VERSION"] = "2.1"
+    with M.File(p) as f:
+        assert f["softmax"].shape == (7, 17, 4) and np.array_equal(f["softmax"], a)
 
 
 def main(work):
